@@ -1,0 +1,135 @@
+/* medplib_hip.h — C ABI of libmedplib_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (ShawnHuang497/MedPLIB) has no native code and no FFI: its hot path is PyTorch modules calling
+ * cuBLAS/cuDNN through torch (SURVEY.md §0.2, §8b "Face 2").  This header is therefore the boundary a maintainer
+ * would bind from the reference's Python modules (ctypes stub in INTEGRATION.md); each entry point cites the
+ * reference site whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, negative MP_ERR_* otherwise (never throws / aborts); mp_last_error_string() explains;
+ *   - plain device pointers (tensor.data_ptr()), sizes and strides in ELEMENTS unless stated; no torch types;
+ *   - no allocation, no ownership transfer; scratch comes from the caller (mp_*_workspace sizes);
+ *   - asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream); thread-safe across streams;
+ *   - dtype tags: MP_BF16 = 0, MP_F32 = 1; bf16 buffers are `void*`.
+ */
+#ifndef MEDPLIB_HIP_H
+#define MEDPLIB_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define MP_OK 0
+#define MP_ERR_SHAPE (-1)
+#define MP_ERR_DTYPE (-2)
+#define MP_ERR_WORKSPACE (-3)
+#define MP_ERR_LAUNCH (-4)
+#define MP_ERR_ARG (-5)
+#define MP_BF16 0
+#define MP_F32 1
+/* activation tags for mp_gemm_bf16_nt */
+#define MP_ACT_NONE 0
+#define MP_ACT_RELU 1
+#define MP_ACT_GELU 2
+#define MP_ACT_QUICK_GELU 3
+#define MP_ACT_SILU 4
+
+int mp_version(void);
+const char* mp_arch(void);
+const char* mp_last_error_string(void);
+
+/* ---- bf16 trunk (CLIP ViT-L, Llama-7B(-MoE), SAM-Med2D ViT-B encoder) ------------------------------------------ */
+
+/* C[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias[N]) + residual[M,N]   — every nn.Linear on the trunk
+ * (HF LlamaAttention/LlamaMLP via medplib_moe_llama.py:127-141; CLIP layers via clip_encoder.py:46-57;
+ * mm_projector multimodal_projector/builder.py:39-46; SAM qkv/proj/MLP image_encoder.py:273-296, common.py:13-28).
+ * K % 64 == 0; m_dev (optional) is a device int overriding M (expert row counts). */
+int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                    const void* residual, int64_t ldr, int M, int N, int K, int act, int out_dtype, float alpha,
+                    const int* m_dev, hipStream_t stream);
+/* `batch` independent GEMMs at fixed strides — the per-expert SwiGLU GEMMs of DeepSpeed `Experts`
+ * (call site medplib_moe_llama.py:604-614). m_dev[b] = rows routed to expert b. */
+int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                            void* C, int64_t ldc, int64_t strideC, const float* bias, int64_t strideBias, int batch,
+                            int M, int N, int K, int act, int out_dtype, const int* m_dev, hipStream_t stream);
+
+/* Fused attention forward; variant 0 = hardware transpose-read V path, 1 = scalar-transposed V (cross-check).
+ * Llama causal + key padding (HF-4.31 eager), CLIP (A.2), SAM window/global attention with decomposed
+ * rel-pos bias (image_encoder.py:280-296, 381-421).  Strides: batch, sequence (head stride = D). */
+int mp_attention_fwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss,
+                          const void* V, int64_t v_sb, int64_t v_ss, void* O, int64_t o_sb, int64_t o_ss,
+                          const uint8_t* key_valid, const float* rel_h, const float* rel_w, int kh, int kw, int B, int H,
+                          int Sq, int Sk, int D, int causal, float scale, int variant, hipStream_t stream);
+
+/* LlamaRMSNorm (HF 4.31; medplib_moe_llama.py:121,138,286). */
+int mp_rmsnorm_bf16(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy, int64_t rows, int dim, float eps,
+                    hipStream_t stream);
+/* nn.LayerNorm over the last dim (CLIP eps 1e-5; SAM eps 1e-6, build_sam.py:91; LayerNorm2d in NHWC, common.py:31). */
+int mp_layernorm_bf16(const void* x, int64_t ldx, const float* w, const float* b, void* y, int64_t ldy, int64_t rows,
+                      int dim, float eps, hipStream_t stream);
+/* Half-split RoPE on the q and k thirds of a fused [tokens, 3*H*D] buffer. */
+int mp_rope_qk_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
+                    int head_dim, hipStream_t stream);
+/* out = silu(gu[:, :ff]) * gu[:, ff:]  (LlamaMLP). */
+int mp_swiglu_bf16(const void* gu, int64_t ldgu, void* out, int64_t ldo, int64_t rows, int ff, hipStream_t stream);
+int mp_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
+int mp_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
+/* y[r,:] = x[r,:] + addend[r % period,:]  (position embeddings: CLIP, SAM image_encoder.py:152-154). */
+int mp_add_rows_bf16(const void* x, const void* addend, void* y, int64_t rows, int dim, int64_t period, hipStream_t stream);
+int mp_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, hipStream_t stream);
+
+/* ---- fp32 trainable tail (SAM-Med2D mask decoder, text_hidden_fcs) ---------------------------------------------- */
+
+/* C = act(alpha * op(A) op(B) + beta*C + bias); two-level batching by element strides
+ * (transformer.py:185-244, mask_decoder.py:141-148,158-186, MedPLIB.py:152-164). */
+int mp_sgemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
+                 const float* bias, int M, int N, int K, float alpha, float beta, int act, int nb0, int nb1, int64_t sA0,
+                 int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0, int64_t sC1, int split_k, hipStream_t stream);
+int mp_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int64_t rows,
+                         int dim, float eps, hipStream_t stream);
+int mp_layernorm_bwd_f32(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, float* dx,
+                         float* dw_accum, float* db_accum, int64_t rows, int dim, hipStream_t stream);
+int mp_softmax_fwd_f32(const float* x, float* y, int64_t rows, int cols, float scale, hipStream_t stream);
+int mp_softmax_bwd_f32(const float* p, const float* dp, float* dx, int64_t rows, int cols, float scale, hipStream_t stream);
+int mp_add_f32(const float* a, const float* b, float* y, int64_t n, int64_t period, hipStream_t stream);
+int mp_act_fwd_f32(const float* x, float* y, int64_t n, int act, hipStream_t stream);
+int mp_act_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, int act, hipStream_t stream);
+int mp_colsum_f32(const float* x, float* out, int64_t rows, int cols, int accumulate, hipStream_t stream);
+/* ConvTranspose2d(k=2,s=2) = GEMM + pixel shuffle (mask_decoder.py:53-59 output_upscaling). */
+int mp_convt2x2_shuffle_fwd_f32(const float* G, const float* bias, float* Y, int B, int h, int w, int Co, hipStream_t stream);
+int mp_convt2x2_shuffle_bwd_f32(const float* dY, float* dG, int B, int h, int w, int Co, hipStream_t stream);
+/* last_hidden_state[seg_token_mask] (MedPLIB.py:461) and expand_embedding (MedPLIB.py:292-308). */
+int mp_gather_rows_bf16_to_f32(const void* src, int64_t ld, const int64_t* idx, float* out, int64_t n_rows, int dim,
+                               hipStream_t stream);
+int mp_gather_rows_f32(const float* src, const int64_t* idx, float* out, int64_t n_rows, int64_t dim, hipStream_t stream);
+int mp_scale_f32(float* x, int64_t n, float s, hipStream_t stream);
+
+/* ---- mask head: resize, losses, metrics -------------------------------------------------------------------------- */
+
+/* postprocess_masks (MedPLIB.py:682-701): crop window (already resolved with Python slice semantics by the caller)
+ * then F.interpolate(bilinear, align_corners=False) to (out_h, out_w). */
+int mp_bilinear_resize_fwd(const void* in, int in_dtype, float* out, int n, int in_h, int in_w, int crop_y0, int crop_x0,
+                           int crop_h, int crop_w, int out_h, int out_w, hipStream_t stream);
+int mp_bilinear_resize_bwd(const float* dout, float* din_zeroed, int n, int in_h, int in_w, int crop_y0, int crop_x0,
+                           int crop_h, int crop_w, int out_h, int out_w, hipStream_t stream);
+/* BCE + Dice + IoU-MSE + Focal and their weighted combination (MedPLIB.py:26-124, 515-572); out10 in the
+ * reference's dict order; stats[n,8] feeds the backward. */
+size_t mp_mask_losses_workspace(int n_masks);
+int mp_mask_losses_fwd(const float* pred, const float* gt, const float* pred_iou, const float* ce_loss, int n_masks, int64_t hw,
+                       float w_ce, float w_bce, float w_dice, float w_iou, float w_focal, float* stats, float* out10,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream);
+int mp_mask_losses_bwd(const float* pred, const float* gt, const float* stats, const float* grad_scale, float* dpred,
+                       float* dpred_iou, int n_masks, int64_t hw, float w_bce, float w_dice, float w_iou, float w_focal,
+                       hipStream_t stream);
+/* (sigmoid(x) > thr) and |pred|,|gt|,|and|,|or| counts (train_ds_medplib.py:702-719,750; vqa_infer.py:565-588). */
+int mp_mask_threshold_iou(const void* pred, int pred_dtype, const float* gt, uint8_t* bin_out,
+                          unsigned long long* counts_zeroed, int n_masks, int64_t hw, float threshold, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDPLIB_HIP_H */

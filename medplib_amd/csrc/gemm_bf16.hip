@@ -1,0 +1,233 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] · W[N,K]^T)      ("NT": both operands K-contiguous,
+// which is nn.Linear's natural layout: activations [tokens, in], weight [out, in]).
+//
+// Replaces the cuBLAS calls behind every nn.Linear / conv-as-GEMM on the reference hot path
+// (HF LlamaAttention/LlamaMLP q,k,v,o,gate,up,down; CLIP fc1/fc2/qkv/out; mm_projector
+// model/medplib/model/multimodal_projector/builder.py:39-46; SAM qkv/proj/MLP image_encoder.py:273-296).
+//
+// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 fragments of
+// v_mfma_f32_16x16x32_bf16.  Operands staged global -> VGPR -> LDS (16 B per lane, XOR-swizzled 16-B chunks so the
+// ds_read_b128 fragment reads are bank-conflict free), double-buffered LDS, one barrier per K-tile, next tile's
+// global loads in flight under the current tile's MFMAs.  XCD-aware block remap keeps one W panel per L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT = 256;
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
+
+struct GemmArgs {
+  const bf16_t* A;  int64_t lda;
+  const bf16_t* W;  int64_t ldw;
+  void* C;          int64_t ldc;
+  const float* bias;          // [N] or null
+  const bf16_t* residual;     // [M,N] (ldr) or null, added after activation
+  int64_t ldr;
+  const int* m_dev;           // optional device-side row count (overrides M when non-null)
+  int M, N, K;
+  int act;
+  int out_f32;
+  float alpha;                // scale applied to the accumulator before bias
+  // batching (blockIdx.y): element strides
+  int64_t sA, sW, sC, sR, sBias;
+  int m_dev_stride;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_GELU: return gelu_erf(v);
+    case ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));
+    case ACT_SILU: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+// byte offset of 16-B chunk `c` (0..7) of row `r` in a [rows][64] bf16 LDS tile, XOR-swizzled
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [buf][A|W][128*64 bf16 = 16 KiB]
+  char* sA0 = smem;
+  char* sW0 = smem + 2 * 16384;
+
+  const int batch = blockIdx.y;
+  const bf16_t* __restrict__ A = g.A + batch * g.sA;
+  const bf16_t* __restrict__ W = g.W + batch * g.sW;
+  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
+  const int N = g.N, K = g.K;
+
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  // bijective XCD remap: blocks that land on the same XCD (bid % 8) get a contiguous range of tile ids
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (m0 >= M) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // global staging coordinates: 4 chunks of A and 4 of W per thread per tile
+  const int ld_row = tid >> 3;   // 0..31  (+32*i)
+  const int ld_c = tid & 7;      // 16-B chunk within the 64-wide K slab
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = min(m0 + ld_row + 32 * i, M - 1);
+    const int rw = min(n0 + ld_row + 32 * i, N - 1);
+    a_ptr[i] = A + (int64_t)ra * g.lda + ld_c * 8;
+    w_ptr[i] = W + (int64_t)rw * g.ldw + ld_c * 8;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ra[4], rw[4];
+  const int nt = K / BK;
+
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const bf16x8*>(a_ptr[i] + (int64_t)t * BK);
+      rw[i] = *reinterpret_cast<const bf16x8*>(w_ptr[i] + (int64_t)t * BK);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* sa = sA0 + buf * 16384;
+    char* sw = sW0 + buf * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ld_row + 32 * i;
+      *reinterpret_cast<bf16x8*>(sa + lds_off(r, ld_c)) = ra[i];
+      *reinterpret_cast<bf16x8*>(sw + lds_off(r, ld_c)) = rw[i];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int fr = lane & 15;   // fragment row (A) / col (W) within 16
+  const int fq = lane >> 4;   // k-chunk selector 0..3
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(t + 1);
+    const char* sa = sA0 + buf * 16384;
+    const char* sw = sW0 + buf * 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(r, kk * 4 + fq));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + fr;
+        fb[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(r, kk * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D layout col = lane&15, row = (lane>>4)*4 + r
+  const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
+  const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
+  bf16_t* Cb = g.out_f32 ? nullptr : reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
+  float* Cf = g.out_f32 ? reinterpret_cast<float*>(g.C) + batch * g.sC : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + fr;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (row >= M) continue;
+        float v = acc[i][j][r] * g.alpha + bv;
+        v = apply_act(v, g.act);
+        if (R) v += (float)R[(int64_t)row * g.ldr + col];
+        if (Cf) Cf[(int64_t)row * g.ldc + col] = v;
+        else Cb[(int64_t)row * g.ldc + col] = (bf16_t)v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// C-ABI: see include/medplib_hip.h
+extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                               const float* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
+                               int out_dtype, float alpha, const int* m_dev, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt: bad shape M=%d N=%d K=%d", M, N, K);
+  MP_REQUIRE(K % BK == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt: K=%d must be a multiple of %d (pad on the host)", K, BK);
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt: lda/ldw must be multiples of 8");
+  MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemm_bf16_nt: bad out dtype %d", out_dtype);
+  MP_REQUIRE(act >= 0 && act <= 4, MP_ERR_ARG, "mp_gemm_bf16_nt: bad activation %d", act);
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
+  g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0;
+  const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles, 1), dim3(NT), 65536, stream, g);
+  return mp_check_launch("mp_gemm_bf16_nt");
+}
+
+// batched variant: `batch` independent problems at fixed element strides (expert GEMMs: one launch over all experts,
+// with per-expert device-side row counts m_dev[b]).
+extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
+                                       int64_t strideW, void* C, int64_t ldc, int64_t strideC, const float* bias,
+                                       int64_t strideBias, int batch, int M, int N, int K, int act, int out_dtype,
+                                       const int* m_dev, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched: bad shape");
+  MP_REQUIRE(K % BK == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched: K=%d must be a multiple of %d", K, BK);
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0, MP_ERR_SHAPE,
+             "mp_gemm_bf16_nt_batched: strides must be multiples of 8");
+  MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemm_bf16_nt_batched: bad out dtype");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.residual = nullptr; g.ldr = 0; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = 1.f;
+  g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1;
+  const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles, batch), dim3(NT), 65536, stream, g);
+  return mp_check_launch("mp_gemm_bf16_nt_batched");
+}

@@ -1,0 +1,121 @@
+// Generic fp32 GEMM for the small, trainable tail of the path (SAM-Med2D mask decoder + text_hidden_fcs, forward and
+// backward): C = act(alpha * op(A) op(B) + bias) with NN / NT / TN operand forms, arbitrary sizes, two-level batching
+// (e.g. batch x heads) through element strides.  Reference sites: two-way transformer Attention/MLP
+// (model/segment_anything_med2d/modeling/transformer.py:185-244), hypernetwork MLPs and ConvTranspose2d-as-GEMM
+// (mask_decoder.py:53-65,141-148), text_hidden_fcs (model/MedPLIB.py:152-164).
+//
+// These problems are tiny (<= 0.3 GFLOP per prompt) and latency-bound; exact fp32 FMA accumulation keeps the parity
+// tolerance against the fp32 CPU oracle tight.  64x64x16 tiles, 256 threads, 4x4 register micro-tile, LDS staged,
+// optional split-K with fp32 atomics for the skinny (M <= 64) weight-streaming cases.
+#include "common.h"
+
+namespace {
+
+struct SgemmArgs {
+  const float* A; const float* B; float* C;
+  const float* bias;   // [N] or null (added before activation)
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int transA, transB;  // op(A) = A^T if transA (A stored [K,M]); op(B) = B^T if transB (B stored [N,K])
+  int nb0, nb1;        // batch dims; blockIdx.z = b0 * nb1 + b1
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  float alpha, beta;
+  int act;             // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
+  int split_k;         // >1: gridDim.y encodes (tile_n, split) and C is accumulated with atomics (beta must be 1, C pre-initialised)
+};
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  __shared__ float sA[BK][BM + 4];
+  __shared__ float sB[BK][BN + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int z = blockIdx.z, b0 = z / g.nb1, b1 = z % g.nb1;
+  const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
+  const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
+  float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tn = blockIdx.y % tiles_n, sp = blockIdx.y / tiles_n;
+  const int m0 = blockIdx.x * BM, n0 = tn * BN;
+  int kbeg = 0, kend = g.K;
+  if (g.split_k > 1) {
+    const int per = ((g.K + g.split_k - 1) / g.split_k + BK - 1) / BK * BK;
+    kbeg = sp * per;
+    kend = min(g.K, kbeg + per);
+    if (kbeg >= kend) return;
+  }
+  float acc[4][4] = {};
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // stage A tile as sA[k][m], B tile as sB[k][n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + i * 256;  // 0..1023
+      int m, k;
+      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & 15; m = id >> 4; }
+      const int gm = m0 + m, gk = k0 + k;
+      float v = 0.f;
+      if (gm < g.M && gk < kend) v = g.transA ? A[(int64_t)gk * g.lda + gm] : A[(int64_t)gm * g.lda + gk];
+      sA[k][m] = v;
+      int n, kb;
+      if (g.transB) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      float w = 0.f;
+      if (gn < g.N && gkb < kend) w = g.transB ? B[(int64_t)gn * g.ldb + gkb] : B[(int64_t)gkb * g.ldb + gn];
+      sB[kb][n] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sA[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = sB[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + ty * 4 + i;
+    if (gm >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn >= g.N) continue;
+      float* c = C + (int64_t)gm * g.ldc + gn;
+      if (g.split_k > 1) {
+        atomicAdd(c, g.alpha * acc[i][j]);
+        continue;
+      }
+      float v = g.alpha * acc[i][j];
+      if (g.beta != 0.f) v += g.beta * (*c);
+      if (g.bias) v += g.bias[gn];
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      else if (g.act == 2) v = gelu_erf(v);
+      else if (g.act == 3) v = 1.f / (1.f + expf(-v));
+      *c = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mp_sgemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                            int64_t ldc, const float* bias, int M, int N, int K, float alpha, float beta, int act,
+                            int nb0, int nb1, int64_t sA0, int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0, int64_t sC1,
+                            int split_k, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nb0 >= 1 && nb1 >= 1, MP_ERR_SHAPE, "mp_sgemm_f32: bad shape");
+  MP_REQUIRE(act >= 0 && act <= 3, MP_ERR_ARG, "mp_sgemm_f32: bad activation");
+  MP_REQUIRE(split_k <= 1 || (beta == 1.f && bias == nullptr && act == 0), MP_ERR_ARG,
+             "mp_sgemm_f32: split_k needs beta=1 (pre-initialised C), no bias, no activation");
+  if (M == 0 || N == 0) return MP_OK;
+  SgemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, nb0, nb1, sA0, sA1, sB0, sB1, sC0, sC1,
+              alpha, beta, act, split_k < 1 ? 1 : split_k};
+  dim3 grid((unsigned)mp_cdiv(M, 64), (unsigned)(mp_cdiv(N, 64) * g.split_k), (unsigned)(nb0 * nb1));
+  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, stream, g);
+  return mp_check_launch("mp_sgemm_f32");
+}

@@ -1,0 +1,363 @@
+"""Thin tensor-level wrappers over the C ABI (include/medplib_hip.h).
+
+torch is used here for device memory and streams only: every function hands `data_ptr()`s, sizes and strides to
+libmedplib_hip.so.  Nothing in this module computes with torch ops, and nothing falls back to the CPU."""
+import torch
+
+from ._lib import lib
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
+SACT_NONE, SACT_RELU, SACT_GELU, SACT_SIGMOID = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (medplib_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _dt(dtype):
+    return BF16 if dtype == torch.bfloat16 else F32
+
+
+# ------------------------------------------------------------------ bf16 trunk ------------------------------------------------
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, out=None, alpha=1.0, m_dev=None):
+    """out[M,N] = act(alpha * a[M,K] @ w[N,K]^T + bias) + residual.  a/w bf16 with unit inner stride."""
+    _chk(a, torch.bfloat16, "gemm.a"); _chk(w, torch.bfloat16, "gemm.w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape == (M, N)
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm.bias")
+    if residual is not None:
+        _chk(residual, torch.bfloat16, "gemm.residual"); assert residual.stride(1) == 1
+    lib().call("mp_gemm_bf16_nt", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
+               residual.stride(0) if residual is not None else 0, M, N, K, act, _dt(out.dtype), float(alpha), _p(m_dev),
+               _stream())
+    return out
+
+
+def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
+    """a [E,M,K], w [E,N,K], out [E,M,N] (bf16 or f32); m_dev int32 [E] device row counts."""
+    _chk(a, torch.bfloat16, "gemm_batched.a"); _chk(w, torch.bfloat16, "gemm_batched.w")
+    E, M, K = a.shape
+    N = w.shape[1]
+    assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
+    lib().call("mp_gemm_bf16_nt_batched", _p(a), a.stride(1), a.stride(0), _p(w), w.stride(1), w.stride(0), _p(out),
+               out.stride(1), out.stride(0), _p(bias), bias.stride(0) if bias is not None else 0, E, M, N, K, act,
+               _dt(out.dtype), _p(m_dev), _stream())
+    return out
+
+
+def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w=None, scale=None, variant=0):
+    """q,k,v: [B,S,H,D] bf16 views (stride(3)==1, stride(2)==D); returns [B,Sq,H*D] bf16."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, torch.bfloat16, "attention." + n)
+        assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Sq, H * D), dtype=torch.bfloat16, device=q.device)
+    assert out.stride(2) == 1
+    if scale is None:
+        scale = D ** -0.5
+    kh = kw = 0
+    if rel_h is not None:
+        _chk(rel_h, torch.float32, "attention.rel_h"); _chk(rel_w, torch.float32, "attention.rel_w")
+        assert rel_h.is_contiguous() and rel_w.is_contiguous()
+        kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "attention.key_valid"); assert key_valid.is_contiguous()
+    lib().call("mp_attention_fwd_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0),
+               v.stride(1), _p(out), out.stride(0), out.stride(1), _p(key_valid), _p(rel_h), _p(rel_w), kh, kw, B, H, Sq, Sk,
+               D, int(causal), float(scale), variant, _stream())
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    _chk(x, torch.bfloat16, "rmsnorm.x"); _chk(w, torch.float32, "rmsnorm.w")
+    x2 = x.reshape(-1, x.shape[-1]); assert x2.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x2)
+    lib().call("mp_rmsnorm_bf16", _p(x2), x2.stride(0), _p(w), _p(out), out.stride(0), x2.shape[0], x2.shape[1], float(eps),
+               _stream())
+    return out.view(x.shape)
+
+
+def layernorm(x, w, b, eps, out=None):
+    _chk(x, torch.bfloat16, "layernorm.x"); _chk(w, torch.float32, "layernorm.w")
+    x2 = x.reshape(-1, x.shape[-1]); assert x2.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x2)
+    lib().call("mp_layernorm_bf16", _p(x2), x2.stride(0), _p(w), _p(b), _p(out), out.stride(0), x2.shape[0], x2.shape[1],
+               float(eps), _stream())
+    return out.view(x.shape)
+
+
+def rope_qk_(qkv, cos_t, sin_t, seq, heads, head_dim):
+    """in place on a fused [tokens, 3*heads*head_dim] bf16 buffer; cos/sin fp32 [>=seq, head_dim/2]."""
+    _chk(qkv, torch.bfloat16, "rope.qkv"); _chk(cos_t, torch.float32, "rope.cos")
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and cos_t.is_contiguous() and sin_t.is_contiguous()
+    assert cos_t.shape[0] >= seq and cos_t.shape[1] == head_dim // 2
+    lib().call("mp_rope_qk_bf16", _p(qkv), qkv.stride(0), _p(cos_t), _p(sin_t), qkv.shape[0], seq, heads, head_dim, _stream())
+    return qkv
+
+
+def swiglu(gu, out=None):
+    _chk(gu, torch.bfloat16, "swiglu.gu")
+    assert gu.dim() == 2 and gu.stride(1) == 1
+    ff = gu.shape[1] // 2
+    if out is None:
+        out = torch.empty((gu.shape[0], ff), dtype=torch.bfloat16, device=gu.device)
+    lib().call("mp_swiglu_bf16", _p(gu), gu.stride(0), _p(out), out.stride(0), gu.shape[0], ff, _stream())
+    return out
+
+
+def cast_to_bf16(x):
+    _chk(x, torch.float32, "cast_to_bf16"); x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_cast_f32_to_bf16", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def cast_to_f32(x):
+    _chk(x, torch.bfloat16, "cast_to_f32"); x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    lib().call("mp_cast_bf16_to_f32", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def add_rows(x, addend, out=None):
+    """x [rows, dim] + addend [period, dim] broadcast with row % period."""
+    _chk(x, torch.bfloat16, "add_rows.x"); _chk(addend, torch.bfloat16, "add_rows.addend")
+    x2 = x.reshape(-1, x.shape[-1]); a2 = addend.reshape(-1, addend.shape[-1])
+    assert x2.is_contiguous() and a2.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x2)
+    lib().call("mp_add_rows_bf16", _p(x2), _p(a2), _p(out), x2.shape[0], x2.shape[1], a2.shape[0], _stream())
+    return out.view(x.shape)
+
+
+def add3(a, b, c=None, out=None):
+    _chk(a, torch.bfloat16, "add3.a")
+    assert a.is_contiguous() and b.is_contiguous() and (c is None or c.is_contiguous())
+    if out is None:
+        out = torch.empty_like(a)
+    lib().call("mp_add3_bf16", _p(a), _p(b), _p(c), _p(out), a.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ fp32 tail -------------------------------------------------
+def sgemm(a, b, trans_a=False, trans_b=False, bias=None, act=SACT_NONE, alpha=1.0, beta=0.0, out=None, split_k=1):
+    """2-D or batched (3-D / 4-D leading batch dims via strides) fp32 GEMM.  Operands may be strided views as long as
+    the innermost stride is 1."""
+    _chk(a, torch.float32, "sgemm.a"); _chk(b, torch.float32, "sgemm.b")
+    nb = a.dim() - 2
+    assert b.dim() == a.dim() and nb in (0, 1, 2) and a.stride(-1) == 1 and b.stride(-1) == 1
+    am, ak = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    bk, bn = (b.shape[-1], b.shape[-2]) if trans_b else (b.shape[-2], b.shape[-1])
+    assert ak == bk, f"sgemm: inner dims differ {ak} vs {bk}"
+    batch = tuple(a.shape[:nb])
+    if out is None:
+        out = torch.empty(batch + (am, bn), dtype=torch.float32, device=a.device)
+        assert beta == 0.0
+    assert out.stride(-1) == 1
+    nb0 = batch[0] if nb >= 1 else 1
+    nb1 = batch[1] if nb == 2 else 1
+
+    def st(t, i):
+        return t.stride(i) if (i < nb and t.shape[i] > 1) else 0
+    if nb == 1:
+        s = [(st(t, 0), 0) for t in (a, b, out)]
+    elif nb == 2:
+        s = [(st(t, 0), st(t, 1)) for t in (a, b, out)]
+    else:
+        s = [(0, 0)] * 3
+    lib().call("mp_sgemm_f32", _p(a), a.stride(-2), int(trans_a), _p(b), b.stride(-2), int(trans_b), _p(out), out.stride(-2),
+               _p(bias), am, bn, ak, float(alpha), float(beta), act, nb0, nb1, s[0][0], s[0][1], s[1][0], s[1][1], s[2][0],
+               s[2][1], split_k, _stream())
+    return out
+
+
+def layernorm_fwd_f32(x, w, b, eps):
+    _chk(x, torch.float32, "layernorm_fwd_f32.x"); assert x.is_contiguous()
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib().call("mp_layernorm_fwd_f32", _p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, dim, float(eps), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd_f32(dy, x, w, mean, rstd, dw_accum, db_accum):
+    assert dy.is_contiguous() and x.is_contiguous()
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    lib().call("mp_layernorm_bwd_f32", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw_accum), _p(db_accum), rows, dim,
+               _stream())
+    return dx
+
+
+def softmax_fwd_f32(x, scale=1.0):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    lib().call("mp_softmax_fwd_f32", _p(x), _p(y), x.numel() // x.shape[-1], x.shape[-1], float(scale), _stream())
+    return y
+
+
+def softmax_bwd_f32(p, dp, scale=1.0):
+    assert p.is_contiguous() and dp.is_contiguous()
+    dx = torch.empty_like(p)
+    lib().call("mp_softmax_bwd_f32", _p(p), _p(dp), _p(dx), p.numel() // p.shape[-1], p.shape[-1], float(scale), _stream())
+    return dx
+
+
+def add_f32(a, b, out=None):
+    """a + b where b is broadcast with period b.numel() over the flattened a."""
+    _chk(a, torch.float32, "add_f32.a"); _chk(b, torch.float32, "add_f32.b")
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() % b.numel() == 0
+    if out is None:
+        out = torch.empty_like(a)
+    lib().call("mp_add_f32", _p(a), _p(b), _p(out), a.numel(), b.numel(), _stream())
+    return out
+
+
+def act_fwd_f32(x, act):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    lib().call("mp_act_fwd_f32", _p(x), _p(y), x.numel(), act, _stream())
+    return y
+
+
+def act_bwd_f32(dy, x, act):
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    lib().call("mp_act_bwd_f32", _p(dy), _p(x), _p(dx), x.numel(), act, _stream())
+    return dx
+
+
+def colsum_f32(x, out=None, accumulate=False):
+    x2 = x.reshape(-1, x.shape[-1]); assert x2.is_contiguous()
+    if out is None:
+        out = torch.empty(x2.shape[1], dtype=torch.float32, device=x.device)
+    lib().call("mp_colsum_f32", _p(x2), _p(out), x2.shape[0], x2.shape[1], int(accumulate), _stream())
+    return out
+
+
+def convt2x2_shuffle_fwd(G, bias, B, h, w, Co):
+    assert G.is_contiguous()
+    Y = torch.empty((B, 2 * h, 2 * w, Co), dtype=torch.float32, device=G.device)
+    lib().call("mp_convt2x2_shuffle_fwd_f32", _p(G), _p(bias), _p(Y), B, h, w, Co, _stream())
+    return Y
+
+
+def convt2x2_shuffle_bwd(dY, B, h, w, Co):
+    assert dY.is_contiguous()
+    dG = torch.empty((B * h * w, Co * 4), dtype=torch.float32, device=dY.device)
+    lib().call("mp_convt2x2_shuffle_bwd_f32", _p(dY), _p(dG), B, h, w, Co, _stream())
+    return dG
+
+
+def gather_rows_bf16_to_f32(src, idx):
+    _chk(src, torch.bfloat16, "gather_rows.src"); _chk(idx, torch.int64, "gather_rows.idx")
+    src2 = src.reshape(-1, src.shape[-1]); assert src2.stride(1) == 1
+    out = torch.empty((idx.numel(), src2.shape[1]), dtype=torch.float32, device=src.device)
+    lib().call("mp_gather_rows_bf16_to_f32", _p(src2), src2.stride(0), _p(idx), _p(out), idx.numel(), src2.shape[1], _stream())
+    return out
+
+
+def gather_rows_f32(src, idx):
+    _chk(src, torch.float32, "gather_rows_f32.src"); _chk(idx, torch.int64, "gather_rows_f32.idx")
+    assert src.is_contiguous()
+    dim = src.numel() // src.shape[0]
+    out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    lib().call("mp_gather_rows_f32", _p(src), _p(idx), _p(out), idx.numel(), dim, _stream())
+    return out
+
+
+def scale_f32_(x, s):
+    assert x.is_contiguous()
+    lib().call("mp_scale_f32", _p(x), x.numel(), float(s), _stream())
+    return x
+
+
+# ------------------------------------------------------------------ mask head -------------------------------------------------
+def py_slice_window(full, start, length):
+    """Resolve masks[..., start:start+length] exactly like Python slicing does (negative starts wrap, ends clamp) —
+    this is the 'crop' of postprocess_masks (model/MedPLIB.py:689-699)."""
+    s, e, _ = slice(start, start + length).indices(full)
+    return s, max(e - s, 0)
+
+
+def postprocess_crop(in_h, in_w, input_size):
+    pad_h, pad_w = in_h - input_size[0], in_w - input_size[1]
+    y0, ch = py_slice_window(in_h, pad_h // 2, in_h - pad_h)
+    x0, cw = py_slice_window(in_w, pad_w // 2, in_w - pad_w)
+    return y0, x0, ch, cw
+
+
+def bilinear_resize_fwd(x, crop, out_hw):
+    """x [n, IH, IW] (f32/bf16) -> [n, OH, OW] f32."""
+    assert x.is_contiguous() and x.dim() == 3
+    n, IH, IW = x.shape
+    y0, x0, ch, cw = crop
+    out = torch.empty((n, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
+    lib().call("mp_bilinear_resize_fwd", _p(x), _dt(x.dtype), _p(out), n, IH, IW, y0, x0, ch, cw, out_hw[0], out_hw[1], _stream())
+    return out
+
+
+def bilinear_resize_bwd(dout, in_hw, crop):
+    assert dout.is_contiguous()
+    n, OH, OW = dout.shape
+    y0, x0, ch, cw = crop
+    din = torch.zeros((n, in_hw[0], in_hw[1]), dtype=torch.float32, device=dout.device)
+    lib().call("mp_bilinear_resize_bwd", _p(dout), _p(din), n, in_hw[0], in_hw[1], y0, x0, ch, cw, OH, OW, _stream())
+    return din
+
+
+def mask_losses_fwd(pred, gt, pred_iou, ce_loss, weights):
+    """pred/gt [n, HW] f32, pred_iou [n] f32, ce_loss 1-elem f32 or None; weights = (ce, bce, dice, iou, focal).
+    Returns (out10, stats)."""
+    _chk(pred, torch.float32, "mask_losses.pred"); _chk(gt, torch.float32, "mask_losses.gt")
+    assert pred.is_contiguous() and gt.is_contiguous() and pred_iou.is_contiguous()
+    n, hw = pred.shape
+    ws = lib().raw("mp_mask_losses_workspace")(n)
+    work = torch.empty(ws, dtype=torch.uint8, device=pred.device)
+    stats = torch.zeros((n, 8), dtype=torch.float32, device=pred.device)
+    out = torch.empty(10, dtype=torch.float32, device=pred.device)
+    lib().call("mp_mask_losses_fwd", _p(pred), _p(gt), _p(pred_iou), _p(ce_loss), n, hw, *[float(w) for w in weights], _p(stats),
+               _p(out), _p(work), ws, _stream())
+    return out, stats
+
+
+def mask_losses_bwd(pred, gt, stats, grad_scale, weights):
+    n, hw = pred.shape
+    dpred = torch.empty_like(pred)
+    dq = torch.empty(n, dtype=torch.float32, device=pred.device)
+    lib().call("mp_mask_losses_bwd", _p(pred), _p(gt), _p(stats), _p(grad_scale), _p(dpred), _p(dq), n, hw,
+               *[float(w) for w in weights[1:]], _stream())
+    return dpred, dq
+
+
+def mask_threshold_iou(pred, gt, threshold=0.1):
+    """pred [n, HW] logits (f32/bf16), gt [n, HW] f32 or None -> (uint8 mask [n,HW], int64 counts [n,4])."""
+    assert pred.is_contiguous()
+    n, hw = pred.shape
+    bin_out = torch.empty((n, hw), dtype=torch.uint8, device=pred.device)
+    counts = torch.zeros((n, 4), dtype=torch.int64, device=pred.device)
+    lib().call("mp_mask_threshold_iou", _p(pred), _dt(pred.dtype), _p(gt), _p(bin_out), _p(counts), n, hw, float(threshold),
+               _stream())
+    return bin_out, counts

@@ -1,0 +1,177 @@
+"""GPU parity: fp32 tail kernels (sgemm, LayerNorm/softmax fwd+bwd, ConvT shuffle, gathers) and the mask-head kernels
+(postprocess resize, fused losses fwd+bwd, threshold/IoU) through the C ABI vs the CPU oracle and the golden vectors
+generated from the reference (tests/golden/mask_head_reference.npz).
+
+Tolerances: fp32 kernels vs fp32 oracle — 1e-5 relative (accumulation order / FMA contraction only); integer outputs
+(threshold mask, counts) bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(name, got, ref, rtol=1e-5, atol=1e-5):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    msg = f"{name}: max|err|={err.max().item():.3e}, ref absmax={ref.abs().max().item():.3e}, bad={int(bad.sum())}/{bad.numel()}"
+    print(msg)
+    assert not bad.any(), msg
+
+
+def test_sgemm_forms(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(6, 256, 256), (2048, 128, 256), (8, 4096, 4096), (70, 33, 19)]:
+        a = torch.randn(M, K, generator=g); b = torch.randn(K, N, generator=g); bias = torch.randn(N, generator=g)
+        _close(f"NN {M},{N},{K}", ops.sgemm(a.to(dev), b.to(dev)), a @ b, rtol=1e-4, atol=1e-4 * K ** 0.5)
+        _close("NT+bias+relu", ops.sgemm(a.to(dev), b.T.contiguous().to(dev), trans_b=True, bias=bias.to(dev), act=ops.SACT_RELU),
+               torch.relu(a @ b + bias), rtol=1e-4, atol=1e-4 * K ** 0.5)
+        _close("TN", ops.sgemm(a.T.contiguous().to(dev), b.to(dev), trans_a=True), a @ b, rtol=1e-4, atol=1e-4 * K ** 0.5)
+    # split-K accumulate into a pre-initialised C
+    a = torch.randn(8, 4096, generator=g); b = torch.randn(4096, 512, generator=g); c0 = torch.randn(8, 512, generator=g)
+    c = c0.clone().to(dev)
+    ops.sgemm(a.to(dev), b.to(dev), out=c, beta=1.0, split_k=8)
+    _close("split_k", c, c0 + a @ b, rtol=1e-4, atol=1e-2)
+    # two-level batch over (batch, heads) with strided head views: scores = q k^T
+    B, Nq, Nk, H, d = 3, 6, 256, 8, 16
+    q = torch.randn(B, Nq, H * d, generator=g); k = torch.randn(B, Nk, H * d, generator=g)
+    qd, kd = q.to(dev), k.to(dev)
+    qv = qd.view(B, Nq, H, d).permute(0, 2, 1, 3)   # [B,H,Nq,d] strided
+    kv = kd.view(B, Nk, H, d).permute(0, 2, 1, 3)
+    s = ops.sgemm(qv, kv, trans_b=True, alpha=0.25)
+    ref = torch.einsum("bqhd,bkhd->bhqk", q.view(B, Nq, H, d), k.view(B, Nk, H, d)) * 0.25
+    _close("batched heads NT", s, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_layernorm_softmax_act_fwd_bwd(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for rows, dim in [(48, 256), (2048, 64), (5, 4096)]:
+        x = torch.randn(rows, dim, generator=g, requires_grad=True)
+        w = (1 + 0.1 * torch.randn(dim, generator=g)).requires_grad_(); b = (0.1 * torch.randn(dim, generator=g)).requires_grad_()
+        dy = torch.randn(rows, dim, generator=g)
+        y = F.layer_norm(x, (dim,), w, b, 1e-5); y.backward(dy)
+        yd, mean, rstd = ops.layernorm_fwd_f32(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), 1e-5)
+        _close(f"ln fwd {rows}x{dim}", yd, y.detach())
+        dw = torch.zeros(dim, device=dev); db = torch.zeros(dim, device=dev)
+        dx = ops.layernorm_bwd_f32(dy.to(dev), x.detach().to(dev), w.detach().to(dev), mean, rstd, dw, db)
+        _close("ln dx", dx, x.grad, rtol=1e-4, atol=1e-5)
+        _close("ln dw", dw, w.grad, rtol=1e-4, atol=1e-4)
+        _close("ln db", db, b.grad, rtol=1e-4, atol=1e-4)
+    x = torch.randn(96, 256, generator=g, requires_grad=True); dp = torch.randn(96, 256, generator=g)
+    p = torch.softmax(x * 0.25, -1); p.backward(dp)
+    pd = ops.softmax_fwd_f32(x.detach().to(dev), 0.25)
+    _close("softmax fwd", pd, p.detach(), rtol=1e-5, atol=1e-7)
+    _close("softmax bwd", ops.softmax_bwd_f32(pd, dp.to(dev), 0.25), x.grad, rtol=1e-4, atol=1e-7)
+    for act, fn in ((ops.SACT_RELU, torch.relu), (ops.SACT_GELU, F.gelu)):
+        x = torch.randn(1000, generator=g, requires_grad=True); dy = torch.randn(1000, generator=g)
+        y = fn(x); y.backward(dy)
+        _close(f"act{act} fwd", ops.act_fwd_f32(x.detach().to(dev), act), y.detach())
+        _close(f"act{act} bwd", ops.act_bwd_f32(dy.to(dev), x.detach().to(dev), act), x.grad, rtol=1e-4, atol=1e-6)
+    x = torch.randn(777, 130, generator=g)
+    _close("colsum", ops.colsum_f32(x.to(dev)), x.sum(0), rtol=1e-4, atol=1e-4)
+    a = torch.randn(4, 6, 8, generator=g); bb = torch.randn(6, 8, generator=g)
+    _close("add_f32 bcast", ops.add_f32(a.to(dev), bb.to(dev)), a + bb)
+
+
+def test_convt2x2_as_gemm_plus_shuffle(dev):
+    """ConvTranspose2d(k=2,s=2) == [B*h*w, Cin] @ W.view(Cin, Cout*4) + pixel shuffle (mask_decoder.py:53-59)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Ci, Co, h, w = 2, 256, 64, 16, 16
+    x = torch.randn(B, Ci, h, w, generator=g, requires_grad=True)
+    W = (torch.randn(Ci, Co, 2, 2, generator=g) * 0.05).requires_grad_(); bias = torch.randn(Co, generator=g)
+    y = F.conv_transpose2d(x, W, bias, stride=2)
+    dy = torch.randn_like(y); y.backward(dy)
+    xt = x.detach().permute(0, 2, 3, 1).reshape(B * h * w, Ci).contiguous().to(dev)
+    Wm = W.detach().reshape(Ci, Co * 4).to(dev)
+    G = ops.sgemm(xt, Wm)
+    Y = ops.convt2x2_shuffle_fwd(G, bias.to(dev), B, h, w, Co)
+    _close("convT fwd", Y, y.detach().permute(0, 2, 3, 1), rtol=1e-4, atol=1e-4)
+    dG = ops.convt2x2_shuffle_bwd(dy.permute(0, 2, 3, 1).contiguous().to(dev), B, h, w, Co)
+    dX = ops.sgemm(dG, Wm, trans_b=True)
+    _close("convT dX", dX, x.grad.permute(0, 2, 3, 1).reshape(B * h * w, Ci), rtol=1e-4, atol=1e-4)
+    dW = ops.sgemm(xt, dG, trans_a=True)
+    _close("convT dW", dW, W.grad.reshape(Ci, Co * 4), rtol=1e-4, atol=1e-3)
+
+
+def test_gathers(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(5, 9, 64, generator=g).to(torch.bfloat16)
+    idx = torch.tensor([44, 0, 13, 13], dtype=torch.int64)
+    out = ops.gather_rows_bf16_to_f32(src.to(dev), idx.to(dev))
+    assert torch.equal(out.cpu(), src.view(-1, 64)[idx].float())
+    emb = torch.randn(3, 4, 5, generator=g)
+    out = ops.gather_rows_f32(emb.to(dev), torch.tensor([2, 2, 0], device=dev))
+    assert torch.equal(out.cpu(), emb[[2, 2, 0]])
+
+
+def test_postprocess_resize_against_reference_golden(dev, golden_dir):
+    """postprocess_masks incl. the reference's Python-slice crop quirks; goldens come from model/MedPLIB.py itself."""
+    from medplib_amd import ops
+    gz = np.load(os.path.join(golden_dir, "mask_head_reference.npz"))
+    for i in range(int(gz["pp_count"])):
+        x = torch.from_numpy(gz[f"pp{i}_in"])[0]                 # [1,64,64]
+        inp = tuple(int(v) for v in gz[f"pp{i}_input_size"]); orig = tuple(int(v) for v in gz[f"pp{i}_original_size"])
+        crop = ops.postprocess_crop(64, 64, inp)
+        out = ops.bilinear_resize_fwd(x.contiguous().to(dev), crop, orig)
+        # fp32 interpolation: identical taps/weights, only FMA contraction may differ -> 1e-6 absolute on O(1) logits
+        _close(f"postprocess case {i} {inp}->{orig} crop={crop}", out, torch.from_numpy(gz[f"pp{i}_out"])[0], rtol=1e-6, atol=2e-6)
+    # backward vs autograd
+    x = torch.randn(3, 64, 64, requires_grad=True)
+    y = F.interpolate(x[:, None, :, 12:52], (77, 50), mode="bilinear", align_corners=False)
+    dy = torch.randn_like(y); y.backward(dy)
+    din = ops.bilinear_resize_bwd(dy[:, 0].contiguous().to(dev), (64, 64), (0, 12, 64, 40))
+    _close("bilinear bwd", din, x.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_mask_losses_fwd_bwd(dev, golden_dir):
+    from medplib_amd import ops
+    gz = np.load(os.path.join(golden_dir, "mask_head_reference.npz"))
+    pred = torch.from_numpy(gz["loss_pred"]); gt = torch.from_numpy(gz["loss_gt"]); piou = torch.from_numpy(gz["loss_pred_iou"])
+    n, _, H, W = pred.shape
+    weights = dict(ce=1.0, bce=2.0, dice=0.5, iou=1.5, focal=3.0)
+    wl = (weights["ce"], weights["bce"], weights["dice"], weights["iou"], weights["focal"])
+    ce = torch.tensor([0.37])
+    p = pred.clone().requires_grad_(); q = piou.clone().requires_grad_()
+    ref = O.combine_mask_losses([p[i] for i in range(n)], [gt[i] for i in range(n)], [q[i] for i in range(n)], ce[0], weights)
+    ref["loss"].backward()
+    out, stats = ops.mask_losses_fwd(pred.view(n, -1).contiguous().to(dev), gt.view(n, -1).contiguous().to(dev),
+                                     piou.view(-1).contiguous().to(dev), ce.to(dev), wl)
+    for i, k in enumerate(O.LOSS_KEYS):
+        _close(f"loss[{k}]", out[i], ref[k].detach(), rtol=2e-5, atol=1e-6)
+    # per-mask terms pinned by the reference golden: sum over masks / (n + 1e-8)
+    terms = gz["loss_terms"]
+    _close("unscaled bce vs reference golden", out[5], torch.tensor(terms[:, 0].sum() / (n + 1e-8)), rtol=2e-5, atol=1e-6)
+    _close("unscaled focal vs reference golden", out[9], torch.tensor(terms[:, 3].sum() / (n + 1e-8)), rtol=2e-5, atol=1e-6)
+    dpred, dq = ops.mask_losses_bwd(pred.view(n, -1).contiguous().to(dev), gt.view(n, -1).contiguous().to(dev), stats, None, wl)
+    _close("dloss/dpred", dpred.view_as(pred), p.grad, rtol=1e-3, atol=1e-8)
+    _close("dloss/dpred_iou", dq, q.grad.view(-1), rtol=1e-4, atol=1e-7)
+
+
+def test_threshold_iou_bit_exact(dev, golden_dir):
+    from medplib_amd import ops
+    gz = np.load(os.path.join(golden_dir, "mask_head_reference.npz"))
+    pred = torch.from_numpy(gz["loss_pred"])[:, 0]; gt = torch.from_numpy(gz["loss_gt"])
+    n = pred.shape[0]
+    b, counts = ops.mask_threshold_iou(pred.reshape(n, -1).contiguous().to(dev), gt.reshape(n, -1).contiguous().to(dev), 0.1)
+    assert np.array_equal(b[0].cpu().numpy().astype(bool).reshape(gz["thr_mask"].shape), gz["thr_mask"]), "mask indices must be bit-exact"
+    assert counts[0].cpu().tolist() == gz["thr_counts"].tolist()
+    for i in range(n):
+        rb, rc, _, _ = O.threshold_iou(pred[i], gt[i])
+        assert torch.equal(b[i].cpu().bool().view_as(rb), rb) and counts[i].cpu().tolist() == list(rc)
+    # full BASELINE size, size-independent property: counts consistent (|and| + |or| = |pred| + |gt|)
+    big = torch.randn(8, 336 * 336) * 4
+    gtb = (torch.rand(8, 336 * 336) > 0.5).float()
+    b, c = ops.mask_threshold_iou(big.to(dev), gtb.to(dev), 0.1)
+    c = c.cpu()
+    assert torch.equal(c[:, 2] + c[:, 3], c[:, 0] + c[:, 1])
+    assert torch.equal(b.cpu().bool(), torch.sigmoid(big) > 0.1)

@@ -1,0 +1,157 @@
+"""GPU parity: bf16 trunk kernels (GEMM, attention, norms, RoPE, SwiGLU) through the C ABI vs the CPU oracle.
+
+Tolerances (stated per test): the HIP path computes on bf16 inputs with fp32 accumulation and rounds outputs to bf16
+once; the oracle computes in fp32 on the SAME bf16-rounded inputs, so the bound is one bf16 rounding of the output
+(2^-8 relative) plus fp32 accumulation-order noise."""
+import math
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _report(name, got, ref, rtol, atol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    msg = (f"{name}: max|err|={err.max().item():.4e} at ref={ref.flatten()[err.argmax()].item():.4e}, "
+           f"ref absmax={ref.abs().max().item():.4e}, bad={int(bad.sum())}/{bad.numel()}")
+    print(msg)
+    assert not bad.any(), msg
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 200, 128), (1, 4096, 4096), (639, 1000, 1024),
+                                   (77, 32267 // 8, 256)])
+def test_gemm_bf16_nt(dev, M, N, K):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.1)
+    ref = O.linear(a.float(), w.float())
+    out = ops.gemm(a.to(dev), w.to(dev))
+    torch.cuda.synchronize()
+    # asymmetric operands: a row/col swap or fragment mis-map shows up as O(1) errors
+    _report(f"gemm {M}x{N}x{K}", out, ref, rtol=2 * BF16_EPS, atol=1e-3 * math.sqrt(K))
+
+
+def test_gemm_epilogues(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 328, 192
+    a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g); res = _bf(torch.randn(M, N, generator=g))
+    base = O.linear(a.float(), w.float(), bias)
+    acts = {ops.ACT_NONE: lambda x: x, ops.ACT_RELU: torch.relu, ops.ACT_GELU: torch.nn.functional.gelu,
+            ops.ACT_QUICK_GELU: O.quick_gelu, ops.ACT_SILU: torch.nn.functional.silu}
+    for act, fn in acts.items():
+        out = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), act=act)
+        _report(f"gemm act={act}", out, fn(base) + res.float(), rtol=2 * BF16_EPS, atol=2e-2)
+    out = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), out_dtype=torch.float32, alpha=0.5)
+    _report("gemm f32 out alpha", out, 0.5 * O.linear(a.float(), w.float()) + bias, rtol=1e-4, atol=1e-3)
+    # strided views (fused qkv slices) and device-side row count
+    big = _bf(torch.randn(M, 3 * K, generator=g)).to(dev)
+    out = ops.gemm(big[:, K:2 * K], w.to(dev))
+    _report("gemm strided A", out, O.linear(big[:, K:2 * K].float().cpu(), w.float()), rtol=2 * BF16_EPS, atol=2e-2)
+    mdev = torch.tensor([130], dtype=torch.int32, device=dev)
+    outb = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out=outb, m_dev=mdev)
+    _report("gemm m_dev rows", outb[:130], O.linear(a.float(), w.float())[:130], rtol=2 * BF16_EPS, atol=2e-2)
+    assert (outb[130:].float() == 7.0).all(), "rows beyond the device-side count must stay untouched"
+
+
+def test_gemm_batched_experts(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(9)
+    E, M, N, K = 3, 260, 192, 128
+    a = _bf(torch.randn(E, M, K, generator=g)); w = _bf(torch.randn(E, N, K, generator=g) * 0.1)
+    counts = torch.tensor([260, 0, 77], dtype=torch.int32)
+    out = torch.zeros(E, M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm_batched(a.to(dev), w.to(dev), out, m_dev=counts.to(dev))
+    for e in range(E):
+        c = int(counts[e])
+        if c:
+            _report(f"expert {e}", out[e, :c], a[e, :c].float() @ w[e].float().T, rtol=2 * BF16_EPS, atol=2e-2)
+        assert (out[e, c:].float() == 0).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,S,H,D,causal,ragged", [(2, 639, 4, 128, True, True), (1, 64, 2, 128, True, False),
+                                                   (2, 577, 3, 64, False, False), (1, 200, 2, 64, False, True)])
+def test_attention(dev, variant, B, S, H, D, causal, ragged):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(S + D + variant)
+    qkv = _bf(torch.randn(B, S, 3, H, D, generator=g))
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    kv = None
+    if ragged:
+        lens = torch.tensor([S - 13 * (i + 1) for i in range(B)])
+        kv = (torch.arange(S)[None, :] < lens[:, None])
+    ref = O.attention(q.float(), k.float(), v.float(), causal=causal, key_valid=kv)
+    dq = qkv.to(dev)
+    out = ops.attention(dq[:, :, 0], dq[:, :, 1], dq[:, :, 2], causal=causal,
+                        key_valid=None if kv is None else kv.to(torch.uint8).to(dev), variant=variant)
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before PV (flash-style): tolerance 2 bf16 ulps of O(1) outputs
+    _report(f"attention v{variant} S={S} D={D}", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
+
+
+def test_attention_relpos_sam_window(dev):
+    """SAM-Med2D windowed attention: 196 tokens (14x14), D=64, decomposed rel-pos bias added unscaled."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(3)
+    Bw, H, hw, D = 3, 12, 14, 64
+    S = hw * hw
+    qkv = _bf(torch.randn(Bw, S, 3, H, D, generator=g))
+    rph, rpw = torch.randn(2 * hw - 1, D, generator=g) * 0.2, torch.randn(2 * hw - 1, D, generator=g) * 0.2
+    q = qkv[:, :, 0].float()
+    qh = q.permute(0, 2, 1, 3).reshape(Bw * H, S, D)
+    rel_h, rel_w = O.decomposed_rel_pos(qh, rph, rpw, (hw, hw))
+    bias = (rel_h.view(Bw * H, S, hw, 1) + rel_w.view(Bw * H, S, 1, hw)).reshape(Bw, H, S, S)
+    ref = O.attention(q, qkv[:, :, 1].float(), qkv[:, :, 2].float(), bias=bias)
+    dq = qkv.to(dev)
+    out = ops.attention(dq[:, :, 0], dq[:, :, 1], dq[:, :, 2], rel_h=rel_h.contiguous().to(dev), rel_w=rel_w.contiguous().to(dev))
+    _report("attention relpos", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
+
+
+def test_rmsnorm_layernorm(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for dim in (4096, 1024, 768, 256):
+        x = _bf(torch.randn(37, dim, generator=g) * 3 + 0.5)
+        w = _bf(1 + 0.1 * torch.randn(dim, generator=g)).float(); b = _bf(0.1 * torch.randn(dim, generator=g)).float()
+        out = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+        _report(f"rmsnorm {dim}", out, O.rmsnorm(x.float(), w, 1e-5), rtol=2 * BF16_EPS, atol=1e-3)
+        out = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6)
+        ref = torch.nn.functional.layer_norm(x.float(), (dim,), w, b, 1e-6)
+        _report(f"layernorm {dim}", out, ref, rtol=2 * BF16_EPS, atol=1e-3)
+
+
+def test_rope_swiglu_misc(dev):
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, S, H, D = 2, 70, 4, 128
+    qkv = _bf(torch.randn(B * S, 3 * H * D, generator=g))
+    cos, sin = O.rope_tables(S, D)
+    d = qkv.to(dev).clone()
+    ops.rope_qk_(d, cos.to(dev), sin.to(dev), S, H, D)
+    x = qkv.float().view(B, S, 3, H, D)
+    _report("rope q", d.view(B, S, 3, H, D)[:, :, 0], O.rope(x[:, :, 0], cos, sin), rtol=BF16_EPS, atol=1e-3)
+    _report("rope k", d.view(B, S, 3, H, D)[:, :, 1], O.rope(x[:, :, 1], cos, sin), rtol=BF16_EPS, atol=1e-3)
+    assert torch.equal(d.view(B, S, 3, H, D)[:, :, 2].cpu(), qkv.view(B, S, 3, H, D)[:, :, 2]), "v must be untouched"
+    gu = _bf(torch.randn(33, 2 * 11008, generator=g))
+    out = ops.swiglu(gu.to(dev))
+    _report("swiglu", out, O.swiglu(gu[:, :11008].float(), gu[:, 11008:].float()), rtol=BF16_EPS, atol=1e-3)
+    xf = torch.randn(1001, generator=g)
+    assert torch.equal(ops.cast_to_bf16(xf.to(dev)).cpu(), xf.to(torch.bfloat16))
+    xb = _bf(torch.randn(5, 16, 24, generator=g)); pos = _bf(torch.randn(16, 24, generator=g))
+    _report("add_rows", ops.add_rows(xb.to(dev), pos.to(dev)), xb.float() + pos.float(), rtol=BF16_EPS, atol=1e-3)
+    _report("add3", ops.add3(xb.to(dev), xb.to(dev), xb.to(dev)), 3 * xb.float(), rtol=BF16_EPS, atol=1e-3)
