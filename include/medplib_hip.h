@@ -129,6 +129,65 @@ int mp_mask_losses_bwd(const float* pred, const float* gt, const float* stats, c
 int mp_mask_threshold_iou(const void* pred, int pred_dtype, const float* gt, uint8_t* bin_out,
                           unsigned long long* counts_zeroed, int n_masks, int64_t hw, float threshold, hipStream_t stream);
 
+/* ---- index-driven glue of the trunk ------------------------------------------------------------------------------ */
+
+/* prepare_inputs_labels_for_multimodal (medplib_arch.py:296-527) as one gather: src_code[r] >= 0 -> embed_tokens row,
+ * == INT64_MIN -> zero pad row, otherwise feats row (-1 - code).  The plan (codes, labels, masks) is built on the host. */
+int mp_splice_rows_bf16(const void* embed, const void* feats, const int64_t* src_code, void* out, int64_t rows, int dim,
+                        hipStream_t stream);
+/* Conv2d(k=p,s=p) patch embedding as im2col (+ zero K padding) for the GEMM: CLIP 14x14, SAM 16x16
+ * (image_encoder.py:424-455). */
+int mp_patch_im2col(const void* img, int img_dtype, void* out, int B, int C, int H, int W, int patch, int k_padded,
+                    hipStream_t stream);
+/* NHWC tap-gather im2col: Adapter Conv3x3/s2 and ConvT4x4/s2 parity classes (image_encoder.py:32-37), neck Conv3x3
+ * (image_encoder.py:133-149).  dy/dx are host arrays of n_taps offsets. */
+int mp_im2col_nhwc_bf16(const void* x, void* out, int B, int H, int W, int C, int OH, int OW, int stride_y, int stride_x,
+                        int n_taps, const int* dy, const int* dx, hipStream_t stream);
+int mp_scatter_parity_bf16(const void* src, const void* add, void* dst, int B, int OH, int OW, int C, int sy, int sx, int py,
+                           int px, int DH, int DW, hipStream_t stream);
+/* window_partition / window_unpartition (+ shortcut add) (image_encoder.py:299-345, Block.forward :217-230). */
+int mp_window_partition_bf16(const void* x, void* win, int B, int H, int W, int C, int ws, hipStream_t stream);
+int mp_window_unpartition_add_bf16(const void* win, const void* shortcut, void* out, int B, int H, int W, int C, int ws,
+                                   hipStream_t stream);
+/* add_decomposed_rel_pos tables rel_h/rel_w from the (unscaled) q of a fused qkv buffer (image_encoder.py:381-421). */
+int mp_relpos_tables_bf16(const void* qkv, int64_t ld, const float* rel_pos_h, const float* rel_pos_w, float* rel_h, float* rel_w,
+                          int Bw, int heads, int hh, int ww, int head_dim, hipStream_t stream);
+/* Adapter_Layer channel gate: global average pool and per-channel scale (image_encoder.py:43-47). */
+int mp_token_mean_bf16(const void* x, float* out, int B, int T, int C, hipStream_t stream);
+int mp_scale_channels_bf16(const void* x, const float* gate, void* y, int B, int T, int C, hipStream_t stream);
+/* HF CLIPVisionEmbeddings: [cls; patches] + position embedding. */
+int mp_clip_embed_bf16(const void* patch, const void* cls, const void* pos, void* out, int B, int n_patches, int C,
+                       hipStream_t stream);
+/* feature_select 'patch': drop the CLS row of every image (clip_encoder.py:31-39). */
+int mp_copy_rows_bf16(const void* src, void* dst, int64_t rows, int dim, int rows_per_batch, int src_batch_rows, int src_row0,
+                      hipStream_t stream);
+
+/* ---- CE and MoE routing ------------------------------------------------------------------------------------------- */
+
+/* per-row -log softmax(logits)[label] on fp32 logits (medplib_moe_llama.py:388-408). */
+int mp_cross_entropy_rows_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t n_rows, int vocab, float* row_loss,
+                              hipStream_t stream);
+/* out = mean(x)*scale + add_scale*sum(add): CE mean (+ router_aux_loss_coef * sum l_aux, medplib_moe_llama.py:410-421). */
+int mp_mean_plus_f32(const float* x, int64_t n, float scale, const float* add, int n_add, float add_scale, float* out,
+                     hipStream_t stream);
+/* DeepSpeed TopKGate: fp32 gate logits + softmax over ALL tokens incl. padding. */
+int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, float* logits, float* gates, int64_t tokens, int dim,
+                     int n_experts, hipStream_t stream);
+/* DeepSpeed top1gating: argmax expert, capacity, random-token-selection from injected uniforms, slots, l_aux. */
+int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,
+                      int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream);
+/* MOELayer dispatch / combine as index gathers (replaces einsum "sec,sm->ecm" / "sec,ecm->sm"). */
+int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
+                         int capacity, hipStream_t stream);
+int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,
+                        int64_t tokens, int dim, int capacity, hipStream_t stream);
+
+/* ---- optimizer (train_ds_medplib.py:383-420: AdamW betas (0.9,0.95), wd 0, clip 1.0) ------------------------------ */
+int mp_sumsq_accum_f32(const float* x, int64_t n, float* out_accum, hipStream_t stream);
+int mp_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_sumsq,
+                      float grad_scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

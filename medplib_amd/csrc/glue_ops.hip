@@ -1,0 +1,328 @@
+// Index-driven HBM kernels that glue the GEMMs of the trunk together: multimodal splice (token-embedding gather +
+// image-feature rows), patch / conv im2col in NHWC, SAM window partition / unpartition, decomposed rel-pos tables,
+// adapter channel gate, CLIP class-token assembly.  All 16 B per lane where the layout allows.
+//
+// Reference sites: medplib_arch.py:296-527 (prepare_inputs_labels_for_multimodal), image_encoder.py:299-345
+// (window_partition/unpartition), :381-421 (add_decomposed_rel_pos), :18-56 (Adapter_Layer), :424-455 (PatchEmbed),
+// HF CLIPVisionEmbeddings.
+#include "common.h"
+
+namespace {
+
+// ---- multimodal splice: out[r, :] = src_code[r] >= 0 ? embed[src_code[r]] : (src_code[r] == PAD ? 0 : feats[-1 - src_code[r]])
+constexpr int64_t SPLICE_PAD = INT64_MIN;
+__global__ void splice_rows_kernel(const bf16_t* __restrict__ embed, const bf16_t* __restrict__ feats,
+                                   const int64_t* __restrict__ src, bf16_t* __restrict__ out, int64_t rows, int dim) {
+  const int per_row = dim / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * per_row) return;
+  const int64_t r = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;
+  const int64_t code = src[r];
+  bf16x8 v;
+  if (code == SPLICE_PAD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+  } else if (code >= 0) {
+    v = *reinterpret_cast<const bf16x8*>(embed + code * dim + c);
+  } else {
+    v = *reinterpret_cast<const bf16x8*>(feats + (-1 - code) * dim + c);
+  }
+  *reinterpret_cast<bf16x8*>(out + r * dim + c) = v;
+}
+
+// ---- patch embedding im2col (non-overlapping p x p patches, NCHW fp32/bf16 image -> [B*gh*gw, Kpad] bf16,
+//      column order (c, py, px) = Conv2d weight.view(out, -1) order; columns >= 3*p*p are zero padding)
+template <typename TIN>
+__global__ void patch_im2col_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W, int p,
+                                    int Kpad) {
+  const int gh = H / p, gw = W / p;
+  const int64_t total = (int64_t)B * gh * gw * Kpad;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % Kpad);
+  const int64_t t = idx / Kpad;
+  const int gx = (int)(t % gw), gy = (int)((t / gw) % gh), b = (int)(t / ((int64_t)gw * gh));
+  float v = 0.f;
+  if (k < C * p * p) {
+    const int c = k / (p * p), py = (k / p) % p, px = k % p;
+    v = ld_f(img, (((int64_t)b * C + c) * H + gy * p + py) * W + gx * p + px);
+  }
+  out[idx] = (bf16_t)v;
+}
+
+// ---- generic NHWC tap-gather im2col: out[(b,oy,ox), t*C + c] = x[b, oy*sy + dy[t], ox*sx + dx[t], c] (0 if outside)
+struct Taps { int n; int dy[16]; int dx[16]; };
+__global__ void im2col_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C, int OH,
+                                   int OW, int sy, int sx, Taps taps) {
+  const int per_pix = taps.n * (C / 8);
+  const int64_t total = (int64_t)B * OH * OW * per_pix;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % per_pix);
+  const int64_t pix = idx / per_pix;
+  const int t = q / (C / 8), c = (q % (C / 8)) * 8;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+  const int iy = oy * sy + taps.dy[t], ix = ox * sx + taps.dx[t];
+  bf16x8 v;
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+    v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + c);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+  }
+  *reinterpret_cast<bf16x8*>(out + pix * ((int64_t)taps.n * C) + (int64_t)t * C + c) = v;
+}
+
+// ---- strided scatter with optional add: dst[b, oy*sy+py, ox*sx+px, :] = src[(b,oy,ox), :] (+ add[same dst index])
+__global__ void scatter_parity_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ add, bf16_t* __restrict__ dst,
+                                      int B, int OH, int OW, int C, int sy, int sx, int py, int px, int DH, int DW) {
+  const int per_pix = C / 8;
+  const int64_t total = (int64_t)B * OH * OW * per_pix;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % per_pix) * 8;
+  const int64_t pix = idx / per_pix;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+  const int64_t d = (((int64_t)b * DH + oy * sy + py) * DW + ox * sx + px) * C + c;
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * C + c);
+  if (add) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(add + d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)a[j]);
+  }
+  *reinterpret_cast<bf16x8*>(dst + d) = v;
+}
+
+// ---- SAM window partition (zero pad) and unpartition (+ shortcut add)
+__global__ void window_partition_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ win, int B, int H, int W, int C,
+                                        int ws, int nwy, int nwx) {
+  const int per_tok = C / 8;
+  const int64_t total = (int64_t)B * nwy * nwx * ws * ws * per_tok;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % per_tok) * 8;
+  int64_t t = idx / per_tok;
+  const int wx_in = (int)(t % ws); t /= ws;
+  const int wy_in = (int)(t % ws); t /= ws;
+  const int wxi = (int)(t % nwx); t /= nwx;
+  const int wyi = (int)(t % nwy);
+  const int b = (int)(t / nwy);
+  const int y = wyi * ws + wy_in, xx = wxi * ws + wx_in;
+  bf16x8 v;
+  if (y < H && xx < W) v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + y) * W + xx) * C + c);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+  }
+  *reinterpret_cast<bf16x8*>(win + (idx / per_tok) * C + c) = v;
+}
+__global__ void window_unpartition_add_kernel(const bf16_t* __restrict__ win, const bf16_t* __restrict__ shortcut,
+                                              bf16_t* __restrict__ out, int B, int H, int W, int C, int ws, int nwy, int nwx) {
+  const int per_tok = C / 8;
+  const int64_t total = (int64_t)B * H * W * per_tok;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % per_tok) * 8;
+  const int64_t tok = idx / per_tok;
+  const int xx = (int)(tok % W), y = (int)((tok / W) % H), b = (int)(tok / ((int64_t)W * H));
+  const int64_t wtok = ((((int64_t)b * nwy + y / ws) * nwx + xx / ws) * ws + y % ws) * ws + xx % ws;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(win + wtok * C + c);
+  const bf16x8 s = *reinterpret_cast<const bf16x8*>(shortcut + tok * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)v[j] + (float)s[j]);
+  *reinterpret_cast<bf16x8*>(out + tok * C + c) = o;
+}
+
+// ---- decomposed rel-pos tables: rel_h[bh, q, kh] = sum_c q[b, q, h, c] * rel_pos_h[(qy - kh) + (hh-1), c] ; same for w
+//      q lives in a fused [Bw, S, 3*H*D] qkv buffer.  One wave per (bh, q); lane = channel (D == 64).
+__global__ __launch_bounds__(256) void relpos_tables_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ rph,
+                                                            const float* __restrict__ rpw, float* __restrict__ rel_h,
+                                                            float* __restrict__ rel_w, int Bw, int H, int hh, int ww) {
+  const int S = hh * ww, D = 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t wq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wq >= (int64_t)Bw * H * S) return;
+  const int q = (int)(wq % S);
+  const int bh = (int)(wq / S), b = bh / H, h = bh % H;
+  const int qy = q / ww, qx = q % ww;
+  const float qv = (float)qkv[((int64_t)b * S + q) * ld + (int64_t)h * D + lane];
+  for (int k = 0; k < hh; ++k) {
+    const float s = wave_sum(qv * rph[(int64_t)(qy - k + hh - 1) * D + lane]);
+    if (lane == 0) rel_h[wq * hh + k] = s;
+  }
+  for (int k = 0; k < ww; ++k) {
+    const float s = wave_sum(qv * rpw[(int64_t)(qx - k + ww - 1) * D + lane]);
+    if (lane == 0) rel_w[wq * ww + k] = s;
+  }
+}
+
+// ---- adapter: per-image token mean (bf16 -> fp32) and channel gate
+__global__ void token_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * C) return;
+  const int c = (int)(idx % C), b = (int)(idx / C);
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += (float)x[((int64_t)b * T + t) * C + c];
+  out[idx] = s / (float)T;
+}
+__global__ void scale_channels_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate, bf16_t* __restrict__ y, int B,
+                                      int T, int C) {
+  const int per_tok = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * T * per_tok) return;
+  const int c = (int)(idx % per_tok) * 8;
+  const int64_t tok = idx / per_tok;
+  const int b = (int)(tok / T);
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + tok * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(gate[(int64_t)b * C + c + j] * (float)v[j]);
+  *reinterpret_cast<bf16x8*>(y + tok * C + c) = o;
+}
+
+// ---- CLIP embeddings: out[b, 0, :] = cls + pos[0]; out[b, 1+i, :] = patch[b, i, :] + pos[1+i]
+__global__ void clip_embed_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos,
+                                  bf16_t* __restrict__ out, int B, int NP, int C) {
+  const int per_tok = C / 8;
+  const int64_t total = (int64_t)B * (NP + 1) * per_tok;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % per_tok) * 8;
+  const int64_t tok = idx / per_tok;
+  const int i = (int)(tok % (NP + 1)), b = (int)(tok / (NP + 1));
+  const bf16x8 a = (i == 0) ? *reinterpret_cast<const bf16x8*>(cls + c)
+                            : *reinterpret_cast<const bf16x8*>(patch + ((int64_t)b * NP + i - 1) * C + c);
+  const bf16x8 p = *reinterpret_cast<const bf16x8*>(pos + (int64_t)i * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)a[j] + (float)p[j]);
+  *reinterpret_cast<bf16x8*>(out + tok * C + c) = o;
+}
+
+// ---- strided row copy: dst[r, :] = src[map(r), :] with src row = (r / rows_per_batch) * src_batch_rows + r % rows_per_batch + src_row0
+//      (drop the CLS token: clip_encoder.py:33-34)
+__global__ void copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int dim, int rows_per_batch,
+                                 int src_batch_rows, int src_row0) {
+  const int per_row = dim / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * per_row) return;
+  const int64_t r = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;
+  const int64_t sr = (r / rows_per_batch) * src_batch_rows + r % rows_per_batch + src_row0;
+  *reinterpret_cast<bf16x8*>(dst + r * dim + c) = *reinterpret_cast<const bf16x8*>(src + sr * dim + c);
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
+
+extern "C" int mp_splice_rows_bf16(const void* embed, const void* feats, const int64_t* src_code, void* out, int64_t rows, int dim,
+                                   hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0, MP_ERR_SHAPE, "mp_splice_rows_bf16: dim must be a multiple of 8");
+  const int64_t n = rows * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(splice_rows_kernel, GRID1D(n), (const bf16_t*)embed, (const bf16_t*)feats, src_code, (bf16_t*)out, rows, dim);
+  return mp_check_launch("mp_splice_rows_bf16");
+}
+
+extern "C" int mp_patch_im2col(const void* img, int img_dtype, void* out, int B, int C, int H, int W, int patch, int k_padded,
+                               hipStream_t stream) {
+  MP_REQUIRE(H % patch == 0 && W % patch == 0 && k_padded >= C * patch * patch, MP_ERR_SHAPE, "mp_patch_im2col: bad shape");
+  const int64_t n = (int64_t)B * (H / patch) * (W / patch) * k_padded;
+  if (n == 0) return MP_OK;
+  if (img_dtype == MP_F32)
+    hipLaunchKernelGGL(patch_im2col_kernel<float>, GRID1D(n), (const float*)img, (bf16_t*)out, B, C, H, W, patch, k_padded);
+  else if (img_dtype == MP_BF16)
+    hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, GRID1D(n), (const bf16_t*)img, (bf16_t*)out, B, C, H, W, patch, k_padded);
+  else MP_REQUIRE(false, MP_ERR_DTYPE, "mp_patch_im2col: bad dtype");
+  return mp_check_launch("mp_patch_im2col");
+}
+
+extern "C" int mp_im2col_nhwc_bf16(const void* x, void* out, int B, int H, int W, int C, int OH, int OW, int stride_y, int stride_x,
+                                   int n_taps, const int* dy, const int* dx, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0 && n_taps >= 1 && n_taps <= 16, MP_ERR_SHAPE, "mp_im2col_nhwc_bf16: bad shape");
+  Taps t{};
+  t.n = n_taps;
+  for (int i = 0; i < n_taps; ++i) { t.dy[i] = dy[i]; t.dx[i] = dx[i]; }   // dy/dx are HOST arrays
+  const int64_t n = (int64_t)B * OH * OW * n_taps * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(im2col_nhwc_kernel, GRID1D(n), (const bf16_t*)x, (bf16_t*)out, B, H, W, C, OH, OW, stride_y, stride_x, t);
+  return mp_check_launch("mp_im2col_nhwc_bf16");
+}
+
+extern "C" int mp_scatter_parity_bf16(const void* src, const void* add, void* dst, int B, int OH, int OW, int C, int sy, int sx,
+                                      int py, int px, int DH, int DW, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0, MP_ERR_SHAPE, "mp_scatter_parity_bf16: bad shape");
+  const int64_t n = (int64_t)B * OH * OW * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(scatter_parity_kernel, GRID1D(n), (const bf16_t*)src, (const bf16_t*)add, (bf16_t*)dst, B, OH, OW, C, sy, sx,
+                     py, px, DH, DW);
+  return mp_check_launch("mp_scatter_parity_bf16");
+}
+
+extern "C" int mp_window_partition_bf16(const void* x, void* win, int B, int H, int W, int C, int ws, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0 && ws > 0, MP_ERR_SHAPE, "mp_window_partition_bf16: bad shape");
+  const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
+  const int64_t n = (int64_t)B * nwy * nwx * ws * ws * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(window_partition_kernel, GRID1D(n), (const bf16_t*)x, (bf16_t*)win, B, H, W, C, ws, nwy, nwx);
+  return mp_check_launch("mp_window_partition_bf16");
+}
+
+extern "C" int mp_window_unpartition_add_bf16(const void* win, const void* shortcut, void* out, int B, int H, int W, int C, int ws,
+                                              hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0 && ws > 0, MP_ERR_SHAPE, "mp_window_unpartition_add_bf16: bad shape");
+  const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(window_unpartition_add_kernel, GRID1D(n), (const bf16_t*)win, (const bf16_t*)shortcut, (bf16_t*)out, B, H, W,
+                     C, ws, nwy, nwx);
+  return mp_check_launch("mp_window_unpartition_add_bf16");
+}
+
+extern "C" int mp_relpos_tables_bf16(const void* qkv, int64_t ld, const float* rel_pos_h, const float* rel_pos_w, float* rel_h,
+                                     float* rel_w, int Bw, int heads, int hh, int ww, int head_dim, hipStream_t stream) {
+  MP_REQUIRE(head_dim == 64, MP_ERR_SHAPE, "mp_relpos_tables_bf16: head_dim must be 64");
+  const int64_t waves = (int64_t)Bw * heads * hh * ww;
+  if (waves == 0) return MP_OK;
+  hipLaunchKernelGGL(relpos_tables_kernel, dim3((unsigned)mp_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)qkv, ld, rel_pos_h,
+                     rel_pos_w, rel_h, rel_w, Bw, heads, hh, ww);
+  return mp_check_launch("mp_relpos_tables_bf16");
+}
+
+extern "C" int mp_token_mean_bf16(const void* x, float* out, int B, int T, int C, hipStream_t stream) {
+  const int64_t n = (int64_t)B * C;
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(token_mean_kernel, GRID1D(n), (const bf16_t*)x, out, B, T, C);
+  return mp_check_launch("mp_token_mean_bf16");
+}
+
+extern "C" int mp_scale_channels_bf16(const void* x, const float* gate, void* y, int B, int T, int C, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0, MP_ERR_SHAPE, "mp_scale_channels_bf16: bad shape");
+  const int64_t n = (int64_t)B * T * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(scale_channels_kernel, GRID1D(n), (const bf16_t*)x, gate, (bf16_t*)y, B, T, C);
+  return mp_check_launch("mp_scale_channels_bf16");
+}
+
+extern "C" int mp_clip_embed_bf16(const void* patch, const void* cls, const void* pos, void* out, int B, int n_patches, int C,
+                                  hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0, MP_ERR_SHAPE, "mp_clip_embed_bf16: bad shape");
+  const int64_t n = (int64_t)B * (n_patches + 1) * (C / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(clip_embed_kernel, GRID1D(n), (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)out, B,
+                     n_patches, C);
+  return mp_check_launch("mp_clip_embed_bf16");
+}
+
+extern "C" int mp_copy_rows_bf16(const void* src, void* dst, int64_t rows, int dim, int rows_per_batch, int src_batch_rows,
+                                 int src_row0, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && rows_per_batch > 0, MP_ERR_SHAPE, "mp_copy_rows_bf16: bad shape");
+  const int64_t n = rows * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, GRID1D(n), (const bf16_t*)src, (bf16_t*)dst, rows, dim, rows_per_batch, src_batch_rows,
+                     src_row0);
+  return mp_check_launch("mp_copy_rows_bf16");
+}

@@ -1,0 +1,170 @@
+"""Llama-7B decoder stack (dense or DeepSpeed-style MoE MLPs) over the HIP kernels.
+
+Mirrors `MoELlamaModel_forward` / `MoELlamaDecoderLayer_forward` (model/medplib/model/language_model/
+medplib_moe_llama.py:110-305) and HF-4.31 LlamaAttention/LlamaMLP/LlamaRMSNorm:
+    x = x + o_proj(attn(rope(q), rope(k), v));  x = x + mlp(rmsnorm(x))   with mlp = SwiGLU or MoE(top-1 experts).
+Weights are held in kernel layout (fused qkv [3d,d], fused gate|up [2ff,d], experts stacked [E,...]) and are
+imported from / exported to the HF checkpoint key layout by load_hf / export_hf."""
+import math
+
+import torch
+
+from .. import ops
+
+
+def _rope_tables(seq, head_dim, theta, device):
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.outer(torch.arange(seq, dtype=torch.float32), inv)
+    return freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device)
+
+
+class LlamaStack:
+    def __init__(self, cfg, device, init_std=0.02, seed=0):
+        self.cfg, self.device = cfg, device
+        d, ff, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+        E = cfg.num_experts
+        self.moe_layers = cfg.moe_layer_set()
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def rn(*shape, std=init_std, dtype=torch.bfloat16):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+        self.embed_tokens = rn(V, d)
+        self.lm_head = rn(V, d)
+        self.norm_w = torch.ones(d, dtype=torch.float32, device=device)
+        self.layers = []
+        for i in range(L):
+            lw = {"qkv": rn(3 * d, d), "o": rn(d, d), "ln1": torch.ones(d, dtype=torch.float32, device=device),
+                  "ln2": torch.ones(d, dtype=torch.float32, device=device)}
+            if i in self.moe_layers:
+                lw["wg"] = rn(E, d, dtype=torch.float32)
+                lw["gu"] = rn(E, 2 * ff, d)
+                lw["down"] = rn(E, d, ff)
+            else:
+                lw["gu"] = rn(2 * ff, d)
+                lw["down"] = rn(d, ff)
+            self.layers.append(lw)
+        self.cos, self.sin = _rope_tables(cfg.max_position_embeddings, cfg.head_dim, cfg.rope_theta, device)
+        self.training = True
+        self.rts_uniform_provider = None   # callable(layer_idx, T, E) -> fp32 [T,E] uniforms (DeepSpeed RTS draws) or None
+
+    # ------------------------------------------------------------------ HF checkpoint layout
+    def load_hf(self, sd, prefix=""):
+        cfg = self.cfg
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+
+        def put(dst, src):
+            dst.copy_(src.to(device=dst.device, dtype=dst.dtype))
+        put(self.embed_tokens, sd[prefix + "model.embed_tokens.weight"])
+        put(self.lm_head, sd[prefix + "lm_head.weight"])
+        put(self.norm_w, sd[prefix + "model.norm.weight"])
+        for i, lw in enumerate(self.layers):
+            p = f"{prefix}model.layers.{i}."
+            for j, n in enumerate(("q", "k", "v")):
+                put(lw["qkv"][j * d:(j + 1) * d], sd[p + f"self_attn.{n}_proj.weight"])
+            put(lw["o"], sd[p + "self_attn.o_proj.weight"])
+            put(lw["ln1"], sd[p + "input_layernorm.weight"])
+            put(lw["ln2"], sd[p + "post_attention_layernorm.weight"])
+            if i in self.moe_layers:
+                put(lw["wg"], sd[p + "mlp.deepspeed_moe.gate.wg.weight"])
+                for e in range(cfg.num_experts):
+                    ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+                    put(lw["gu"][e, :ff], sd[ep + "gate_proj.weight"])
+                    put(lw["gu"][e, ff:], sd[ep + "up_proj.weight"])
+                    put(lw["down"][e], sd[ep + "down_proj.weight"])
+            else:
+                put(lw["gu"][:ff], sd[p + "mlp.gate_proj.weight"])
+                put(lw["gu"][ff:], sd[p + "mlp.up_proj.weight"])
+                put(lw["down"], sd[p + "mlp.down_proj.weight"])
+
+    def export_hf(self, prefix=""):
+        cfg = self.cfg
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        bf = torch.bfloat16
+        sd = {prefix + "model.embed_tokens.weight": self.embed_tokens, prefix + "lm_head.weight": self.lm_head,
+              prefix + "model.norm.weight": self.norm_w.to(bf)}
+        for i, lw in enumerate(self.layers):
+            p = f"{prefix}model.layers.{i}."
+            for j, n in enumerate(("q", "k", "v")):
+                sd[p + f"self_attn.{n}_proj.weight"] = lw["qkv"][j * d:(j + 1) * d]
+            sd[p + "self_attn.o_proj.weight"] = lw["o"]
+            sd[p + "input_layernorm.weight"] = lw["ln1"].to(bf)
+            sd[p + "post_attention_layernorm.weight"] = lw["ln2"].to(bf)
+            if i in self.moe_layers:
+                sd[p + "mlp.deepspeed_moe.gate.wg.weight"] = lw["wg"]
+                for e in range(cfg.num_experts):
+                    ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+                    sd[ep + "gate_proj.weight"] = lw["gu"][e, :ff]
+                    sd[ep + "up_proj.weight"] = lw["gu"][e, ff:]
+                    sd[ep + "down_proj.weight"] = lw["down"][e]
+            else:
+                sd[p + "mlp.gate_proj.weight"] = lw["gu"][:ff]
+                sd[p + "mlp.up_proj.weight"] = lw["gu"][ff:]
+                sd[p + "mlp.down_proj.weight"] = lw["down"]
+        return sd
+
+    # ------------------------------------------------------------------ forward
+    def capacity(self, T):
+        """DeepSpeed _capacity: ceil(T / E * cf), at least min_capacity."""
+        cfg = self.cfg
+        cf = cfg.capacity_factor if self.training else cfg.eval_capacity_factor
+        return max(int(math.ceil(T / cfg.num_experts * cf)), cfg.min_capacity)
+
+    def _mlp(self, i, lw, h, x):
+        """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]."""
+        cfg = self.cfg
+        T = h.shape[0]
+        if i not in self.moe_layers:
+            act = ops.swiglu(ops.gemm(h, lw["gu"]))
+            return ops.gemm(act, lw["down"], residual=x), None, None
+        E, ff, d = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
+        cap = self.capacity(T)
+        _, gates = ops.moe_gate(h, lw["wg"])
+        rts = self.rts_uniform_provider(i, T, E) if self.rts_uniform_provider is not None else None
+        expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, rts)
+        buf = ops.moe_dispatch(h, expert, slot, E, cap)
+        gu = torch.empty((E, cap, 2 * ff), dtype=torch.bfloat16, device=h.device)
+        ops.gemm_batched(buf, lw["gu"], gu, m_dev=kept)
+        act = ops.swiglu(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
+        y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
+        ops.gemm_batched(act, lw["down"], y, m_dev=kept)
+        out = ops.moe_combine(y, expert, slot, weight, x, cap)
+        return out, l_aux, (expert, slot, counts)
+
+    def forward(self, inputs_embeds, key_valid=None, collect_routing=False):
+        """inputs_embeds [B,S,d] bf16; key_valid uint8 [B,S] (1 = real token) or None.
+        Returns (last_hidden_state after the final RMSNorm [B,S,d], [l_aux per MoE layer], routing or None)."""
+        cfg = self.cfg
+        B, S, d = inputs_embeds.shape
+        H, D = cfg.num_attention_heads, cfg.head_dim
+        x = inputs_embeds.reshape(B * S, d)
+        aux, routing = [], []
+        for i, lw in enumerate(self.layers):
+            h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
+            qkv = ops.gemm(h, lw["qkv"])
+            ops.rope_qk_(qkv, self.cos, self.sin, S, H, D)
+            q5 = qkv.view(B, S, 3, H, D)
+            attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
+            x = ops.gemm(attn.view(B * S, d), lw["o"], residual=x)
+            h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
+            x, l_aux, r = self._mlp(i, lw, h, x)
+            if l_aux is not None:
+                aux.append(l_aux)
+                if collect_routing:
+                    routing.append(r)
+        out = ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps)
+        return out.view(B, S, d), aux, (routing if collect_routing else None)
+
+    def cross_entropy(self, last_hidden, sup_rows, sup_labels, aux):
+        """CE over supervised rows only (row-wise op; unsupervised rows never reach the loss — SURVEY B.8):
+        fp32 logits = lm_head(hidden[sup_rows]) (medplib_moe_llama.py:388-389), mean CE (:392-408),
+        + router_aux_loss_coef * sum(l_aux) (:410-421).  sup_rows int64 [n] flat row ids, sup_labels int64 [n]."""
+        cfg = self.cfg
+        d = cfg.hidden_size
+        if sup_rows.numel() == 0:
+            return torch.full((1,), float("nan"), dtype=torch.float32, device=last_hidden.device)
+        rows = ops.gather_rows_bf16_to_f32(last_hidden.view(-1, d), sup_rows)
+        rows = ops.cast_to_bf16(rows)                     # exact: the rows were bf16
+        logits = ops.gemm(rows, self.lm_head, out_dtype=torch.float32)
+        row_loss = ops.cross_entropy_rows(logits, sup_labels)
+        add = torch.cat(aux) if (aux and cfg.router_aux_loss_coef != 0.0) else None
+        return ops.mean_plus(row_loss, 1.0, add, cfg.router_aux_loss_coef)

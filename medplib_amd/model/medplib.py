@@ -1,0 +1,245 @@
+"""`MedPLIBForCausalLM` / `LISAForCausalLM` — host-side mirror of model/MedPLIB.py and model/LISA.py over the HIP path.
+
+Same constructor kwargs (model/MedPLIB.py:195-234), same `forward(**batch)` batch-dict contract
+(datasets/DataCollatorForSupervisedDataset.py:11-138), same 10-key loss dict (MedPLIB.py:561-572) or
+`{pred_masks, gt_masks}` when `inference=True` (MedPLIB.py:507-511), same HF / SAM checkpoint key layout
+(SURVEY §8b).  The Python-level serialisation of the reference (per-image SAM loop, per-token seg-mask loop,
+per-sample splice loop, per-mask decoder loop) is replaced by batched kernels.
+
+Dead work the reference performs but never consumes is not executed (results are identical — row-wise ops):
+full-vocabulary fp32 logits for unsupervised rows, text_hidden_fcs on non-<SEG> rows, the 32 intermediate hidden
+states, CLIP's last layer, mask tokens 1-3."""
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import autograd_ops as A
+from .clip import ClipTower
+from .config import MedPLIBConfig
+from .llama import LlamaStack
+from .sam import MaskDecoder, PromptEncoderText, SamImageEncoder
+from .splice import plan_splice
+
+LOSS_KEYS = ["loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", "unscale_mask_bce_loss",
+             "unscale_mask_dice_loss", "unscale_mask_loss", "unscale_mask_iou_loss", "unscale_mask_focal_loss"]
+
+
+def _np_ids(t):
+    if isinstance(t, np.ndarray):
+        return t
+    return t.detach().cpu().numpy()
+
+
+class _VisualModel(nn.Module):
+    """`model.visual_model` (build_sam_vit_b, model/MedPLIB.py:141-150)."""
+
+    def __init__(self, cfg, device):
+        super().__init__()
+        self.image_encoder = SamImageEncoder(cfg, device)          # frozen bf16 kernel-layout weights
+        self.prompt_encoder = PromptEncoderText(cfg.sam_out_chans, cfg.sam_grid)
+        self.mask_decoder = MaskDecoder(cfg.sam_out_chans, cfg.sam_grid)
+
+
+class _Inner(nn.Module):
+    """`model` (MedPLIBModel): LLM stack + vision tower + projector + SAM + text_hidden_fcs."""
+
+    def __init__(self, cfg, device):
+        super().__init__()
+        self.llm = LlamaStack(cfg, device)
+        self.vision_tower = ClipTower(cfg, device)
+        self.visual_model = _VisualModel(cfg, device)
+        d = cfg.hidden_size
+        self.text_hidden_fcs = nn.ModuleList([nn.Sequential(nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, cfg.out_dim),
+                                                            nn.Dropout(0.0))])
+
+
+class MedPLIBForCausalLM(nn.Module):
+    moe_default = True
+
+    def __init__(self, config: Optional[MedPLIBConfig] = None, device="cuda", **kwargs):
+        super().__init__()
+        cfg = config if config is not None else MedPLIBConfig()
+        # kwargs the reference pops / reads (model/MedPLIB.py:195-234); unknown ones are accepted and ignored like there
+        for k_cfg, k_kw in (("ce_loss_weight",) * 2, ("dice_loss_weight",) * 2, ("bce_loss_weight",) * 2,
+                            ("iou_loss_weight",) * 2, ("focal_loss_weight",) * 2, ("seg_token_idx",) * 2,
+                            ("out_dim",) * 2, ("train_mask_decoder",) * 2, ("top_k_experts",) * 2,
+                            ("capacity_factor",) * 2, ("eval_capacity_factor",) * 2, ("min_capacity",) * 2,
+                            ("router_aux_loss_coef",) * 2, ("moe_layers_idx",) * 2, ("mm_use_im_start_end", "use_mm_start_end")):
+            if kwargs.get(k_kw) is not None:
+                setattr(cfg, k_cfg, kwargs[k_kw])
+        if kwargs.get("num_experts") is not None:
+            ne = kwargs["num_experts"]
+            cfg.num_experts = int(ne[0] if isinstance(ne, (list, tuple)) else ne)
+        if not self.moe_default:
+            cfg.moe_enable = False
+        if cfg.top_k_experts != 1 and cfg.moe_enable:
+            raise NotImplementedError("top-2 gating (DeepSpeed top2gating) is not built yet; stage-IV uses top-1 (DESIGN.md)")
+        self.config = cfg
+        self.device_ = torch.device(device)
+        self.model = _Inner(cfg, self.device_)
+        self.to_device()
+        self.seg_token_idx = cfg.seg_token_idx
+        self.inference_threshold = 0.1
+
+    # ------------------------------------------------------------------ plumbing
+    def to_device(self):
+        nn.Module.to(self, self.device_)
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def trainable_parameters(self):
+        """Stage-III 'LoRA off' selection (train_ds_medplib.py:316-326 with sft_modules mask_decoder,text_hidden_fcs)."""
+        ps = list(self.model.text_hidden_fcs.parameters())
+        if self.config.train_mask_decoder:
+            ps += list(self.model.visual_model.mask_decoder.parameters())
+        return ps
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.model.llm.training = mode
+        return self
+
+    # ------------------------------------------------------------------ checkpoint layout
+    def load_hf_state_dict(self, sd):
+        m = self.model
+        m.llm.load_hf(sd)
+        m.vision_tower.load_hf(sd)
+        vm = {k[len("model.visual_model."):]: v for k, v in sd.items() if k.startswith("model.visual_model.")}
+        self.load_sam_state_dict(vm)
+        fc = {k[len("model.text_hidden_fcs."):]: v for k, v in sd.items() if k.startswith("model.text_hidden_fcs.")}
+        m.text_hidden_fcs.load_state_dict({k: v.float() for k, v in fc.items()})
+
+    def load_sam_state_dict(self, sd):
+        """`torch.load(path)['model']` key layout of SAM-Med2D checkpoints (build_sam.py:123-128), loaded non-strict."""
+        vm = self.model.visual_model
+        vm.image_encoder.load_ref(sd, "image_encoder.")
+        dec = {k[len("mask_decoder."):]: v.float() for k, v in sd.items() if k.startswith("mask_decoder.")}
+        vm.mask_decoder.load_state_dict(dec)
+        pe = {k[len("prompt_encoder."):]: v.float() for k, v in sd.items() if k.startswith("prompt_encoder.")}
+        vm.prompt_encoder.load_state_dict(pe, strict=False)
+        vm.prompt_encoder._pe_cache = None
+
+    # ------------------------------------------------------------------ pieces of model_forward
+    def get_visual_embs(self, images):
+        """get_visual_embs (MedPLIB.py:274-285): whole batch in one pass, tokens [B, 256, 256] bf16 (NHWC order)."""
+        return self.model.visual_model.image_encoder.forward(images)
+
+    @staticmethod
+    def expand_index(valid_mask_bool, batch):
+        """expand_embedding (MedPLIB.py:292-308) as a row index list: image i repeated once per mask of sample i."""
+        if valid_mask_bool is None or len(valid_mask_bool) == 0:
+            return list(range(batch))
+        idx = []
+        for i, m in enumerate(valid_mask_bool):
+            idx += [i] * (len(m) if m else 0)
+        return idx
+
+    def _postprocess(self, low_res, resize_list, shapes):
+        """postprocess_masks (MedPLIB.py:682-701) grouped by (input_size, original_size) so equal shapes share a launch."""
+        n = low_res.shape[0]
+        groups = {}
+        for i in range(n):
+            groups.setdefault((tuple(int(v) for v in resize_list[i]), tuple(int(v) for v in shapes[i])), []).append(i)
+        outs = [None] * n
+        if len(groups) == 1:
+            (inp, orig), _ = next(iter(groups.items()))
+            crop = ops.postprocess_crop(low_res.shape[-2], low_res.shape[-1], inp)
+            full = A.BilinearResizeFn.apply(low_res, crop, orig)
+            return full, [full[i:i + 1] for i in range(n)]
+        for (inp, orig), ids in groups.items():
+            crop = ops.postprocess_crop(low_res.shape[-2], low_res.shape[-1], inp)
+            sel = low_res[ids] if len(ids) != n else low_res
+            r = A.BilinearResizeFn.apply(sel, crop, orig)
+            for j, i in enumerate(ids):
+                outs[i] = r[j:j + 1]
+        return None, outs
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, **kwargs):
+        return self.model_forward(**kwargs)
+
+    def model_forward(self, images, images_clip, input_ids, labels, attention_mask=None, masks_list=None, label_list=None,
+                      resize_list=None, region_masks=None, offset=None, inference=False, seg_flag=True, valid_mask_bool=None,
+                      rp_flag=False, valid_region_masks_bool=None, attention_masks=None, **kwargs):
+        cfg = self.config
+        if attention_mask is None:
+            attention_mask = attention_masks            # LISA.model_forward spells it `attention_masks` (LISA.py:267)
+        if region_masks:
+            raise NotImplementedError("region prompts (extract_region_feature) are outside the built path (SURVEY §8f)")
+        dev = self.device_
+        ids_np = _np_ids(input_ids)
+        lab_np = _np_ids(labels) if labels is not None else None
+        att_np = _np_ids(attention_mask).astype(bool) if attention_mask is not None else None
+        B = ids_np.shape[0]
+        image_token_lengths = kwargs.get("image_token_lengths")
+        if isinstance(images_clip, (list, tuple)) or images_clip.dim() == 5:
+            clip_in = torch.cat([im for im in images_clip], 0)
+            flat_lengths = [cfg.clip_num_patches] * clip_in.shape[0]
+            plan = plan_splice(ids_np, lab_np, att_np, flat_lengths, seg_token_idx=self.seg_token_idx,
+                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else cfg.clip_num_patches)
+        else:
+            clip_in = images_clip
+            plan = plan_splice(ids_np, lab_np, att_np, cfg.clip_num_patches, seg_token_idx=self.seg_token_idx,
+                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else cfg.clip_num_patches)
+        m = self.model
+        with torch.no_grad():
+            feats = m.vision_tower.encode_images(clip_in)
+            src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev, non_blocking=True)
+            embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(B, plan.seq_len, cfg.hidden_size)
+            key_valid = None
+            if plan.attention_mask is not None and not plan.attention_mask.all():
+                key_valid = torch.from_numpy(plan.attention_mask.astype(np.uint8)).to(dev, non_blocking=True)
+            last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
+            sup_rows, sup_labels = plan.supervised() if lab_np is not None else (np.zeros(0, np.int64),) * 2
+            ce = m.llm.cross_entropy(last_hidden, torch.from_numpy(sup_rows).to(dev), torch.from_numpy(sup_labels).to(dev), aux)
+        if not seg_flag:
+            z = torch.zeros(1, dtype=torch.float32, device=dev)
+            ce_w = ops.mean_plus(ce, cfg.ce_loss_weight)          # ce * ce_loss_weight
+            out = {k: z[0] for k in LOSS_KEYS}
+            out["loss"] = out["ce_loss"] = ce_w[0]
+            return out
+
+        # ---- <SEG> rows -> text_hidden_fcs -> prompt + mask decoder (MedPLIB.py:456-502), batched over all masks
+        seg_rows = plan.seg_rows()
+        n_masks_given = len(masks_list) if masks_list is not None else 0
+        if kwargs.get("icl_image_counts") is not None and n_masks_given > 0:
+            seg_rows = seg_rows[-n_masks_given:]                   # MedPLIB.py:462-463
+        with torch.no_grad():
+            image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
+            exp = self.expand_index(valid_mask_bool, image_tokens.shape[0])
+            if exp != list(range(image_tokens.shape[0])):
+                image_tokens = ops.gather_rows_f32(image_tokens, torch.tensor(exp, dtype=torch.int64, device=dev))
+            hidden_rows = ops.gather_rows_bf16_to_f32(last_hidden.view(-1, cfg.hidden_size), torch.from_numpy(seg_rows).to(dev))
+        n = hidden_rows.shape[0]
+        assert n <= image_tokens.shape[0], "more <SEG> rows than expanded image embeddings"   # pairing by position, :473-487
+        if n < image_tokens.shape[0]:
+            image_tokens = image_tokens[:n].contiguous()
+        fc = m.text_hidden_fcs[0]
+        pred_emb = A.linear(A.linear(hidden_rows, fc[0].weight, fc[0].bias, ops.SACT_RELU), fc[2].weight, fc[2].bias)
+        pe = m.visual_model.prompt_encoder
+        low_res, iou_pred = m.visual_model.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight,
+                                                         pred_emb.view(n, 1, -1))
+        shapes = [tuple(l.shape[-2:]) for l in label_list[:n]]
+        full, pred_masks = self._postprocess(low_res, resize_list[:n], shapes)
+        if inference:
+            return {"pred_masks": pred_masks, "gt_masks": masks_list}
+
+        # ---- fused mask losses (MedPLIB.py:515-572)
+        if full is None:
+            raise NotImplementedError("mask losses over masks of different sizes in one step are not built yet (DESIGN.md)")
+        H, W = full.shape[-2:]
+        gt = torch.stack([g.reshape(H, W) for g in masks_list[:n]]).to(device=dev, dtype=torch.float32).view(n, H * W)
+        weights = (cfg.ce_loss_weight, cfg.bce_loss_weight, cfg.dice_loss_weight, cfg.iou_loss_weight, cfg.focal_loss_weight)
+        out10 = A.MaskLossFn.apply(full.view(n, H * W), gt, iou_pred, ce, weights)
+        return {k: out10[i] for i, k in enumerate(LOSS_KEYS)}
+
+
+class LISAForCausalLM(MedPLIBForCausalLM):
+    """Dense (non-MoE) twin (model/LISA.py:180-471): same path with plain LlamaMLP layers; accepts the collator's
+    `attention_mask` as well as LISA's own `attention_masks` spelling."""
+    moe_default = False

@@ -361,3 +361,161 @@ def mask_threshold_iou(pred, gt, threshold=0.1):
     lib().call("mp_mask_threshold_iou", _p(pred), _dt(pred.dtype), _p(gt), _p(bin_out), _p(counts), n, hw, float(threshold),
                _stream())
     return bin_out, counts
+
+
+# ------------------------------------------------------------------ glue --------------------------------------------------------
+SPLICE_PAD = -(2 ** 63)
+
+
+def splice_rows(embed, feats, src_code, dim):
+    """out[r] = embed[src_code[r]] | feats[-1-src_code[r]] | 0 (SPLICE_PAD).  src_code int64 on the GPU."""
+    _chk(embed, torch.bfloat16, "splice.embed"); _chk(src_code, torch.int64, "splice.src_code")
+    assert embed.is_contiguous() and (feats is None or feats.is_contiguous())
+    out = torch.empty((src_code.numel(), dim), dtype=torch.bfloat16, device=embed.device)
+    lib().call("mp_splice_rows_bf16", _p(embed), _p(feats), _p(src_code), _p(out), src_code.numel(), dim, _stream())
+    return out
+
+
+def patch_im2col(img, patch, k_padded):
+    assert img.is_contiguous() and img.dim() == 4
+    B, C, H, W = img.shape
+    out = torch.empty((B * (H // patch) * (W // patch), k_padded), dtype=torch.bfloat16, device=img.device)
+    lib().call("mp_patch_im2col", _p(img), _dt(img.dtype), _p(out), B, C, H, W, patch, k_padded, _stream())
+    return out
+
+
+def im2col_nhwc(x, OH, OW, stride, taps):
+    """x [B,H,W,C] bf16 -> [B*OH*OW, len(taps)*C]; taps = [(dy, dx), ...]."""
+    import ctypes
+    _chk(x, torch.bfloat16, "im2col.x"); assert x.is_contiguous()
+    B, H, W, C = x.shape
+    n = len(taps)
+    dy = (ctypes.c_int * n)(*[t[0] for t in taps]); dx = (ctypes.c_int * n)(*[t[1] for t in taps])
+    out = torch.empty((B * OH * OW, n * C), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_im2col_nhwc_bf16", _p(x), _p(out), B, H, W, C, OH, OW, stride, stride, n, ctypes.cast(dy, ctypes.c_void_p),
+               ctypes.cast(dx, ctypes.c_void_p), _stream())
+    return out
+
+
+def scatter_parity(src, add, dst, B, OH, OW, C, s, py, px, DH, DW):
+    lib().call("mp_scatter_parity_bf16", _p(src), _p(add), _p(dst), B, OH, OW, C, s, s, py, px, DH, DW, _stream())
+    return dst
+
+
+def window_partition(x, ws):
+    _chk(x, torch.bfloat16, "window_partition.x"); assert x.is_contiguous()
+    B, H, W, C = x.shape
+    nwy, nwx = -(-H // ws), -(-W // ws)
+    win = torch.empty((B * nwy * nwx, ws * ws, C), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_window_partition_bf16", _p(x), _p(win), B, H, W, C, ws, _stream())
+    return win
+
+
+def window_unpartition_add(win, shortcut, ws):
+    assert win.is_contiguous() and shortcut.is_contiguous()
+    B, H, W, C = shortcut.shape
+    out = torch.empty_like(shortcut)
+    lib().call("mp_window_unpartition_add_bf16", _p(win), _p(shortcut), _p(out), B, H, W, C, ws, _stream())
+    return out
+
+
+def relpos_tables(qkv, rel_pos_h, rel_pos_w, Bw, heads, hh, ww):
+    """qkv [Bw*hh*ww, 3*heads*64] bf16 -> rel_h [Bw*heads, hh*ww, hh], rel_w [Bw*heads, hh*ww, ww] fp32."""
+    _chk(qkv, torch.bfloat16, "relpos.qkv"); _chk(rel_pos_h, torch.float32, "relpos.rel_pos_h")
+    S = hh * ww
+    rel_h = torch.empty((Bw * heads, S, hh), dtype=torch.float32, device=qkv.device)
+    rel_w = torch.empty((Bw * heads, S, ww), dtype=torch.float32, device=qkv.device)
+    lib().call("mp_relpos_tables_bf16", _p(qkv), qkv.stride(0), _p(rel_pos_h), _p(rel_pos_w), _p(rel_h), _p(rel_w), Bw, heads, hh, ww,
+               64, _stream())
+    return rel_h, rel_w
+
+
+def token_mean(x, B, T, C):
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    lib().call("mp_token_mean_bf16", _p(x), _p(out), B, T, C, _stream())
+    return out
+
+
+def scale_channels(x, gate, B, T, C):
+    y = torch.empty_like(x)
+    lib().call("mp_scale_channels_bf16", _p(x), _p(gate), _p(y), B, T, C, _stream())
+    return y
+
+
+def clip_embed(patch, cls, pos, B, n_patches, C):
+    out = torch.empty((B, n_patches + 1, C), dtype=torch.bfloat16, device=patch.device)
+    lib().call("mp_clip_embed_bf16", _p(patch), _p(cls), _p(pos), _p(out), B, n_patches, C, _stream())
+    return out
+
+
+def copy_rows(src, rows, dim, rows_per_batch, src_batch_rows, src_row0):
+    dst = torch.empty((rows, dim), dtype=torch.bfloat16, device=src.device)
+    lib().call("mp_copy_rows_bf16", _p(src), _p(dst), rows, dim, rows_per_batch, src_batch_rows, src_row0, _stream())
+    return dst
+
+
+# ------------------------------------------------------------------ CE / MoE ---------------------------------------------------
+def cross_entropy_rows(logits, labels):
+    _chk(logits, torch.float32, "ce.logits"); _chk(labels, torch.int64, "ce.labels")
+    assert logits.stride(1) == 1
+    out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    lib().call("mp_cross_entropy_rows_f32", _p(logits), logits.stride(0), _p(labels), logits.shape[0], logits.shape[1], _p(out), _stream())
+    return out
+
+
+def mean_plus(x, scale=1.0, add=None, add_scale=0.0):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    lib().call("mp_mean_plus_f32", _p(x), x.numel(), float(scale), _p(add), 0 if add is None else add.numel(), float(add_scale),
+               _p(out), _stream())
+    return out
+
+
+def moe_gate(x, wg):
+    _chk(x, torch.bfloat16, "moe_gate.x"); _chk(wg, torch.float32, "moe_gate.wg")
+    T, d = x.shape
+    E = wg.shape[0]
+    logits = torch.empty((T, E), dtype=torch.float32, device=x.device)
+    gates = torch.empty((T, E), dtype=torch.float32, device=x.device)
+    lib().call("mp_moe_gate_bf16", _p(x), x.stride(0), _p(wg), _p(logits), _p(gates), T, d, E, _stream())
+    return logits, gates
+
+
+def moe_route_top1(gates, capacity, rts_uniform=None):
+    T, E = gates.shape
+    dev = gates.device
+    expert = torch.empty(T, dtype=torch.int32, device=dev); slot = torch.empty(T, dtype=torch.int32, device=dev)
+    weight = torch.empty(T, dtype=torch.float32, device=dev)
+    kept = torch.empty(E, dtype=torch.int32, device=dev); counts = torch.empty(E, dtype=torch.int64, device=dev)
+    l_aux = torch.empty(1, dtype=torch.float32, device=dev)
+    lib().call("mp_moe_route_top1", _p(gates), _p(rts_uniform), T, E, int(capacity), _p(expert), _p(slot), _p(weight), _p(kept),
+               _p(counts), _p(l_aux), _stream())
+    return expert, slot, weight, kept, counts, l_aux
+
+
+def moe_dispatch(x, expert, slot, n_experts, capacity, buf=None):
+    T, d = x.shape
+    if buf is None:
+        buf = torch.empty((n_experts, capacity, d), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_moe_dispatch_bf16", _p(x), x.stride(0), _p(expert), _p(slot), _p(buf), T, d, capacity, _stream())
+    return buf
+
+
+def moe_combine(y, expert, slot, weight, residual, capacity):
+    T = expert.numel()
+    d = y.shape[-1]
+    out = torch.empty((T, d), dtype=torch.bfloat16, device=y.device)
+    lib().call("mp_moe_combine_bf16", _p(y), _p(expert), _p(slot), _p(weight), _p(residual), _p(out), T, d, capacity, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ optimizer --------------------------------------------------
+def sumsq_accum(x, out):
+    lib().call("mp_sumsq_accum_f32", _p(x), x.numel(), _p(out), _stream())
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, max_norm=0.0, grad_sumsq=None, grad_scale=1.0):
+    for t in (p, g, m, v):
+        _chk(t, torch.float32, "adamw"); assert t.is_contiguous()
+    lib().call("mp_adamw_step_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+               float(wd), int(step), float(max_norm), _p(grad_sumsq), float(grad_scale), _stream())

@@ -1,0 +1,212 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/ops.py header).
+
+CPU fp32 restatement of the LLM side of the path from an HF-layout state dict (SURVEY §8b key names):
+CLIP ViT-L vision tower + mm_projector, the multimodal splice, the Llama decoder stack with dense or DeepSpeed-MoE
+MLPs, fp32 logits + filtered CE, and the <SEG> mask.
+
+Pinning: the splice / seg-mask / CE functions restate reference code that is present in /root/reference and are
+checked against it by oracle/make_golden.py (tests/golden/glue_reference.npz).  Llama/CLIP arithmetic is third-party
+(transformers==4.31.0, requirements.txt:137) — cross-checked in tests against the installed transformers' modules,
+"parity unpinned" w.r.t. 4.31.0 itself.  DeepSpeed-MoE (deepspeed==0.13.1, requirements.txt:22) is absent from the
+container: restated from SURVEY Appendix A.3, **parity unpinned**, guarded by known-answer tests."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .ops import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+
+
+# ----------------------------------------------------------------------------------------------- CLIP + projector
+def clip_features(images, W, cfg, prefix="model.vision_tower.vision_tower.vision_model."):
+    """HF CLIPVisionModel hidden_states[select_layer][:, 1:] (clip_encoder.py:31-60)."""
+    C, H, p = cfg.clip_hidden_size, cfg.clip_num_heads, cfg.clip_patch_size
+    x = F.conv2d(images, W[prefix + "embeddings.patch_embedding.weight"], stride=p).flatten(2).transpose(1, 2)
+    cls = W[prefix + "embeddings.class_embedding"].expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], 1) + W[prefix + "embeddings.position_embedding.weight"]
+    x = F.layer_norm(x, (C,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], cfg.clip_ln_eps)
+    hidden = [x]
+    for i in range(cfg.clip_num_layers):
+        lp = f"{prefix}encoder.layers.{i}."
+        h = F.layer_norm(x, (C,), W[lp + "layer_norm1.weight"], W[lp + "layer_norm1.bias"], cfg.clip_ln_eps)
+        q = F.linear(h, W[lp + "self_attn.q_proj.weight"], W[lp + "self_attn.q_proj.bias"])
+        k = F.linear(h, W[lp + "self_attn.k_proj.weight"], W[lp + "self_attn.k_proj.bias"])
+        v = F.linear(h, W[lp + "self_attn.v_proj.weight"], W[lp + "self_attn.v_proj.bias"])
+        B, S, _ = q.shape
+        a = ops.attention(q.view(B, S, H, -1), k.view(B, S, H, -1), v.view(B, S, H, -1))
+        x = x + F.linear(a, W[lp + "self_attn.out_proj.weight"], W[lp + "self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (C,), W[lp + "layer_norm2.weight"], W[lp + "layer_norm2.bias"], cfg.clip_ln_eps)
+        h = ops.quick_gelu(F.linear(h, W[lp + "mlp.fc1.weight"], W[lp + "mlp.fc1.bias"]))
+        x = x + F.linear(h, W[lp + "mlp.fc2.weight"], W[lp + "mlp.fc2.bias"])
+        hidden.append(x)
+    return hidden[cfg.mm_vision_select_layer][:, 1:]
+
+
+def mm_projector(x, W, prefix="model.mm_projector."):
+    """mlp2x_gelu (multimodal_projector/builder.py:39-46)."""
+    return F.linear(F.gelu(F.linear(x, W[prefix + "0.weight"], W[prefix + "0.bias"])), W[prefix + "2.weight"], W[prefix + "2.bias"])
+
+
+# ----------------------------------------------------------------------------------------------- splice + seg mask
+def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, embed_tokens, per_token=False):
+    """medplib_arch.py:296-527 restated literally (mm_use_im_start_end branch; region prompts excluded).
+    image_features: [n_img, n_feat, d] (4-D images layout: one per sample, consumed per sample) or a flat list with one
+    entry per placeholder (multi-image layouts).  Returns (attention_mask, inputs_embeds, labels)."""
+    new_embeds, new_labels = [], [] if labels is not None else None
+    cur_image_idx = 0
+    for b, cur_ids in enumerate(input_ids):
+        if (cur_ids == IMAGE_TOKEN_INDEX).sum() == 0:
+            new_embeds.append(embed_tokens[cur_ids])
+            if labels is not None:
+                new_labels.append(labels[b])
+            if not per_token:
+                cur_image_idx += 1
+            continue
+        idx = torch.where(cur_ids == IMAGE_TOKEN_INDEX)[0]
+        cur_e, cur_l = [], []
+        cur_labels = labels[b] if labels is not None else None
+        while idx.numel() > 0:
+            feats = image_features[cur_image_idx]
+            s = idx[0]
+            cur_e.append(embed_tokens[cur_ids[:s]])
+            cur_e.append(feats)
+            cur_e.append(embed_tokens[cur_ids[s + 1:s + 2]])
+            if labels is not None:
+                cur_l.append(cur_labels[:s])
+                cur_l.append(torch.full((feats.shape[0],), IGNORE_INDEX, dtype=labels.dtype))
+                cur_l.append(cur_labels[s + 1:s + 2])
+                cur_labels = cur_labels[s + 2:]
+            cur_image_idx += 1
+            cur_ids = cur_ids[s + 2:]
+            idx = torch.where(cur_ids == IMAGE_TOKEN_INDEX)[0]
+        if cur_ids.numel() > 0:
+            cur_e.append(embed_tokens[cur_ids])
+            if labels is not None:
+                cur_l.append(cur_labels)
+        new_embeds.append(torch.cat(cur_e, 0))
+        if labels is not None:
+            new_labels.append(torch.cat(cur_l, 0))
+    L = input_ids.shape[1]
+    max_len = max(x.shape[0] for x in new_embeds)
+    emb = torch.stack([torch.cat([x, torch.zeros(max_len - x.shape[0], x.shape[1], dtype=x.dtype)], 0) for x in new_embeds])
+    lab = None
+    if labels is not None:
+        lab = torch.stack([torch.cat([x, torch.full((max_len - x.shape[0],), IGNORE_INDEX, dtype=x.dtype)]) for x in new_labels])
+    att = None
+    if attention_mask is not None:
+        rows = []
+        for b in range(len(new_embeds)):
+            n = new_embeds[b].shape[0]
+            rows.append(torch.cat([torch.ones(n - L, dtype=torch.bool), attention_mask[b].bool(),
+                                   torch.zeros(max_len - n, dtype=torch.bool)]))
+        att = torch.stack(rows)
+    return att, emb, lab
+
+
+def build_seg_token_mask(input_ids, seg_token_idx, image_token_len, image_token_lengths=None):
+    """model/MedPLIB.py:310-355 restated literally."""
+    shifted = torch.zeros_like(input_ids, dtype=torch.bool)
+    shifted[:, :-1] = input_ids[:, 1:] == seg_token_idx
+    out = []
+    for b, (ids, segs) in enumerate(zip(input_ids, shifted)):
+        cur, k = [], 0
+        for tok, is_seg in zip(ids, segs):
+            if tok == IMAGE_TOKEN_INDEX:
+                n = image_token_len
+                if image_token_lengths is not None and len(image_token_lengths) > b and len(image_token_lengths[b]) > k:
+                    n = image_token_lengths[b][k]
+                k += 1
+                cur.append(torch.zeros(n, dtype=torch.bool))
+            else:
+                cur.append(is_seg.view(1))
+        out.append(torch.cat(cur))
+    m = max(x.shape[0] for x in out)
+    return torch.stack([torch.cat([x, torch.zeros(m - x.shape[0], dtype=torch.bool)]) for x in out])
+
+
+# ----------------------------------------------------------------------------------------------- DeepSpeed MoE (top-1)
+def moe_top1(x, wg, experts, capacity, rts_uniform=None):
+    """DeepSpeed 0.13.1 TopKGate(k=1) + MOELayer on one rank — parity unpinned (third-party).
+    x [T,d] fp32; wg [E,d]; experts: list of callables; rts_uniform [T,E] (the `uniform(mask1.shape)` draw) or None.
+    Returns (out [T,d], l_aux, exp_counts [E], expert idx [T], slot [T] (-1 = dropped))."""
+    T, E = x.shape[0], wg.shape[0]
+    logits = x.float() @ wg.float().t()
+    gates = F.softmax(logits, dim=1)
+    idx = torch.argmax(gates, dim=1)
+    mask1 = F.one_hot(idx, num_classes=E)
+    exp_counts = mask1.sum(0)
+    me, ce = gates.mean(0), mask1.float().mean(0)
+    l_aux = torch.sum(me * ce) * E
+    mask1_rand = mask1 * rts_uniform if rts_uniform is not None else mask1.float()
+    cap = min(capacity, T)
+    if rts_uniform is None:
+        # no draws supplied: stable first-come selection (documented deviation point; DeepSpeed's own behaviour without
+        # RTS relies on topk tie-breaking)
+        keep = (torch.cumsum(mask1, 0) - 1 < capacity) & mask1.bool()
+        new_mask1 = keep.long()
+    else:
+        top_idx = torch.topk(mask1_rand, k=cap, dim=0)[1]
+        new_mask1 = mask1 * torch.zeros_like(mask1).scatter_(0, top_idx, 1)
+    loc = torch.cumsum(new_mask1, 0) - 1
+    slot = torch.sum(loc * new_mask1, 1)
+    kept = new_mask1.sum(1).bool()
+    gate_w = (gates * new_mask1.float()).sum(1)
+    out = torch.zeros_like(x, dtype=torch.float32)
+    for e in range(E):
+        sel = kept & (idx == e)
+        if sel.any():
+            out[sel] = gate_w[sel, None] * experts[e](x[sel].float())
+    slot = torch.where(kept, slot, torch.full_like(slot, -1))
+    return out, l_aux, exp_counts, idx, slot
+
+
+# ----------------------------------------------------------------------------------------------- Llama stack
+def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="", collect=None):
+    """MoELlamaModel_forward + MoELlamaDecoderLayer_forward (medplib_moe_llama.py:110-305) over HF-4.31 Llama modules
+    (SURVEY A.1).  embeds [B,S,d]; key_valid bool [B,S] or None; rts: dict layer -> uniforms [T,E].
+    Returns (final-normed hidden [B,S,d], [l_aux...])."""
+    B, S, d = embeds.shape
+    H, D, ff = cfg.num_attention_heads, cfg.head_dim, cfg.intermediate_size
+    cos, sin = ops.rope_tables(S, D, cfg.rope_theta)
+    moe_layers = cfg.moe_layer_set()
+    x = embeds.float()
+    aux = []
+    for i in range(cfg.num_hidden_layers):
+        p = f"{prefix}model.layers.{i}."
+        h = ops.rmsnorm(x, W[p + "input_layernorm.weight"].float(), cfg.rms_norm_eps)
+        q = F.linear(h, W[p + "self_attn.q_proj.weight"]).view(B, S, H, D)
+        k = F.linear(h, W[p + "self_attn.k_proj.weight"]).view(B, S, H, D)
+        v = F.linear(h, W[p + "self_attn.v_proj.weight"]).view(B, S, H, D)
+        a = ops.attention(ops.rope(q, cos, sin), ops.rope(k, cos, sin), v, causal=True, key_valid=key_valid)
+        x = x + F.linear(a, W[p + "self_attn.o_proj.weight"])
+        h = ops.rmsnorm(x, W[p + "post_attention_layernorm.weight"].float(), cfg.rms_norm_eps)
+        if i in moe_layers:
+            T = B * S
+            cf = cfg.capacity_factor if training else cfg.eval_capacity_factor
+            cap = max(int(math.ceil(T / cfg.num_experts * cf)), cfg.min_capacity)
+            experts = []
+            for e in range(cfg.num_experts):
+                ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+                experts.append(lambda t, ep=ep: F.linear(ops.swiglu(F.linear(t, W[ep + "gate_proj.weight"]),
+                                                                    F.linear(t, W[ep + "up_proj.weight"])), W[ep + "down_proj.weight"]))
+            out, l_aux, counts, idx, slot = moe_top1(h.reshape(T, d), W[p + "mlp.deepspeed_moe.gate.wg.weight"], experts, cap,
+                                                     None if rts is None else rts.get(i))
+            aux.append(l_aux)
+            if collect is not None:
+                collect.append((idx, slot, counts))
+            x = x + out.view(B, S, d)
+        else:
+            m = F.linear(ops.swiglu(F.linear(h, W[p + "mlp.gate_proj.weight"]), F.linear(h, W[p + "mlp.up_proj.weight"])),
+                         W[p + "mlp.down_proj.weight"])
+            x = x + m
+    return ops.rmsnorm(x, W[prefix + "model.norm.weight"].float(), cfg.rms_norm_eps), aux
+
+
+def causal_lm_loss(hidden, labels, W, cfg, aux, prefix=""):
+    """medplib_moe_llama.py:388-421: fp32 logits, filtered shifted CE, + router_aux_loss_coef * sum(l_aux)."""
+    logits = F.linear(hidden, W[prefix + "lm_head.weight"]).float()
+    loss = ops.cross_entropy_filtered(logits, labels)
+    if aux:
+        loss = loss + cfg.router_aux_loss_coef * sum(aux)
+    return loss, logits

@@ -1,0 +1,135 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/ops.py header).
+
+End-to-end CPU fp32 restatement of `MedPLIBForCausalLM.model_forward` / `LISAForCausalLM.model_forward`
+(model/MedPLIB.py:364-572, model/LISA.py:260-471) from an HF-layout state dict, plus seeded weight / batch generators
+shared by the tests, smoke() and bench.py's cpu_baseline leg."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import llm, ops, sam
+
+
+def init_hf_weights(cfg, seed=0, sam_seed=1234):
+    """Seeded random weights in the HF checkpoint key layout, values rounded to bf16 where the product
+    stores bf16 so both sides see identical numbers.  SAM-Med2D part: sam.init_weights under `model.visual_model.`."""
+    g = torch.Generator().manual_seed(seed)
+    d, ff, V, C, I = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.clip_hidden_size, cfg.clip_intermediate_size
+
+    def rn(*shape, s=0.02, bf=True):
+        t = torch.randn(*shape, generator=g) * s
+        return t.to(torch.bfloat16).float() if bf else t
+    W = {"model.embed_tokens.weight": rn(V, d, s=0.5), "lm_head.weight": rn(V, d, s=0.05), "model.norm.weight": 1 + rn(d, s=0.1)}
+    moe = cfg.moe_layer_set()
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for n in ("q", "k", "v", "o"):
+            W[p + f"self_attn.{n}_proj.weight"] = rn(d, d, s=1.0 / d ** 0.5)
+        W[p + "input_layernorm.weight"] = 1 + rn(d, s=0.1)
+        W[p + "post_attention_layernorm.weight"] = 1 + rn(d, s=0.1)
+        if i in moe:
+            W[p + "mlp.deepspeed_moe.gate.wg.weight"] = rn(cfg.num_experts, d, s=0.05, bf=False)
+            for e in range(cfg.num_experts):
+                ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+                W[ep + "gate_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+                W[ep + "up_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+                W[ep + "down_proj.weight"] = rn(d, ff, s=1.0 / ff ** 0.5)
+        else:
+            W[p + "mlp.gate_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+            W[p + "mlp.up_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+            W[p + "mlp.down_proj.weight"] = rn(d, ff, s=1.0 / ff ** 0.5)
+    tp = "model.vision_tower.vision_tower.vision_model."
+    ps = cfg.clip_patch_size
+    W[tp + "embeddings.patch_embedding.weight"] = rn(C, 3, ps, ps, s=0.03)
+    W[tp + "embeddings.class_embedding"] = rn(C, s=0.5)
+    W[tp + "embeddings.position_embedding.weight"] = rn(cfg.clip_num_patches + 1, C, s=0.1)
+    W[tp + "pre_layrnorm.weight"] = 1 + rn(C, s=0.1); W[tp + "pre_layrnorm.bias"] = rn(C, s=0.1)
+    for i in range(cfg.clip_num_layers):
+        lp = f"{tp}encoder.layers.{i}."
+        for n in ("layer_norm1", "layer_norm2"):
+            W[lp + n + ".weight"] = 1 + rn(C, s=0.1); W[lp + n + ".bias"] = rn(C, s=0.1)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[lp + f"self_attn.{n}.weight"] = rn(C, C, s=1.0 / C ** 0.5); W[lp + f"self_attn.{n}.bias"] = rn(C, s=0.05)
+        W[lp + "mlp.fc1.weight"] = rn(I, C, s=1.0 / C ** 0.5); W[lp + "mlp.fc1.bias"] = rn(I, s=0.05)
+        W[lp + "mlp.fc2.weight"] = rn(C, I, s=1.0 / I ** 0.5); W[lp + "mlp.fc2.bias"] = rn(C, s=0.05)
+    W["model.mm_projector.0.weight"] = rn(d, C, s=1.0 / C ** 0.5); W["model.mm_projector.0.bias"] = rn(d, s=0.05)
+    W["model.mm_projector.2.weight"] = rn(d, d, s=1.0 / d ** 0.5); W["model.mm_projector.2.bias"] = rn(d, s=0.05)
+    W["model.text_hidden_fcs.0.0.weight"] = rn(d, d, s=1.0 / d ** 0.5, bf=False); W["model.text_hidden_fcs.0.0.bias"] = rn(d, s=0.05, bf=False)
+    W["model.text_hidden_fcs.0.2.weight"] = rn(cfg.out_dim, d, s=1.0 / d ** 0.5, bf=False)
+    W["model.text_hidden_fcs.0.2.bias"] = rn(cfg.out_dim, s=0.05, bf=False)
+    S = sam.init_weights(seed=sam_seed, encoder_depth=cfg.sam_depth)
+    for k, v in S.items():
+        if k.startswith("image_encoder.") and "rel_pos" not in k and "norm" not in k and ".bias" not in k and "channel" not in k \
+                and "neck.1" not in k and "neck.3" not in k:
+            v = v.to(torch.bfloat16).float()          # the product stores these GEMM operands in bf16
+        W["model.visual_model." + k] = v
+    return W
+
+
+def make_batch(cfg, B, L=64, H=96, Wd=80, seed=0, ragged=False, sam_size=256):
+    """Synthetic batch in the collator's contract (datasets/DataCollatorForSupervisedDataset.py:11-138):
+    one IMAGE placeholder bracketed by im_start/im_end, <SEG> near the end, labels supervised on the tail."""
+    g = torch.Generator().manual_seed(seed)
+    V = cfg.vocab_size
+    ids = torch.randint(3, min(V, cfg.seg_token_idx) - 1, (B, L), generator=g)
+    img_pos = min(35, L // 2)
+    labels = torch.full((B, L), ops.IGNORE_INDEX, dtype=torch.int64)
+    att = torch.ones(B, L, dtype=torch.bool)
+    for b in range(B):
+        npad = ((b * 3) % 5) if ragged else 0
+        n = L - npad                                  # real tokens; right padding like the collator (pad id 0, label -100)
+        ids[b, 0] = 1
+        ids[b, img_pos - 1], ids[b, img_pos], ids[b, img_pos + 1] = V - 2, ops.IMAGE_TOKEN_INDEX, V - 1   # <im_start> <image> <im_end>
+        ids[b, n - 3] = cfg.seg_token_idx
+        ids[b, n - 1] = 2
+        ids[b, n:] = 0
+        labels[b, n - 8:n] = ids[b, n - 8:n]
+        att[b, n:] = False
+    images = torch.randn(B, 3, sam_size, sam_size, generator=g)
+    images_clip = torch.randn(B, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g)
+    masks = []
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(Wd), indexing="ij")
+    for b in range(B):
+        cy, cx = torch.rand(2, generator=g) * torch.tensor([H, Wd])
+        r = 8 + torch.rand(1, generator=g) * min(H, Wd) / 3
+        masks.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r ** 2).float())
+    return {"images": images, "images_clip": images_clip, "input_ids": ids, "labels": labels, "attention_mask": att,
+            "masks_list": masks, "label_list": [torch.full((H, Wd), 255.0) for _ in range(B)],
+            "resize_list": [(sam_size, sam_size)] * B, "valid_mask_bool": [[True]] * B, "offset": None, "region_masks": [],
+            "inference": False, "seg_flag": True}
+
+
+def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False):
+    """model/MedPLIB.py:364-572 end to end on the CPU in fp32."""
+    ids, labels, att = batch["input_ids"], batch["labels"], batch["attention_mask"]
+    B = ids.shape[0]
+    with torch.no_grad():
+        image_emb = sam.image_encoder(batch["images"], {k[len("model.visual_model."):]: v for k, v in W.items()
+                                                        if k.startswith("model.visual_model.")}, depth=cfg.sam_depth)
+        feats = llm.mm_projector(llm.clip_features(batch["images_clip"], W, cfg), W)
+        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feats, W["model.embed_tokens.weight"])
+        kv = None if att2.all() else att2
+        hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
+        ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)
+    seg_mask = llm.build_seg_token_mask(ids, cfg.seg_token_idx, cfg.clip_num_patches)
+    SW = {k[len("model.visual_model."):]: v for k, v in W.items() if k.startswith("model.visual_model.")}
+    hid = hidden.detach()
+    fc = lambda x: F.linear(F.relu(F.linear(x, W["model.text_hidden_fcs.0.0.weight"], W["model.text_hidden_fcs.0.0.bias"])),
+                            W["model.text_hidden_fcs.0.2.weight"], W["model.text_hidden_fcs.0.2.bias"])
+    last = fc(hid)                                            # applied to every row like the reference (MedPLIB.py:456)
+    pred_emb = last[seg_mask]
+    pe = sam.dense_pe(SW)
+    pred_masks, pred_ious, low = [], [], []
+    for i in range(len(pred_emb)):
+        sp, de = sam.prompt_encoder_text(pred_emb[i].view(1, 1, -1), SW)
+        lm, io = sam.mask_decoder(image_emb[i:i + 1], pe, sp, de, SW)
+        low.append(lm)
+        pm = ops.postprocess_masks(lm, batch["resize_list"][i], tuple(batch["label_list"][i].shape))
+        pred_masks.append(pm[:, 0]); pred_ious.append(io[:, 0])
+    weights = dict(ce=cfg.ce_loss_weight, bce=cfg.bce_loss_weight, dice=cfg.dice_loss_weight, iou=cfg.iou_loss_weight,
+                   focal=cfg.focal_loss_weight)
+    out = ops.combine_mask_losses(pred_masks, batch["masks_list"], pred_ious, ce, weights)
+    if return_intermediates:
+        return out, dict(hidden=hidden, ce=ce, seg_mask=seg_mask, pred_emb=pred_emb, low_res=torch.cat(low), pred_masks=pred_masks,
+                         pred_ious=torch.cat(pred_ious), image_emb=image_emb, feats=feats, embeds=embeds, labels=lab2, att=att2)
+    return out
