@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — MedPLIB hot path on MI355X: training samples/s for "336x336 image + 64-token prompt".
+
+Workload (BASELINE.json configs[3], the config the train-samples/s metric is quoted on): MedPLIB-7B-MoE (Llama-7B dims,
+E=2 top-1 experts in all 32 layers, capacity_factor 1.5), CLIP ViT-L/14-336, SAM-Med2D ViT-B@256; stage-III training step
+with LoRA off (trainable: mask decoder + text_hidden_fcs, 21.9 M parameters), CE + BCE + Dice + Focal(+IoU) losses,
+per-GPU micro-batch 8, data parallel (weak scaling), bf16 trunk / fp32 trainable tail, synthetic data, seeded random
+weights at true dimensions.
+
+One step = forward of the whole path + backward through the trainable tail + gradient all-reduce + AdamW step.
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FWD_TFLOP_PER_SAMPLE = 9.15
+
+
+def synthetic_batch(cfg, B, device, seed):
+    """SURVEY §8(d) synthetic inputs: N(0,1) images, 64-token prompt with one <image> placeholder at position 35 bracketed
+    by <im_start>/<im_end>, <SEG> at 61, EOS at 63, labels supervised from position 56, one binary disc mask per sample."""
+    g = torch.Generator().manual_seed(seed)
+    L, V = 64, cfg.vocab_size
+    ids = torch.randint(3, 31999, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, 34], ids[:, 35], ids[:, 36] = V - 2, -200, V - 1
+    ids[:, 61] = cfg.seg_token_idx
+    ids[:, 63] = 2
+    labels = ids.clone()
+    labels[:, :56] = -100
+    att = torch.ones(B, L, dtype=torch.bool)
+    H = W = 336
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    masks = []
+    for _ in range(B):
+        cy, cx = (torch.rand(2, generator=g) * 336).tolist()
+        r = 20 + 80 * torch.rand(1, generator=g).item()
+        masks.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r * r).float().to(device))
+    return {
+        "images": torch.randn(B, 3, 256, 256, generator=g).to(device),
+        "images_clip": torch.randn(B, 3, 336, 336, generator=g).to(torch.bfloat16).to(device),
+        "input_ids": ids.numpy(), "labels": labels.numpy(), "attention_mask": att.numpy(),     # index tensors stay on the host
+        "masks_list": masks, "label_list": [torch.empty(H, W, device="meta") for _ in range(B)],
+        "resize_list": [(256, 256)] * B, "valid_mask_bool": [[True]] * B, "offset": None, "region_masks": [],
+        "inference": False, "seg_flag": True,
+    }
+
+
+def cpu_baseline(cfg, steps=2):
+    """The oracle (CPU fp32 port of the reference path) timed on the host cores on a bounded sample of the same workload:
+    B=1 training step (forward of the whole path + backward through mask decoder / text_hidden_fcs).  To bound host memory
+    and initialisation time the 32 decoder layers alias ONE layer's random weights (arithmetic and memory traffic per
+    layer are unchanged: a layer's 1.6 GB of fp32 weights do not fit in cache)."""
+    from oracle import model as OM
+    import copy
+    torch.set_num_threads(os.cpu_count())
+    cfg1 = copy.deepcopy(cfg)
+    cfg1.num_hidden_layers = 1
+    W = OM.init_hf_weights(cfg1, seed=0)
+    for i in range(1, cfg.num_hidden_layers):
+        for k in [k for k in W if k.startswith("model.layers.0.")]:
+            W[k.replace("model.layers.0.", f"model.layers.{i}.")] = W[k]
+    train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
+    for k in train:
+        W[k] = W[k].clone().requires_grad_()
+    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=42)
+    times = []
+    for _ in range(steps + 1):
+        t0 = time.time()
+        out = OM.model_forward(batch, W, cfg, training=True)
+        out["loss"].backward()
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": 1.0 / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 training step at B=1 (1 of the 8 per-GPU samples), true dims, median of {steps} after 1 warm-up, "
+                      f"{t:.2f} s/step; decoder-layer weights aliased across the 32 layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU micro-batch (BASELINE config: 8)")
+    ap.add_argument("--layers", type=int, default=32, help="debug only; the reported config is 32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")
+
+    from medplib_amd import engine, ops
+    from medplib_amd.model.config import MedPLIBConfig
+    from medplib_amd.model.medplib import MedPLIBForCausalLM
+
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers)
+    model = MedPLIBForCausalLM(cfg, device=device).train()
+    ds_config = {"train_micro_batch_size_per_gpu": args.batch, "gradient_accumulation_steps": 1,
+                 "optimizer": {"type": "AdamW", "params": {"lr": 3e-4, "weight_decay": 0.0, "betas": (0.9, 0.95)}},
+                 "gradient_clipping": 1.0,
+                 "scheduler": {"type": "WarmupDecayLR", "params": {"total_num_steps": 10000, "warmup_min_lr": 0,
+                                                                     "warmup_max_lr": 3e-4, "warmup_num_steps": 100,
+                                                                     "warmup_type": "linear"}}}
+    eng, _, _, _ = engine.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
+    batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
+
+    def step():
+        out = eng(**batch)
+        eng.backward(out["loss"])
+        eng.step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    loss0 = float(out["loss"]) if args.warmup else float("nan")
+
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.GEMM_TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        samples = world * args.batch * args.steps
+        value = samples / dt
+        roof = None
+        if timer is not None:
+            flops, ms, launches = timer.summary()
+            achieved = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // args.steps, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                    "gemm_ms_per_step": round(ms / args.steps, 2)}
+        res = {
+            "metric": "train samples/sec (img+64tok)", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E=2 top-1 experts x32 layers), "
+                                   "336x336 CLIP image + 256x256 SAM image + 64-token prompt (S=639 after splice), "
+                                   f"per-GPU batch {args.batch}, DP={world}",
+                       "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
+                       "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel},
+            "model_tflops_per_gpu": round(FWD_TFLOP_PER_SAMPLE * args.batch * args.steps / dt, 1),
+            "loss_after_warmup": loss0, "loss_last": float(out["loss"]),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:   # the GPU number stands on its own; say why the host leg is missing
+                res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

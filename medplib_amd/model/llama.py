@@ -123,6 +123,8 @@ class LlamaStack:
         expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, rts)
         buf = ops.moe_dispatch(h, expert, slot, E, cap)
         gu = torch.empty((E, cap, 2 * ff), dtype=torch.bfloat16, device=h.device)
+        if ops.GEMM_TIMER is not None:
+            ops.GEMM_TIMER.batched_rows = T      # algorithmic rows of the expert GEMMs: every token visits one expert
         ops.gemm_batched(buf, lw["gu"], gu, m_dev=kept)
         act = ops.swiglu(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
         y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)

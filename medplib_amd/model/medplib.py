@@ -83,6 +83,8 @@ class MedPLIBForCausalLM(nn.Module):
         self.to_device()
         self.seg_token_idx = cfg.seg_token_idx
         self.inference_threshold = 0.1
+        self.capture_intermediates = False      # tests: keep the trunk outputs that feed the trainable tail
+        self.captured = {}
 
     # ------------------------------------------------------------------ plumbing
     def to_device(self):
@@ -211,6 +213,8 @@ class MedPLIBForCausalLM(nn.Module):
             seg_rows = seg_rows[-n_masks_given:]                   # MedPLIB.py:462-463
         with torch.no_grad():
             image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
+            if self.capture_intermediates:
+                self.captured = {"last_hidden": last_hidden, "image_tokens": image_tokens, "ce": ce}
             exp = self.expand_index(valid_mask_bool, image_tokens.shape[0])
             if exp != list(range(image_tokens.shape[0])):
                 image_tokens = ops.gather_rows_f32(image_tokens, torch.tensor(exp, dtype=torch.int64, device=dev))

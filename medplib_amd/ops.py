@@ -30,6 +30,32 @@ def _dt(dtype):
     return BF16 if dtype == torch.bfloat16 else F32
 
 
+class KernelTimer:
+    """Optional HIP-event bracketing of one kernel family (bench.py roofline): events are recorded on the stream the
+    kernel is launched on (torch's current stream) and only read back after the timed region."""
+
+    def __init__(self):
+        self.records = []          # (work, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, work, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.append((work, start, ev))
+
+    def summary(self):
+        """-> (total work, total ms, launches) after a synchronize."""
+        total_ms = sum(s.elapsed_time(e) for _, s, e in self.records)
+        return sum(w for w, _, _ in self.records), total_ms, len(self.records)
+
+
+GEMM_TIMER = None     # set to a KernelTimer by bench.py
+
+
 # ------------------------------------------------------------------ bf16 trunk ------------------------------------------------
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, out=None, alpha=1.0, m_dev=None):
     """out[M,N] = act(alpha * a[M,K] @ w[N,K]^T + bias) + residual.  a/w bf16 with unit inner stride."""
@@ -44,9 +70,12 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
         _chk(bias, torch.float32, "gemm.bias")
     if residual is not None:
         _chk(residual, torch.bfloat16, "gemm.residual"); assert residual.stride(1) == 1
+    t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
     lib().call("mp_gemm_bf16_nt", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
                residual.stride(0) if residual is not None else 0, M, N, K, act, _dt(out.dtype), float(alpha), _p(m_dev),
                _stream())
+    if t0 is not None:
+        GEMM_TIMER.end(2.0 * M * N * K, t0)
     return out
 
 
@@ -56,9 +85,14 @@ def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
     E, M, K = a.shape
     N = w.shape[1]
     assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
+    t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
     lib().call("mp_gemm_bf16_nt_batched", _p(a), a.stride(1), a.stride(0), _p(w), w.stride(1), w.stride(0), _p(out),
                out.stride(1), out.stride(0), _p(bias), bias.stride(0) if bias is not None else 0, E, M, N, K, act,
                _dt(out.dtype), _p(m_dev), _stream())
+    if t0 is not None:
+        # algorithmic rows: with device-side counts the routed rows of a top-1 MoE sum to `work_rows` (set by the caller)
+        rows = getattr(GEMM_TIMER, "batched_rows", None) or E * M
+        GEMM_TIMER.end(2.0 * rows * N * K, t0)
     return out
 
 

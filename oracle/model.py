@@ -99,8 +99,10 @@ def make_batch(cfg, B, L=64, H=96, Wd=80, seed=0, ragged=False, sam_size=256):
             "inference": False, "seg_flag": True}
 
 
-def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False):
-    """model/MedPLIB.py:364-572 end to end on the CPU in fp32."""
+def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None):
+    """model/MedPLIB.py:364-572 end to end on the CPU in fp32.  `override` (tests only) may inject `hidden` [B,S,d],
+    `image_emb` [B,256,16,16] and `ce` so the trainable tail can be checked on exactly the trunk outputs another
+    implementation produced."""
     ids, labels, att = batch["input_ids"], batch["labels"], batch["attention_mask"]
     B = ids.shape[0]
     with torch.no_grad():
@@ -111,6 +113,8 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         kv = None if att2.all() else att2
         hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
         ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)
+        if override:
+            hidden = override.get("hidden", hidden); image_emb = override.get("image_emb", image_emb); ce = override.get("ce", ce)
     seg_mask = llm.build_seg_token_mask(ids, cfg.seg_token_idx, cfg.clip_num_patches)
     SW = {k[len("model.visual_model."):]: v for k, v in W.items() if k.startswith("model.visual_model.")}
     hid = hidden.detach()

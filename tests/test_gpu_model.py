@@ -28,6 +28,25 @@ def _stat(name, got, ref, atol, rtol=0.0):
     assert err.max().item() <= atol + rtol * scale, msg
 
 
+def _check_grads(params, ref_grads, rtol, tag):
+    """Per-tensor max error relative to that tensor's gradient scale, with an absolute floor of 1e-5 x the largest gradient
+    in the set (some gradients are analytically zero — e.g. the k_proj bias, softmax being shift-invariant — and consist
+    of rounding noise on both sides)."""
+    gmax = max(r.abs().max().item() for r in ref_grads.values() if r is not None)
+    worst = 0.0
+    for n, p in params.items():
+        ref = ref_grads[n]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        if ref is None:                       # unused hypernets 1-3: no gradient on either side
+            assert got.abs().max().item() == 0.0, n
+            continue
+        err = (got.cpu() - ref).abs().max().item()
+        rel = err / (ref.abs().max().item() + 1e-5 * gmax)
+        worst = max(worst, rel)
+        assert rel < rtol, f"{tag} grad {n}: max err {err:.3e}, ref max {ref.abs().max().item():.3e}, rel {rel:.3e}"
+    print(f"{tag} grads: worst relative error {worst:.3e} (largest gradient {gmax:.3e})")
+
+
 def _model(cfg, dev, W, cls=None):
     from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
     cls = cls or (MedPLIBForCausalLM if cfg.moe_enable else LISAForCausalLM)
@@ -60,19 +79,26 @@ def test_llama_stack(dev, moe):
     coll = []
     ref, aux_ref = OL.llama_forward(emb.float(), kv, W, cfg, training=True, collect=coll)
     out, aux, routing = m.model.llm.forward(emb.to(dev), kv.to(torch.uint8).to(dev), collect_routing=True)
-    _stat(f"llama hidden moe={moe}", out, ref, atol=0.0, rtol=8 * 2 ** -8)
-    if moe:
-        # layer 0 sees bit-identical inputs on both sides up to bf16 rounding of the normed activations; token->expert and
-        # token->slot indices must agree exactly wherever the two gate logits are not within bf16 noise of each other
-        for li, ((e_ref, s_ref, c_ref), (e, s, c)) in enumerate(zip(coll, routing)):
-            e, s, c = e.cpu().long(), s.cpu().long(), c.cpu()
-            agree = (e == e_ref).float().mean().item()
-            print(f"layer {li}: expert agreement {agree:.4f}, counts ref {c_ref.tolist()} got {c.tolist()}")
-            assert agree > 0.98
-            if torch.equal(e, e_ref):
-                assert torch.equal(s, s_ref) and torch.equal(c, c_ref)
-        for a, b in zip(aux, aux_ref):
-            _stat("l_aux", a, b.view(1), atol=2e-3)
+    if not moe:
+        _stat("llama hidden dense", out, ref, atol=0.0, rtol=8 * 2 ** -8)
+        return
+    # A token whose two gate probabilities are within bf16 noise of each other may legitimately pick the other expert
+    # (the trunk is bf16, the oracle fp32); such tokens are identified from the routing tables and excluded from the
+    # hidden-state comparison — everything else must match, and where a layer's expert ids agree everywhere its slots
+    # and counts must be bit-exact.
+    flipped = torch.zeros(B * S, dtype=torch.bool)
+    for li, ((e_ref, s_ref, c_ref), (e, s_, c)) in enumerate(zip(coll, routing)):
+        e, s_, c = e.cpu().long(), s_.cpu().long(), c.cpu()
+        flipped |= (e != e_ref)
+        print(f"layer {li}: expert agreement {(e == e_ref).float().mean().item():.4f}, counts ref {c_ref.tolist()} got {c.tolist()}")
+        if torch.equal(e, e_ref):
+            assert torch.equal(s_, s_ref) and torch.equal(c, c_ref)
+    assert flipped.float().mean().item() < 0.03, "too many routing disagreements for bf16 noise"
+    keep = ~flipped
+    _stat("llama hidden moe (tokens with identical routing)", out.view(B * S, -1).cpu()[keep], ref.view(B * S, -1)[keep],
+          atol=0.0, rtol=12 * 2 ** -8)
+    for a, b in zip(aux, aux_ref):
+        _stat("l_aux", a, b.view(1), atol=5e-3)
 
 
 def test_moe_routing_bit_exact_on_identical_gates(dev):
@@ -142,17 +168,8 @@ def test_mask_decoder_forward_backward(dev, golden_dir):
     m, io = OS.mask_decoder(torch.from_numpy(emb), OS.dense_pe(Wr), sp, de, Wr)
     ((m[:, 0] * gl).sum() + (io[:, 0] * gi).sum()).backward()
     _stat("d text_embeds", t_dev.grad, tr.grad, atol=0.0, rtol=2e-4)
-    worst = 0.0
-    for n, p in dec.named_parameters():
-        ref = Wr["mask_decoder." + n].grad
-        if ref is None:            # hypernets 1-3 / iou rows 1-3 of unused outputs
-            assert p.grad is None or p.grad.abs().max().item() == 0.0, n
-            continue
-        got = p.grad if p.grad is not None else torch.zeros_like(p)
-        e = (got.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
-        worst = max(worst, e)
-        assert e < 1e-3, f"grad {n}: rel err {e:.3e}"
-    print(f"decoder grads: worst relative error {worst:.3e}")
+    _check_grads({n: p for n, p in dec.named_parameters()}, {n: Wr["mask_decoder." + n].grad for n, _ in dec.named_parameters()},
+                 rtol=1e-3, tag="decoder")
 
 
 @pytest.mark.parametrize("moe,ragged", [(True, True), (False, False)])
@@ -160,6 +177,7 @@ def test_model_forward_losses_and_grads(dev, moe, ragged):
     cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2, iou_loss_weight=0.7)
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
+    m.capture_intermediates = True
     batch = OM.make_batch(cfg, 3, ragged=ragged)
     train_keys = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
     Wr = {k: (v.clone().requires_grad_() if k in train_keys else v) for k, v in W.items()}
@@ -176,17 +194,18 @@ def test_model_forward_losses_and_grads(dev, moe, ragged):
         _stat(f"loss[{k}]", out[k], ref[k], atol=3e-2)
     out["loss"].backward()
     named = dict(m.named_parameters())
-    worst = 0.0
-    for k in train_keys:
-        p = named[k]
-        r = Wr[k].grad
-        if r is None:
-            continue
-        got = p.grad if p.grad is not None else torch.zeros_like(p)
-        e = (got.cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
-        worst = max(worst, e)
-        assert e < 0.08, f"grad {k}: rel err {e:.3e}"
-    print(f"model_forward grads: worst relative error {worst:.3e}")
+    # Gradients: a ReLU unit of text_hidden_fcs whose pre-activation sits within bf16 noise of zero switches on/off between the
+    # bf16 trunk and the fp32 oracle, which toggles whole rows of dW — so the gradient check feeds the ORACLE tail exactly the
+    # trunk outputs the HIP path produced (hidden states, SAM embedding, CE) and then demands fp32-level agreement.
+    Wr2 = {k: (v.detach().clone().requires_grad_() if k in train_keys else v) for k, v in W.items()}
+    cap = m.captured
+    ov = {"hidden": cap["last_hidden"].float().cpu(), "ce": cap["ce"].cpu()[0],
+          "image_emb": cap["image_tokens"].cpu().view(-1, 16, 16, 256).permute(0, 3, 1, 2).contiguous()}
+    ref2 = OM.model_forward(bq, Wr2, cfg, training=True, override=ov)
+    ref2["loss"].backward()
+    for k in O.LOSS_KEYS:
+        _stat(f"tail-injected loss[{k}]", out[k], ref2[k], atol=2e-4)
+    _check_grads({k: named[k] for k in train_keys}, {k: Wr2[k].grad for k in train_keys}, rtol=2e-3, tag="model_forward (same trunk outputs)")
     # inference branch: same masks, returned instead of losses (MedPLIB.py:507-511)
     gb["inference"] = True
     with torch.no_grad():
