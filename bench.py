@@ -65,7 +65,9 @@ def cpu_baseline(cfg, steps=2):
     layer are unchanged: a layer's 1.6 GB of fp32 weights do not fit in cache)."""
     from oracle import model as OM
     import copy
-    torch.set_num_threads(os.cpu_count())
+    # 32 threads is the fastest setting measured on the GPU box's 2 x EPYC 9575F (one llama layer: 0.29 s @32, 0.40 s @64,
+    # 0.61 s @128 — the oracle's eager ops stop scaling past one CCD group); `cores` reports what was used.
+    torch.set_num_threads(min(32, os.cpu_count()))
     cfg1 = copy.deepcopy(cfg)
     cfg1.num_hidden_layers = 1
     W = OM.init_hf_weights(cfg1, seed=0)
@@ -132,7 +134,9 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    loss0 = float(out["loss"]) if args.warmup else float("nan")
+    loss0 = float(out["loss"].detach()) if args.warmup else float("nan")
+    if rank == 0:
+        print(f"[bench] warm-up done, loss {loss0:.4f}", file=sys.stderr, flush=True)
 
     timer = None
     if not args.no_kernel_timer:
@@ -175,9 +179,10 @@ def main():
                        "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel},
             "model_tflops_per_gpu": round(FWD_TFLOP_PER_SAMPLE * args.batch * args.steps / dt, 1),
-            "loss_after_warmup": loss0, "loss_last": float(out["loss"]),
+            "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
             "roofline": roof,
         }
+        print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg)
