@@ -10,6 +10,7 @@
 // ds_read_b128 fragment reads are bank-conflict free), double-buffered LDS, one barrier per K-tile, next tile's
 // global loads in flight under the current tile's MFMAs.  XCD-aware block remap keeps one W panel per L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -48,6 +49,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // byte offset of 16-B chunk `c` (0..7) of row `r` in a [rows][64] bf16 LDS tile, XOR-swizzled
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
+template <bool GLDS>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [buf][A|W][128*64 bf16 = 16 KiB]
@@ -77,56 +79,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // global staging coordinates: 4 chunks of A and 4 of W per thread per tile
-  const int ld_row = tid >> 3;   // 0..31  (+32*i)
-  const int ld_c = tid & 7;      // 16-B chunk within the 64-wide K slab
-  const bf16_t* a_ptr[4];
-  const bf16_t* w_ptr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = min(m0 + ld_row + 32 * i, M - 1);
-    const int rw = min(n0 + ld_row + 32 * i, N - 1);
-    a_ptr[i] = A + (int64_t)ra * g.lda + ld_c * 8;
-    w_ptr[i] = W + (int64_t)rw * g.ldw + ld_c * 8;
-  }
-
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 ra[4], rw[4];
   const int nt = K / BK;
-
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const bf16x8*>(a_ptr[i] + (int64_t)t * BK);
-      rw[i] = *reinterpret_cast<const bf16x8*>(w_ptr[i] + (int64_t)t * BK);
-    }
-  };
-  auto lstore = [&](int buf) {
-    char* sa = sA0 + buf * 16384;
-    char* sw = sW0 + buf * 16384;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = ld_row + 32 * i;
-      *reinterpret_cast<bf16x8*>(sa + lds_off(r, ld_c)) = ra[i];
-      *reinterpret_cast<bf16x8*>(sw + lds_off(r, ld_c)) = rw[i];
-    }
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
   const int fr = lane & 15;   // fragment row (A) / col (W) within 16
   const int fq = lane >> 4;   // k-chunk selector 0..3
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) gload(t + 1);
+  auto compute = [&](int buf) {
     const char* sa = sA0 + buf * 16384;
     const char* sw = sW0 + buf * 16384;
 #pragma unroll
@@ -148,8 +111,74 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nt) lstore(buf ^ 1);
+  };
+
+  if constexpr (GLDS) {
+    // Direct global -> LDS DMA (global_load_lds_dwordx4): each wave-instruction fills 1 KiB of LDS lane-linearly, so the
+    // XOR swizzle lives on the SOURCE address: LDS chunk position p = instr*64 + lane holds (row p/8, logical chunk
+    // (p%8) ^ (row&7)) — the same image lds_off() reads.  Wave w owns instructions w*4 .. w*4+3 of each operand.
+    const int sub_row = lane >> 3;                      // 0..7 within the 8-row group of one instruction
+    const int src_c = (lane & 7) ^ sub_row;             // logical 16-B chunk this lane fetches
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + sub_row;
+      a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
+      w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
+    }
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int lbase = buf * 16384 + (wave * 4 + i) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK),
+                                         (__attribute__((address_space(3))) void*)(sA0 + lbase), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK),
+                                         (__attribute__((address_space(3))) void*)(sW0 + lbase), 16, 0, 0);
+      }
+    };
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+      __syncthreads();                       // tile t landed (vmcnt(0) + barrier); everyone is done reading buf[(t+1)&1]
+      if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+      compute(t & 1);
+    }
+  } else {
+    // register-staged variant (global -> VGPR -> ds_write_b128)
+    const int ld_row = tid >> 3;   // 0..31  (+32*i)
+    const int ld_c = tid & 7;      // 16-B chunk within the 64-wide K slab
+    const bf16_t* a_ptr[4];
+    const bf16_t* w_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_ptr[i] = A + (int64_t)min(m0 + ld_row + 32 * i, M - 1) * g.lda + ld_c * 8;
+      w_ptr[i] = W + (int64_t)min(n0 + ld_row + 32 * i, N - 1) * g.ldw + ld_c * 8;
+    }
+    bf16x8 ra[4], rw[4];
+    auto gload = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const bf16x8*>(a_ptr[i] + (int64_t)t * BK);
+        rw[i] = *reinterpret_cast<const bf16x8*>(w_ptr[i] + (int64_t)t * BK);
+      }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = ld_row + 32 * i;
+        *reinterpret_cast<bf16x8*>(sA0 + buf * 16384 + lds_off(r, ld_c)) = ra[i];
+        *reinterpret_cast<bf16x8*>(sW0 + buf * 16384 + lds_off(r, ld_c)) = rw[i];
+      }
+    };
+    gload(0);
+    lstore(0);
     __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) gload(t + 1);
+      compute(t & 1);
+      if (t + 1 < nt) lstore((t & 1) ^ 1);
+      __syncthreads();
+    }
   }
 
   // epilogue: D layout col = lane&15, row = (lane>>4)*4 + r
@@ -180,6 +209,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MP_GEMM_VARIANT");     // 1 (default) = global_load_lds staging, 0 = register staging
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  if (gemm_variant() == 1) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, grid, dim3(NT), 65536, stream, g);
+  else hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, grid, dim3(NT), 65536, stream, g);
+}
+
 // C-ABI: see include/medplib_hip.h
 extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                const float* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
@@ -196,12 +245,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0;
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles, 1), dim3(NT), 65536, stream, g);
+  launch_gemm(g, dim3(tiles, 1), stream);
   return mp_check_launch("mp_gemm_bf16_nt");
 }
 
@@ -223,11 +267,6 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = 1.f;
   g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1;
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles, batch), dim3(NT), 65536, stream, g);
+  launch_gemm(g, dim3(tiles, batch), stream);
   return mp_check_launch("mp_gemm_bf16_nt_batched");
 }
