@@ -7,6 +7,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  — MUST precede loading libmedplib_hip.so: torch brings its own libamdhip64; loading ours first
+#                              would start a second HIP runtime instance that cannot see torch's device allocations.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmedplib_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "medplib_hip.h")
