@@ -1,0 +1,255 @@
+// 256x256x64 "ping-pong" bf16 MFMA GEMM for gfx950 (large trunk GEMMs: Llama qkv / o / gate|up / down, experts).
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128x64 output tile = 8x4 fragments of
+// v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  One workgroup per CU (128 KiB LDS: 2 stages x (A 32 KiB + B 32 KiB)),
+// two waves per SIMD: waves w and w+4 share a SIMD, and the two M-halves (wave groups) run ONE BARRIER OUT OF PHASE, so on
+// every SIMD one wave is in a 16-MFMA segment while its partner is in its LDS-read / DMA-issue segment:
+//
+//   group 0:        LOAD(p) | B | MFMA(p) | B | LOAD(p+1) | B | MFMA(p+1) | B ...
+//   group 1:   B  |  LOAD(p) | B | MFMA(p) | B | LOAD(p+1) | B | MFMA(p+1) ...
+//
+// A K-tile (64 deep) is four phases = the four 64x32 quadrants of the wave tile, ordered (0,0) (0,1) (1,1) (1,0) so that
+// consecutive phases reuse either the A or the B fragments already in registers (12/4/8/4 ds_read_b128 per phase).
+// Operands arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear LDS image, XOR swizzle applied on the SOURCE address);
+// the 8 DMA instructions per wave per K-tile are issued in the LOAD segments of phases 0-2 of the previous tile and retired
+// with one counted wait (vmcnt(0)) at the end of phase 3's LOAD segment, one barrier before anybody reads that stage.
+// Hazards: RAW — vmcnt(0) by the issuing wave, then >= 1 barrier, then the ds_reads; WAR — the last reads of a stage are
+// retired (lgkmcnt(0)) before the barrier that precedes the first DMA into that stage.
+// Epilogue: accumulators -> LDS (per-wave 128x64 bf16 image) -> 16-byte row-contiguous global stores with fused
+// bias / activation / residual.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64, NT2 = 512;
+constexpr int STAGE_BYTES = 65536, OP_BYTES = 32768;
+
+__device__ __forceinline__ int lds_off2(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// raw s_barrier (no fence: a __syncthreads() would drain the in-flight LDS-DMA with vmcnt(0)); the empty asm statements are
+// compiler-only memory fences so no LDS access is moved across the barrier at IR level, sched_barrier pins the machine schedule
+#define MP_BAR()                           \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+
+__global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int batch = blockIdx.y;
+  const bf16_t* __restrict__ A = g.A + batch * g.sA;
+  const bf16_t* __restrict__ W = g.W + batch * g.sW;
+  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
+  const int N = g.N, K = g.K;
+
+  const int tiles_m = (g.M + BM2 - 1) / BM2;
+  const int tiles_n = (N + BN2 - 1) / BN2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  if (m0 >= M) return;                       // whole workgroup exits together (block-uniform)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- DMA source pointers: instruction j (0..31) of an operand covers rows 8j..8j+7; this wave issues j = wave*4 + i
+  const int sub_row = lane >> 3;
+  const int src_c = (lane & 7) ^ sub_row;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + sub_row;
+    a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
+    w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
+  }
+  auto dma_a = [&](int i, int t, int stage) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wave * 4 + i) * 1024),
+                                     16, 0, 0);
+  };
+  auto dma_w = [&](int i, int t, int stage) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024),
+                                     16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 fa[4][2];   // A fragments of the current M-quadrant: [m-frag within quadrant][kk]
+  bf16x8 fb[2][2];   // B fragments of the current N-quadrant: [n-frag within quadrant][kk]
+
+  auto load_a = [&](int qm, const char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fa[i][kk] = *reinterpret_cast<const bf16x8*>(st + lds_off2(wr * 128 + (qm * 4 + i) * 16 + fr, kk * 4 + fq));
+  };
+  auto load_b = [&](int qn, const char* st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fb[j][kk] = *reinterpret_cast<const bf16x8*>(st + OP_BYTES + lds_off2(wc * 64 + (qn * 2 + j) * 16 + fr, kk * 4 + fq));
+  };
+#define MP_MFMA_Q(QM, QN)                                                                                  \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          acc[(QM) * 4 + i][(QN) * 2 + j] =                                                                 \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], fb[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+  } while (0)
+
+  const int nt = K / BK2;
+
+  // ---- prologue: tile 0 into stage 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dma_a(i, 0, 0); dma_w(i, 0, 0); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MP_BAR();
+  if (wr == 1) MP_BAR();                     // stagger group 1 by one barrier
+
+  for (int t = 0; t < nt; ++t) {
+    const int stage = t & 1;
+    const char* st = smem + stage * STAGE_BYTES;
+    const bool more = (t + 1 < nt);
+    // ---------------- phase 0: quadrant (0,0) ----------------
+    if (more) { dma_a(0, t + 1, stage ^ 1); dma_a(1, t + 1, stage ^ 1); dma_w(0, t + 1, stage ^ 1); }
+    load_b(0, st);
+    load_a(0, st);
+    MP_BAR();
+    MP_MFMA_Q(0, 0);
+    MP_BAR();
+    // ---------------- phase 1: quadrant (0,1) ----------------
+    if (more) { dma_a(2, t + 1, stage ^ 1); dma_a(3, t + 1, stage ^ 1); dma_w(1, t + 1, stage ^ 1); }
+    load_b(1, st);
+    MP_BAR();
+    MP_MFMA_Q(0, 1);
+    MP_BAR();
+    // ---------------- phase 2: quadrant (1,1) ----------------
+    if (more) { dma_w(2, t + 1, stage ^ 1); dma_w(3, t + 1, stage ^ 1); }
+    load_a(1, st);
+    MP_BAR();
+    MP_MFMA_Q(1, 1);
+    MP_BAR();
+    // ---------------- phase 3: quadrant (1,0) ----------------
+    load_b(0, st);
+    // retire this tile's last LDS reads (WAR vs the DMA into this stage two phases from now) and the next tile's DMA
+    // (RAW: landed before the barrier that precedes its first read)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MP_BAR();
+    MP_MFMA_Q(1, 0);
+    MP_BAR();
+  }
+  if (wr == 0) MP_BAR();                     // balance the stagger barrier of group 1
+
+  // ---------------- epilogue ----------------
+  // per-wave 128x64 bf16 image in LDS (row stride 144 B = 128 + 16 pad -> conflict-light 2-byte writes and 16-byte reads)
+  constexpr int EP_LD = 144;
+  const bool via_lds = !g.out_f32;
+  if (via_lds) {
+    char* ep = smem + wave * 16384;          // this wave's 16 KiB slice; two halves of 64 rows x 144 B = 9216 B each
+    const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
+    float bias_v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + fr;
+      bias_v[j] = (bias0 && col < N) ? bias0[col] : 0.f;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = half * 4 + ii;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<bf16_t*>(ep + (ii * 16 + fq * 4 + r) * EP_LD + (j * 16 + fr) * 2) =
+                (bf16_t)apply_act(acc[i][j][r] * g.alpha + bias_v[j], g.act);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // 64 rows x 128 B: lane handles row (it*8 + lane/8), 16-B chunk lane%8; bias and activation are already applied
+      const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
+        const int row = m0 + wr * 128 + half * 64 + lr;
+        const int col = n0 + wc * 64 + lc;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + lc * 2);
+        if (row < M && col < N) {
+          if (col + 8 <= N && ((g.ldc & 7) == 0) && (!R || (g.ldr & 7) == 0)) {
+            if (R) {
+              const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = v;
+          } else {
+            for (int e = 0; e < 8 && col + e < N; ++e) {
+              float f = (float)v[e];
+              if (R) f += (float)R[(int64_t)row * g.ldr + col + e];
+              Cb[(int64_t)row * g.ldc + col + e] = (bf16_t)f;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
+    const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
+    float* Cf = reinterpret_cast<float*>(g.C) + batch * g.sC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + fr;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wr * 128 + i * 16 + fq * 4 + r;
+          if (row >= M) continue;
+          float v = apply_act(acc[i][j][r] * g.alpha + bv, g.act);
+          if (R) v += (float)R[(int64_t)row * g.ldr + col];
+          Cf[(int64_t)row * g.ldc + col] = v;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    attr_set = true;
+  }
+  const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
+  hipLaunchKernelGGL(gemm256_bf16_nt_kernel, dim3(tiles, batch), dim3(NT2), 2 * STAGE_BYTES, stream, g);
+  return mp_check_launch("mp_gemm_bf16_nt(256)");
+}

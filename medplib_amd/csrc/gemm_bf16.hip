@@ -10,41 +10,13 @@
 // ds_read_b128 fragment reads are bank-conflict free), double-buffered LDS, one barrier per K-tile, next tile's
 // global loads in flight under the current tile's MFMAs.  XCD-aware block remap keeps one W panel per L2.
 #include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NT = 256;
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
-
-struct GemmArgs {
-  const bf16_t* A;  int64_t lda;
-  const bf16_t* W;  int64_t ldw;
-  void* C;          int64_t ldc;
-  const float* bias;          // [N] or null
-  const bf16_t* residual;     // [M,N] (ldr) or null, added after activation
-  int64_t ldr;
-  const int* m_dev;           // optional device-side row count (overrides M when non-null)
-  int M, N, K;
-  int act;
-  int out_f32;
-  float alpha;                // scale applied to the accumulator before bias
-  // batching (blockIdx.y): element strides
-  int64_t sA, sW, sC, sR, sBias;
-  int m_dev_stride;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_GELU: return gelu_erf(v);
-    case ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));
-    case ACT_SILU: return v / (1.f + __expf(-v));
-    default: return v;
-  }
-}
 
 // byte offset of 16-B chunk `c` (0..7) of row `r` in a [rows][64] bf16 LDS tile, XOR-swizzled
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
@@ -212,10 +184,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("MP_GEMM_VARIANT");     // 1 (default) = global_load_lds staging, 0 = register staging
-    v = (e && e[0] == '0') ? 0 : 1;
+    // 2 (default) = auto: 256x256 ping-pong kernel for large problems, 128x128 LDS-DMA kernel otherwise;
+    // 1 = always 128x128 LDS-DMA staging; 0 = 128x128 register staging (A/B reference)
+    const char* e = getenv("MP_GEMM_VARIANT");
+    v = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 2;
   }
   return v;
+}
+
+static bool use_256(const GemmArgs& g, int batch) {
+  if (gemm_variant() != 2) return false;
+  const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
+  return g.M >= 1024 && g.N >= 1024 && tiles >= 128;
 }
 
 static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
@@ -225,7 +205,7 @@ static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_set = true;
   }
-  if (gemm_variant() == 1) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, grid, dim3(NT), 65536, stream, g);
+  if (gemm_variant() >= 1) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, grid, dim3(NT), 65536, stream, g);
   else hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, grid, dim3(NT), 65536, stream, g);
 }
 
@@ -244,6 +224,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0;
+  if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, 1), stream);
   return mp_check_launch("mp_gemm_bf16_nt");
@@ -266,6 +247,7 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   g.bias = bias; g.residual = nullptr; g.ldr = 0; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = 1.f;
   g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1;
+  if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);
   return mp_check_launch("mp_gemm_bf16_nt_batched");

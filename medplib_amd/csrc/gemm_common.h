@@ -1,0 +1,37 @@
+// Shared argument block and epilogue helpers of the bf16 MFMA GEMM kernels (gemm_bf16.hip: 128x128 tiles,
+// gemm256_bf16.hip: 256x256 ping-pong tiles).
+#pragma once
+#include "common.h"
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
+
+struct GemmArgs {
+  const bf16_t* A;  int64_t lda;
+  const bf16_t* W;  int64_t ldw;
+  void* C;          int64_t ldc;
+  const float* bias;          // [N] or null
+  const bf16_t* residual;     // [M,N] (ldr) or null, added after activation
+  int64_t ldr;
+  const int* m_dev;           // optional device-side row count (overrides M when non-null)
+  int M, N, K;
+  int act;
+  int out_f32;
+  float alpha;                // scale applied to the accumulator before bias
+  // batching (blockIdx.y): element strides
+  int64_t sA, sW, sC, sR, sBias;
+  int m_dev_stride;
+};
+
+static __device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_GELU: return gelu_erf(v);
+    case ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));
+    case ACT_SILU: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+
+// implemented in gemm256_bf16.hip
+int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream);

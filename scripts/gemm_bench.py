@@ -38,5 +38,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         run_variant(os.environ.get("MP_GEMM_VARIANT", "1"))
     else:
-        for v in (sys.argv[1:] or ["0", "1"]):
+        for v in (sys.argv[1:] or ["1", "2"]):
             subprocess.run([sys.executable, __file__, "--child"], env=dict(os.environ, MP_GEMM_VARIANT=v))

@@ -155,3 +155,40 @@ def test_rope_swiglu_misc(dev):
     xb = _bf(torch.randn(5, 16, 24, generator=g)); pos = _bf(torch.randn(16, 24, generator=g))
     _report("add_rows", ops.add_rows(xb.to(dev), pos.to(dev)), xb.float() + pos.float(), rtol=BF16_EPS, atol=1e-3)
     _report("add3", ops.add3(xb.to(dev), xb.to(dev), xb.to(dev)), 3 * xb.float(), rtol=BF16_EPS, atol=1e-3)
+
+
+def test_gemm_256_pingpong_kernel(dev):
+    """Shapes large enough for the auto heuristic to pick the 256x256 ping-pong kernel: ragged M / N edges, fused epilogues,
+    fp32 output, unaligned ldc, batched experts with device-side row counts.  Two runs must be bit-identical (race screen)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for (M, N, K) in [(2048, 4096, 512), (1279, 6144, 1024), (5112, 4096, 4096)]:
+        a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.05)
+        ref = O.linear(a.float(), w.float())
+        ad, wd = a.to(dev), w.to(dev)
+        out = ops.gemm(ad, wd)
+        _report(f"gemm256 {M}x{N}x{K}", out, ref, rtol=2 * BF16_EPS, atol=1e-3 * math.sqrt(K))
+        for _ in range(3):
+            assert torch.equal(ops.gemm(ad, wd), out), "non-deterministic result: LDS race in the ping-pong schedule"
+    M, N, K = 1500, 2056, 256
+    a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g); res = _bf(torch.randn(M, N, generator=g))
+    base = O.linear(a.float(), w.float(), bias)
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_GELU, torch.nn.functional.gelu), (ops.ACT_SILU, torch.nn.functional.silu)):
+        out = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), act=act)
+        # act(x) is rounded to bf16 before the residual add (HF's own order): 2 roundings -> 3 ulps
+        _report(f"gemm256 epilogue act={act}", out, fn(base) + res.float(), rtol=3 * BF16_EPS, atol=3e-2)
+    out = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), out_dtype=torch.float32, alpha=0.5)
+    _report("gemm256 f32 out", out, 0.5 * O.linear(a.float(), w.float()) + bias, rtol=1e-4, atol=1e-3)
+    N2 = 2051                                             # ldc not a multiple of 8 -> scalar store path
+    w2 = _bf(torch.randn(N2, K, generator=g) * 0.1)
+    _report("gemm256 odd N", ops.gemm(a.to(dev), w2.to(dev)), O.linear(a.float(), w2.float()), rtol=2 * BF16_EPS, atol=2e-2)
+    E, cap, N, K = 2, 1400, 2048, 512
+    ab = _bf(torch.randn(E, cap, K, generator=g)); wb = _bf(torch.randn(E, N, K, generator=g) * 0.05)
+    counts = torch.tensor([1400, 513], dtype=torch.int32)
+    outb = torch.zeros(E, cap, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm_batched(ab.to(dev), wb.to(dev), outb, m_dev=counts.to(dev))
+    for e in range(E):
+        c = int(counts[e])
+        _report(f"gemm256 expert {e}", outb[e, :c], ab[e, :c].float() @ wb[e].float().T, rtol=2 * BF16_EPS, atol=2e-2)
+        assert (outb[e, c:].float() == 0).all()
