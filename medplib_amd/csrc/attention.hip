@@ -87,27 +87,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const float* relh = a.rel_h ? a.rel_h + (int64_t)bh * a.Sq * a.kh : nullptr;
   const float* relw = a.rel_w ? a.rel_w + (int64_t)bh * a.Sq * a.kw : nullptr;
 
+  // K/V tiles travel global -> registers -> LDS; the loads for tile t+1 are issued right after tile t has been written
+  // to LDS, so their latency is covered by the QK^T / softmax / PV work of tile t.
+  constexpr int NCH = (KT * CH) / 256;     // 16-B chunks per thread per operand per tile
+  bf16x8 kreg[NCH], vreg[NCH];
+  auto gload = [&](int t) {
+    const int k0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      const int r = id / CH, c = id % CH;
+      const int kr = min(k0 + r, a.Sk - 1);
+      kreg[i] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)kr * a.k_ss + c * 8);
+      vreg[i] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)kr * a.v_ss + c * 8);
+    }
+  };
+  gload(0);
+
   for (int t = 0; t < n_tiles; ++t) {
     const int k0 = t * KT;
     __syncthreads();  // previous tile's LDS reads complete
     // ---- stage K and V tiles ----
 #pragma unroll
-    for (int i = 0; i < (KT * CH) / 256; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int id = tid + i * 256;
       const int r = id / CH, c = id % CH;
-      const int kr = min(k0 + r, a.Sk - 1);
-      const bf16x8 kvv = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)kr * a.k_ss + c * 8);
-      *reinterpret_cast<bf16x8*>(sK + k_off<D>(r, c)) = kvv;
-      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)kr * a.v_ss + c * 8);
+      *reinterpret_cast<bf16x8*>(sK + k_off<D>(r, c)) = kreg[i];
       if constexpr (VT_SCALAR) {
         bf16_t* vt = reinterpret_cast<bf16_t*>(sV);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * VT_LD + r] = vv[j];
+        for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * VT_LD + r] = vreg[i][j];
       } else {
-        *reinterpret_cast<bf16x8*>(sV + r * (D * 2) + c * 16) = vv;
+        *reinterpret_cast<bf16x8*>(sV + r * (D * 2) + c * 16) = vreg[i];
       }
     }
     __syncthreads();
+    if (t + 1 < n_tiles) gload(t + 1);
 
     // ---- S = Q K^T (16 q rows x 64 keys per wave) ----
     f32x4 s[4];
@@ -172,7 +187,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) pw[(fq * 4 + r) * KT + n * 16 + fr] = (bf16_t)s[n][r];
-    __syncthreads();
+    // sP[wave] is written and read by this wave only: DS operations of one wave execute in order, a compiler fence suffices
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // ---- O += P V : A = P[16 x 64 keys], B = V[keys x D] ----
 #pragma unroll

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
                                                               long long* __restrict__ exp_counts, float* __restrict__ l_aux) {
   __shared__ float red[16];
   __shared__ int cnt_sh[MAXE];
-  __shared__ int scan[1024][MAXE];   // 32 KiB
+  __shared__ int scan[16][MAXE];     // per-wave kept totals
   const int tid = threadIdx.x;
   if (tid < MAXE) cnt_sh[tid] = 0;
   __syncthreads();
@@ -144,9 +144,11 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     slot[s] = keep;
   }
   __syncthreads();
-  // exclusive scan of kept tokens per expert in token order: thread `tid` owns a contiguous chunk
+  // exclusive scan of kept tokens per expert in token order: thread `tid` owns a contiguous chunk; wave-level shuffle scan of
+  // the per-thread totals, then the 16 wave totals are combined through LDS
   const int chunk = (T + 1023) / 1024;
   const int s0 = tid * chunk, s1 = min(T, s0 + chunk);
+  const int lane = tid & 63, wv = tid >> 6;
   int loc[MAXE];
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) loc[e] = 0;
@@ -156,22 +158,26 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
 #pragma unroll
       for (int k = 0; k < MAXE; ++k) if (k == e) loc[k] += 1;
     }
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) scan[tid][e] = loc[e];
-  __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 per-thread totals (per expert)
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v[MAXE];
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) v[e] = (tid >= off) ? scan[tid - off][e] : 0;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) scan[tid][e] += v[e];
-    __syncthreads();
-  }
   int base[MAXE];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) base[e] = scan[tid][e] - loc[e];
+  for (int e = 0; e < MAXE; ++e) {
+    base[e] = 0;
+    if (e < E) {
+      int v = loc[e];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+      }
+      if (lane == 63) scan[wv][e] = v;        // wave total
+      base[e] = v - loc[e];                   // exclusive prefix within the wave
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e)
+    if (e < E)
+      for (int w = 0; w < wv; ++w) base[e] += scan[w][e];
   for (int s = s0; s < s1; ++s) {
     if (slot[s]) {
       const int e = expert[s];
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     }
   }
   if (tid == 1023)
-    for (int e = 0; e < E; ++e) kept_counts[e] = scan[1023][e];
+    for (int e = 0; e < E; ++e) kept_counts[e] = base[e];
 }
 
 // buf[expert[s], slot[s], :] = x[s, :]

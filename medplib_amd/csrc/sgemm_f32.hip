@@ -45,25 +45,39 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
     if (kbeg >= kend) return;
   }
   float acc[4][4] = {};
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // stage A tile as sA[k][m], B tile as sB[k][n]
+  // global -> register prefetch of the NEXT K-slab overlaps the FMA loop on the current one
+  float ra[4], rb[4];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int id = tid + i * 256;  // 0..1023
       int m, k;
       if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & 15; m = id >> 4; }
       const int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < g.M && gk < kend) v = g.transA ? A[(int64_t)gk * g.lda + gm] : A[(int64_t)gm * g.lda + gk];
-      sA[k][m] = v;
+      ra[i] = (gm < g.M && gk < kend) ? (g.transA ? A[(int64_t)gk * g.lda + gm] : A[(int64_t)gm * g.lda + gk]) : 0.f;
       int n, kb;
       if (g.transB) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
       const int gn = n0 + n, gkb = k0 + kb;
-      float w = 0.f;
-      if (gn < g.N && gkb < kend) w = g.transB ? B[(int64_t)gn * g.ldb + gkb] : B[(int64_t)gkb * g.ldb + gn];
-      sB[kb][n] = w;
+      rb[i] = (gn < g.N && gkb < kend) ? (g.transB ? B[(int64_t)gn * g.ldb + gkb] : B[(int64_t)gkb * g.ldb + gn]) : 0.f;
     }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + i * 256;
+      int m, k;
+      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & 15; m = id >> 4; }
+      sA[k][m] = ra[i];
+      int n, kb;
+      if (g.transB) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      sB[kb][n] = rb[i];
+    }
+  };
+  if (kbeg < kend) gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    lstore();
     __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
       float a[4], b[4];

@@ -205,6 +205,24 @@ def sgemm(a, b, trans_a=False, trans_b=False, bias=None, act=SACT_NONE, alpha=1.
     bk, bn = (b.shape[-1], b.shape[-2]) if trans_b else (b.shape[-2], b.shape[-1])
     assert ak == bk, f"sgemm: inner dims differ {ak} vs {bk}"
     batch = tuple(a.shape[:nb])
+    if (nb == 0 and out is None and beta == 0.0 and split_k == 1 and ak >= 512 and act != SACT_SIGMOID
+            and -(-am // 64) * -(-bn // 64) <= 64):
+        # skinny problem with a long K: deterministic split-K — the K chunks run as a batched GEMM into [splits, M, N]
+        # partials (one launch, `splits` x more workgroups), then a fixed-order column sum (+ bias, activation)
+        splits = next((sp for sp in (16, 8, 4, 2) if ak % sp == 0 and (ak // sp) % 16 == 0 and ak // sp >= 128), 1)
+        if splits > 1:
+            chunk = ak // splits
+            ws = torch.empty((splits, am, bn), dtype=torch.float32, device=a.device)
+            sa = chunk * a.stride(-2) if trans_a else chunk
+            sb = chunk if trans_b else chunk * b.stride(-2)
+            lib().call("mp_sgemm_f32", _p(a), a.stride(-2), int(trans_a), _p(b), b.stride(-2), int(trans_b), _p(ws), bn, None,
+                       am, bn, chunk, float(alpha), 0.0, SACT_NONE, splits, 1, sa, 0, sb, 0, am * bn, 0, 1, _stream())
+            res = colsum_f32(ws.view(splits, am * bn)).view(am, bn)
+            if bias is not None:
+                res = add_f32(res, bias)
+            if act != SACT_NONE:
+                res = act_fwd_f32(res, act)
+            return res
     if out is None:
         out = torch.empty(batch + (am, bn), dtype=torch.float32, device=a.device)
         assert beta == 0.0
