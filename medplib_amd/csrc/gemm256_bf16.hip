@@ -45,15 +45,25 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
   const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
   const int N = g.N, K = g.K;
 
-  const int tiles_m = (g.M + BM2 - 1) / BM2;
+  // tile space from the EFFECTIVE row count (device-side expert counts): surplus workgroups of the capacity-sized grid exit
+  // here, and the XCD remap below stays balanced over the tiles that really exist
+  const int tiles_m = (M + BM2 - 1) / BM2;
   const int tiles_n = (N + BN2 - 1) / BN2;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (bid >= nwg) return;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  // grouped order: ids walk GROUP_M consecutive M-tiles before stepping N, so the ~32-64 workgroups that are co-resident on
+  // one XCD cover a GROUP_M x (32/GROUP_M) block of tiles and share both their A and their W panels through that XCD's L2
+  const int GROUP_M = g.group_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = bid / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
   const int m0 = tm * BM2, n0 = tn * BN2;
   if (m0 >= M) return;                       // whole workgroup exits together (block-uniform)
 

@@ -43,7 +43,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  // grouped order: ids walk GROUP_M consecutive M-tiles before stepping N, so the ~32-64 workgroups that are co-resident on
+  // one XCD cover a GROUP_M x (32/GROUP_M) block of tiles and share both their A and their W panels through that XCD's L2
+  const int GROUP_M = g.group_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = bid / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
   if (m0 >= M) return;
 
@@ -192,6 +199,15 @@ static int gemm_variant() {
   return v;
 }
 
+static int gemm_group_m() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MP_GEMM_GROUP_M");
+    v = (e && atoi(e) >= 1) ? atoi(e) : 4;
+  }
+  return v;
+}
+
 static bool use_256(const GemmArgs& g, int batch) {
   if (gemm_variant() != 2) return false;
   const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
@@ -223,7 +239,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
   g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
-  g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0;
+  g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, 1), stream);
@@ -246,7 +262,7 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
   g.bias = bias; g.residual = nullptr; g.ldr = 0; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = 1.f;
-  g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1;
+  g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1; g.group_m = gemm_group_m();
   if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);

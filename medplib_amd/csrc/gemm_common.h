@@ -20,6 +20,7 @@ struct GemmArgs {
   // batching (blockIdx.y): element strides
   int64_t sA, sW, sC, sR, sBias;
   int m_dev_stride;
+  int group_m;                // M-tiles per group in the L2-friendly tile order (1 = plain column-major order)
 };
 
 static __device__ __forceinline__ float apply_act(float v, int act) {
