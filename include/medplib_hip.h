@@ -37,6 +37,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define MP_ACT_GELU 2
 #define MP_ACT_QUICK_GELU 3
 #define MP_ACT_SILU 4
+/* fused SwiGLU epilogue: W rows = gate/up interleaved in blocks of 32; C = silu(gate)*up is [M, N/2] (LlamaMLP) */
+#define MP_ACT_SWIGLU_PAIR 5
 
 int mp_version(void);
 const char* mp_arch(void);

@@ -128,18 +128,18 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     const int e = expert[s];
     int keep = 1;
     if (cnt_sh[e] > capacity) {
-      int rank = 0;
       if (rts) {
+        int rank = 0;
         const float u = rts[(int64_t)s * E + e];
         for (int t = 0; t < T; ++t) {
           if (expert[t] != e) continue;
           const float ut = rts[(int64_t)t * E + e];
           rank += (ut > u) || (ut == u && t < s);
         }
-      } else {
-        for (int t = 0; t < s; ++t) rank += (expert[t] == e);
+        keep = rank < capacity;
       }
-      keep = rank < capacity;
+      // without RTS draws the selection is first-come: rank == the token-order prefix count computed by the scan below, so
+      // every token stays flagged here and the slots >= capacity are dropped after the scan (no O(T^2) pass)
     }
     slot[s] = keep;
   }
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
       int v = 0;
 #pragma unroll
       for (int k = 0; k < MAXE; ++k) if (k == e) { v = base[k]; base[k] += 1; }
-      slot[s] = v;
+      slot[s] = (v < capacity) ? v : -1;
     } else {
       slot[s] = -1;
     }
   }
   if (tid == 1023)
-    for (int e = 0; e < E; ++e) kept_counts[e] = base[e];
+    for (int e = 0; e < E; ++e) kept_counts[e] = min(base[e], capacity);
 }
 
 // buf[expert[s], slot[s], :] = x[s, :]

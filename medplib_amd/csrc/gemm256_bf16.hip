@@ -176,6 +176,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
   // per-wave 128x64 bf16 image in LDS (row stride 144 B = 128 + 16 pad -> conflict-light 2-byte writes and 16-byte reads)
   constexpr int EP_LD = 144;
   const bool via_lds = !g.out_f32;
+  const bool swiglu = (g.act == ACT_SWIGLU_PAIR);
   if (via_lds) {
     char* ep = smem + wave * 16384;          // this wave's 16 KiB slice; two halves of 64 rows x 144 B = 9216 B each
     const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
@@ -195,13 +196,37 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             *reinterpret_cast<bf16_t*>(ep + (ii * 16 + fq * 4 + r) * EP_LD + (j * 16 + fr) * 2) =
-                (bf16_t)apply_act(acc[i][j][r] * g.alpha + bias_v[j], g.act);
+                (bf16_t)apply_act(acc[i][j][r] * g.alpha + bias_v[j], swiglu ? ACT_NONE : g.act);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // 64 rows x 128 B: lane handles row (it*8 + lane/8), 16-B chunk lane%8; bias and activation are already applied
       const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
       bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
+      if (swiglu) {
+        // this wave's 64 columns are [gate c0..c0+31 | up c0..c0+31]: out[row, c0 + q*8 .. +8] = silu(gate) * up
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 64 + lane;
+          const int lr = idx >> 2, q = idx & 3;
+          const int row = m0 + wr * 128 + half * 64 + lr;
+          const int col = ((n0 + wc * 64) >> 1) + q * 8;
+          const bf16x8 gv = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + q * 16);
+          const bf16x8 uv = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + 64 + q * 16);
+          if (row < M && col + 8 <= (N >> 1)) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gf = (float)gv[e];
+              o[e] = (bf16_t)(gf / (1.f + __expf(-gf)) * (float)uv[e]);
+            }
+            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = o;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;

@@ -209,6 +209,7 @@ static int gemm_group_m() {
 }
 
 static bool use_256(const GemmArgs& g, int batch) {
+  if (g.act == ACT_SWIGLU_PAIR) return true;          // the paired epilogue exists in the 256x256 kernel only
   if (gemm_variant() != 2) return false;
   const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
   return g.M >= 1024 && g.N >= 1024 && tiles >= 128;
@@ -233,7 +234,9 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   MP_REQUIRE(K % BK == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt: K=%d must be a multiple of %d (pad on the host)", K, BK);
   MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt: lda/ldw must be multiples of 8");
   MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemm_bf16_nt: bad out dtype %d", out_dtype);
-  MP_REQUIRE(act >= 0 && act <= 4, MP_ERR_ARG, "mp_gemm_bf16_nt: bad activation %d", act);
+  MP_REQUIRE(act >= 0 && act <= 5, MP_ERR_ARG, "mp_gemm_bf16_nt: bad activation %d", act);
+  MP_REQUIRE(act != ACT_SWIGLU_PAIR || (N % 64 == 0 && out_dtype == MP_BF16 && residual == nullptr && ldc % 8 == 0), MP_ERR_ARG,
+             "mp_gemm_bf16_nt: SWIGLU_PAIR needs N %% 64 == 0, bf16 output [M, N/2] with ldc %% 8 == 0 and no residual");
   if (M == 0) return MP_OK;
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
@@ -257,6 +260,9 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0, MP_ERR_SHAPE,
              "mp_gemm_bf16_nt_batched: strides must be multiples of 8");
   MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemm_bf16_nt_batched: bad out dtype");
+  MP_REQUIRE(act >= 0 && act <= 5, MP_ERR_ARG, "mp_gemm_bf16_nt_batched: bad activation %d", act);
+  MP_REQUIRE(act != ACT_SWIGLU_PAIR || (N % 64 == 0 && out_dtype == MP_BF16 && ldc % 8 == 0), MP_ERR_ARG,
+             "mp_gemm_bf16_nt_batched: SWIGLU_PAIR needs N %% 64 == 0 and a bf16 [M, N/2] output");
   if (M == 0) return MP_OK;
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;

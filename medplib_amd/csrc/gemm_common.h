@@ -3,7 +3,10 @@
 #pragma once
 #include "common.h"
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4,
+       // fused SwiGLU: W holds gate/up rows interleaved in blocks of 32 ([g0..31 | u0..31 | g32..63 | u32..63 | ...]); the epilogue
+       // writes silu(gate) * up, so C is [M, N/2] (256x256 kernel only)
+       ACT_SWIGLU_PAIR = 5 };
 
 struct GemmArgs {
   const bf16_t* A;  int64_t lda;

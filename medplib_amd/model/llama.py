@@ -3,7 +3,8 @@
 Mirrors `MoELlamaModel_forward` / `MoELlamaDecoderLayer_forward` (model/medplib/model/language_model/
 medplib_moe_llama.py:110-305) and HF-4.31 LlamaAttention/LlamaMLP/LlamaRMSNorm:
     x = x + o_proj(attn(rope(q), rope(k), v));  x = x + mlp(rmsnorm(x))   with mlp = SwiGLU or MoE(top-1 experts).
-Weights are held in kernel layout (fused qkv [3d,d], fused gate|up [2ff,d], experts stacked [E,...]) and are
+Weights are held in kernel layout (fused qkv [3d,d], gate/up fused [2ff,d] with rows interleaved in blocks of 32 for the
+SwiGLU-in-epilogue GEMM, experts stacked [E,...]) and are
 imported from / exported to the HF checkpoint key layout by load_hf / export_hf."""
 import math
 
@@ -68,12 +69,10 @@ class LlamaStack:
                 put(lw["wg"], sd[p + "mlp.deepspeed_moe.gate.wg.weight"])
                 for e in range(cfg.num_experts):
                     ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
-                    put(lw["gu"][e, :ff], sd[ep + "gate_proj.weight"])
-                    put(lw["gu"][e, ff:], sd[ep + "up_proj.weight"])
+                    put(lw["gu"][e], ops.swiglu_interleave(sd[ep + "gate_proj.weight"], sd[ep + "up_proj.weight"]))
                     put(lw["down"][e], sd[ep + "down_proj.weight"])
             else:
-                put(lw["gu"][:ff], sd[p + "mlp.gate_proj.weight"])
-                put(lw["gu"][ff:], sd[p + "mlp.up_proj.weight"])
+                put(lw["gu"], ops.swiglu_interleave(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
                 put(lw["down"], sd[p + "mlp.down_proj.weight"])
 
     def export_hf(self, prefix=""):
@@ -93,12 +92,10 @@ class LlamaStack:
                 sd[p + "mlp.deepspeed_moe.gate.wg.weight"] = lw["wg"]
                 for e in range(cfg.num_experts):
                     ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
-                    sd[ep + "gate_proj.weight"] = lw["gu"][e, :ff]
-                    sd[ep + "up_proj.weight"] = lw["gu"][e, ff:]
+                    sd[ep + "gate_proj.weight"], sd[ep + "up_proj.weight"] = ops.swiglu_deinterleave(lw["gu"][e])
                     sd[ep + "down_proj.weight"] = lw["down"][e]
             else:
-                sd[p + "mlp.gate_proj.weight"] = lw["gu"][:ff]
-                sd[p + "mlp.up_proj.weight"] = lw["gu"][ff:]
+                sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = ops.swiglu_deinterleave(lw["gu"])
                 sd[p + "mlp.down_proj.weight"] = lw["down"]
         return sd
 
@@ -114,7 +111,7 @@ class LlamaStack:
         cfg = self.cfg
         T = h.shape[0]
         if i not in self.moe_layers:
-            act = ops.swiglu(ops.gemm(h, lw["gu"]))
+            act = ops.gemm(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR)       # silu(gate)*up fused into the GEMM epilogue
             return ops.gemm(act, lw["down"], residual=x), None, None
         E, ff, d = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
         cap = self.capacity(T)
@@ -122,11 +119,10 @@ class LlamaStack:
         rts = self.rts_uniform_provider(i, T, E) if self.rts_uniform_provider is not None else None
         expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, rts)
         buf = ops.moe_dispatch(h, expert, slot, E, cap)
-        gu = torch.empty((E, cap, 2 * ff), dtype=torch.bfloat16, device=h.device)
+        act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
         if ops.GEMM_TIMER is not None:
             ops.GEMM_TIMER.batched_rows = T      # algorithmic rows of the expert GEMMs: every token visits one expert
-        ops.gemm_batched(buf, lw["gu"], gu, m_dev=kept)
-        act = ops.swiglu(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
+        ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
         y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
         ops.gemm_batched(act, lw["down"], y, m_dev=kept)
         out = ops.moe_combine(y, expert, slot, weight, x, cap)

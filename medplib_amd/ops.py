@@ -7,7 +7,7 @@ import torch
 from ._lib import lib
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICK_GELU, ACT_SILU, ACT_SWIGLU_PAIR = 0, 1, 2, 3, 4, 5
 SACT_NONE, SACT_RELU, SACT_GELU, SACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -63,9 +63,10 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU_PAIR else N
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    assert out.stride(1) == 1 and out.shape == (M, N)
+        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape == (M, n_out)
     if bias is not None:
         _chk(bias, torch.float32, "gemm.bias")
     if residual is not None:
@@ -148,6 +149,20 @@ def rope_qk_(qkv, cos_t, sin_t, seq, heads, head_dim):
     assert cos_t.shape[0] >= seq and cos_t.shape[1] == head_dim // 2
     lib().call("mp_rope_qk_bf16", _p(qkv), qkv.stride(0), _p(cos_t), _p(sin_t), qkv.shape[0], seq, heads, head_dim, _stream())
     return qkv
+
+
+def swiglu_interleave(gate, up):
+    """Pack gate/up projection weights [ff, d] into the row order the SWIGLU_PAIR epilogue expects: blocks of 32 gate rows
+    followed by the 32 matching up rows.  (Pure data movement.)"""
+    ff, d = gate.shape
+    assert ff % 32 == 0 and up.shape == gate.shape
+    return torch.stack([gate.view(ff // 32, 32, d), up.view(ff // 32, 32, d)], 1).reshape(2 * ff, d)
+
+
+def swiglu_deinterleave(gu):
+    two_ff, d = gu.shape
+    v = gu.view(two_ff // 64, 2, 32, d)
+    return v[:, 0].reshape(two_ff // 2, d), v[:, 1].reshape(two_ff // 2, d)
 
 
 def swiglu(gu, out=None):

@@ -192,3 +192,33 @@ def test_gemm_256_pingpong_kernel(dev):
         c = int(counts[e])
         _report(f"gemm256 expert {e}", outb[e, :c], ab[e, :c].float() @ wb[e].float().T, rtol=2 * BF16_EPS, atol=2e-2)
         assert (outb[e, c:].float() == 0).all()
+
+
+def test_gemm_swiglu_pair_epilogue(dev):
+    """LlamaMLP gate/up GEMM with silu(gate)*up fused into the epilogue (weights interleaved in blocks of 32), dense and
+    batched-expert forms; must equal the unfused GEMM + SwiGLU kernel bit for bit (same bf16 rounding points)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (M, ff, K) in [(300, 320, 256), (1500, 1024, 512)]:
+        a = _bf(torch.randn(M, K, generator=g)); wg = _bf(torch.randn(ff, K, generator=g) * 0.1); wu = _bf(torch.randn(ff, K, generator=g) * 0.1)
+        ref = O.swiglu(O.linear(a.float(), wg.float()), O.linear(a.float(), wu.float()))
+        wi = ops.swiglu_interleave(wg.to(dev), wu.to(dev))
+        g2, u2 = ops.swiglu_deinterleave(wi)
+        assert torch.equal(g2.cpu(), wg) and torch.equal(u2.cpu(), wu)
+        out = ops.gemm(a.to(dev), wi, act=ops.ACT_SWIGLU_PAIR)
+        assert out.shape == (M, ff)
+        _report(f"swiglu-pair gemm {M}x{ff}x{K}", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
+        unfused = ops.swiglu(ops.gemm(a.to(dev), torch.cat([wg, wu]).to(dev)))
+        assert torch.equal(out, unfused), "fused and unfused SwiGLU must round identically"
+    E, cap, ff, K = 2, 700, 512, 256
+    ab = _bf(torch.randn(E, cap, K, generator=g))
+    wgs = _bf(torch.randn(E, ff, K, generator=g) * 0.1); wus = _bf(torch.randn(E, ff, K, generator=g) * 0.1)
+    wi = torch.stack([ops.swiglu_interleave(wgs[e].to(dev), wus[e].to(dev)) for e in range(E)])
+    counts = torch.tensor([700, 301], dtype=torch.int32)
+    out = torch.zeros(E, cap, ff, dtype=torch.bfloat16, device=dev)
+    ops.gemm_batched(ab.to(dev), wi, out, m_dev=counts.to(dev), act=ops.ACT_SWIGLU_PAIR)
+    for e in range(E):
+        c = int(counts[e])
+        ref = O.swiglu(ab[e, :c].float() @ wgs[e].float().T, ab[e, :c].float() @ wus[e].float().T)
+        _report(f"swiglu-pair expert {e}", out[e, :c], ref, rtol=3 * BF16_EPS, atol=2e-2)
+        assert (out[e, c:].float() == 0).all()
