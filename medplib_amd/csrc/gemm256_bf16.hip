@@ -18,6 +18,7 @@
 // Epilogue: accumulators -> LDS (per-wave 128x64 bf16 image) -> 16-byte row-contiguous global stores with fused
 // bias / activation / residual.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,148 +38,15 @@ __device__ __forceinline__ int lds_off2(int r, int c) { return r * 128 + ((c ^ (
     asm volatile("" ::: "memory");         \
   } while (0)
 
-__global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int batch = blockIdx.y;
-  const bf16_t* __restrict__ A = g.A + batch * g.sA;
-  const bf16_t* __restrict__ W = g.W + batch * g.sW;
-  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
-  const int N = g.N, K = g.K;
-
-  // tile space from the EFFECTIVE row count (device-side expert counts): surplus workgroups of the capacity-sized grid exit
-  // here, and the XCD remap below stays balanced over the tiles that really exist
-  const int tiles_m = (M + BM2 - 1) / BM2;
-  const int tiles_n = (N + BN2 - 1) / BN2;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (bid >= nwg) return;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  // grouped order: ids walk GROUP_M consecutive M-tiles before stepping N, so the ~32-64 workgroups that are co-resident on
-  // one XCD cover a GROUP_M x (32/GROUP_M) block of tiles and share both their A and their W panels through that XCD's L2
-  const int GROUP_M = g.group_m;
-  const int per_group = GROUP_M * tiles_n;
-  const int grp = bid / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-  if (m0 >= M) return;                       // whole workgroup exits together (block-uniform)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  // ---- DMA source pointers: instruction j (0..31) of an operand covers rows 8j..8j+7; this wave issues j = wave*4 + i
-  const int sub_row = lane >> 3;
-  const int src_c = (lane & 7) ^ sub_row;
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + sub_row;
-    a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
-    w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
-  }
-  auto dma_a = [&](int i, int t, int stage) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
-                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wave * 4 + i) * 1024),
-                                     16, 0, 0);
-  };
-  auto dma_w = [&](int i, int t, int stage) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
-                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024),
-                                     16, 0, 0);
-  };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  bf16x8 fa[4][2];   // A fragments of the current M-quadrant: [m-frag within quadrant][kk]
-  bf16x8 fb[2][2];   // B fragments of the current N-quadrant: [n-frag within quadrant][kk]
-
-  auto load_a = [&](int qm, const char* st) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fa[i][kk] = *reinterpret_cast<const bf16x8*>(st + lds_off2(wr * 128 + (qm * 4 + i) * 16 + fr, kk * 4 + fq));
-  };
-  auto load_b = [&](int qn, const char* st) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fb[j][kk] = *reinterpret_cast<const bf16x8*>(st + OP_BYTES + lds_off2(wc * 64 + (qn * 2 + j) * 16 + fr, kk * 4 + fq));
-  };
-#define MP_MFMA_Q(QM, QN)                                                                                  \
-  do {                                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          acc[(QM) * 4 + i][(QN) * 2 + j] =                                                                 \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], fb[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                          \
-  } while (0)
-
-  const int nt = K / BK2;
-
-  // ---- prologue: tile 0 into stage 0
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { dma_a(i, 0, 0); dma_w(i, 0, 0); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MP_BAR();
-  if (wr == 1) MP_BAR();                     // stagger group 1 by one barrier
-
-  for (int t = 0; t < nt; ++t) {
-    const int stage = t & 1;
-    const char* st = smem + stage * STAGE_BYTES;
-    const bool more = (t + 1 < nt);
-    // ---------------- phase 0: quadrant (0,0) ----------------
-    if (more) { dma_a(0, t + 1, stage ^ 1); dma_a(1, t + 1, stage ^ 1); dma_w(0, t + 1, stage ^ 1); }
-    load_b(0, st);
-    load_a(0, st);
-    MP_BAR();
-    MP_MFMA_Q(0, 0);
-    MP_BAR();
-    // ---------------- phase 1: quadrant (0,1) ----------------
-    if (more) { dma_a(2, t + 1, stage ^ 1); dma_a(3, t + 1, stage ^ 1); dma_w(1, t + 1, stage ^ 1); }
-    load_b(1, st);
-    MP_BAR();
-    MP_MFMA_Q(0, 1);
-    MP_BAR();
-    // ---------------- phase 2: quadrant (1,1) ----------------
-    if (more) { dma_w(2, t + 1, stage ^ 1); dma_w(3, t + 1, stage ^ 1); }
-    load_a(1, st);
-    MP_BAR();
-    MP_MFMA_Q(1, 1);
-    MP_BAR();
-    // ---------------- phase 3: quadrant (1,0) ----------------
-    load_b(0, st);
-    // retire this tile's last LDS reads (WAR vs the DMA into this stage two phases from now) and the next tile's DMA
-    // (RAW: landed before the barrier that precedes its first read)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    MP_BAR();
-    MP_MFMA_Q(1, 0);
-    MP_BAR();
-  }
-  if (wr == 0) MP_BAR();                     // balance the stagger barrier of group 1
-
-  // ---------------- epilogue ----------------
-  // per-wave 128x64 bf16 image in LDS (row stride 144 B = 128 + 16 pad -> conflict-light 2-byte writes and 16-byte reads)
+// Accumulators -> per-wave LDS image -> 16-byte row-contiguous global stores with fused bias / activation / residual /
+// SwiGLU pairing (bf16 output), or direct fp32 stores.
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], char* smem, int batch, int M, int N, int m0,
+                                                 int n0, int wave, int wr, int wc, int lane, int fr, int fq) {
   constexpr int EP_LD = 144;
   const bool via_lds = !g.out_f32;
   const bool swiglu = (g.act == ACT_SWIGLU_PAIR);
   if (via_lds) {
-    char* ep = smem + wave * 16384;          // this wave's 16 KiB slice; two halves of 64 rows x 144 B = 9216 B each
+    char* ep = smem + wave * 16384;
     const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
     float bias_v[4];
 #pragma unroll
@@ -200,11 +68,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // 64 rows x 128 B: lane handles row (it*8 + lane/8), 16-B chunk lane%8; bias and activation are already applied
       const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
       bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
       if (swiglu) {
-        // this wave's 64 columns are [gate c0..c0+31 | up c0..c0+31]: out[row, c0 + q*8 .. +8] = silu(gate) * up
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 64 + lane;
@@ -276,15 +142,350 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
   }
 }
 
+
+// ABL (ablation builds for scripts/gemm_bench.py only): 0 = product kernel, 1 = no MFMA, 2 = no LDS fragment reads, 3 = no DMA
+template <int ABL>
+__global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int batch = blockIdx.y;
+  const bf16_t* __restrict__ A = g.A + batch * g.sA;
+  const bf16_t* __restrict__ W = g.W + batch * g.sW;
+  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
+  const int N = g.N, K = g.K;
+
+  // tile space from the EFFECTIVE row count (device-side expert counts): surplus workgroups of the capacity-sized grid exit
+  // here, and the XCD remap below stays balanced over the tiles that really exist
+  const int tiles_m = (M + BM2 - 1) / BM2;
+  const int tiles_n = (N + BN2 - 1) / BN2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  if (bid >= nwg) return;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  // grouped order: ids walk GROUP_M consecutive M-tiles before stepping N, so the ~32-64 workgroups that are co-resident on
+  // one XCD cover a GROUP_M x (32/GROUP_M) block of tiles and share both their A and their W panels through that XCD's L2
+  const int GROUP_M = g.group_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = bid / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  if (m0 >= M) return;                       // whole workgroup exits together (block-uniform)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- DMA source pointers: instruction j (0..31) of an operand covers rows 8j..8j+7; this wave issues j = wave*4 + i
+  const int sub_row = lane >> 3;
+  const int src_c = (lane & 7) ^ sub_row;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + sub_row;
+    a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
+    w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
+  }
+  auto dma_a = [&](int i, int t, int stage) {
+    if constexpr (ABL == 3) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wave * 4 + i) * 1024),
+                                     16, 0, 0);
+  };
+  auto dma_w = [&](int i, int t, int stage) {
+    if constexpr (ABL == 3) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024),
+                                     16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 fa[4][2];   // A fragments of the current M-quadrant: [m-frag within quadrant][kk]
+  bf16x8 fb[2][2];   // B fragments of the current N-quadrant: [n-frag within quadrant][kk]
+  if constexpr (ABL == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) for (int kk = 0; kk < 2; ++kk) for (int e = 0; e < 8; ++e) { fa[i][kk][e] = (bf16_t)(float)(lane + i); if (i < 2) fb[i][kk][e] = (bf16_t)(float)(lane - i); }
+  }
+
+  auto load_a = [&](int qm, const char* st) {
+    if constexpr (ABL == 2) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fa[i][kk] = *reinterpret_cast<const bf16x8*>(st + lds_off2(wr * 128 + (qm * 4 + i) * 16 + fr, kk * 4 + fq));
+  };
+  auto load_b = [&](int qn, const char* st) {
+    if constexpr (ABL == 2) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fb[j][kk] = *reinterpret_cast<const bf16x8*>(st + OP_BYTES + lds_off2(wc * 64 + (qn * 2 + j) * 16 + fr, kk * 4 + fq));
+  };
+#define MP_MFMA_Q(QM, QN)                                                                                  \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          if constexpr (ABL == 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(fb[j][kk])); }                   \
+          else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                            \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], fb[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+  } while (0)
+
+  const int nt = K / BK2;
+
+  // ---- prologue: tile 0 into stage 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dma_a(i, 0, 0); dma_w(i, 0, 0); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MP_BAR();
+  if (wr == 1) MP_BAR();                     // stagger group 1 by one barrier
+
+  for (int t = 0; t < nt; ++t) {
+    const int stage = t & 1;
+    const char* st = smem + stage * STAGE_BYTES;
+    const bool more = (t + 1 < nt);
+    // ---------------- phase 0: quadrant (0,0) ----------------
+    if (more) { dma_a(0, t + 1, stage ^ 1); dma_a(1, t + 1, stage ^ 1); dma_w(0, t + 1, stage ^ 1); }
+    load_b(0, st);
+    load_a(0, st);
+    MP_BAR();
+    MP_MFMA_Q(0, 0);
+    MP_BAR();
+    // ---------------- phase 1: quadrant (0,1) ----------------
+    if (more) { dma_a(2, t + 1, stage ^ 1); dma_a(3, t + 1, stage ^ 1); dma_w(1, t + 1, stage ^ 1); }
+    load_b(1, st);
+    MP_BAR();
+    MP_MFMA_Q(0, 1);
+    MP_BAR();
+    // ---------------- phase 2: quadrant (1,1) ----------------
+    if (more) { dma_w(2, t + 1, stage ^ 1); dma_w(3, t + 1, stage ^ 1); }
+    load_a(1, st);
+    MP_BAR();
+    MP_MFMA_Q(1, 1);
+    MP_BAR();
+    // ---------------- phase 3: quadrant (1,0) ----------------
+    load_b(0, st);
+    // retire this tile's last LDS reads (WAR vs the DMA into this stage two phases from now) and the next tile's DMA
+    // (RAW: landed before the barrier that precedes its first read)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MP_BAR();
+    MP_MFMA_Q(1, 0);
+    MP_BAR();
+  }
+  if (wr == 0) MP_BAR();                     // balance the stagger barrier of group 1
+
+  gemm256_epilogue(g, acc, smem, batch, M, N, m0, n0, wave, wr, wc, lane, fr, fq);
+}
+
+
+
+// =====================================================================================================================
+// v3: v1's geometry (BK = 64, 128-B rows = whole cache lines per DMA row, 2 stages) with a CONTINUOUS DMA stream: the stage
+// is recycled region by region as soon as its last reader phase has retired, two DMA instructions per wave in EVERY phase,
+// retired by one counted wait (vmcnt(6)) per K-tile — the memory pipe never drains.
+//   reads:  P0 A-q0 + B-q0 (kept in fb0 for P3)   P1 B-q1   P2 A-q1   P3 none
+//   DMA  :  P0 A-q1 of tile t+1 | P1 A-q0 of tile t+2 | P2 B[0,1] of tile t+2 | P3 B[2,3] of tile t+2
+// (A-q0 rows are free after P0, B after P1, A-q1 rows after P2.)  Every LOAD segment ends with lgkmcnt(0) before its barrier,
+// so a region's reads are retired by all waves before the barrier that precedes the first DMA into it.
+template <int ABL>
+__global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int batch = blockIdx.y;
+  const bf16_t* __restrict__ A = g.A + batch * g.sA;
+  const bf16_t* __restrict__ W = g.W + batch * g.sW;
+  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
+  const int N = g.N, K = g.K;
+  const int tiles_m = (M + BM2 - 1) / BM2;
+  const int tiles_n = (N + BN2 - 1) / BN2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  if (bid >= nwg) return;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int GROUP_M = g.group_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = bid / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // DMA instruction j of an operand covers rows 8j..8j+7.  A: wave w issues j = w + 8*i, so i = 0,2 are the quadrant-0 rows
+  // (0-63 of each M half) and i = 1,3 the quadrant-1 rows.  B: j = 4*w + i.
+  const int sub_row = lane >> 3;
+  const int src_c = (lane & 7) ^ sub_row;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int arow = (wave + 8 * i) * 8 + sub_row;
+    const int wrow = (wave * 4 + i) * 8 + sub_row;
+    a_src[i] = A + (int64_t)min(m0 + arow, M - 1) * g.lda + src_c * 8;
+    w_src[i] = W + (int64_t)min(n0 + wrow, N - 1) * g.ldw + src_c * 8;
+  }
+  auto dma_a = [&](int i, int t) {
+    if constexpr (ABL == 3) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  auto dma_w = [&](int i, int t) {
+    if constexpr (ABL == 3) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
+                                     (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  if constexpr (ABL == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) for (int kk = 0; kk < 2; ++kk) for (int e = 0; e < 8; ++e) {
+      fa[i][kk][e] = (bf16_t)(float)(lane + i);
+      if (i < 2) { fb0[i][kk][e] = (bf16_t)(float)(lane - i); fb1[i][kk][e] = (bf16_t)(float)(lane - 2 * i); }
+    }
+  }
+  auto load_a = [&](int qm, const char* st) {
+    if constexpr (ABL == 2) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fa[i][kk] = *reinterpret_cast<const bf16x8*>(st + lds_off2(wr * 128 + (qm * 4 + i) * 16 + fr, kk * 4 + fq));
+  };
+#define MP_LOAD_B(FB, QN, ST)                                                                                \
+  do {                                                                                                      \
+    if constexpr (ABL != 2) {                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
+          FB[j][kk] = *reinterpret_cast<const bf16x8*>((ST) + OP_BYTES + lds_off2(wc * 64 + ((QN) * 2 + j) * 16 + fr, kk * 4 + fq)); \
+    }                                                                                                       \
+  } while (0)
+#define MP_MFMA_Q3(QM, QN, FB)                                                                             \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+          if constexpr (ABL == 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(FB[j][kk])); }                   \
+          else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                            \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], FB[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+  } while (0)
+#define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+  const int nt = K / BK2;
+  // ---- prologue: all of tile 0, and tile 1 except its A-q1 rows (those are issued in P0 of tile 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dma_a(i, 0); dma_w(i, 0); }
+  if (nt > 1) {
+    dma_a(0, 1); dma_a(2, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_w(i, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  MP_BAR();
+  if (wr == 1) MP_BAR();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE_BYTES;
+    const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+    // ---------------- P0: quadrant (0,0) ----------------
+    if (n1) { dma_a(1, t + 1); dma_a(3, t + 1); }
+    MP_LOAD_B(fb0, 0, st);
+    load_a(0, st);
+    MP_LGKM0();
+    MP_BAR();
+    MP_MFMA_Q3(0, 0, fb0);
+    MP_BAR();
+    // ---------------- P1: quadrant (0,1) ----------------
+    if (n2) { dma_a(0, t + 2); dma_a(2, t + 2); }
+    MP_LOAD_B(fb1, 1, st);
+    MP_LGKM0();
+    MP_BAR();
+    MP_MFMA_Q3(0, 1, fb1);
+    MP_BAR();
+    // ---------------- P2: quadrant (1,1) ----------------
+    if (n2) { dma_w(0, t + 2); dma_w(1, t + 2); }
+    load_a(1, st);
+    MP_LGKM0();
+    MP_BAR();
+    MP_MFMA_Q3(1, 1, fb1);
+    MP_BAR();
+    // ---------------- P3: quadrant (1,0) ----------------
+    if (n2) { dma_w(2, t + 2); dma_w(3, t + 2); }
+    if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything up to A-q1 of tile t+1 has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MP_BAR();
+    MP_MFMA_Q3(1, 0, fb0);
+    MP_BAR();
+  }
+  if (wr == 0) MP_BAR();
+  gemm256_epilogue(g, acc, smem, batch, M, N, m0, n0, wave, wr, wc, lane, fr, fq);
+}
+
+
 }  // namespace
 
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    attr_set = true;
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("MP_GEMM_ABLATE");
+    abl = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 0;
+    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  }
+  static int ver = -1;
+  if (ver < 0) {
+    // 3 (default) = continuous LDS-DMA stream with region-level stage recycling; 1 = per-tile DMA bursts (A/B reference)
+    const char* e = getenv("MP_GEMM256_VERSION");
+    ver = (e && e[0] == '1') ? 1 : 3;
+    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   }
   const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
-  hipLaunchKernelGGL(gemm256_bf16_nt_kernel, dim3(tiles, batch), dim3(NT2), 2 * STAGE_BYTES, stream, g);
+  const dim3 grid(tiles, batch), blk(NT2);
+  if (ver == 3) {
+    if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, grid, blk, 2 * STAGE_BYTES, stream, g);
+    else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, grid, blk, 2 * STAGE_BYTES, stream, g);
+    else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, grid, blk, 2 * STAGE_BYTES, stream, g);
+    else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, grid, blk, 2 * STAGE_BYTES, stream, g);
+    return mp_check_launch("mp_gemm_bf16_nt(256v3)");
+  }
+  if (abl == 1) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<1>, grid, blk, 2 * STAGE_BYTES, stream, g);
+  else if (abl == 2) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<2>, grid, blk, 2 * STAGE_BYTES, stream, g);
+  else if (abl == 3) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<3>, grid, blk, 2 * STAGE_BYTES, stream, g);
+  else hipLaunchKernelGGL(gemm256_bf16_nt_kernel<0>, grid, blk, 2 * STAGE_BYTES, stream, g);
   return mp_check_launch("mp_gemm_bf16_nt(256)");
 }

@@ -60,6 +60,12 @@ if __name__ == "__main__":
         run_variant(os.environ.get("MP_GEMM_VARIANT", "1"))
     else:
         for v in (sys.argv[1:] or ["1", "2"]):
-            var, _, grp = v.partition(":")
-            print(f"== variant {var} group_m {grp or 'default'}", flush=True)
-            subprocess.run([sys.executable, __file__, "--child"], env=dict(os.environ, MP_GEMM_VARIANT=var, **({"MP_GEMM_GROUP_M": grp} if grp else {})))
+            var, _, rest = v.partition(":")
+            grp, _, abl = rest.partition(":")
+            print(f"== variant {var} group_m {grp or 'default'} ablate {abl or 0}", flush=True)
+            env = dict(os.environ, MP_GEMM_VARIANT=var)
+            if grp:
+                env["MP_GEMM_GROUP_M"] = grp
+            if abl:
+                env["MP_GEMM_ABLATE"] = abl
+            subprocess.run([sys.executable, __file__, "--child"], env=env)
