@@ -75,7 +75,9 @@ int mp_layernorm_bf16(const void* x, int64_t ldx, const float* w, const float* b
                       int dim, float eps, hipStream_t stream);
 /* Half-split RoPE on the q and k thirds of a fused [tokens, 3*H*D] buffer. */
 int mp_rope_qk_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
-                    int head_dim, hipStream_t stream);
+                    int head_dim, int pos_offset, hipStream_t stream);
+/* greedy next-token pick over fp32 logits (HF generate do_sample=False, MedPLIB.py:592-606). */
+int mp_argmax_rows_f32(const float* x, int64_t ld, int64_t rows, int cols, int64_t* out, hipStream_t stream);
 /* out = silu(gu[:, :ff]) * gu[:, ff:]  (LlamaMLP). */
 int mp_swiglu_bf16(const void* gu, int64_t ldgu, void* out, int64_t ldo, int64_t rows, int ff, hipStream_t stream);
 int mp_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bf16_kernel(const bf16_
 // RoPE in place on the q and k thirds of a fused [T, 3*H*D] qkv buffer (D = 128 -> half = 64).
 // One thread handles 8 consecutive dims of the low half and the matching 8 of the high half.
 __global__ void rope_qk_bf16_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                    int64_t T, int S, int H, int D, int64_t ld) {
+                                    int64_t T, int S, int H, int D, int64_t ld, int pos0) {
   const int half = D / 2;
   const int per_head = half / 8;                 // threads per head
   const int64_t per_tok = (int64_t)2 * H * per_head;  // q and k
@@ -100,7 +100,7 @@ __global__ void rope_qk_bf16_kernel(bf16_t* __restrict__ qkv, const float* __res
   const int which = r / (H * per_head);  // 0 = q, 1 = k
   r %= H * per_head;
   const int h = r / per_head, c = (r % per_head) * 8;
-  const int pos = (int)(tok % S);
+  const int pos = (int)(tok % S) + pos0;
   bf16_t* base = qkv + tok * ld + (int64_t)which * H * D + (int64_t)h * D;
   bf16x8 lo = *reinterpret_cast<bf16x8*>(base + c);
   bf16x8 hi = *reinterpret_cast<bf16x8*>(base + half + c);
@@ -182,7 +182,36 @@ __global__ void add3_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __r
   *reinterpret_cast<bf16x8*>(y + i) = o;
 }
 
+// greedy decoding: index of the maximum of each row (first index on exact ties, like torch.argmax on CPU)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ld, int cols, int64_t* __restrict__ out) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const float* r = x + (int64_t)blockIdx.x * ld;
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    const float v = r[i];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      const float v = sv[threadIdx.x + off]; const int i = si[threadIdx.x + off];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+}
+
 }  // namespace
+
+extern "C" int mp_argmax_rows_f32(const float* x, int64_t ld, int64_t rows, int cols, int64_t* out, hipStream_t stream) {
+  MP_REQUIRE(cols > 0, MP_ERR_SHAPE, "mp_argmax_rows_f32: bad shape");
+  if (rows == 0) return MP_OK;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ld, cols, out);
+  return mp_check_launch("mp_argmax_rows_f32");
+}
 
 extern "C" int mp_rmsnorm_bf16(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy, int64_t rows, int dim,
                                float eps, hipStream_t stream) {
@@ -205,12 +234,12 @@ extern "C" int mp_layernorm_bf16(const void* x, int64_t ldx, const float* w, con
 }
 
 extern "C" int mp_rope_qk_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t tokens, int seq,
-                               int heads, int head_dim, hipStream_t stream) {
+                               int heads, int head_dim, int pos_offset, hipStream_t stream) {
   MP_REQUIRE(head_dim % 16 == 0 && ld % 8 == 0 && seq > 0, MP_ERR_SHAPE, "mp_rope_qk_bf16: bad shape");
   const int64_t n = tokens * 2 * heads * (head_dim / 16);
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(rope_qk_bf16_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (bf16_t*)qkv, cos_t, sin_t,
-                     tokens, seq, heads, head_dim, ld);
+                     tokens, seq, heads, head_dim, ld, pos_offset);
   return mp_check_launch("mp_rope_qk_bf16");
 }
 

@@ -128,20 +128,37 @@ class LlamaStack:
         out = ops.moe_combine(y, expert, slot, weight, x, cap)
         return out, l_aux, (expert, slot, counts)
 
-    def forward(self, inputs_embeds, key_valid=None, collect_routing=False):
+    def new_kv_cache(self, batch, max_len):
+        """KV cache for `evaluate()`'s greedy decode (HF `use_cache=True`, MedPLIB.py:592-606): post-RoPE K and V per layer."""
+        cfg = self.cfg
+        shape = (batch, max_len, cfg.num_attention_heads, cfg.head_dim)
+        return {"len": 0, "k": [torch.empty(shape, dtype=torch.bfloat16, device=self.device) for _ in self.layers],
+                "v": [torch.empty(shape, dtype=torch.bfloat16, device=self.device) for _ in self.layers]}
+
+    def forward(self, inputs_embeds, key_valid=None, collect_routing=False, kv_cache=None):
         """inputs_embeds [B,S,d] bf16; key_valid uint8 [B,S] (1 = real token) or None.
+        With kv_cache: the S new tokens sit at positions cache.len .. cache.len+S-1, their K/V are appended and attention runs
+        over the whole cache (prefill when cache.len == 0, single-token decode afterwards).
         Returns (last_hidden_state after the final RMSNorm [B,S,d], [l_aux per MoE layer], routing or None)."""
         cfg = self.cfg
         B, S, d = inputs_embeds.shape
         H, D = cfg.num_attention_heads, cfg.head_dim
         x = inputs_embeds.reshape(B * S, d)
         aux, routing = [], []
+        pos0 = kv_cache["len"] if kv_cache is not None else 0
         for i, lw in enumerate(self.layers):
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
             qkv = ops.gemm(h, lw["qkv"])
-            ops.rope_qk_(qkv, self.cos, self.sin, S, H, D)
+            ops.rope_qk_(qkv, self.cos, self.sin, S, H, D, pos_offset=pos0)
             q5 = qkv.view(B, S, 3, H, D)
-            attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
+            if kv_cache is not None:
+                kv_cache["k"][i][:, pos0:pos0 + S].copy_(q5[:, :, 1])
+                kv_cache["v"][i][:, pos0:pos0 + S].copy_(q5[:, :, 2])
+            if kv_cache is not None and pos0 > 0:
+                assert S == 1 and key_valid is None, "cached decode is single-token, un-padded (the reference evaluates with batch 1)"
+                attn = ops.attention(q5[:, :, 0], kv_cache["k"][i][:, :pos0 + 1], kv_cache["v"][i][:, :pos0 + 1], causal=False)
+            else:
+                attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
             x = ops.gemm(attn.view(B * S, d), lw["o"], residual=x)
             h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
             x, l_aux, r = self._mlp(i, lw, h, x)
@@ -149,8 +166,14 @@ class LlamaStack:
                 aux.append(l_aux)
                 if collect_routing:
                     routing.append(r)
+        if kv_cache is not None:
+            kv_cache["len"] = pos0 + S
         out = ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps)
         return out.view(B, S, d), aux, (routing if collect_routing else None)
+
+    def next_token_logits(self, hidden_row):
+        """fp32 logits of one position: lm_head(hidden).float() (medplib_moe_llama.py:388-389).  hidden_row [n, d] bf16."""
+        return ops.gemm(hidden_row.contiguous(), self.lm_head, out_dtype=torch.float32)
 
     def cross_entropy(self, last_hidden, sup_rows, sup_labels, aux):
         """CE over supervised rows only (row-wise op; unsupervised rows never reach the loss — SURVEY B.8):

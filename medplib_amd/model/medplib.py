@@ -243,6 +243,70 @@ class MedPLIBForCausalLM(nn.Module):
         return {k: out10[i] for i, k in enumerate(LOSS_KEYS)}
 
 
+    # ------------------------------------------------------------------ evaluate (MedPLIB.py:574-680)
+    @torch.no_grad()
+    def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, region_masks=(), valid_region_masks_bool=(),
+                 max_new_tokens=512, tokenizer=None, attention_mask=None, inference_demo=False, mask_images=None,
+                 image_token_types=None, image_token_lengths=None, eos_token_id=2):
+        """Greedy generation with a KV cache (prefill + single-token decode steps), then one mask per sample from the hidden
+        state that predicts the first <SEG> (or position -2 when no <SEG> was generated) — MedPLIB.py:574-680.
+        Returns (output_ids [1, L + n_generated] int64 on the host, [pred_mask [1,H,W]]).
+
+        Reference quirk kept: the concatenated per-step hidden states cover the spliced prompt and the first n-1 generated
+        tokens (the last generated token is never fed back), i.e. one position FEWER than build_seg_token_mask(output_ids)
+        yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
+        cfg, dev, m = self.config, self.device_, self.model
+        if region_masks:
+            raise NotImplementedError("region prompts are outside the built path (SURVEY §8f)")
+        ids = _np_ids(input_ids).astype(np.int64)
+        assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
+        was_training = self.training
+        self.train(False)
+        nfeat = cfg.clip_num_patches
+        plan = plan_splice(ids, None, None, nfeat)
+        feats = m.vision_tower.encode_images(images_clip)
+        src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev)
+        S = plan.seq_len
+        embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(1, S, cfg.hidden_size)
+        cache = m.llm.new_kv_cache(1, S + max_new_tokens)
+        hidden, _, _ = m.llm.forward(embeds, None, kv_cache=cache)
+        hiddens = [hidden]
+        generated = []
+        for _ in range(max_new_tokens):
+            logits = m.llm.next_token_logits(hiddens[-1][0, -1:])
+            tok = int(ops.argmax_rows(logits)[0])
+            generated.append(tok)
+            if tok == eos_token_id or len(generated) == max_new_tokens:
+                break
+            emb = ops.splice_rows(m.llm.embed_tokens, None, torch.tensor([tok], dtype=torch.int64, device=dev), cfg.hidden_size)
+            h, _, _ = m.llm.forward(emb.view(1, 1, -1), None, kv_cache=cache)
+            hiddens.append(h)
+        output_ids = np.concatenate([ids, np.asarray(generated, dtype=np.int64)[None]], 1)
+        all_hidden = torch.cat(hiddens, 1)                                  # [1, S + n_gen - 1, d]
+        n_hidden = all_hidden.shape[1]
+        if (output_ids[:, 1:] == self.seg_token_idx).sum() == 0 and inference_demo:
+            self.train(was_training)
+            return torch.from_numpy(output_ids), []
+        seg_plan = plan_splice(output_ids, None, None, nfeat, seg_token_idx=self.seg_token_idx,
+                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else nfeat)
+        seg_rows = np.flatnonzero(seg_plan.seg_mask[0, :n_hidden])
+        if seg_rows.size >= 1:
+            row = int(seg_rows[0])                                          # first <SEG> when several (MedPLIB.py:639-641)
+        else:
+            row = n_hidden - 2                                              # last_hidden_state[:1, -2:-1] (MedPLIB.py:642-644)
+        hid = ops.gather_rows_bf16_to_f32(all_hidden.view(-1, cfg.hidden_size), torch.tensor([row], dtype=torch.int64, device=dev))
+        fc = m.text_hidden_fcs[0]
+        pred_emb = A.linear(A.linear(hid, fc[0].weight, fc[0].bias, ops.SACT_RELU), fc[2].weight, fc[2].bias)
+        image_tokens = ops.cast_to_f32(self.get_visual_embs(images))[:1].contiguous()
+        pe = m.visual_model.prompt_encoder
+        low_res, _ = m.visual_model.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight, pred_emb.view(1, 1, -1))
+        osz = original_size_list[0]
+        shape = tuple(osz.shape[-2:]) if hasattr(osz, "shape") else tuple(osz)
+        _, pred_masks = self._postprocess(low_res, resize_list[:1], [shape])
+        self.train(was_training)
+        return torch.from_numpy(output_ids), pred_masks
+
+
 class LISAForCausalLM(MedPLIBForCausalLM):
     """Dense (non-MoE) twin (model/LISA.py:180-471): same path with plain LlamaMLP layers; accepts the collator's
     `attention_mask` as well as LISA's own `attention_masks` spelling."""

@@ -142,13 +142,22 @@ def layernorm(x, w, b, eps, out=None):
     return out.view(x.shape)
 
 
-def rope_qk_(qkv, cos_t, sin_t, seq, heads, head_dim):
-    """in place on a fused [tokens, 3*heads*head_dim] bf16 buffer; cos/sin fp32 [>=seq, head_dim/2]."""
+def rope_qk_(qkv, cos_t, sin_t, seq, heads, head_dim, pos_offset=0):
+    """in place on a fused [tokens, 3*heads*head_dim] bf16 buffer; cos/sin fp32 [>=seq+pos_offset, head_dim/2]; token t of a
+    sequence gets position (t % seq) + pos_offset (pos_offset = cached length when decoding)."""
     _chk(qkv, torch.bfloat16, "rope.qkv"); _chk(cos_t, torch.float32, "rope.cos")
     assert qkv.dim() == 2 and qkv.stride(1) == 1 and cos_t.is_contiguous() and sin_t.is_contiguous()
-    assert cos_t.shape[0] >= seq and cos_t.shape[1] == head_dim // 2
-    lib().call("mp_rope_qk_bf16", _p(qkv), qkv.stride(0), _p(cos_t), _p(sin_t), qkv.shape[0], seq, heads, head_dim, _stream())
+    assert cos_t.shape[0] >= seq + pos_offset and cos_t.shape[1] == head_dim // 2
+    lib().call("mp_rope_qk_bf16", _p(qkv), qkv.stride(0), _p(cos_t), _p(sin_t), qkv.shape[0], seq, heads, head_dim, int(pos_offset),
+               _stream())
     return qkv
+
+
+def argmax_rows(x):
+    _chk(x, torch.float32, "argmax_rows.x"); assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    lib().call("mp_argmax_rows_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream())
+    return out
 
 
 def swiglu_interleave(gate, up):

@@ -137,3 +137,44 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         return out, dict(hidden=hidden, ce=ce, seg_mask=seg_mask, pred_emb=pred_emb, low_res=torch.cat(low), pred_masks=pred_masks,
                          pred_ious=torch.cat(pred_ious), image_emb=image_emb, feats=feats, embeds=embeds, labels=lab2, att=att2)
     return out
+
+
+def evaluate(batch, W, cfg, max_new_tokens=8, eos_token_id=2, return_debug=False):
+    """`MedPLIBForCausalLM.evaluate` (model/MedPLIB.py:574-680) on the CPU in fp32: greedy decoding (HF generate, do_sample=False)
+    restated without a KV cache (each step re-runs the causal stack on the grown sequence — identical values), the
+    concatenated last-layer hidden states, <SEG> pick rules and one mask.  B = 1."""
+    ids = batch["input_ids"]
+    assert ids.shape[0] == 1
+    with torch.no_grad():
+        feats = llm.mm_projector(llm.clip_features(batch["images_clip"], W, cfg), W)
+        _, embeds, _ = llm.prepare_inputs_labels_for_multimodal(ids, None, None, feats, W["model.embed_tokens.weight"])
+        seq = embeds
+        generated, gaps = [], []
+        for _ in range(max_new_tokens):
+            hidden, _ = llm.llama_forward(seq, None, W, cfg, training=False)
+            logits = F.linear(hidden[:, -1], W["lm_head.weight"]).float()
+            top2 = torch.topk(logits[0], 2).values
+            gaps.append(float(top2[0] - top2[1]))
+            tok = int(torch.argmax(logits, -1))
+            generated.append(tok)
+            if tok == eos_token_id or len(generated) == max_new_tokens:
+                break
+            seq = torch.cat([seq, W["model.embed_tokens.weight"][tok].view(1, 1, -1)], 1)
+        output_ids = torch.cat([ids, torch.tensor([generated])], 1)
+        n_hidden = hidden.shape[1]
+        seg_mask = llm.build_seg_token_mask(output_ids, cfg.seg_token_idx, cfg.clip_num_patches)[:, :n_hidden]
+        last = F.linear(F.relu(F.linear(hidden, W["model.text_hidden_fcs.0.0.weight"], W["model.text_hidden_fcs.0.0.bias"])),
+                        W["model.text_hidden_fcs.0.2.weight"], W["model.text_hidden_fcs.0.2.bias"])
+        pred = last[seg_mask]
+        if pred.shape[0] > 1:
+            pred = pred[:1]
+        elif pred.shape[0] == 0:
+            pred = last[:1, -2:-1, :].squeeze(1)
+        SW = {k[len("model.visual_model."):]: v for k, v in W.items() if k.startswith("model.visual_model.")}
+        image_emb = sam.image_encoder(batch["images"], SW, depth=cfg.sam_depth)
+        sp, de = sam.prompt_encoder_text(pred[0].view(1, 1, -1), SW)
+        lm, _ = sam.mask_decoder(image_emb[:1], sam.dense_pe(SW), sp, de, SW)
+        pm = ops.postprocess_masks(lm, batch["resize_list"][0], tuple(batch["label_list"][0].shape))
+    if return_debug:
+        return output_ids, [pm[:, 0]], dict(gaps=gaps, hidden=hidden)
+    return output_ids, [pm[:, 0]]

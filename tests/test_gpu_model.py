@@ -238,3 +238,32 @@ def test_engine_step_matches_reference_adamw(dev):
         _stat(f"adamw step {step} weight", lin.weight, ref.weight, atol=2e-6)
         _stat(f"adamw step {step} bias", lin.bias, ref.bias, atol=2e-6)
     assert eng.global_steps == 3 and lin.weight.grad.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("moe", [True, False])
+def test_evaluate_greedy_decode_and_mask(dev, moe):
+    """evaluate(): KV-cache greedy decode must reproduce the oracle's token ids exactly (a divergence is accepted only at a
+    step where the oracle's top-2 logit gap is below bf16 noise), then the <SEG>-row mask must match."""
+    cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2)
+    W = OM.init_hf_weights(cfg, seed=3)
+    m = _model(cfg, dev, W).eval()
+    for seed, force_seg in ((0, False), (1, True)):
+        batch = OM.make_batch(cfg, 1, seed=seed)
+        bq = dict(batch, images_clip=batch["images_clip"].to(torch.bfloat16).float(), images=batch["images"].to(torch.bfloat16).float())
+        if not force_seg:
+            bq["input_ids"] = batch["input_ids"].clone(); bq["input_ids"][0, -3] = 7     # no <SEG> in the prompt: exercises the -2 rule
+        ids_ref, masks_ref, dbg = OM.evaluate(bq, W, cfg, max_new_tokens=6, return_debug=True)
+        out_ids, masks = m.evaluate(bq["images_clip"].to(dev), bq["images"].to(dev), bq["input_ids"], batch["resize_list"],
+                                    batch["label_list"], max_new_tokens=6)
+        a, b = out_ids[0].tolist(), ids_ref[0].tolist()
+        n_in = bq["input_ids"].shape[1]
+        agree = 0
+        while agree < min(len(a), len(b)) and a[agree] == b[agree]:
+            agree += 1
+        print(f"moe={moe} seed={seed}: generated {a[n_in:]} vs oracle {b[n_in:]}, oracle top-2 gaps {['%.3f' % g for g in dbg['gaps']]}")
+        if agree < max(len(a), len(b)):
+            step = agree - n_in
+            assert 0 <= step < len(dbg["gaps"]) and dbg["gaps"][step] < 5e-2, "token ids diverge at a step that is not a near tie"
+        else:
+            _stat("evaluate pred_mask", masks[0], masks_ref[0], atol=0.2)
+            assert masks[0].shape == masks_ref[0].shape
