@@ -114,6 +114,13 @@ int mp_scale_f32(float* x, int64_t n, float s, hipStream_t stream);
 
 /* ---- mask head: resize, losses, metrics -------------------------------------------------------------------------- */
 
+/* Fused inference upsampler: ConvT2x2/s2(256->64) + LayerNorm2d + GELU + ConvT2x2/s2(64->32) + GELU [+ hyper_in @ upscaled]
+ * in one pass over HBM (mask_decoder.py:53-59,141-148).  src [B, h*w, 256] bf16 tokens (NHWC); w1_packed [256][256] =
+ * W1.permute(2,3,1,0), w2_packed [128][64] = W2.permute(2,3,1,0); up [B,32,4h,4w] bf16 (NCHW, may be null);
+ * mask [B,4h,4w] f32 = sum_c hyper[b,c] * up[b,c] (may be null). */
+int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packed, const float* b1, const float* ln_w, const float* ln_b,
+                                const void* w2_packed, const float* b2, const float* hyper, void* up, float* mask, int B, int h,
+                                int w, float ln_eps, hipStream_t stream);
 /* postprocess_masks (MedPLIB.py:682-701): crop window (already resolved with Python slice semantics by the caller)
  * then F.interpolate(bilinear, align_corners=False) to (out_h, out_w). */
 int mp_bilinear_resize_fwd(const void* in, int in_dtype, float* out, int n, int in_h, int in_w, int crop_y0, int crop_x0,

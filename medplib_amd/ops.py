@@ -371,6 +371,24 @@ def scale_f32_(x, s):
 
 
 # ------------------------------------------------------------------ mask head -------------------------------------------------
+def pack_upsampler_weights(w1, w2):
+    """ConvTranspose2d weights [Cin, Cout, 2, 2] -> GEMM operands of the fused upsampler: [(kh,kw,cout), cin] bf16."""
+    w1p = w1.permute(2, 3, 1, 0).reshape(4 * w1.shape[1], w1.shape[0]).contiguous().to(torch.bfloat16)
+    w2p = w2.permute(2, 3, 1, 0).reshape(4 * w2.shape[1], w2.shape[0]).contiguous().to(torch.bfloat16)
+    return w1p, w2p
+
+
+def mask_upsample_fused(src, w1p, b1, ln_w, ln_b, w2p, b2, h, w, hyper=None, want_up=True, eps=1e-6):
+    """src [B, h*w, 256] bf16 -> (up [B,32,4h,4w] bf16 or None, mask [B,4h,4w] f32 or None)."""
+    _chk(src, torch.bfloat16, "upsample.src"); assert src.is_contiguous() and src.shape[1] == h * w and src.shape[2] == 256
+    B = src.shape[0]
+    up = torch.empty((B, 32, 4 * h, 4 * w), dtype=torch.bfloat16, device=src.device) if want_up else None
+    mask = torch.empty((B, 4 * h, 4 * w), dtype=torch.float32, device=src.device) if hyper is not None else None
+    lib().call("mp_mask_upsample_fused_bf16", _p(src), _p(w1p), _p(b1), _p(ln_w), _p(ln_b), _p(w2p), _p(b2), _p(hyper), _p(up),
+               _p(mask), B, h, w, float(eps), _stream())
+    return up, mask
+
+
 def py_slice_window(full, start, length):
     """Resolve masks[..., start:start+length] exactly like Python slicing does (negative starts wrap, ends clamp) —
     this is the 'crop' of postprocess_masks (model/MedPLIB.py:689-699)."""

@@ -176,3 +176,30 @@ def test_threshold_iou_bit_exact(dev, golden_dir):
     c = c.cpu()
     assert torch.equal(c[:, 2] + c[:, 3], c[:, 0] + c[:, 1])
     assert torch.equal(b.cpu().bool(), torch.sigmoid(big) > 0.1)
+
+
+@pytest.mark.parametrize("grid,B", [(16, 8), (64, 2)])
+def test_fused_upsampler_matches_reference_chain(dev, grid, B):
+    """mask_decoder.output_upscaling + hyper product as ONE kernel (bf16), at the model's 256-px geometry (16x16 tokens) and at
+    the 1024-px SAM geometry (64x64 tokens), against the oracle's conv_transpose2d / LayerNorm2d / GELU chain run in fp32 on
+    the same bf16-rounded inputs.  Tolerance: intermediate activations are rounded to bf16 once (2 ulps of O(1) values)."""
+    from medplib_amd import ops
+    from oracle import sam as OS
+    W = OS.init_weights(seed=5)
+    g = torch.Generator().manual_seed(grid)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    src = bf(torch.randn(B, 256, grid, grid, generator=g))
+    Wq = dict(W)
+    Wq["mask_decoder.output_upscaling.0.weight"] = bf(W["mask_decoder.output_upscaling.0.weight"])
+    Wq["mask_decoder.output_upscaling.3.weight"] = bf(W["mask_decoder.output_upscaling.3.weight"])
+    ref_up = OS.output_upscaling(src, Wq)                                        # [B,32,4g,4g]
+    hyper = torch.randn(B, 32, generator=g)
+    ref_mask = (hyper[:, None, :] @ bf(ref_up).view(B, 32, -1)).view(B, 4 * grid, 4 * grid)
+    w1p, w2p = ops.pack_upsampler_weights(W["mask_decoder.output_upscaling.0.weight"].to(dev), W["mask_decoder.output_upscaling.3.weight"].to(dev))
+    tok = src.permute(0, 2, 3, 1).reshape(B, grid * grid, 256).contiguous().to(torch.bfloat16).to(dev)
+    d = lambda k: W[k].to(dev)
+    up, mask = ops.mask_upsample_fused(tok, w1p, d("mask_decoder.output_upscaling.0.bias"), d("mask_decoder.output_upscaling.1.weight"),
+                                       d("mask_decoder.output_upscaling.1.bias"), w2p, d("mask_decoder.output_upscaling.3.bias"),
+                                       grid, grid, hyper=hyper.to(dev))
+    _close(f"fused upsampler up (grid {grid})", up, ref_up, rtol=2 ** -7, atol=2e-2)
+    _close(f"fused upsampler mask (grid {grid})", mask, ref_mask, rtol=1e-2, atol=8e-2)
