@@ -10,18 +10,31 @@
 // Both transposed convolutions are GEMMs over tokens (MFMA 16x16x32 bf16):
 //   G1[token, sub*64 + c]        = X[token, :256] . W1[:, c, kh, kw]        sub = kh*2+kw        (K = 256, N = 256)
 //   G2[(token,sub), sub2*32+c2]  = gelu(LN_c(G1[token, sub, :])) . W2[:, c2, kh2, kw2]            (K = 64,  N = 128)
-// One persistent workgroup per CU keeps the packed W1 (128 KiB) in LDS and walks 32-token groups; wave `w` owns sub-pixel
-// `w` of the first ConvT, so LayerNorm2d is a 64-channel reduction inside the wave (4 fragments x 16 lanes).  The 4x4
-// output patches of 16 consecutive tokens of one image row are staged in LDS as [c2][y][64 x] and leave as whole 128-B rows.
+// Persistent 1024-thread workgroups, one per CU, each specialised on one kh (row parity of the first ConvT): its half of the
+// packed W1 (64 KiB) and W2 (16 KiB) stay in LDS.  The kh = 0 / kh = 1 partners of a token range sit on the same XCD so the
+// second read of the tokens is an L2 hit.  Each of the 16 waves walks 16-token groups (16 consecutive tokens of one image row)
+// on its own -- no workgroup barrier after the weight staging; four waves per SIMD let the MFMA phases of one wave run under
+// the LayerNorm / GELU VALU phases of the others.  A wave computes both kw sub-pixels, so LayerNorm2d is a 16-lane DPP
+// reduction and, after the second ConvT, lane (fr, fq) owns for channel c2 = fr (+16) the 16 consecutive output pixels of
+// tokens 4fq..4fq+3 on output lines 2kh and 2kh+1: they leave as two 16-byte stores per line straight from registers.  The
+// only LDS round trip is the per-wave C-layout -> A-layout transposition of the 32x64 intermediate (4 KiB per wave).
+// LDS: 64 K (W1 half) + 16 K (W2) + 16 x 4 K = 144 KiB.
+// The kernel is bounded by VALU issue, not HBM: 768 GELUs per token; GELU is evaluated as
+//   gelu(x) = max(x,0) - |x| * Phi(-|x|),   Phi(-a) = 2^q5(a)   (degree-5 fit, |abs error| < 5e-7, all-packed v_pk_fma_f32)
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
 
-constexpr int UP_THREADS = 256;
-constexpr int W1_BYTES = 256 * 256 * 2;        // [n1 = sub*64 + c][k = 256] bf16, 512-B rows, 16-B chunks XOR-swizzled by (n1 & 7)
-constexpr int T_BYTES = 4 * 16 * 64 * 2;       // per-wave transposition buffer [16 tokens][64 ch] bf16 (+ swizzle)
-constexpr int OUT_BYTES = 32 * 4 * 64 * 2;     // staging [c2][yy][64 x] bf16
-constexpr int UP_LDS = W1_BYTES + T_BYTES + OUT_BYTES;   // 131072 + 8192 + 16384 = 155648
+constexpr int UP_THREADS = 1024;
+constexpr int UP_WAVES = UP_THREADS / 64;
+constexpr int W1H_BYTES = 128 * 256 * 2;       // [n = kw*64 + c][k = 256] bf16, 512-B rows, 16-B chunks XOR-swizzled by (n & 7)
+constexpr int W2_BYTES = 128 * 64 * 2;         // [n2 = sub2*32 + c2][k = 64] bf16, 128-B rows, chunks XOR-swizzled by (n2 & 7)
+constexpr int T_WAVE_BYTES = 32 * 64 * 2;      // per-wave transposition buffer [kw*16 + token][64 ch] bf16 (swizzled)
+constexpr int UP_LDS = W1H_BYTES + W2_BYTES + UP_WAVES * T_WAVE_BYTES;   // 147456
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct UpArgs {
   const bf16_t* src;      // [B, h*w, 256]
@@ -37,146 +50,225 @@ struct UpArgs {
   float eps;
 };
 
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+// GELU(erf), two values per lane so every multiply-add is a v_pk_fma_f32.  gelu(x) = relu(x) - a Phi(-a), a = |x| = 2 relu(x) - x,
+// log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute error of a Phi(-a) over [0, 12], 4.8e-7 in fp32; the
+// leading coefficient is negative so the tail underflows to 0 for any |x|).  One v_exp_f32 per value instead of exp + rcp.
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  const f32x2 xp = __builtin_elementwise_max(x, splat2(0.f));
+  const f32x2 a = __builtin_elementwise_fma(splat2(2.f), xp, -x);
+  f32x2 q = __builtin_elementwise_fma(splat2(-0.0004733088717330247f), a, splat2(0.007084553129971027f));
+  q = __builtin_elementwise_fma(q, a, splat2(-0.05182736739516258f));
+  q = __builtin_elementwise_fma(q, a, splat2(-0.4599924683570862f));
+  q = __builtin_elementwise_fma(q, a, splat2(-1.1507878303527832f));
+  q = __builtin_elementwise_fma(q, a, splat2(-1.000037670135498f));
+  const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  return __builtin_elementwise_fma(-a, e, xp);
+}
+
+// all-reduce (sum) over the 16 lanes of a DPP row for four independent values: 16 v_add_f32_dpp, no LDS traffic.  The four
+// chains are interleaved so every DPP source was written >= 3 instructions earlier (the VALU-write -> DPP-read hazard needs
+// two wait states, which the leading s_nop covers for the first step).
+__device__ __forceinline__ void row16_sum4(float& v0, float& v1, float& v2, float& v3) {
+#define MP_DPP4(ctrl)                                                                 \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+  asm("s_nop 1\n" MP_DPP4("quad_perm:[1,0,3,2]") MP_DPP4("quad_perm:[2,3,0,1]") MP_DPP4("row_half_mirror") MP_DPP4("row_mirror")
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+#undef MP_DPP4
+}
+
 __device__ __forceinline__ int w1_off(int n, int c) { return n * 512 + ((c ^ (n & 7)) << 4); }      // c = 16-B chunk 0..31
 
+template <bool WITH_UP, bool WITH_MASK>
 __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW1 = smem;
-  char* sT = smem + W1_BYTES;
-  bf16_t* sOut = reinterpret_cast<bf16_t*>(smem + W1_BYTES + T_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* sW2 = smem + W1H_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
+  bf16_t* tw = reinterpret_cast<bf16_t*>(smem + W1H_BYTES + W2_BYTES + wave * T_WAVE_BYTES);
 
-  // ---- stage W1 once per workgroup (16 KiB per pass of 256 threads x 4 x 16 B)
-  for (int id = tid; id < 256 * 32; id += UP_THREADS) {
-    const int n = id >> 5, c = id & 31;
-    *reinterpret_cast<bf16x8*>(sW1 + w1_off(n, c)) = *reinterpret_cast<const bf16x8*>(a.w1p + (int64_t)n * 256 + c * 8);
-  }
-  // per-lane constants: bias / LN params of this lane's 4 channels (c = j*16 + fr), W2 fragments (this wave's K slice is all 64)
-  float b1v[4], lwv[4], lbv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { b1v[j] = a.b1[j * 16 + fr]; lwv[j] = a.lnw[j * 16 + fr]; lbv[j] = a.lnb[j * 16 + fr]; }
-  bf16x8 w2f[8][2];           // B fragments of GEMM2: n2 = nf*16 + fr, k chunk kk*4 + fq
-#pragma unroll
-  for (int nf = 0; nf < 8; ++nf)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      w2f[nf][kk] = *reinterpret_cast<const bf16x8*>(a.w2p + (int64_t)(nf * 16 + fr) * 64 + (kk * 4 + fq) * 8);
-  float b2v[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) b2v[p] = a.b2[p * 16 + fr];
-  __syncthreads();
+  // workgroup -> (kh, group set): partners share blockIdx % 8, i.e. the XCD and its L2
+  int kh, gset;
+  const int n_gsets = gridDim.x >> 1;
+  if ((gridDim.x & 15) == 0) { const int loc = blockIdx.x >> 3; kh = loc & 1; gset = (loc >> 1) * 8 + (blockIdx.x & 7); }
+  else { kh = blockIdx.x & 1; gset = blockIdx.x >> 1; }
 
   const int tokens_per_img = a.h * a.w;
   const int64_t n_tokens = (int64_t)a.B * tokens_per_img;
-  const int64_t n_groups = (n_tokens + 15) / 16;
-  const int kh = wave >> 1, kw = wave & 1;     // this wave's sub-pixel of the first ConvT
-  const int OW = 4 * a.w, OH = 4 * a.h;
+  const int64_t n_groups = n_tokens / 16;                  // w % 16 == 0: groups are whole
+  const int nw = blockDim.x >> 6;                          // waves in this launch (1..16: small problems spread over more CUs)
+  const int64_t stride = (int64_t)n_gsets * nw;
+  int64_t grp = (int64_t)gset * nw + wave;
 
-  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  // ---- stage this kh's half of W1 (64 instructions of 1 KiB = 2 rows each, 4 per wave) and W2 (16 x 1 KiB = 8 rows each, one
+  //      per wave) by LDS-DMA; the LDS image is lane-linear, so the XOR swizzle sits on the source address
+  for (int j = wave; j < 64; j += nw) {
+    const int n = 2 * j + (lane >> 5), pc = lane & 31;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w1p + (int64_t)(kh * 128 + n) * 256 + ((pc ^ (n & 7)) << 3)),
+                                     (__attribute__((address_space(3))) void*)(sW1 + j * 1024), 16, 0, 0);
+  }
+  for (int j = wave; j < 16; j += nw) {
+    const int n = 8 * j + (lane >> 3), pc = lane & 7;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w2p + (int64_t)n * 64 + ((pc ^ (n & 7)) << 3)),
+                                     (__attribute__((address_space(3))) void*)(sW2 + j * 1024), 16, 0, 0);
+  }
+  // per-lane constants (channel = j*16 + fr)
+  float b1v[4], lwv[4], lbv[4], b2v[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { b1v[j] = a.b1[j * 16 + fr]; lwv[j] = a.lnw[j * 16 + fr]; lbv[j] = a.lnb[j * 16 + fr]; }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) b2v[p] = a.b2[p * 16 + fr];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int OW = 4 * a.w, OH = 4 * a.h;
+  for (; grp < n_groups; grp += stride) {
     const int64_t t0 = grp * 16;
     const int b = (int)(t0 / tokens_per_img);
     const int ti = (int)(t0 % tokens_per_img);
-    const int irow = ti / a.w, j0 = ti % a.w;          // 16 consecutive tokens of one image row (w % 16 == 0)
-    // ---------------- GEMM1: 16 tokens x 64 channels of sub-pixel `wave` ----------------
-    f32x4 acc1[4];
+    const int irow = ti / a.w, j0 = ti % a.w;
+    bf16x8 xa[8];          // four waves per SIMD hide this latency; a register prefetch would cost 32 VGPRs across the whole body
+    {
+      const bf16_t* xrow = a.src + (t0 + fr) * 256;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* xrow = a.src + (min(t0 + fr, n_tokens - 1)) * 256;
+      for (int kk = 0; kk < 8; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(xrow + (kk * 4 + fq) * 8);
+    }
+    float h0 = 0.f, h1 = 0.f;
+    if (WITH_MASK) { h0 = a.hyper[(int64_t)b * 32 + fr]; h1 = a.hyper[(int64_t)b * 32 + 16 + fr]; }
+    // ---------------- GEMM1: 16 tokens x (2 kw x 64 channels) ----------------
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[kw][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xrow + (kk * 4 + fq) * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sW1 + w1_off(wave * 64 + j * 16 + fr, kk * 4 + fq));
-        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, acc1[j], 0, 0, 0);
-      }
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sW1 + w1_off(kw * 64 + j * 16 + fr, kk * 4 + fq));
+          acc1[kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb, acc1[kw][j], 0, 0, 0);
+        }
     }
     // ---------------- + bias, LayerNorm2d over the 64 channels, GELU (C layout: channel = j*16 + fr, token = fq*4 + r) ----
-    bf16_t* tw = reinterpret_cast<bf16_t*>(sT + wave * (16 * 64 * 2));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v[4], s = 0.f;
+    for (int kw = 0; kw < 2; ++kw) {
+      f32x2 v[2][4];                          // [token pair rp][j]: tokens r = 2rp, 2rp+1 -> packed arithmetic
+      f32x2 s[2] = {splat2(0.f), splat2(0.f)};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = acc1[j][r] + b1v[j]; s += v[j]; }
+      for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-      const float mean = s * (1.f / 64.f);
-      float q = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          v[rp][j] = f32x2{acc1[kw][j][2 * rp], acc1[kw][j][2 * rp + 1]} + splat2(b1v[j]);
+          s[rp] += v[rp][j];
+        }
+      {
+        float s0 = s[0].x, s1 = s[0].y, s2 = s[1].x, s3 = s[1].y;
+        row16_sum4(s0, s1, s2, s3);
+        s[0] = f32x2{s0, s1}; s[1] = f32x2{s2, s3};
+      }
+      f32x2 q[2] = {splat2(0.f), splat2(0.f)};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; q += d * d; }
+      for (int rp = 0; rp < 2; ++rp) {
+        const f32x2 mean = s[rp] * splat2(1.f / 64.f);
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) q += __shfl_xor(q, off, 64);
-      const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + a.eps);
-      const int tk = fq * 4 + r;
+        for (int j = 0; j < 4; ++j) { v[rp][j] -= mean; q[rp] = __builtin_elementwise_fma(v[rp][j], v[rp][j], q[rp]); }
+      }
+      {
+        float q0 = q[0].x, q1 = q[0].y, q2 = q[1].x, q3 = q[1].y;
+        row16_sum4(q0, q1, q2, q3);
+        q[0] = f32x2{q0, q1}; q[1] = f32x2{q2, q3};
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float y = gelu_erf((v[j] - mean) * rstd * lwv[j] + lbv[j]);
-        // transposition buffer [token][64 ch], 16-B chunks XOR-swizzled by (token & 7): A-operand reads are conflict-light
-        const int ch = j * 16 + fr;
-        tw[tk * 64 + ((((ch >> 3) ^ (tk & 7)) << 3) | (ch & 7))] = (bf16_t)y;
+      for (int rp = 0; rp < 2; ++rp) {
+        const f32x2 var = __builtin_elementwise_fma(q[rp], splat2(1.f / 64.f), splat2(a.eps));
+        const f32x2 rstd = {__builtin_amdgcn_rsqf(var.x), __builtin_amdgcn_rsqf(var.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 y = gelu2(__builtin_elementwise_fma(v[rp][j] * rstd, splat2(lwv[j]), splat2(lbv[j])));
+          const int ch = j * 16 + fr;       // transposition buffer [kw*16 + token][64 ch], 16-B chunks XOR-swizzled by (token & 7)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int tk = fq * 4 + 2 * rp + e;
+            tw[(kw * 16 + tk) * 64 + ((((ch >> 3) ^ (tk & 7)) << 3) | (ch & 7))] = (bf16_t)y[e];
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---------------- GEMM2: [16 tokens] x [128 = sub2*32 + c2], K = 64 ----------------
-    f32x4 acc2[8];
+    bf16x8 ya[2][2];
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf) acc2[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kw = 0; kw < 2; ++kw)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 ya = *reinterpret_cast<const bf16x8*>(tw + fr * 64 + (((kk * 4 + fq) ^ (fr & 7)) << 3));
+      for (int kk = 0; kk < 2; ++kk)
+        ya[kw][kk] = *reinterpret_cast<const bf16x8*>(tw + (kw * 16 + fr) * 64 + (((kk * 4 + fq) ^ (fr & 7)) << 3));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // the transposition buffer may be overwritten by the next group
+    // ---------------- GEMM2 per output line 2kh + kh2: [2 kw x 16 tokens] x [kw2, half] (64 of the 128 columns), K = 64 ----------------
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) acc2[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya, w2f[nf][kk], acc2[nf], 0, 0, 0);
-    }
-    // ---------------- + bias, GELU, [hyper dot], stage as [c2][yy][x] ----------------
-    __syncthreads();                                  // previous group's staging buffer has been drained
-    const float* hy = a.hyper ? a.hyper + (int64_t)b * 32 : nullptr;
+    for (int kh2 = 0; kh2 < 2; ++kh2) {
+      // acc2[kw][q], q = kw2*2 + half: n2 = (kh2*4 + q)*16 + fr -> c2 = half*16 + fr; acc2[..][r] is token fq*4 + r
+      f32x4 acc2[2][4];
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf) {
-      const int sub2 = nf >> 1, c2 = (nf & 1) * 16 + fr;
-      const int kh2 = sub2 >> 1, kw2 = sub2 & 1;
-      const int yy = 2 * kh + kh2;
-      const float hv = hy ? hy[c2] : 0.f;
+      for (int kw = 0; kw < 2; ++kw)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tk = fq * 4 + r;
-        const float y = gelu_erf(acc2[nf][r] + b2v[nf & 1]);
-        const int xx = 4 * tk + 2 * kw + kw2;
-        sOut[(c2 * 4 + yy) * 64 + xx] = (bf16_t)y;
-        if (a.mask) {
-          // the reference multiplies the bf16-rounded upscaled embedding; keep that rounding point
-          float m = hv * (float)(bf16_t)y;
+        for (int qn = 0; qn < 4; ++qn) acc2[kw][qn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int off = 1; off < 16; off <<= 1) m += __shfl_xor(m, off, 64);
-          acc2[nf][r] = m;                             // partial over this fragment's 16 channels (same value in the 16 lanes)
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+          const int n2 = (kh2 * 4 + qn) * 16 + fr;
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sW2 + n2 * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 4));
+#pragma unroll
+          for (int kw = 0; kw < 2; ++kw) acc2[kw][qn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[kw][kk], wb, acc2[kw][qn], 0, 0, 0);
+        }
+      // ---------------- + bias, GELU, store: lane owns pixels 16fq .. 16fq+15 (= r*4 + kw*2 + kw2) of this line ----------------
+      float msum[16];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16_t px[16];
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+          for (int kw2 = 0; kw2 < 2; ++kw2) {
+            const f32x4 c = acc2[kw][kw2 * 2 + half];
+            const f32x2 g01 = gelu2(f32x2{c[0], c[1]} + splat2(b2v[half]));
+            const f32x2 g23 = gelu2(f32x2{c[2], c[3]} + splat2(b2v[half]));
+            px[0 * 4 + kw * 2 + kw2] = (bf16_t)g01.x;
+            px[1 * 4 + kw * 2 + kw2] = (bf16_t)g01.y;
+            px[2 * 4 + kw * 2 + kw2] = (bf16_t)g23.x;
+            px[3 * 4 + kw * 2 + kw2] = (bf16_t)g23.y;
+          }
+        if (WITH_UP) {
+          bf16_t* dst = a.up + (((int64_t)b * 32 + half * 16 + fr) * OH + 4 * irow + 2 * kh + kh2) * OW + 4 * j0 + 16 * fq;
+          bf16x8 lo, hi;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { lo[i] = px[i]; hi[i] = px[8 + i]; }
+          *reinterpret_cast<bf16x8*>(dst) = lo;
+          *reinterpret_cast<bf16x8*>(dst + 8) = hi;
+        }
+        if (WITH_MASK) {      // the reference multiplies the bf16-rounded upscaled embedding: keep that rounding point
+          const float hv = half ? h1 : h0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) msum[i] = half ? fmaf(hv, (float)px[i], msum[i]) : hv * (float)px[i];
         }
       }
-    }
-    if (a.mask && fr == 0) {
+      if (WITH_MASK) {
 #pragma unroll
-      for (int sub2 = 0; sub2 < 4; ++sub2)
+        for (int i = 0; i < 16; i += 4) row16_sum4(msum[i], msum[i + 1], msum[i + 2], msum[i + 3]);
+        if (fr == 0) {
+          float* dst = a.mask + ((int64_t)b * OH + 4 * irow + 2 * kh + kh2) * OW + 4 * j0 + 16 * fq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int tk = fq * 4 + r;
-          if (t0 + tk < n_tokens) {
-            const int yy = 2 * kh + (sub2 >> 1), xx = 4 * (j0 + tk) + 2 * kw + (sub2 & 1);
-            a.mask[((int64_t)b * OH + 4 * irow + yy) * OW + xx] = acc2[2 * sub2][r] + acc2[2 * sub2 + 1][r];
-          }
+          for (int i = 0; i < 16; i += 4) *reinterpret_cast<float4*>(dst + i) = float4{msum[i], msum[i + 1], msum[i + 2], msum[i + 3]};
         }
-    }
-    __syncthreads();
-    if (a.up) {
-      // 128 rows (c2, yy) of 64 pixels = 128 B each: 8 lanes per row, 16 B per lane
-      const int valid_x = (int)min((int64_t)64, 4 * (n_tokens - t0));
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int id = it * UP_THREADS + tid;
-        const int row = id >> 3, ch = (id & 7) * 8;
-        const int c2 = row >> 2, yy = row & 3;
-        if (ch < valid_x)
-          *reinterpret_cast<bf16x8*>(a.up + (((int64_t)b * 32 + c2) * OH + 4 * irow + yy) * OW + 4 * j0 + ch) =
-              *reinterpret_cast<const bf16x8*>(sOut + row * 64 + ch);
       }
     }
   }
@@ -190,15 +282,19 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
   MP_REQUIRE(B > 0 && h > 0 && w > 0 && w % 16 == 0, MP_ERR_SHAPE, "mp_mask_upsample_fused_bf16: token-grid width must be a multiple of 16");
   MP_REQUIRE(up != nullptr || mask != nullptr, MP_ERR_ARG, "mp_mask_upsample_fused_bf16: nothing to produce");
   MP_REQUIRE(mask == nullptr || hyper != nullptr, MP_ERR_ARG, "mp_mask_upsample_fused_bf16: mask output needs hyper");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)upsample_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
-    attr_set = true;
-  }
   UpArgs a{(const bf16_t*)src, (const bf16_t*)w1_packed, b1, ln_w, ln_b, (const bf16_t*)w2_packed, b2, hyper, (bf16_t*)up, mask,
            B, h, w, ln_eps};
   const int64_t groups = mp_cdiv((int64_t)B * h * w, 16);
-  const int grid = (int)(groups < 256 ? groups : 256);
-  hipLaunchKernelGGL(upsample_fused_kernel, dim3(grid), dim3(UP_THREADS), UP_LDS, stream, a);
+  // one group per wave and pass; two workgroups (kh = 0, 1) per group set; up to 128 group sets (256 CUs), then more waves
+  const int nw = (int)std::min<int64_t>(UP_WAVES, mp_cdiv(groups, 128));
+  const int64_t gsets = mp_cdiv(groups, nw);
+  const int grid = 2 * (int)(gsets < 128 ? gsets : 128);
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), UP_LDS, stream, a);
+  };
+  if (up && mask) launch(upsample_fused_kernel<true, true>);
+  else if (up) launch(upsample_fused_kernel<true, false>);
+  else launch(upsample_fused_kernel<false, true>);
   return mp_check_launch("mp_mask_upsample_fused_bf16");
 }

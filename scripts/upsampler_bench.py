@@ -44,8 +44,12 @@ for grid in (16, 64):
     except Exception as e:          # graph capture unavailable: plain back-to-back launches
         graph = None
         print("graph capture failed:", repr(e), file=sys.stderr)
+    # pre-heat: a few ms of dense GEMM so the measurement is not taken on idle (un-ramped) clocks
+    ha = torch.randn(4096, 4096, device=dev).to(torch.bfloat16); hw = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
+    for _ in range(30):
+        ops.gemm(ha, hw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = 200
     e0.record()
     for _ in range(reps):
         if graph is not None:
