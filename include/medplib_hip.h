@@ -59,6 +59,11 @@ int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const v
                             void* C, int64_t ldc, int64_t strideC, const float* bias, int64_t strideBias, int batch,
                             int M, int N, int K, int act, int out_dtype, const int* m_dev, hipStream_t stream);
 
+/* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
+ * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
+ * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */
+int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
+
 /* Fused attention forward; variant 0 = hardware transpose-read V path, 1 = scalar-transposed V (cross-check).
  * Llama causal + key padding (HF-4.31 eager), CLIP (A.2), SAM window/global attention with decomposed
  * rel-pos bias (image_encoder.py:280-296, 381-421).  Strides: batch, sequence (head stride = D). */

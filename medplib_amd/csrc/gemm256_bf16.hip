@@ -19,6 +19,7 @@
 // bias / activation / residual.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -302,30 +303,72 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
 //   DMA  :  P0 A-q1 of tile t+1 | P1 A-q0 of tile t+2 | P2 B[0,1] of tile t+2 | P3 B[2,3] of tile t+2
 // (A-q0 rows are free after P0, B after P1, A-q1 rows after P2.)  Every LOAD segment ends with lgkmcnt(0) before its barrier,
 // so a region's reads are retired by all waves before the barrier that precedes the first DMA into it.
+//
+// Work decode (flat 1-D grid over all batches) and TAIL SPLIT-K.  T = tiles of all batches (from the effective, device-side row
+// counts).  The first full = floor(T / CUs) * CUs tiles are whole-K units, XCD-chunked so that the units co-resident on one XCD
+// cover neighbouring tiles.  The remaining rem = T - full tiles would occupy rem of the CUs for a whole tile-time (Llama's
+// N = 4096 GEMMs at 5112 rows: 320 tiles = 1.25 waves -> 62 % of the machine); instead each is cut into S = floor(CUs / rem)
+// K-ranges that run side by side, so the tail costs 1/S tile-time.  A split unit writes its fp32 accumulators to the
+// workspace in register order (coalesced 16-byte stores), takes a ticket, and the LAST arriver of a tile sums the S partials
+// in ascending split order (its own from registers) -- a fixed order, so the result does not depend on the arrival order --
+// and runs the normal epilogue.
+constexpr int MAX_FLAT_BATCH = 8;
+
 template <int ABL>
 __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int batch = blockIdx.y;
+  const int N = g.N;
+  const int tiles_n = (N + BN2 - 1) / BN2;
+  // ---- tile counts per batch (block-uniform scalar work)
+  int T = 0;
+  int pre[MAX_FLAT_BATCH];
+#pragma unroll
+  for (int b = 0; b < MAX_FLAT_BATCH; ++b) {
+    pre[b] = T;
+    if (b < g.nbatch) {
+      const int Mb = g.m_dev ? min(g.M, g.m_dev[b * g.m_dev_stride]) : g.M;
+      T += ((Mb + BM2 - 1) / BM2) * tiles_n;
+    }
+  }
+  const int C = g.n_cu;
+  const int full = (T / C) * C, rem = T - full;
+  const int nt_all = g.K / BK2;
+  int S = 1;
+  if (g.ws && rem > 0) S = max(1, min(min(C / rem, g.max_split), nt_all / 4));
+  int bid = blockIdx.x;
+  if (bid >= full + rem * S) return;
+  int flat, split = 0;
+  if (bid < full) {
+    const int q = full >> 3, xcd = bid & 7, loc = bid >> 3;      // full is a multiple of the CU count, hence of 8
+    flat = xcd * q + loc;
+  } else {
+    const int r = bid - full;
+    flat = full + r % rem;
+    split = r / rem;
+  }
+  const bool is_split = (bid >= full) && S > 1;
+  int batch = 0, pbase = 0;
+#pragma unroll
+  for (int b = 1; b < MAX_FLAT_BATCH; ++b) if (b < g.nbatch && flat >= pre[b]) { batch = b; pbase = pre[b]; }
+  const int lid = flat - pbase;
   const bf16_t* __restrict__ A = g.A + batch * g.sA;
   const bf16_t* __restrict__ W = g.W + batch * g.sW;
   const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
-  const int N = g.N, K = g.K;
   const int tiles_m = (M + BM2 - 1) / BM2;
-  const int tiles_n = (N + BN2 - 1) / BN2;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (bid >= nwg) return;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
   const int GROUP_M = g.group_m;
   const int per_group = GROUP_M * tiles_n;
-  const int grp = bid / per_group;
+  const int grp = lid / per_group;
   const int first_m = grp * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+  const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
   const int m0 = tm * BM2, n0 = tn * BN2;
+  // K range of this unit (in BK2 tiles)
+  int kt0 = 0, nt = nt_all;
+  if (is_split) {
+    const int base = nt_all / S, extra = nt_all % S;
+    kt0 = split * base + min(split, extra);
+    nt = base + (split < extra ? 1 : 0);
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -343,8 +386,8 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   for (int i = 0; i < 4; ++i) {
     const int arow = (wave + 8 * i) * 8 + sub_row;
     const int wrow = (wave * 4 + i) * 8 + sub_row;
-    a_src[i] = A + (int64_t)min(m0 + arow, M - 1) * g.lda + src_c * 8;
-    w_src[i] = W + (int64_t)min(n0 + wrow, N - 1) * g.ldw + src_c * 8;
+    a_src[i] = A + (int64_t)min(m0 + arow, M - 1) * g.lda + src_c * 8 + (int64_t)kt0 * BK2;
+    w_src[i] = W + (int64_t)min(n0 + wrow, N - 1) * g.ldw + src_c * 8 + (int64_t)kt0 * BK2;
   }
   auto dma_a = [&](int i, int t) {
     if constexpr (ABL == 3) return;
@@ -399,7 +442,6 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   } while (0)
 #define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-  const int nt = K / BK2;
   // ---- prologue: all of tile 0, and tile 1 except its A-q1 rows (those are issued in P0 of tile 0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dma_a(i, 0); dma_w(i, 0); }
@@ -448,11 +490,71 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     MP_BAR();
   }
   if (wr == 0) MP_BAR();
+  if (is_split) {
+    const int tail = flat - full;
+    // Partials travel as agent-scope relaxed atomics (global_store/load ... sc1: written through to / read from the
+    // memory-side coherence point), so no L2 write-back or invalidate is needed for the other XCDs to see them -- an
+    // agent-scope fence per wave costs an L2-wide flush each and made the tail slower than the unsplit tile.
+    unsigned long long* wsu = reinterpret_cast<unsigned long long*>(g.ws + ((int64_t)tail * S) * (BM2 * BN2));
+    unsigned long long* mine = wsu + (int64_t)split * (BM2 * BN2 / 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float lo = acc[i][j][2 * h], hi = acc[i][j][2 * h + 1];
+          const unsigned long long v = (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+          __hip_atomic_store(mine + ((i * 4 + j) * 2 + h) * NT2 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(g.tickets + tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *flag;
+    __syncthreads();                                   // smem is reused by the epilogue
+    if (ticket != S - 1) return;
+    if (tid == 0) __hip_atomic_store(g.tickets + tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting
+    // sum the S partials in ascending split order (own one re-read from the workspace: the order, hence the rounding, is then
+    // independent of which unit arrived last)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; ++sp) {
+      const unsigned long long* part = wsu + (int64_t)sp * (BM2 * BN2 / 2);
+#pragma unroll
+      for (int ip = 0; ip < 4; ++ip) {                 // 16 loads in flight, then their adds
+        unsigned long long t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          t[q] = __hip_atomic_load(part + (ip * 16 + q) * NT2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = ip * 2 + (q >> 3), j = (q >> 1) & 3, h = q & 1;
+          acc[i][j][2 * h] += __uint_as_float((unsigned)(t[q] & 0xffffffffull));
+          acc[i][j][2 * h + 1] += __uint_as_float((unsigned)(t[q] >> 32));
+        }
+      }
+    }
+  }
   gemm256_epilogue(g, acc, smem, batch, M, N, m0, n0, wave, wr, wc, lane, fr, fq);
 }
 
 
 }  // namespace
+
+// tail split-K workspace, registered by the host (mp_gemm_set_workspace): >= n_cu * 256 KiB of fp32 partials + n_cu tickets
+static float* g_split_ws = nullptr;
+static int* g_split_tickets = nullptr;
+static int64_t g_split_ws_bytes = 0;
+
+extern "C" int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
+  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_workspace: need >= 256 zeroed int tickets");
+  g_split_ws = (float*)ws; g_split_tickets = tickets; g_split_ws_bytes = ws ? ws_bytes : 0;
+  return MP_OK;
+}
 
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   static int abl = -1;
@@ -476,11 +578,25 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   }
   const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
   const dim3 grid(tiles, batch), blk(NT2);
-  if (ver == 3) {
-    if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, grid, blk, 2 * STAGE_BYTES, stream, g);
-    else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, grid, blk, 2 * STAGE_BYTES, stream, g);
-    else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, grid, blk, 2 * STAGE_BYTES, stream, g);
-    else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, grid, blk, 2 * STAGE_BYTES, stream, g);
+  if (ver == 3 && batch <= MAX_FLAT_BATCH) {
+    static int n_cu = 0, max_split = -1;
+    if (!n_cu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+      n_cu = std::min(n_cu, 256);                      // workspace / ticket sizing
+      const char* e = getenv("MP_GEMM_MAX_SPLIT");     // 1 = no tail split (A/B), default 8
+      max_split = (e && atoi(e) >= 1) ? atoi(e) : 8;
+    }
+    GemmArgs gf = g;
+    gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split;
+    gf.ws = g_split_ws; gf.tickets = g_split_tickets;
+    if (!gf.ws || g_split_ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
+    const dim3 fgrid(tiles * batch + n_cu);
+    if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+    else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+    else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+    else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
     return mp_check_launch("mp_gemm_bf16_nt(256v3)");
   }
   if (abl == 1) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<1>, grid, blk, 2 * STAGE_BYTES, stream, g);

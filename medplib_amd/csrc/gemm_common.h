@@ -24,6 +24,11 @@ struct GemmArgs {
   int64_t sA, sW, sC, sR, sBias;
   int m_dev_stride;
   int group_m;                // M-tiles per group in the L2-friendly tile order (1 = plain column-major order)
+  // tail split-K of the 256x256 kernel (see gemm256_bf16.hip): fp32 partial workspace + per-tile arrival tickets, or null
+  float* ws; int* tickets;
+  int n_cu;                   // compute units the tile waves are counted against
+  int nbatch;                 // batch count (the flat work decode walks all batches)
+  int max_split;              // upper bound on the tail split factor (1 = off)
 };
 
 static __device__ __forceinline__ float apply_act(float v, int act) {

@@ -57,6 +57,20 @@ GEMM_TIMER = None     # set to a KernelTimer by bench.py
 
 
 # ------------------------------------------------------------------ bf16 trunk ------------------------------------------------
+_GEMM_WS = None
+
+
+def _ensure_gemm_workspace(device):
+    """Register the scratch of the 256x256 GEMM's tail split-K once per process (one process drives one GPU): 64 MiB of fp32
+    partials + 256 zeroed arrival tickets.  The library itself never allocates (mp_gemm_set_workspace)."""
+    global _GEMM_WS
+    if _GEMM_WS is None:
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        tickets = torch.zeros(256, dtype=torch.int32, device=device)
+        lib().call("mp_gemm_set_workspace", _p(ws), ws.numel(), _p(tickets), tickets.numel())
+        _GEMM_WS = (ws, tickets)
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, out=None, alpha=1.0, m_dev=None):
     """out[M,N] = act(alpha * a[M,K] @ w[N,K]^T + bias) + residual.  a/w bf16 with unit inner stride."""
     _chk(a, torch.bfloat16, "gemm.a"); _chk(w, torch.bfloat16, "gemm.w")
@@ -71,6 +85,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
         _chk(bias, torch.float32, "gemm.bias")
     if residual is not None:
         _chk(residual, torch.bfloat16, "gemm.residual"); assert residual.stride(1) == 1
+    _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
     lib().call("mp_gemm_bf16_nt", _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), _p(residual),
                residual.stride(0) if residual is not None else 0, M, N, K, act, _dt(out.dtype), float(alpha), _p(m_dev),
@@ -86,6 +101,7 @@ def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
     E, M, K = a.shape
     N = w.shape[1]
     assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
+    _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
     lib().call("mp_gemm_bf16_nt_batched", _p(a), a.stride(1), a.stride(0), _p(w), w.stride(1), w.stride(0), _p(out),
                out.stride(1), out.stride(0), _p(bias), bias.stride(0) if bias is not None else 0, E, M, N, K, act,

@@ -53,6 +53,20 @@ def run_variant(v):
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 12
     print(f"  {name:28s} {ms * 1e3:8.1f} us  {2.0 * 2 * routed * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+    # expert down projection (N = 4096: 2 x 160 tiles -> the tail split-K case of the flat batched decode)
+    N, K = 4096, 11008
+    a = torch.randn(2, cap, K, device=dev).to(torch.bfloat16)
+    ws = [(torch.randn(2, N, K, device=dev) * 0.05).to(torch.bfloat16) for _ in range(3)]
+    out = torch.empty(2, cap, N, dtype=torch.bfloat16, device=dev)
+    for i in range(3):
+        ops.gemm_batched(a, ws[i % 3], out, m_dev=cnt)
+    torch.cuda.synchronize()
+    s.record()
+    for i in range(12):
+        ops.gemm_batched(a, ws[i % 3], out, m_dev=cnt)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 12
+    print(f"  {'experts down (E=2, 2556 routed)':28s} {ms * 1e3:8.1f} us  {2.0 * 2 * routed * N * K / ms / 1e9:7.1f} TF/s", flush=True)
 
 
 if __name__ == "__main__":
