@@ -168,6 +168,13 @@ int mp_window_unpartition_add_bf16(const void* win, const void* shortcut, void* 
 /* add_decomposed_rel_pos tables rel_h/rel_w from the (unscaled) q of a fused qkv buffer (image_encoder.py:381-421). */
 int mp_relpos_tables_bf16(const void* qkv, int64_t ld, const float* rel_pos_h, const float* rel_pos_w, float* rel_h, float* rel_w,
                           int Bw, int heads, int hh, int ww, int head_dim, hipStream_t stream);
+/* nn.AdaptiveAvgPool1d over the token axis of a token-major [n, len_in, C] tensor: TokenCompressor 576 -> 256 and
+ * MaskTokenEncoder 441 -> 64 (medplib_arch.py:67-77, 98-108). */
+int mp_adaptive_avgpool_tokens_bf16(const void* x, void* out, int n, int len_in, int len_out, int C, hipStream_t stream);
+/* First layer of MaskTokenEncoder: Conv2d(1, CO, k3, s2, p1) + GELU on [n, H, W] masks (bf16 or f32, rounded to bf16 like the
+ * reference's cast, medplib_arch.py:103-104) -> NHWC [n, OH, OW, CO] bf16; w [CO, 9] f32, bias [CO] f32 (medplib_arch.py:84-85). */
+int mp_conv3x3s2_c1_gelu_bf16(const void* img, int img_dtype, const float* w, const float* bias, void* out, int n, int H, int W,
+                              int CO, hipStream_t stream);
 /* Adapter_Layer channel gate: global average pool and per-channel scale (image_encoder.py:43-47). */
 int mp_token_mean_bf16(const void* x, float* out, int B, int T, int C, hipStream_t stream);
 int mp_scale_channels_bf16(const void* x, const float* gate, void* y, int B, int T, int C, hipStream_t stream);

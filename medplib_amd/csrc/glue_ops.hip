@@ -214,6 +214,65 @@ __global__ void copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restr
   *reinterpret_cast<bf16x8*>(dst + r * dim + c) = *reinterpret_cast<const bf16x8*>(src + sr * dim + c);
 }
 
+
+// ---- nn.AdaptiveAvgPool1d over the token axis of a token-major tensor: out[n, i, c] = mean_{t in [floor(i*Lin/Lout),
+//      ceil((i+1)*Lin/Lout))} x[n, t, c]  (TokenCompressor 576 -> 256, MaskTokenEncoder 441 -> 64; medplib_arch.py:67-108).
+//      fp32 accumulation, one bf16 rounding.
+__global__ void adaptive_avgpool_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int n, int Lin, int Lout, int C) {
+  const int per_row = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * Lout * per_row) return;
+  const int c = (int)(idx % per_row) * 8;
+  const int i = (int)((idx / per_row) % Lout);
+  const int b = (int)(idx / ((int64_t)per_row * Lout));
+  const int t0 = (int)(((int64_t)i * Lin) / Lout);
+  const int t1 = (int)((((int64_t)(i + 1)) * Lin + Lout - 1) / Lout);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((int64_t)b * Lin + t) * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+  }
+  const float inv = 1.f / (float)(t1 - t0);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j] * inv);
+  *reinterpret_cast<bf16x8*>(out + ((int64_t)b * Lout + i) * C + c) = o;
+}
+
+// ---- first layer of MaskTokenEncoder: Conv2d(1, CO, k3, s2, p1) + GELU on a single-channel mask image, NHWC bf16 output
+//      (medplib_arch.py:84-85).  One thread per (pixel, 8 output channels): 9 taps x 8 FMAs, HBM-bound on the output.
+template <typename TIN>
+__global__ void conv3x3s2_c1_gelu_kernel(const TIN* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                         bf16_t* __restrict__ out, int n, int H, int W, int OH, int OW, int CO) {
+  const int per_pix = CO / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * OH * OW * per_pix) return;
+  const int co = (int)(idx % per_pix) * 8;
+  const int64_t pix = idx / per_pix;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias[co + j];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      // the reference casts the mask to the model dtype first (medplib_arch.py:103-104)
+      const float v = (float)(bf16_t)ld_f(img, ((int64_t)b * H + iy) * W + ix);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[(co + j) * 9 + ky * 3 + kx], acc[j]);
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)gelu_erf(acc[j]);
+  *reinterpret_cast<bf16x8*>(out + pix * CO + co) = o;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -325,4 +384,26 @@ extern "C" int mp_copy_rows_bf16(const void* src, void* dst, int64_t rows, int d
   hipLaunchKernelGGL(copy_rows_kernel, GRID1D(n), (const bf16_t*)src, (bf16_t*)dst, rows, dim, rows_per_batch, src_batch_rows,
                      src_row0);
   return mp_check_launch("mp_copy_rows_bf16");
+}
+
+extern "C" int mp_adaptive_avgpool_tokens_bf16(const void* x, void* out, int n, int len_in, int len_out, int C, hipStream_t stream) {
+  MP_REQUIRE(n > 0 && len_in > 0 && len_out > 0 && C % 8 == 0, MP_ERR_SHAPE, "mp_adaptive_avgpool_tokens_bf16: bad shape");
+  const int64_t total = (int64_t)n * len_out * (C / 8);
+  hipLaunchKernelGGL(adaptive_avgpool_tokens_kernel, dim3((unsigned)mp_cdiv(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                     (bf16_t*)out, n, len_in, len_out, C);
+  return mp_check_launch("mp_adaptive_avgpool_tokens_bf16");
+}
+
+extern "C" int mp_conv3x3s2_c1_gelu_bf16(const void* img, int img_dtype, const float* w, const float* bias, void* out, int n, int H,
+                                         int W, int CO, hipStream_t stream) {
+  MP_REQUIRE(n > 0 && H > 0 && W > 0 && CO % 8 == 0, MP_ERR_SHAPE, "mp_conv3x3s2_c1_gelu_bf16: bad shape");
+  MP_REQUIRE(img_dtype == MP_BF16 || img_dtype == MP_F32, MP_ERR_DTYPE, "mp_conv3x3s2_c1_gelu_bf16: bad image dtype");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)n * OH * OW * (CO / 8);
+  const dim3 grid((unsigned)mp_cdiv(total, 256)), blk(256);
+  if (img_dtype == MP_F32)
+    hipLaunchKernelGGL(conv3x3s2_c1_gelu_kernel<float>, grid, blk, 0, stream, (const float*)img, w, bias, (bf16_t*)out, n, H, W, OH, OW, CO);
+  else
+    hipLaunchKernelGGL(conv3x3s2_c1_gelu_kernel<bf16_t>, grid, blk, 0, stream, (const bf16_t*)img, w, bias, (bf16_t*)out, n, H, W, OH, OW, CO);
+  return mp_check_launch("mp_conv3x3s2_c1_gelu_bf16");
 }

@@ -42,18 +42,22 @@ class SplicePlan:
 
 def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_mask: Optional[np.ndarray],
                 feature_lengths, images_per_sample: Optional[Sequence[int]] = None, seg_token_idx: Optional[int] = None,
-                seg_feature_lengths=None) -> SplicePlan:
+                seg_feature_lengths=None, feature_bases: Optional[Sequence[int]] = None) -> SplicePlan:
     """input_ids [B, L] int64 with IMAGE_TOKEN_INDEX placeholders.
 
     feature_lengths: int (every image expands to that many rows; one image per sample, consumed in batch order even by
       samples without a placeholder — medplib_arch.py:299-313) or a flat list with one entry per placeholder in
       (sample, position) order (multi-image ICL layouts, medplib_arch.py:246-278).
     seg_feature_lengths: the lengths build_seg_token_mask uses (image_token_len or image_token_lengths[b][k],
-      MedPLIB.py:318-341); defaults to feature_lengths."""
+      MedPLIB.py:318-341); defaults to feature_lengths.
+    feature_bases: first feature row of each placeholder (flat, with per-placeholder feature_lengths) when the feature
+      buffer is not laid out in placeholder order — ICL separate mode keeps all image blocks first and the mask-encoder
+      blocks after them (medplib_arch.py:246-267 interleaves them by `image_token_types`)."""
     ids = np.asarray(input_ids, dtype=np.int64)
     B, L = ids.shape
     assert not (ids == REGION_TOKEN_INDEX).any(), "region prompts (REGION_TOKEN_INDEX) are outside this path"
     per_token = not np.isscalar(feature_lengths)
+    assert feature_bases is None or per_token, "feature_bases needs per-placeholder feature_lengths"
     flat_lengths = list(feature_lengths) if per_token else None
     seg_lens = seg_feature_lengths if seg_feature_lengths is not None else feature_lengths
     seg_per_sample = (not np.isscalar(seg_lens)) and len(seg_lens) > 0 and not np.isscalar(seg_lens[0])
@@ -73,8 +77,9 @@ def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_m
             feat_row += nfeat            # the sample's (unused) image still occupies its feature rows
         for k, p in enumerate(pos):
             nfeat = int(flat_lengths[feat_idx]) if per_token else int(feature_lengths)
+            base = feat_row if feature_bases is None else int(feature_bases[feat_idx])
             src_parts.append(cur[prev:p])
-            src_parts.append(-1 - (feat_row + np.arange(nfeat, dtype=np.int64)))
+            src_parts.append(-1 - (base + np.arange(nfeat, dtype=np.int64)))
             if labels is not None:
                 lab_parts.append(labels[b, prev:p])
                 lab_parts.append(np.full(nfeat, IGNORE_INDEX, dtype=np.int64))
@@ -124,3 +129,19 @@ def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_m
         for b in range(B):
             seg[b, :rows_seg[b].shape[0]] = rows_seg[b]
     return SplicePlan(src, lab, att, seg, np.asarray(lens, dtype=np.int64), feat_row)
+
+
+def icl_feature_layout(image_token_types, image_len: int, mask_len: int):
+    """Per-placeholder (lengths, bases) for ICL separate mode: the feature buffer holds every image block (image_len rows each,
+    in image order) followed by every mask-encoder block (mask_len rows each, in mask order); placeholders draw from the two
+    lists in the order `image_token_types` gives (medplib_arch.py:256-266)."""
+    n_img = sum(1 for row in image_token_types for t in row if t != "mask")
+    lengths, bases = [], []
+    ii = mi = 0
+    for row in image_token_types:
+        for t in row:
+            if t == "mask":
+                lengths.append(mask_len); bases.append(n_img * image_len + mi * mask_len); mi += 1
+            else:
+                lengths.append(image_len); bases.append(ii * image_len); ii += 1
+    return lengths, bases

@@ -4,8 +4,9 @@ CPU fp32 restatement of the LLM side of the path from an HF-layout state dict (S
 CLIP ViT-L vision tower + mm_projector, the multimodal splice, the Llama decoder stack with dense or DeepSpeed-MoE
 MLPs, fp32 logits + filtered CE, and the <SEG> mask.
 
-Pinning: the splice / seg-mask / CE functions restate reference code that is present in /root/reference and are
-checked against it by oracle/make_golden.py (tests/golden/glue_reference.npz).  Llama/CLIP arithmetic is third-party
+Pinning: the splice / seg-mask / TokenCompressor / MaskTokenEncoder functions restate reference code that is present in
+/root/reference and are checked against the EXECUTED reference by oracle/make_golden.py (tests/golden/glue_reference.npz:
+`LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal`, `MedPLIBForCausalLM.build_seg_token_mask`, the two modules).  Llama/CLIP arithmetic is third-party
 (transformers==4.31.0, requirements.txt:137) — cross-checked in tests against the installed transformers' modules,
 "parity unpinned" w.r.t. 4.31.0 itself.  DeepSpeed-MoE (deepspeed==0.13.1, requirements.txt:22) is absent from the
 container: restated from SURVEY Appendix A.3, **parity unpinned**, guarded by known-answer tests."""
@@ -46,6 +47,64 @@ def clip_features(images, W, cfg, prefix="model.vision_tower.vision_tower.vision
 def mm_projector(x, W, prefix="model.mm_projector."):
     """mlp2x_gelu (multimodal_projector/builder.py:39-46)."""
     return F.linear(F.gelu(F.linear(x, W[prefix + "0.weight"], W[prefix + "0.bias"])), W[prefix + "2.weight"], W[prefix + "2.bias"])
+
+
+def token_compressor(x, W, num_tokens, prefix="model.mm_token_compressor."):
+    """TokenCompressor.forward (medplib_arch.py:67-77): AdaptiveAvgPool1d over tokens -> LayerNorm(eps 1e-5) -> Linear.
+    x [n, 576, d] -> [n, num_tokens, d]."""
+    d = x.shape[-1]
+    x = F.adaptive_avg_pool1d(x.transpose(1, 2), num_tokens).transpose(1, 2)
+    x = F.layer_norm(x, (d,), W[prefix + "norm.weight"], W[prefix + "norm.bias"], 1e-5)
+    return F.linear(x, W[prefix + "proj.weight"], W[prefix + "proj.bias"])
+
+
+def mask_token_encoder(masks, W, num_tokens, prefix="model.mask_encoder."):
+    """MaskTokenEncoder.forward (medplib_arch.py:80-108): 4 x [Conv2d k3 s2 p1 + GELU] (1->64->128->256->256),
+    flatten(2) -> AdaptiveAvgPool1d(num_tokens) -> transpose -> Linear(256, hidden) -> LayerNorm(hidden).
+    masks [n, 1, H, W] (or [n, H, W]) -> [n, num_tokens, hidden]."""
+    if masks.dim() == 3:
+        masks = masks.unsqueeze(1)
+    if masks.shape[1] != 1:
+        masks = masks[:, :1]
+    x = masks.to(W[prefix + "proj.weight"].dtype)
+    for i in (0, 2, 4, 6):
+        x = F.gelu(F.conv2d(x, W[prefix + f"encoder.{i}.weight"], W[prefix + f"encoder.{i}.bias"], stride=2, padding=1))
+    x = F.adaptive_avg_pool1d(x.flatten(2), num_tokens).transpose(1, 2)
+    x = F.linear(x, W[prefix + "proj.weight"], W[prefix + "proj.bias"])
+    return F.layer_norm(x, (x.shape[-1],), W[prefix + "norm.weight"], W[prefix + "norm.bias"], 1e-5)
+
+
+def init_icl_weights(hidden, seed, scale=0.1):
+    """Seeded TokenCompressor / MaskTokenEncoder weights in the checkpoint key layout (model.mm_token_compressor.*,
+    model.mask_encoder.*; medplib_arch.py:67-108).  Used by make_golden (loaded into the reference modules) and by the tests."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, s=scale):
+        return torch.randn(*shape, generator=g) * s
+    W = {"model.mm_token_compressor.norm.weight": 1 + rn(hidden), "model.mm_token_compressor.norm.bias": rn(hidden),
+         "model.mm_token_compressor.proj.weight": rn(hidden, hidden, s=hidden ** -0.5), "model.mm_token_compressor.proj.bias": rn(hidden)}
+    cin = 1
+    for i, cout in zip((0, 2, 4, 6), (64, 128, 256, 256)):
+        W[f"model.mask_encoder.encoder.{i}.weight"] = rn(cout, cin, 3, 3, s=(cin * 9) ** -0.5)
+        W[f"model.mask_encoder.encoder.{i}.bias"] = rn(cout)
+        cin = cout
+    W["model.mask_encoder.proj.weight"] = rn(hidden, 256, s=256 ** -0.5)
+    W["model.mask_encoder.proj.bias"] = rn(hidden)
+    W["model.mask_encoder.norm.weight"] = 1 + rn(hidden)
+    W["model.mask_encoder.norm.bias"] = rn(hidden)
+    return W
+
+
+def combine_icl_features(image_features, mask_features, image_token_types):
+    """medplib_arch.py:246-267: one feature block per placeholder, drawn from the image or the mask list by its type."""
+    out, ii, mi = [], 0, 0
+    for sample_types in image_token_types:
+        for t in sample_types:
+            if t == "mask":
+                out.append(mask_features[mi]); mi += 1
+            else:
+                out.append(image_features[ii]); ii += 1
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- splice + seg mask

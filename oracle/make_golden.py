@@ -77,10 +77,10 @@ def golden_sam():
                         low_res_masks=r_masks.numpy(), iou_pred=r_iou.numpy())
 
 
-def golden_mask_head():
-    """postprocess_masks / losses / metrics: run the reference functions from model/MedPLIB.py.  That module imports
-    deepspeed/transformers at import time, so the four loss callables and postprocess_masks are exercised through a
-    minimal stub environment (types.ModuleType stand-ins for deepspeed & friends, SURVEY Appendix C)."""
+def _import_reference_medplib():
+    """Import the reference's model/MedPLIB.py.  It pulls deepspeed / torchvision / cv2 at import time, none of which exist in
+    the image, so those names are registered as EMPTY types.ModuleType stand-ins (no behaviour is faked: nothing on the paths
+    exercised here calls into them)."""
     import types
     import transformers  # noqa: F401  (must be fully imported before the stubs go in: its lazy loader probes find_spec)
     import transformers.modeling_utils, transformers.generation  # noqa: F401,E401
@@ -96,12 +96,205 @@ def golden_mask_head():
     sys.modules["torchvision.transforms.functional"].to_pil_image = lambda *a, **k: None
     sys.modules["torchvision.ops.boxes"].batched_nms = lambda *a, **k: None
     sys.modules["torchvision.ops.boxes"].box_area = lambda *a, **k: None
-    sys.path.insert(0, REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
     try:
         import model.MedPLIB as M
     except Exception as e:  # pragma: no cover
         print("reference model.MedPLIB import failed:", repr(e))
         raise
+    return M
+
+
+def golden_glue():
+    """Splice / <SEG> mask / TokenCompressor / MaskTokenEncoder: run the reference's own
+    `LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal` (medplib_arch.py:217-527), `build_seg_token_mask`
+    (MedPLIB.py:310-355), `TokenCompressor` / `MaskTokenEncoder` (medplib_arch.py:67-108) on seeded tiny-dim inputs.  The mixin
+    is hosted by a minimal nn.Module that supplies what it asks of `get_model()` (embed_tokens, mm_projector, a vision tower
+    that returns a fixed linear read-out of the pixels, compressor, mask encoder)."""
+    import types
+    from . import llm
+    M = _import_reference_medplib()
+    import model.medplib.model.medplib_arch as A
+    d, Cv, P, V = 8, 4, 6, 40          # hidden, vision width, patches per image, vocab
+    SEG = 33
+    g = torch.Generator().manual_seed(11)
+
+    class Tower(torch.nn.Module):
+        num_patches = P
+        hidden_size = Cv
+
+        def forward(self, images):
+            return images.flatten(1)[:, :P * Cv].reshape(images.shape[0], P, Cv)
+
+        @property
+        def dummy_feature(self):
+            return torch.zeros(1, Cv)
+
+    class Inner(torch.nn.Module):
+        def __init__(self, compress, mask_enc):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(V, d)
+            self.mm_projector = torch.nn.Linear(Cv, d)
+            self.vision_tower = Tower()
+            self.region_fea_adapter = torch.nn.Linear(Cv, d)
+            if compress:
+                self.mm_token_compressor = A.TokenCompressor(d, compress)
+            if mask_enc:
+                self.mask_encoder = A.MaskTokenEncoder(d, mask_enc)
+
+        def get_vision_tower(self):
+            return self.vision_tower
+
+    class Host(torch.nn.Module, A.LlavaMetaForCausalLM):
+        def __init__(self, compress=0, mask_enc=0):
+            torch.nn.Module.__init__(self)
+            self.inner = Inner(compress, mask_enc)
+            self.config = types.SimpleNamespace(mm_use_im_start_end=True, tune_mm_mlp_adapter=False, mm_token_compress=bool(compress),
+                                                mm_compressed_token_count=compress, icl_mask_encoder=bool(mask_enc))
+            self.seg_token_idx = SEG
+            self.device = torch.device("cpu")
+
+        def get_model(self):
+            return self.inner
+
+        def get_input_embeddings(self):
+            return self.inner.embed_tokens
+
+        def get_output_embeddings(self):
+            return self.inner.mm_projector
+
+    def seed_params(mod, seed):
+        gg = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for prm in mod.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=gg) * 0.3)
+
+    def weights_of(host):
+        return {"model." + k: v.detach().clone() for k, v in host.inner.state_dict().items()}
+
+    out = {}
+
+    def ids_row(L, img_pos, seg_pos, pad_from=None):
+        r = torch.randint(3, 30, (L,), generator=g)
+        for p_ in img_pos:
+            r[p_] = -200
+            r[p_ - 1] = 31; r[p_ + 1] = 32            # <im_start>, <im_end>
+        for p_ in seg_pos:
+            r[p_] = SEG
+        if pad_from is not None:
+            r[pad_from:] = 0
+        return r
+
+    def run_case(tag, host, ids, labels, att, images, mask_images=None, types_=None, lengths=None, default_len=None):
+        host.eval()
+        with torch.no_grad():
+            _, new_att, _, emb, new_lab = host.prepare_inputs_labels_for_multimodal(ids, att, None, labels, images, None, None,
+                                                                                     mask_images=mask_images, image_token_types=types_)
+            seg = M.MedPLIBForCausalLM.build_seg_token_mask(host, ids, image_token_len=default_len, image_token_lengths=lengths)
+        # ---- the restatement must agree bit for bit
+        W = weights_of(host)
+        with torch.no_grad():
+            if isinstance(images, (list, tuple)) or images.dim() == 5:
+                cat = torch.cat([im for im in images], 0)
+            else:
+                cat = images
+            # the host's projector is a single Linear (the mlp2x projector itself is pinned through clip/projector tests)
+            feats = torch.nn.functional.linear(host.inner.vision_tower(cat), W["model.mm_projector.weight"], W["model.mm_projector.bias"])
+            if host.config.mm_token_compress:
+                feats = llm.token_compressor(feats, W, host.config.mm_compressed_token_count)
+            per_token = False
+            if types_ is not None and mask_images is not None and len(mask_images) > 0:
+                mf = llm.mask_token_encoder(torch.cat([m for m in mask_images], 0), W, host.inner.mask_encoder.num_tokens)
+                feat_list = llm.combine_icl_features(list(feats), list(mf), types_)
+                per_token = True
+            elif isinstance(images, (list, tuple)) or images.dim() == 5:
+                feat_list = list(feats); per_token = True
+            else:
+                feat_list = feats
+            o_att, o_emb, o_lab = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token)
+            o_seg = llm.build_seg_token_mask(ids, SEG, default_len, lengths)
+        assert torch.equal(o_lab, new_lab) and torch.equal(o_att, new_att) and torch.equal(o_seg, seg), tag
+        assert torch.allclose(o_emb, emb, rtol=0, atol=1e-6), (tag, (o_emb - emb).abs().max())
+        out[f"{tag}_ids"] = ids.numpy(); out[f"{tag}_labels"] = labels.numpy(); out[f"{tag}_att"] = att.numpy()
+        out[f"{tag}_new_labels"] = new_lab.numpy(); out[f"{tag}_new_att"] = new_att.numpy(); out[f"{tag}_embeds"] = emb.numpy()
+        out[f"{tag}_seg_mask"] = seg.numpy()
+        for k, v in W.items():
+            if "mask_encoder" not in k:          # regenerated from llm.init_icl_weights(d, icl_seed) by the tests
+                out[f"{tag}_W_{k}"] = v.numpy()
+        if isinstance(images, (list, tuple)):
+            out[f"{tag}_n_images"] = np.array([im.shape[0] for im in images]); out[f"{tag}_images"] = torch.cat(list(images), 0).numpy()
+        else:
+            out[f"{tag}_images"] = images.numpy()
+        if mask_images is not None:
+            out[f"{tag}_n_masks"] = np.array([m.shape[0] for m in mask_images]); out[f"{tag}_mask_images"] = torch.cat(list(mask_images), 0).numpy()
+        if types_ is not None:
+            out[f"{tag}_types"] = np.array([[1 if t == "mask" else 0 for t in row] for row in types_], dtype=np.int64)
+        if lengths is not None:
+            out[f"{tag}_lengths"] = np.array(lengths, dtype=np.int64)
+        print("glue case", tag, "S =", emb.shape[1], "ok")
+
+    # ---- case A: one image per sample (4-D images), a sample WITHOUT a placeholder, ragged right padding, two <SEG>
+    host = Host(); seed_params(host, 1)
+    L = 14
+    ids = torch.stack([ids_row(L, [4], [9, 12]), ids_row(L, [], [6]), ids_row(L, [7], [11], pad_from=12)])
+    att = torch.ones(3, L, dtype=torch.bool); att[2, 12:] = False
+    labels = ids.clone(); labels[:, :5] = -100; labels[2, 12:] = -100
+    images = torch.randn(3, 3, 4, 4, generator=g)
+    run_case("A", host, ids, labels, att, images, default_len=P)
+
+    # ---- case B: multi-image list layout (ICL overlay: 3 and 2 images), compressor 6 -> 4 tokens
+    host = Host(compress=4); seed_params(host, 2)
+    L = 20
+    ids = torch.stack([ids_row(L, [3, 8, 13], [17]), ids_row(L, [5, 11], [15], pad_from=18)])
+    att = torch.ones(2, L, dtype=torch.bool); att[1, 18:] = False
+    labels = ids.clone(); labels[:, :14] = -100
+    images = [torch.randn(3, 3, 4, 4, generator=g), torch.randn(2, 3, 4, 4, generator=g)]
+    run_case("B", host, ids, labels, att, images, default_len=4)
+
+    # ---- case C: ICL separate mode with mask encoder: [image, mask] x 2 + [image]; mask encoder 3 tokens; compressor 4
+    host = Host(compress=4, mask_enc=3); seed_params(host, 3)
+    Wc = llm.init_icl_weights(d, 303)
+    host.inner.mask_encoder.load_state_dict({k[len("model.mask_encoder."):]: v for k, v in Wc.items() if k.startswith("model.mask_encoder.")})
+    out["C_icl_seed"] = np.int64(303)
+    L = 26
+    ids = torch.stack([ids_row(L, [2, 6, 10, 14, 18], [23]), ids_row(L, [3, 7, 11, 15, 19], [22, 24])])
+    att = torch.ones(2, L, dtype=torch.bool)
+    labels = ids.clone(); labels[:, :20] = -100
+    images = [torch.randn(3, 3, 4, 4, generator=g), torch.randn(3, 3, 4, 4, generator=g)]
+    mask_images = [(torch.rand(2, 1, 32, 32, generator=g) > 0.6).float(), (torch.rand(2, 1, 32, 32, generator=g) > 0.4).float()]
+    types_ = [["image", "mask", "image", "mask", "image"]] * 2
+    lengths = [[4, 3, 4, 3, 4]] * 2
+    run_case("C", host, ids, labels, att, images, mask_images, types_, lengths, default_len=4)
+
+    # ---- the two modules at the real token counts (576 -> 256; 336x336 mask -> 441 -> 64); weights come from
+    #      llm.init_icl_weights(seed) on both sides, so only inputs and expected outputs are stored
+    hid, wseed = 64, 77
+    Wi = llm.init_icl_weights(hid, wseed)
+    tc = A.TokenCompressor(hid, 256)
+    tc.load_state_dict({k[len("model.mm_token_compressor."):]: v for k, v in Wi.items() if k.startswith("model.mm_token_compressor.")})
+    x = torch.randn(1, 576, hid, generator=g)
+    with torch.no_grad():
+        y = tc(x)
+    assert torch.equal(llm.token_compressor(x, Wi, 256), y)
+    me = A.MaskTokenEncoder(hid, 64)
+    me.load_state_dict({k[len("model.mask_encoder."):]: v for k, v in Wi.items() if k.startswith("model.mask_encoder.")})
+    mk = (torch.rand(2, 1, 336, 336, generator=g) > 0.5).float()
+    with torch.no_grad():
+        ym = me(mk)
+    assert torch.allclose(llm.mask_token_encoder(mk, Wi, 64), ym, rtol=0, atol=1e-6)
+    out.update(icl_hidden=np.int64(hid), icl_weight_seed=np.int64(wseed), tc_x=x.numpy(), tc_y=y.numpy(),
+               me_mask_bits=np.packbits(mk.numpy().astype(np.uint8)), me_y=ym.numpy(),
+               icl_weight_checksum=np.float64(sum(float(v.double().sum()) for v in Wi.values())))
+    np.savez_compressed(os.path.join(OUT, "glue_reference.npz"), **out)
+    print("glue goldens ok")
+
+
+def golden_mask_head():
+    """postprocess_masks / losses / metrics: run the reference functions from model/MedPLIB.py.  That module imports
+    deepspeed/transformers at import time, so the four loss callables and postprocess_masks are exercised through a
+    minimal stub environment (types.ModuleType stand-ins for deepspeed & friends, SURVEY Appendix C)."""
+    M = _import_reference_medplib()
     g = torch.Generator().manual_seed(7)
     cases = []
     post = M.MedPLIBForCausalLM.postprocess_masks
@@ -141,8 +334,10 @@ def golden_mask_head():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sam", "mask_head"]
+    which = sys.argv[1:] or ["sam", "mask_head", "glue"]
     if "sam" in which:
         golden_sam()
     if "mask_head" in which:
         golden_mask_head()
+    if "glue" in which:
+        golden_glue()

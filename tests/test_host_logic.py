@@ -149,3 +149,33 @@ def test_gradient_bucket_allreduce_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_splice_plan_matches_executed_reference(golden_dir, tag):
+    """plan_splice (+ the gather it drives) vs the outputs of the reference's prepare_inputs_labels_for_multimodal /
+    build_seg_token_mask themselves (tests/golden/glue_reference.npz): labels, attention mask, <SEG> mask bit-exact; the
+    gathered rows equal the reference's inputs_embeds."""
+    from test_oracle_golden import _glue_case
+    g = np.load(os.path.join(golden_dir, "glue_reference.npz"))
+    c = _glue_case(g, tag)
+    ids, labels, att = c["ids"].numpy(), c["labels"].numpy(), c["att"].numpy()
+    feats = c["feats"].reshape(-1, c["feats"].shape[-1])
+    if c["types"] is not None:
+        lengths, bases = splice.icl_feature_layout(c["types"], c["n_tok"], 3)
+        feats = torch.cat([feats, c["mask_feats"].reshape(-1, feats.shape[-1])])
+        plan = splice.plan_splice(ids, labels, att, lengths, seg_token_idx=33, seg_feature_lengths=c["lengths"], feature_bases=bases)
+    elif c["per_token"]:
+        n_ph = int((ids == splice.IMAGE_TOKEN_INDEX).sum())
+        plan = splice.plan_splice(ids, labels, att, [c["n_tok"]] * n_ph, seg_token_idx=33, seg_feature_lengths=c["n_tok"])
+    else:
+        plan = splice.plan_splice(ids, labels, att, c["n_tok"], seg_token_idx=33)
+    assert np.array_equal(plan.labels, g[f"{tag}_new_labels"]) and np.array_equal(plan.attention_mask, g[f"{tag}_new_att"])
+    assert np.array_equal(plan.seg_mask, g[f"{tag}_seg_mask"])
+    embed = c["W"]["model.embed_tokens.weight"]
+    code = plan.src_code.reshape(-1)
+    out = torch.zeros(code.shape[0], embed.shape[1])
+    for r, cc in enumerate(code):
+        if cc != splice.SPLICE_PAD:
+            out[r] = embed[cc] if cc >= 0 else feats[-1 - cc]
+    assert np.abs(out.view(plan.src_code.shape[0], -1, embed.shape[1]).numpy() - g[f"{tag}_embeds"]).max() < 1e-6

@@ -40,3 +40,51 @@ def test_mask_head_oracle_matches_reference_golden(golden_dir):
     b, counts, iou, dice = ops.threshold_iou(pred[0, 0], gt[0])
     assert np.array_equal(b.numpy(), g["thr_mask"]) and list(counts) == list(g["thr_counts"])
     assert abs(iou - float(g["thr_iou"])) < 1e-12 and abs(dice - float(g["thr_dice"])) < 1e-12
+
+
+def _glue_case(g, tag):
+    from oracle import llm
+    W = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_W_")}
+    ids, labels, att = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("ids", "labels", "att"))
+    images = torch.from_numpy(g[f"{tag}_images"])
+    P, Cv = 6, 4
+    feats = torch.nn.functional.linear(images.flatten(1)[:, :P * Cv].reshape(images.shape[0], P, Cv),
+                                       W["model.mm_projector.weight"], W["model.mm_projector.bias"])
+    n_tok = P
+    if "model.mm_token_compressor.proj.weight" in W:
+        n_tok = 4
+        feats = llm.token_compressor(feats, W, n_tok)
+    per_token, types, lengths, mask_feats = f"{tag}_n_images" in g.files, None, None, None
+    feat_list = list(feats) if per_token else feats
+    if f"{tag}_types" in g.files:
+        Wm = llm.init_icl_weights(feats.shape[-1], int(g[f"{tag}_icl_seed"]))
+        mask_feats = llm.mask_token_encoder(torch.from_numpy(g[f"{tag}_mask_images"]), Wm, 3)
+        types = [["mask" if t else "image" for t in row] for row in g[f"{tag}_types"]]
+        lengths = [list(map(int, row)) for row in g[f"{tag}_lengths"]]
+        feat_list = llm.combine_icl_features(list(feats), list(mask_feats), types)
+    return dict(W=W, ids=ids, labels=labels, att=att, feats=feats, mask_feats=mask_feats, feat_list=feat_list, per_token=per_token,
+                types=types, lengths=lengths, n_tok=n_tok)
+
+
+def test_glue_oracle_matches_executed_reference(golden_dir):
+    """Splice (3 layouts incl. ICL separate mode with the mask encoder), <SEG> mask, TokenCompressor, MaskTokenEncoder vs the
+    outputs of the reference's own functions (oracle/make_golden.py: golden_glue)."""
+    from oracle import llm
+    g = np.load(os.path.join(golden_dir, "glue_reference.npz"))
+    for tag in ("A", "B", "C"):
+        c = _glue_case(g, tag)
+        with torch.no_grad():
+            att, emb, lab = llm.prepare_inputs_labels_for_multimodal(c["ids"], c["att"], c["labels"], c["feat_list"],
+                                                                     c["W"]["model.embed_tokens.weight"], c["per_token"])
+            seg = llm.build_seg_token_mask(c["ids"], 33, c["n_tok"], c["lengths"])
+        assert np.array_equal(lab.numpy(), g[f"{tag}_new_labels"]) and np.array_equal(att.numpy(), g[f"{tag}_new_att"]), tag
+        assert np.array_equal(seg.numpy(), g[f"{tag}_seg_mask"]), tag
+        assert np.abs(emb.numpy() - g[f"{tag}_embeds"]).max() < 1e-6, tag
+    W = llm.init_icl_weights(int(g["icl_hidden"]), int(g["icl_weight_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in W.values()) - float(g["icl_weight_checksum"])) < 1e-6, "seeded weights drifted"
+    with torch.no_grad():
+        y = llm.token_compressor(torch.from_numpy(g["tc_x"]), W, 256)
+        mk = torch.from_numpy(np.unpackbits(g["me_mask_bits"])[: 2 * 336 * 336].reshape(2, 1, 336, 336).astype(np.float32))
+        ym = llm.mask_token_encoder(mk, W, 64)
+    assert np.abs(y.numpy() - g["tc_y"]).max() < 1e-6
+    assert np.abs(ym.numpy() - g["me_y"]).max() < 1e-5
