@@ -34,6 +34,11 @@ class MedPLIBConfig:
     clip_ln_eps: float = 1e-5
     mm_vision_select_layer: int = -2
     mm_use_im_start_end: bool = True
+    # ICL front end (medplib_arch.py:67-131; scripts/train_medplib_icl.sh)
+    mm_token_compress: bool = False
+    mm_compressed_token_count: int = 256
+    icl_mask_encoder: bool = False
+    mask_encoder_token_count: int = 64
     # SAM-Med2D ViT-B @ 256 (build_sam.py:51-121)
     sam_image_size: int = 256
     sam_embed_dim: int = 768
@@ -59,6 +64,11 @@ class MedPLIBConfig:
     @property
     def clip_num_patches(self):
         return (self.clip_image_size // self.clip_patch_size) ** 2
+
+    @property
+    def image_token_len(self):
+        """rows one image placeholder expands to (build_seg_token_mask's default, MedPLIB.py:318-323)."""
+        return self.mm_compressed_token_count if self.mm_token_compress else self.clip_num_patches
 
     @property
     def sam_grid(self):

@@ -21,7 +21,8 @@ from .clip import ClipTower
 from .config import MedPLIBConfig
 from .llama import LlamaStack
 from .sam import MaskDecoder, PromptEncoderText, SamImageEncoder
-from .splice import plan_splice
+from .icl import MaskTokenEncoder, TokenCompressor
+from .splice import IMAGE_TOKEN_INDEX, icl_feature_layout, plan_splice
 
 LOSS_KEYS = ["loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", "unscale_mask_bce_loss",
              "unscale_mask_dice_loss", "unscale_mask_loss", "unscale_mask_iou_loss", "unscale_mask_focal_loss"]
@@ -52,6 +53,8 @@ class _Inner(nn.Module):
         self.vision_tower = ClipTower(cfg, device)
         self.visual_model = _VisualModel(cfg, device)
         d = cfg.hidden_size
+        self.mm_token_compressor = TokenCompressor(d, cfg.mm_compressed_token_count, device) if cfg.mm_token_compress else None
+        self.mask_encoder = MaskTokenEncoder(d, cfg.mask_encoder_token_count, device) if cfg.icl_mask_encoder else None
         self.text_hidden_fcs = nn.ModuleList([nn.Sequential(nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, cfg.out_dim),
                                                             nn.Dropout(0.0))])
 
@@ -67,7 +70,9 @@ class MedPLIBForCausalLM(nn.Module):
                             ("iou_loss_weight",) * 2, ("focal_loss_weight",) * 2, ("seg_token_idx",) * 2,
                             ("out_dim",) * 2, ("train_mask_decoder",) * 2, ("top_k_experts",) * 2,
                             ("capacity_factor",) * 2, ("eval_capacity_factor",) * 2, ("min_capacity",) * 2,
-                            ("router_aux_loss_coef",) * 2, ("moe_layers_idx",) * 2, ("mm_use_im_start_end", "use_mm_start_end")):
+                            ("router_aux_loss_coef",) * 2, ("moe_layers_idx",) * 2, ("mm_use_im_start_end", "use_mm_start_end"),
+                            ("mm_token_compress",) * 2, ("mm_compressed_token_count",) * 2, ("icl_mask_encoder",) * 2,
+                            ("mask_encoder_token_count",) * 2):
             if kwargs.get(k_kw) is not None:
                 setattr(cfg, k_cfg, kwargs[k_kw])
         if kwargs.get("num_experts") is not None:
@@ -115,6 +120,10 @@ class MedPLIBForCausalLM(nn.Module):
         self.load_sam_state_dict(vm)
         fc = {k[len("model.text_hidden_fcs."):]: v for k, v in sd.items() if k.startswith("model.text_hidden_fcs.")}
         m.text_hidden_fcs.load_state_dict({k: v.float() for k, v in fc.items()})
+        if m.mm_token_compressor is not None:
+            m.mm_token_compressor.load_hf(sd)
+        if m.mask_encoder is not None:
+            m.mask_encoder.load_hf(sd)
 
     def load_sam_state_dict(self, sd):
         """`torch.load(path)['model']` key layout of SAM-Med2D checkpoints (build_sam.py:123-128), loaded non-strict."""
@@ -161,6 +170,35 @@ class MedPLIBForCausalLM(nn.Module):
                 outs[i] = r[j:j + 1]
         return None, outs
 
+    def _encode_and_plan(self, ids_np, lab_np, att_np, images_clip, mask_images=None, image_token_types=None,
+                         image_token_lengths=None, with_seg=True):
+        """encode_images (+ TokenCompressor) / encode_masks and the splice plan for the three image layouts of
+        prepare_inputs_labels_for_multimodal (medplib_arch.py:246-279): 4-D tensor = one image per sample; list / 5-D =
+        several images per sample; list + mask_images + image_token_types = ICL separate mode with the mask encoder.
+        Returns (plan, feature rows [n_rows, hidden] bf16)."""
+        cfg, m = self.config, self.model
+        tok = cfg.image_token_len
+        seg_idx = self.seg_token_idx if with_seg else None
+        seg_lens = image_token_lengths if image_token_lengths is not None else tok
+        multi = isinstance(images_clip, (list, tuple)) or images_clip.dim() == 5
+        clip_in = torch.cat([im for im in images_clip], 0) if multi else images_clip
+        feats = m.vision_tower.encode_images(clip_in)
+        if m.mm_token_compressor is not None:
+            feats = m.mm_token_compressor.forward(feats, clip_in.shape[0], cfg.clip_num_patches)
+        if image_token_types is not None and mask_images is not None and len(mask_images) > 0:
+            assert multi, "ICL separate mode expects a list (or 5-D tensor) of images"     # medplib_arch.py:247
+            if m.mask_encoder is None:
+                raise ValueError("mask_images given but the model was built without icl_mask_encoder")
+            mfeats = m.mask_encoder.forward(torch.cat([mk for mk in mask_images], 0).to(self.device_))
+            lengths, bases = icl_feature_layout(image_token_types, tok, cfg.mask_encoder_token_count)
+            plan = plan_splice(ids_np, lab_np, att_np, lengths, seg_token_idx=seg_idx, seg_feature_lengths=seg_lens, feature_bases=bases)
+            feats = torch.cat([feats, mfeats], 0)
+        elif multi:
+            plan = plan_splice(ids_np, lab_np, att_np, [tok] * clip_in.shape[0], seg_token_idx=seg_idx, seg_feature_lengths=seg_lens)
+        else:
+            plan = plan_splice(ids_np, lab_np, att_np, tok, seg_token_idx=seg_idx, seg_feature_lengths=seg_lens)
+        return plan, feats
+
     # ------------------------------------------------------------------ forward
     def forward(self, **kwargs):
         return self.model_forward(**kwargs)
@@ -178,19 +216,10 @@ class MedPLIBForCausalLM(nn.Module):
         lab_np = _np_ids(labels) if labels is not None else None
         att_np = _np_ids(attention_mask).astype(bool) if attention_mask is not None else None
         B = ids_np.shape[0]
-        image_token_lengths = kwargs.get("image_token_lengths")
-        if isinstance(images_clip, (list, tuple)) or images_clip.dim() == 5:
-            clip_in = torch.cat([im for im in images_clip], 0)
-            flat_lengths = [cfg.clip_num_patches] * clip_in.shape[0]
-            plan = plan_splice(ids_np, lab_np, att_np, flat_lengths, seg_token_idx=self.seg_token_idx,
-                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else cfg.clip_num_patches)
-        else:
-            clip_in = images_clip
-            plan = plan_splice(ids_np, lab_np, att_np, cfg.clip_num_patches, seg_token_idx=self.seg_token_idx,
-                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else cfg.clip_num_patches)
         m = self.model
         with torch.no_grad():
-            feats = m.vision_tower.encode_images(clip_in)
+            plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, kwargs.get("mask_images"),
+                                                kwargs.get("image_token_types"), kwargs.get("image_token_lengths"))
             src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev, non_blocking=True)
             embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(B, plan.seq_len, cfg.hidden_size)
             key_valid = None
@@ -262,9 +291,9 @@ class MedPLIBForCausalLM(nn.Module):
         assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
         was_training = self.training
         self.train(False)
-        nfeat = cfg.clip_num_patches
-        plan = plan_splice(ids, None, None, nfeat)
-        feats = m.vision_tower.encode_images(images_clip)
+        nfeat = cfg.image_token_len
+        plan, feats = self._encode_and_plan(ids, None, None, images_clip, mask_images, image_token_types, image_token_lengths,
+                                            with_seg=False)
         src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev)
         S = plan.seq_len
         embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(1, S, cfg.hidden_size)
@@ -287,7 +316,8 @@ class MedPLIBForCausalLM(nn.Module):
         if (output_ids[:, 1:] == self.seg_token_idx).sum() == 0 and inference_demo:
             self.train(was_training)
             return torch.from_numpy(output_ids), []
-        seg_plan = plan_splice(output_ids, None, None, nfeat, seg_token_idx=self.seg_token_idx,
+        n_ph = int((output_ids == IMAGE_TOKEN_INDEX).sum())
+        seg_plan = plan_splice(output_ids, None, None, nfeat if n_ph <= 1 else [nfeat] * n_ph, seg_token_idx=self.seg_token_idx,
                                seg_feature_lengths=image_token_lengths if image_token_lengths is not None else nfeat)
         seg_rows = np.flatnonzero(seg_plan.seg_mask[0, :n_hidden])
         if seg_rows.size >= 1:

@@ -558,6 +558,27 @@ def clip_embed(patch, cls, pos, B, n_patches, C):
     return out
 
 
+def adaptive_avgpool_tokens(x, len_out):
+    """x [n, len_in, C] bf16 -> [n, len_out, C] (nn.AdaptiveAvgPool1d over the token axis)."""
+    _chk(x, torch.bfloat16, "adaptive_avgpool_tokens.x"); assert x.is_contiguous() and x.dim() == 3
+    n, len_in, C = x.shape
+    out = torch.empty((n, len_out, C), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_adaptive_avgpool_tokens_bf16", _p(x), _p(out), n, len_in, len_out, C, _stream())
+    return out
+
+
+def conv3x3s2_c1_gelu(img, w, bias):
+    """img [n, H, W] (bf16 or f32) -> NHWC [n, OH, OW, CO] bf16 = gelu(Conv2d(1, CO, 3, stride 2, pad 1)); w [CO, 9] f32."""
+    assert img.is_contiguous() and img.dim() == 3 and img.is_cuda
+    _chk(w, torch.float32, "conv3x3s2_c1.w"); _chk(bias, torch.float32, "conv3x3s2_c1.bias")
+    n, H, W = img.shape
+    CO = w.shape[0]
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty((n, OH, OW, CO), dtype=torch.bfloat16, device=img.device)
+    lib().call("mp_conv3x3s2_c1_gelu_bf16", _p(img), _dt(img.dtype), _p(w), _p(bias), _p(out), n, H, W, CO, _stream())
+    return out
+
+
 def copy_rows(src, rows, dim, rows_per_batch, src_batch_rows, src_row0):
     dst = torch.empty((rows, dim), dtype=torch.bfloat16, device=src.device)
     lib().call("mp_copy_rows_bf16", _p(src), _p(dst), rows, dim, rows_per_batch, src_batch_rows, src_row0, _stream())

@@ -57,6 +57,10 @@ def init_hf_weights(cfg, seed=0, sam_seed=1234):
     W["model.text_hidden_fcs.0.0.weight"] = rn(d, d, s=1.0 / d ** 0.5, bf=False); W["model.text_hidden_fcs.0.0.bias"] = rn(d, s=0.05, bf=False)
     W["model.text_hidden_fcs.0.2.weight"] = rn(cfg.out_dim, d, s=1.0 / d ** 0.5, bf=False)
     W["model.text_hidden_fcs.0.2.bias"] = rn(cfg.out_dim, s=0.05, bf=False)
+    if getattr(cfg, "mm_token_compress", False) or getattr(cfg, "icl_mask_encoder", False):
+        for k, v in llm.init_icl_weights(d, seed + 7).items():
+            if ("mm_token_compressor" in k and cfg.mm_token_compress) or ("mask_encoder" in k and cfg.icl_mask_encoder):
+                W[k] = v.to(torch.bfloat16).float()
     S = sam.init_weights(seed=sam_seed, encoder_depth=cfg.sam_depth)
     for k, v in S.items():
         if k.startswith("image_encoder.") and "rel_pos" not in k and "norm" not in k and ".bias" not in k and "channel" not in k \
@@ -99,6 +103,36 @@ def make_batch(cfg, B, L=64, H=96, Wd=80, seed=0, ragged=False, sam_size=256):
             "inference": False, "seg_flag": True}
 
 
+def make_batch_icl(cfg, B, n_ctx=2, H=96, Wd=80, seed=0, sam_size=256, mask_size=64):
+    """ICL separate-mode batch (BASELINE config 5 shape, datasets/ICLLazySupervisedDataset.py + collator :105-108): per sample
+    n_ctx in-context (image, mask) pairs + the query image = 2*n_ctx+1 placeholders, `image_token_types` [image, mask]*n_ctx +
+    [image], `image_token_lengths` per placeholder, one <SEG> per sample."""
+    g = torch.Generator().manual_seed(seed)
+    V = cfg.vocab_size
+    n_ph = 2 * n_ctx + 1
+    L = 8 + 4 * n_ph + 12
+    ids = torch.randint(3, min(V, cfg.seg_token_idx) - 1, (B, L), generator=g)
+    labels = torch.full((B, L), ops.IGNORE_INDEX, dtype=torch.int64)
+    att = torch.ones(B, L, dtype=torch.bool)
+    for b in range(B):
+        ids[b, 0] = 1
+        for k in range(n_ph):
+            p = 6 + 4 * k
+            ids[b, p - 1], ids[b, p], ids[b, p + 1] = V - 2, ops.IMAGE_TOKEN_INDEX, V - 1
+        ids[b, L - 3] = cfg.seg_token_idx
+        ids[b, L - 1] = 2
+        labels[b, L - 8:] = ids[b, L - 8:]
+    tok = cfg.mm_compressed_token_count if cfg.mm_token_compress else cfg.clip_num_patches
+    types = [["image", "mask"] * n_ctx + ["image"] for _ in range(B)]
+    lengths = [[tok, cfg.mask_encoder_token_count] * n_ctx + [tok] for _ in range(B)]
+    images_clip = [torch.randn(n_ctx + 1, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g) for _ in range(B)]
+    mask_images = [(torch.rand(n_ctx, 1, mask_size, mask_size, generator=g) > 0.5).float() for _ in range(B)]
+    base = make_batch(cfg, B, L=64, H=H, Wd=Wd, seed=seed + 1, sam_size=sam_size)
+    base.update(input_ids=ids, labels=labels, attention_mask=att, images_clip=images_clip, mask_images=mask_images,
+                image_token_types=types, image_token_lengths=lengths, icl_image_counts=[n_ctx + 1] * B)
+    return base
+
+
 def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None):
     """model/MedPLIB.py:364-572 end to end on the CPU in fp32.  `override` (tests only) may inject `hidden` [B,S,d],
     `image_emb` [B,256,16,16] and `ce` so the trainable tail can be checked on exactly the trunk outputs another
@@ -108,20 +142,34 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
     with torch.no_grad():
         image_emb = sam.image_encoder(batch["images"], {k[len("model.visual_model."):]: v for k, v in W.items()
                                                         if k.startswith("model.visual_model.")}, depth=cfg.sam_depth)
-        feats = llm.mm_projector(llm.clip_features(batch["images_clip"], W, cfg), W)
-        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feats, W["model.embed_tokens.weight"])
+        clip_in = batch["images_clip"]
+        multi = isinstance(clip_in, (list, tuple)) or clip_in.dim() == 5
+        feats = llm.mm_projector(llm.clip_features(torch.cat(list(clip_in), 0) if multi else clip_in, W, cfg), W)
+        tok = cfg.clip_num_patches
+        if getattr(cfg, "mm_token_compress", False):                    # encode_images, medplib_arch.py:198-202
+            tok = cfg.mm_compressed_token_count
+            feats = llm.token_compressor(feats, W, tok)
+        feat_list, per_token = feats, False
+        if batch.get("image_token_types") is not None and batch.get("mask_images") is not None and len(batch["mask_images"]) > 0:
+            mf = llm.mask_token_encoder(torch.cat(list(batch["mask_images"]), 0), W, cfg.mask_encoder_token_count)
+            feat_list, per_token = llm.combine_icl_features(list(feats), list(mf), batch["image_token_types"]), True
+        elif multi:
+            feat_list, per_token = list(feats), True
+        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token)
         kv = None if att2.all() else att2
         hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
         ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)
         if override:
             hidden = override.get("hidden", hidden); image_emb = override.get("image_emb", image_emb); ce = override.get("ce", ce)
-    seg_mask = llm.build_seg_token_mask(ids, cfg.seg_token_idx, cfg.clip_num_patches)
+    seg_mask = llm.build_seg_token_mask(ids, cfg.seg_token_idx, tok, batch.get("image_token_lengths"))
     SW = {k[len("model.visual_model."):]: v for k, v in W.items() if k.startswith("model.visual_model.")}
     hid = hidden.detach()
     fc = lambda x: F.linear(F.relu(F.linear(x, W["model.text_hidden_fcs.0.0.weight"], W["model.text_hidden_fcs.0.0.bias"])),
                             W["model.text_hidden_fcs.0.2.weight"], W["model.text_hidden_fcs.0.2.bias"])
     last = fc(hid)                                            # applied to every row like the reference (MedPLIB.py:456)
     pred_emb = last[seg_mask]
+    if batch.get("icl_image_counts") is not None and len(batch["masks_list"]) > 0:
+        pred_emb = pred_emb[-len(batch["masks_list"]):]          # MedPLIB.py:462-463
     pe = sam.dense_pe(SW)
     pred_masks, pred_ious, low = [], [], []
     for i in range(len(pred_emb)):

@@ -267,3 +267,54 @@ def test_evaluate_greedy_decode_and_mask(dev, moe):
         else:
             _stat("evaluate pred_mask", masks[0], masks_ref[0], atol=0.2)
             assert masks[0].shape == masks_ref[0].shape
+
+
+def test_icl_token_compressor_and_mask_encoder(dev, golden_dir):
+    """TokenCompressor / MaskTokenEncoder (medplib_arch.py:67-108) through the HIP path vs the outputs of the REFERENCE modules
+    (tests/golden/glue_reference.npz; weights regenerated from the stored seed).  bf16 storage of the conv / proj weights and
+    activations against the reference's fp32 run: 3e-2 on O(1) LayerNorm outputs."""
+    from medplib_amd.model.icl import MaskTokenEncoder, TokenCompressor
+    g = np.load(os.path.join(golden_dir, "glue_reference.npz"))
+    hid = int(g["icl_hidden"])
+    W = OL.init_icl_weights(hid, int(g["icl_weight_seed"]))
+    tc = TokenCompressor(hid, 256, dev); tc.load_hf(W)
+    x = torch.from_numpy(g["tc_x"])
+    y = tc.forward(x.to(dev).to(torch.bfloat16).view(-1, hid), 1, 576)
+    Wq = {k: (v.to(torch.bfloat16).float() if k.endswith("proj.weight") else v) for k, v in W.items()}
+    ref = OL.token_compressor(x.to(torch.bfloat16).float(), Wq, 256)
+    _stat("token_compressor vs oracle (same bf16 operands)", y.view(1, 256, hid), ref, atol=3e-2)
+    _stat("token_compressor vs reference golden", y.view(1, 256, hid), torch.from_numpy(g["tc_y"]), atol=5e-2)
+    me = MaskTokenEncoder(hid, 64, dev); me.load_hf(W)
+    mk = torch.from_numpy(np.unpackbits(g["me_mask_bits"])[: 2 * 336 * 336].reshape(2, 1, 336, 336).astype(np.float32))
+    ym = me.forward(mk.to(dev))
+    _stat("mask_token_encoder vs reference golden", ym.view(2, 64, hid), torch.from_numpy(g["me_y"]), atol=6e-2)
+    # export -> load round trip keeps the checkpoint key layout (export rounds the fp32-held tensors to the checkpoint's bf16
+    # once; after that the round trip is exact)
+    me2 = MaskTokenEncoder(hid, 64, dev); me2.load_hf({k: v.float().cpu() for k, v in me.export_hf().items()})
+    me3 = MaskTokenEncoder(hid, 64, dev); me3.load_hf({k: v.float().cpu() for k, v in me2.export_hf().items()})
+    assert set(me.export_hf()) == {k for k in W if k.startswith("model.mask_encoder.")}
+    assert torch.equal(me3.forward(mk.to(dev)), me2.forward(mk.to(dev)))
+
+
+def test_model_forward_icl_separate_mode(dev):
+    """BASELINE config 5 shape at tiny dims: list of (n_ctx + 1) CLIP images per sample, mask images through the mask encoder,
+    TokenCompressor, 2*n_ctx + 1 placeholders per sample; spliced labels / attention mask / <SEG> rows are exact by construction
+    (plan_splice is pinned against the executed reference on the CPU), losses vs the fp32 oracle."""
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, mm_token_compress=True, mm_compressed_token_count=8, icl_mask_encoder=True,
+                             mask_encoder_token_count=4)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    m.capture_intermediates = True
+    batch = OM.make_batch_icl(cfg, 2, n_ctx=2)
+    bq = dict(batch)
+    bq["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]; bq["images"] = batch["images"].to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref, inter = OM.model_forward(bq, W, cfg, training=True, return_intermediates=True)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
+    out = m(**gb)
+    S = inter["embeds"].shape[1]
+    assert m.captured["last_hidden"].shape[1] == S == batch["input_ids"].shape[1] + 3 * 7 + 2 * 3
+    for k in O.LOSS_KEYS:
+        _stat(f"icl loss[{k}]", out[k], ref[k], atol=3e-2)
