@@ -199,11 +199,22 @@ int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, float* logits,
 /* DeepSpeed top1gating: argmax expert, capacity, random-token-selection from injected uniforms, slots, l_aux. */
 int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,
                       int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream);
-/* MOELayer dispatch / combine as index gathers (replaces einsum "sec,sm->ecm" / "sec,ecm->sm"). */
+/* DeepSpeed top2gating (sharded_moe.py, deepspeed==0.13.1): first choice = argmax gates, second = argmax of
+ * logits + noise (Gumbel draws, or NULL) with the first masked; locations by cumsum in token order, second choices behind all
+ * first choices; choices at location >= capacity dropped; surviving gate pair renormalised.  Entry layout of
+ * expert/slot/weight ([2*tokens]): first choices at [0, tokens), second at [tokens, 2*tokens). */
+int mp_moe_route_top2(const float* gates, const float* logits, const float* noise, int tokens, int n_experts, int capacity,
+                      int* expert, int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux,
+                      hipStream_t stream);
+/* Stateless draws for the gate: U(0,1) (RTS, top1gating) or Gumbel(0,1) (gumbel != 0; top2gating second-expert sampling)
+ * from a hash of (seed, offset + i).  DeepSpeed uses torch's generator for these: same distribution, different stream. */
+int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, int gumbel, hipStream_t stream);
+/* MOELayer dispatch / combine as index gathers (replaces einsum "sec,sm->ecm" / "sec,ecm->sm"); top_k (1 or 2) entries per
+ * token in the layout above. */
 int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
-                         int capacity, hipStream_t stream);
+                         int capacity, int top_k, hipStream_t stream);
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,
-                        int64_t tokens, int dim, int capacity, hipStream_t stream);
+                        int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
 
 /* ---- optimizer (train_ds_medplib.py:383-420: AdamW betas (0.9,0.95), wd 0, clip 1.0) ------------------------------ */
 int mp_sumsq_accum_f32(const float* x, int64_t n, float* out_accum, hipStream_t stream);

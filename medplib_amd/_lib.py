@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "medplib_hip.h")
 _CT = {
     "int": ctypes.c_int,
     "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
     "float": ctypes.c_float,
     "size_t": ctypes.c_size_t,
     "hipStream_t": ctypes.c_void_p,

@@ -193,42 +193,168 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     for (int e = 0; e < E; ++e) kept_counts[e] = min(base[e], capacity);
 }
 
-// buf[expert[s], slot[s], :] = x[s, :]
+// buf[expert[j*T + s], slot[j*T + s], :] = x[s, :]   for the top_k choices j of token s
 __global__ void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int* __restrict__ expert, const int* __restrict__ slot,
-                                    bf16_t* __restrict__ buf, int64_t T, int d, int capacity) {
+                                    bf16_t* __restrict__ buf, int64_t T, int d, int capacity, int top_k) {
   const int per_row = d / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= T * per_row) return;
-  const int64_t s = idx / per_row;
+  if (idx >= T * top_k * per_row) return;
+  const int64_t en = idx / per_row;              // entry = choice * T + token
+  const int64_t s = en % T;
   const int c = (int)(idx % per_row) * 8;
-  const int sl = slot[s];
+  const int sl = slot[en];
   if (sl < 0) return;
-  *reinterpret_cast<bf16x8*>(buf + ((int64_t)expert[s] * capacity + sl) * d + c) = *reinterpret_cast<const bf16x8*>(x + s * ldx + c);
+  *reinterpret_cast<bf16x8*>(buf + ((int64_t)expert[en] * capacity + sl) * d + c) = *reinterpret_cast<const bf16x8*>(x + s * ldx + c);
 }
 
-// out[s, :] = residual[s, :] + weight[s] * y[expert[s], slot[s], :]     (dropped tokens: residual only)
+// out[s, :] = residual[s, :] + sum_j weight[j*T + s] * y[expert[j*T + s], slot[j*T + s], :]     (dropped choices contribute nothing)
 __global__ void moe_combine_kernel(const bf16_t* __restrict__ y, const int* __restrict__ expert, const int* __restrict__ slot,
                                    const float* __restrict__ weight, const bf16_t* __restrict__ residual, bf16_t* __restrict__ out,
-                                   int64_t T, int d, int capacity) {
+                                   int64_t T, int d, int capacity, int top_k) {
   const int per_row = d / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * per_row) return;
   const int64_t s = idx / per_row;
   const int c = (int)(idx % per_row) * 8;
-  const int sl = slot[s];
-  bf16x8 r;
-  if (residual) r = *reinterpret_cast<const bf16x8*>(residual + s * d + c);
-  bf16x8 o;
-  if (sl >= 0) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + ((int64_t)expert[s] * capacity + sl) * d + c);
-    const float w = weight[s];
+  float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((residual ? (float)r[j] : 0.f) + w * (float)v[j]);
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int k = 0; k < top_k; ++k) {
+    const int64_t en = (int64_t)k * T + s;
+    const int sl = slot[en];
+    if (sl < 0) continue;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + ((int64_t)expert[en] * capacity + sl) * d + c);
+    const float w = weight[en];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, (float)v[j], acc[j]);
+  }
+  bf16x8 o;
+  if (residual) {
+    const bf16x8 r = *reinterpret_cast<const bf16x8*>(residual + s * d + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)r[j] + acc[j]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = residual ? r[j] : (bf16_t)0.f;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
   }
   *reinterpret_cast<bf16x8*>(out + s * d + c) = o;
+}
+
+// ---------------- top-2 routing (single block, 1024 threads) ----------------
+// DeepSpeed 0.13.1 top2gating: e1 = argmax gates; e2 = argmax over e != e1 of logits + noise (Gumbel
+// draws, `top2_2nd_expert_sampling`; null = no noise); loc1 = cumsum(mask1) - 1, loc2 = cumsum(mask2) - 1 + sum(mask1);
+// l_aux = E^2 * mean_e(mean_s gates * mean_s mask1); exp_counts = sum(mask1 + mask2) before dropping; a choice is dropped when
+// its location >= capacity (first-come by token position); the two surviving gate values are renormalised to sum to 1
+// (denominator clamped at fp32 eps).  Entry layout: first choices at [0, T), second choices at [T, 2T).
+__global__ __launch_bounds__(1024) void moe_route_top2_kernel(const float* __restrict__ gates, const float* __restrict__ logits,
+                                                              const float* __restrict__ noise, int T, int E, int capacity,
+                                                              int* __restrict__ expert, int* __restrict__ slot, float* __restrict__ weight,
+                                                              int* __restrict__ kept_counts, long long* __restrict__ exp_counts,
+                                                              float* __restrict__ l_aux) {
+  __shared__ float red[16];
+  __shared__ int tot1[MAXE], tot2[MAXE];
+  __shared__ int scan1[16][MAXE], scan2[16][MAXE];
+  const int tid = threadIdx.x;
+  if (tid < MAXE) { tot1[tid] = 0; tot2[tid] = 0; }
+  __syncthreads();
+  // each thread owns a contiguous chunk of tokens (token order = cumsum order)
+  const int chunk = (T + 1023) / 1024;
+  const int s0 = min(T, tid * chunk), s1 = min(T, s0 + chunk);
+  const int lane = tid & 63, wv = tid >> 6;
+  float me[MAXE];
+  int c1[MAXE], c2[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { me[e] = 0.f; c1[e] = 0; c2[e] = 0; }
+  for (int s = s0; s < s1; ++s) {
+    int b1 = 0;
+    float bv = gates[(int64_t)s * E];
+    for (int e = 0; e < E; ++e) {
+      const float g = gates[(int64_t)s * E + e];
+      if (e > 0 && g > bv) { bv = g; b1 = e; }
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) if (k == e) me[k] += g;
+    }
+    int b2 = -1;
+    float b2v = -INFINITY;
+    for (int e = 0; e < E; ++e) {
+      if (e == b1) continue;
+      const float v = logits[(int64_t)s * E + e] + (noise ? noise[(int64_t)s * E + e] : 0.f);
+      if (b2 < 0 || v > b2v) { b2v = v; b2 = e; }
+    }
+    if (b2 < 0) b2 = b1;                       // E == 1: degenerate, second choice dropped below
+    expert[s] = b1; expert[T + s] = b2;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) { if (k == b1) c1[k] += 1; if (k == b2 && E > 1) c2[k] += 1; }
+  }
+  // l_aux and totals
+  float aux = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float m = 0.f; int a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) if (k == e) { m = me[k]; a = c1[k]; b = c2[k]; }
+    const float msum = block_sum(m, red);
+    if (a) atomicAdd(&tot1[e], a);
+    if (b) atomicAdd(&tot2[e], b);
+    __syncthreads();
+    aux += (msum / (float)T) * ((float)tot1[e] / (float)T);
+  }
+  if (tid == 0) {
+    l_aux[0] = aux * (float)E;               // mean_e(me*ce) * E * E
+    for (int e = 0; e < E; ++e) { exp_counts[e] = (long long)tot1[e] + tot2[e]; kept_counts[e] = min(capacity, tot1[e] + tot2[e]); }
+  }
+  // exclusive prefix of the per-thread counts (token order) for both choices
+  int base1[MAXE], base2[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    base1[e] = 0; base2[e] = 0;
+    if (e < E) {
+      int v1 = c1[e], v2 = c2[e];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int n1 = __shfl_up(v1, off, 64), n2 = __shfl_up(v2, off, 64);
+        if (lane >= off) { v1 += n1; v2 += n2; }
+      }
+      if (lane == 63) { scan1[wv][e] = v1; scan2[wv][e] = v2; }
+      base1[e] = v1 - c1[e]; base2[e] = v2 - c2[e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e)
+    if (e < E) {
+      for (int w = 0; w < wv; ++w) { base1[e] += scan1[w][e]; base2[e] += scan2[w][e]; }
+      base2[e] += tot1[e];                    // second choices sit behind ALL first choices of that expert
+    }
+  for (int s = s0; s < s1; ++s) {
+    const int e1 = expert[s], e2 = expert[T + s];
+    int l1 = 0, l2 = 0;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      if (k == e1) { l1 = base1[k]; base1[k] += 1; }
+      if (k == e2 && E > 1) { l2 = base2[k]; base2[k] += 1; }
+    }
+    const bool k1 = l1 < capacity, k2 = (E > 1) && l2 < capacity;
+    float g1 = k1 ? gates[(int64_t)s * E + e1] : 0.f;
+    float g2 = k2 ? gates[(int64_t)s * E + e2] : 0.f;
+    const float den = fmaxf(g1 + g2, 1.1920929e-07f);
+    slot[s] = k1 ? l1 : -1; slot[T + s] = k2 ? l2 : -1;
+    weight[s] = g1 / den; weight[T + s] = g2 / den;
+  }
+}
+
+// ---------------- counter-based random draws for the gate (RTS uniforms, top-2 Gumbel noise) ----------------
+// out[i] = U(0,1) (mode 0) or Gumbel(0,1) = -log(-log U) (mode 1) from a SplitMix64 hash of (seed, offset + i): stateless,
+// reproducible for a given (seed, offset), independent of the launch geometry.  DeepSpeed draws these from torch's generator
+// (sharded_moe.py: uniform_map / gumbel_rsample); the streams cannot match bit for bit, only in distribution.
+__global__ void gate_noise_kernel(float* __restrict__ out, int64_t n, unsigned long long seed, unsigned long long offset, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + (offset + (unsigned long long)i + 1ull) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = ((float)(z >> 40) + 0.5f) * (1.f / 16777216.f);      // 24 random bits, strictly inside (0, 1)
+  out[i] = mode == 1 ? -logf(-logf(u)) : u;
 }
 
 }  // namespace
@@ -264,22 +390,39 @@ extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, i
   return mp_check_launch("mp_moe_route_top1");
 }
 
+extern "C" int mp_moe_route_top2(const float* gates, const float* logits, const float* noise, int tokens, int n_experts, int capacity,
+                                 int* expert, int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux,
+                                 hipStream_t stream) {
+  MP_REQUIRE(n_experts >= 1 && n_experts <= MAXE && tokens > 0 && capacity >= 0, MP_ERR_SHAPE, "mp_moe_route_top2: bad shape");
+  hipLaunchKernelGGL(moe_route_top2_kernel, dim3(1), dim3(1024), 0, stream, gates, logits, noise, tokens, n_experts, capacity, expert,
+                     slot, weight, kept_counts, exp_counts, l_aux);
+  return mp_check_launch("mp_moe_route_top2");
+}
+
+extern "C" int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, int gumbel, hipStream_t stream) {
+  MP_REQUIRE(n >= 0, MP_ERR_SHAPE, "mp_gate_noise_f32: bad size");
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(gate_noise_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, out, n, (unsigned long long)seed,
+                     (unsigned long long)offset, gumbel ? 1 : 0);
+  return mp_check_launch("mp_gate_noise_f32");
+}
+
 extern "C" int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
-                                    int capacity, hipStream_t stream) {
-  MP_REQUIRE(dim % 8 == 0 && ldx % 8 == 0, MP_ERR_SHAPE, "mp_moe_dispatch_bf16: bad shape");
-  const int64_t n = tokens * (dim / 8);
+                                    int capacity, int top_k, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && ldx % 8 == 0 && top_k >= 1 && top_k <= 2, MP_ERR_SHAPE, "mp_moe_dispatch_bf16: bad shape");
+  const int64_t n = tokens * top_k * (dim / 8);
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(moe_dispatch_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, expert, slot,
-                     (bf16_t*)buf, tokens, dim, capacity);
+                     (bf16_t*)buf, tokens, dim, capacity, top_k);
   return mp_check_launch("mp_moe_dispatch_bf16");
 }
 
 extern "C" int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual,
-                                   void* out, int64_t tokens, int dim, int capacity, hipStream_t stream) {
-  MP_REQUIRE(dim % 8 == 0, MP_ERR_SHAPE, "mp_moe_combine_bf16: bad shape");
+                                   void* out, int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && top_k >= 1 && top_k <= 2, MP_ERR_SHAPE, "mp_moe_combine_bf16: bad shape");
   const int64_t n = tokens * (dim / 8);
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)y, expert, slot, weight,
-                     (const bf16_t*)residual, (bf16_t*)out, tokens, dim, capacity);
+                     (const bf16_t*)residual, (bf16_t*)out, tokens, dim, capacity, top_k);
   return mp_check_launch("mp_moe_combine_bf16");
 }

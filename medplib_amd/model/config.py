@@ -24,6 +24,10 @@ class MedPLIBConfig:
     min_capacity: int = 0
     moe_layers_idx: Optional[List[int]] = None      # None -> all layers ('dense' moe_mode)
     router_aux_loss_coef: float = 0.0
+    # DeepSpeed's gate draws (use_rts=True random token selection in top1gating, Gumbel second-expert sampling in top2gating):
+    # generated on the device by mp_gate_noise_f32.  Parity tests switch this off or inject the draws into both sides.
+    moe_gate_sampling: bool = True
+    moe_gate_seed: int = 42
     # CLIP ViT-L/14-336
     clip_image_size: int = 336
     clip_patch_size: int = 14
@@ -90,6 +94,6 @@ class MedPLIBConfig:
         """Small dims for tests: same structure, every kernel constraint (K % 64, head dims 128 / 64) still exercised."""
         d = dict(vocab_size=515, hidden_size=256, intermediate_size=320, num_hidden_layers=2, num_attention_heads=2,
                  clip_image_size=56, clip_patch_size=14, clip_hidden_size=128, clip_intermediate_size=256, clip_num_layers=3,
-                 clip_num_heads=2, seg_token_idx=500, sam_depth=12)
+                 clip_num_heads=2, seg_token_idx=500, sam_depth=12, moe_gate_sampling=False)
         d.update(kw)
         return MedPLIBConfig(**d)

@@ -46,7 +46,8 @@ class LlamaStack:
             self.layers.append(lw)
         self.cos, self.sin = _rope_tables(cfg.max_position_embeddings, cfg.head_dim, cfg.rope_theta, device)
         self.training = True
-        self.rts_uniform_provider = None   # callable(layer_idx, T, E) -> fp32 [T,E] uniforms (DeepSpeed RTS draws) or None
+        self.rts_uniform_provider = None   # callable(layer_idx, T, E) -> fp32 [T,E] gate draws (RTS uniforms / top-2 Gumbel) or None
+        self.gate_pass = 0                 # forward passes so far: part of the key of the stateless gate-draw generator
 
     # ------------------------------------------------------------------ HF checkpoint layout
     def load_hf(self, sd, prefix=""):
@@ -101,10 +102,20 @@ class LlamaStack:
 
     # ------------------------------------------------------------------ forward
     def capacity(self, T):
-        """DeepSpeed _capacity: ceil(T / E * cf), at least min_capacity."""
+        """DeepSpeed _capacity: ceil(T / E * cf), at least min_capacity; top2gating passes 2 * cf."""
         cfg = self.cfg
         cf = cfg.capacity_factor if self.training else cfg.eval_capacity_factor
-        return max(int(math.ceil(T / cfg.num_experts * cf)), cfg.min_capacity)
+        return max(int(math.ceil(T / cfg.num_experts * cf * cfg.top_k_experts)), cfg.min_capacity)
+
+    def _gate_draws(self, i, T, E, gumbel):
+        """Random draws of the gate: an injected provider (tests: the same numbers go to the oracle) or, when the config asks for
+        DeepSpeed's sampling behaviour, the stateless generator keyed by (seed, forward pass, layer)."""
+        if self.rts_uniform_provider is not None:
+            return self.rts_uniform_provider(i, T, E)
+        if not self.cfg.moe_gate_sampling:
+            return None
+        off = (self.gate_pass * len(self.layers) + i) * T * E
+        return ops.gate_noise(T * E, self.cfg.moe_gate_seed, off, gumbel, self.device)
 
     def _mlp(self, i, lw, h, x):
         """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]."""
@@ -115,17 +126,20 @@ class LlamaStack:
             return ops.gemm(act, lw["down"], residual=x), None, None
         E, ff, d = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
         cap = self.capacity(T)
-        _, gates = ops.moe_gate(h, lw["wg"])
-        rts = self.rts_uniform_provider(i, T, E) if self.rts_uniform_provider is not None else None
-        expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, rts)
-        buf = ops.moe_dispatch(h, expert, slot, E, cap)
+        k = cfg.top_k_experts
+        logits, gates = ops.moe_gate(h, lw["wg"])
+        if k == 1:
+            expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
+        else:
+            expert, slot, weight, kept, counts, l_aux = ops.moe_route_top2(gates, logits, cap, self._gate_draws(i, T, E, gumbel=True))
+        buf = ops.moe_dispatch(h, expert, slot, E, cap, top_k=k)
         act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
         if ops.GEMM_TIMER is not None:
-            ops.GEMM_TIMER.batched_rows = T      # algorithmic rows of the expert GEMMs: every token visits one expert
+            ops.GEMM_TIMER.batched_rows = k * T      # algorithmic rows of the expert GEMMs: every token visits k experts
         ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
         y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
         ops.gemm_batched(act, lw["down"], y, m_dev=kept)
-        out = ops.moe_combine(y, expert, slot, weight, x, cap)
+        out = ops.moe_combine(y, expert, slot, weight, x, cap, top_k=k)
         return out, l_aux, (expert, slot, counts)
 
     def new_kv_cache(self, batch, max_len):
@@ -145,6 +159,7 @@ class LlamaStack:
         H, D = cfg.num_attention_heads, cfg.head_dim
         x = inputs_embeds.reshape(B * S, d)
         aux, routing = [], []
+        self.gate_pass += 1
         pos0 = kv_cache["len"] if kv_cache is not None else 0
         for i, lw in enumerate(self.layers):
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)

@@ -80,8 +80,8 @@ class MedPLIBForCausalLM(nn.Module):
             cfg.num_experts = int(ne[0] if isinstance(ne, (list, tuple)) else ne)
         if not self.moe_default:
             cfg.moe_enable = False
-        if cfg.top_k_experts != 1 and cfg.moe_enable:
-            raise NotImplementedError("top-2 gating (DeepSpeed top2gating) is not built yet; stage-IV uses top-1 (DESIGN.md)")
+        if cfg.top_k_experts not in (1, 2) and cfg.moe_enable:
+            raise ValueError("DeepSpeed MoE supports k = 1 or 2 only (TopKGate asserts the same)")
         self.config = cfg
         self.device_ = torch.device(device)
         self.model = _Inner(cfg, self.device_)

@@ -623,19 +623,38 @@ def moe_route_top1(gates, capacity, rts_uniform=None):
     return expert, slot, weight, kept, counts, l_aux
 
 
-def moe_dispatch(x, expert, slot, n_experts, capacity, buf=None):
+def moe_route_top2(gates, logits, capacity, noise=None):
+    """DeepSpeed top2gating; returns entry arrays of length 2T (first choices, then second choices)."""
+    T, E = gates.shape
+    dev = gates.device
+    expert = torch.empty(2 * T, dtype=torch.int32, device=dev); slot = torch.empty(2 * T, dtype=torch.int32, device=dev)
+    weight = torch.empty(2 * T, dtype=torch.float32, device=dev)
+    kept = torch.empty(E, dtype=torch.int32, device=dev); counts = torch.empty(E, dtype=torch.int64, device=dev)
+    l_aux = torch.empty(1, dtype=torch.float32, device=dev)
+    lib().call("mp_moe_route_top2", _p(gates), _p(logits), _p(noise), T, E, int(capacity), _p(expert), _p(slot), _p(weight), _p(kept),
+               _p(counts), _p(l_aux), _stream())
+    return expert, slot, weight, kept, counts, l_aux
+
+
+def gate_noise(n, seed, offset, gumbel, device):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    lib().call("mp_gate_noise_f32", _p(out), n, int(seed), int(offset), 1 if gumbel else 0, _stream())
+    return out
+
+
+def moe_dispatch(x, expert, slot, n_experts, capacity, buf=None, top_k=1):
     T, d = x.shape
     if buf is None:
         buf = torch.empty((n_experts, capacity, d), dtype=torch.bfloat16, device=x.device)
-    lib().call("mp_moe_dispatch_bf16", _p(x), x.stride(0), _p(expert), _p(slot), _p(buf), T, d, capacity, _stream())
+    lib().call("mp_moe_dispatch_bf16", _p(x), x.stride(0), _p(expert), _p(slot), _p(buf), T, d, capacity, top_k, _stream())
     return buf
 
 
-def moe_combine(y, expert, slot, weight, residual, capacity):
-    T = expert.numel()
+def moe_combine(y, expert, slot, weight, residual, capacity, top_k=1):
+    T = expert.numel() // top_k
     d = y.shape[-1]
     out = torch.empty((T, d), dtype=torch.bfloat16, device=y.device)
-    lib().call("mp_moe_combine_bf16", _p(y), _p(expert), _p(slot), _p(weight), _p(residual), _p(out), T, d, capacity, _stream())
+    lib().call("mp_moe_combine_bf16", _p(y), _p(expert), _p(slot), _p(weight), _p(residual), _p(out), T, d, capacity, top_k, _stream())
     return out
 
 

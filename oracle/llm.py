@@ -220,6 +220,41 @@ def moe_top1(x, wg, experts, capacity, rts_uniform=None):
     return out, l_aux, exp_counts, idx, slot
 
 
+def moe_top2(x, wg, experts, capacity, noise=None):
+    """DeepSpeed 0.13.1 top2gating + MOELayer on one rank (deepspeed/moe/sharded_moe.py — third-party,
+    absent from the container: **parity unpinned**, restated literally from the published algorithm).
+    noise [T,E]: the Gumbel draws of `top2_2nd_expert_sampling` (None = no sampling noise).
+    Returns (out [T,d], l_aux, exp_counts [E], (idx1, idx2) [T], (slot1, slot2) [T] (-1 = dropped), (w1, w2))."""
+    T, E = x.shape[0], wg.shape[0]
+    logits = x.float() @ wg.float().t()
+    gates = F.softmax(logits, dim=1)
+    idx1 = torch.argmax(gates, dim=1)
+    mask1 = F.one_hot(idx1, num_classes=E)
+    lw = logits + noise if noise is not None else logits
+    idx2 = torch.argmax(lw.masked_fill(mask1.bool(), float("-inf")), dim=1)
+    mask2 = F.one_hot(idx2, num_classes=E)
+    loc1 = torch.cumsum(mask1, 0) - 1
+    loc2 = torch.cumsum(mask2, 0) - 1
+    loc2 = loc2 + mask1.sum(0, keepdim=True)                 # second choices queue behind all first choices
+    me, ce = gates.mean(0), mask1.float().mean(0)
+    l_aux = torch.mean(me * ce) * E * E
+    exp_counts = (mask1 + mask2).sum(0)
+    mask1 = mask1 * (loc1 < capacity)
+    mask2 = mask2 * (loc2 < capacity)
+    slot1, slot2 = (loc1 * mask1).sum(1), (loc2 * mask2).sum(1)
+    g1, g2 = (gates * mask1.float()).sum(1), (gates * mask2.float()).sum(1)
+    den = torch.clamp(g1 + g2, min=torch.finfo(torch.float32).eps)
+    g1, g2 = g1 / den, g2 / den
+    k1, k2 = mask1.sum(1).bool(), mask2.sum(1).bool()
+    out = torch.zeros_like(x, dtype=torch.float32)
+    for e in range(E):
+        for sel, g in ((k1 & (idx1 == e), g1), (k2 & (idx2 == e), g2)):
+            if sel.any():
+                out[sel] += g[sel, None] * experts[e](x[sel].float())
+    slot1 = torch.where(k1, slot1, torch.full_like(slot1, -1)); slot2 = torch.where(k2, slot2, torch.full_like(slot2, -1))
+    return out, l_aux, exp_counts, (idx1, idx2), (slot1, slot2), (g1, g2)
+
+
 # ----------------------------------------------------------------------------------------------- Llama stack
 def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="", collect=None):
     """MoELlamaModel_forward + MoELlamaDecoderLayer_forward (medplib_moe_llama.py:110-305) over HF-4.31 Llama modules
@@ -243,14 +278,18 @@ def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="",
         if i in moe_layers:
             T = B * S
             cf = cfg.capacity_factor if training else cfg.eval_capacity_factor
-            cap = max(int(math.ceil(T / cfg.num_experts * cf)), cfg.min_capacity)
+            cap = max(int(math.ceil(T / cfg.num_experts * cf * cfg.top_k_experts)), cfg.min_capacity)   # top2gating: 2 * cf
             experts = []
             for e in range(cfg.num_experts):
                 ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
                 experts.append(lambda t, ep=ep: F.linear(ops.swiglu(F.linear(t, W[ep + "gate_proj.weight"]),
                                                                     F.linear(t, W[ep + "up_proj.weight"])), W[ep + "down_proj.weight"]))
-            out, l_aux, counts, idx, slot = moe_top1(h.reshape(T, d), W[p + "mlp.deepspeed_moe.gate.wg.weight"], experts, cap,
-                                                     None if rts is None else rts.get(i))
+            if cfg.top_k_experts == 2:
+                out, l_aux, counts, idx, slot, _ = moe_top2(h.reshape(T, d), W[p + "mlp.deepspeed_moe.gate.wg.weight"], experts, cap,
+                                                            None if rts is None else rts.get(i))
+            else:
+                out, l_aux, counts, idx, slot = moe_top1(h.reshape(T, d), W[p + "mlp.deepspeed_moe.gate.wg.weight"], experts, cap,
+                                                         None if rts is None else rts.get(i))
             aux.append(l_aux)
             if collect is not None:
                 collect.append((idx, slot, counts))

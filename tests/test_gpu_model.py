@@ -318,3 +318,77 @@ def test_model_forward_icl_separate_mode(dev):
     assert m.captured["last_hidden"].shape[1] == S == batch["input_ids"].shape[1] + 3 * 7 + 2 * 3
     for k in O.LOSS_KEYS:
         _stat(f"icl loss[{k}]", out[k], ref[k], atol=3e-2)
+
+
+def test_moe_top2_routing_bit_exact_on_identical_gates(dev):
+    """DeepSpeed top2gating: with the same fp32 logits / gate probabilities and the same injected Gumbel draws on both
+    sides, both expert ids, both slots, counts and l_aux are exact, including second choices queued behind all first choices and
+    first-come capacity drops; renormalised pair weights to fp32 rounding.  Known answer: identity experts -> output = x for every
+    token that keeps at least one choice (the pair weights sum to 1)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(4)
+    T, d = 1200, 64
+    for E, cap, with_noise in ((3, 2 * T, True), (3, 500, True), (2, 700, False), (4, 350, True)):
+        x = torch.randn(T, d, generator=g)
+        wg = torch.randn(E, d, generator=g) * 0.3
+        wg[0] += 0.1 * x.mean(0)
+        noise = None
+        if with_noise:
+            u = torch.rand(T, E, generator=g).clamp_(1e-6, 1 - 1e-6)
+            noise = -torch.log(-torch.log(u))
+        out, l_aux, counts, (i1, i2), (s1, s2), (w1, w2) = OL.moe_top2(x, wg, [lambda t: t] * E, cap, noise)
+        logits = x @ wg.t()
+        gates = torch.softmax(logits, 1)
+        e, s, w, kept, c, la = ops.moe_route_top2(gates.to(dev), logits.to(dev), cap, None if noise is None else noise.to(dev))
+        e, s, w = e.cpu().long(), s.cpu().long(), w.cpu()
+        assert torch.equal(e[:T], i1) and torch.equal(e[T:], i2), "expert ids"
+        assert torch.equal(s[:T], s1) and torch.equal(s[T:], s2), f"slots (E={E}, cap={cap})"
+        assert torch.equal(c.cpu(), counts)
+        kept_ref = torch.stack([((i1 == k) & (s1 >= 0)).sum() + ((i2 == k) & (s2 >= 0)).sum() for k in range(E)])
+        assert torch.equal(kept.cpu().long(), kept_ref)
+        assert abs(la.item() - l_aux.item()) < 1e-6
+        assert (w[:T] - w1).abs().max().item() < 1e-6 and (w[T:] - w2).abs().max().item() < 1e-6
+        xb = x.to(torch.bfloat16).to(dev)
+        buf = ops.moe_dispatch(xb, e.int().to(dev), s.int().to(dev), E, cap, top_k=2)
+        y = ops.moe_combine(buf, e.int().to(dev), s.int().to(dev), w.to(dev), None, cap, top_k=2).float().cpu()
+        _stat(f"top-2 combine (E={E}, cap={cap})", y, out, atol=3e-2)
+        any_kept = (s1 >= 0) | (s2 >= 0)
+        assert (out[any_kept] - x[any_kept]).abs().max().item() < 1e-5 and (out[~any_kept] == 0).all()
+    # stateless gate draws: reproducible, in (0,1), right first moments
+    u = ops.gate_noise(1 << 16, 42, 7, False, dev)
+    assert torch.equal(u, ops.gate_noise(1 << 16, 42, 7, False, dev)) and not torch.equal(u, ops.gate_noise(1 << 16, 42, 8, False, dev))
+    assert 0 < u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 5e-3 and abs(u.var().item() - 1 / 12) < 2e-3
+    gn = ops.gate_noise(1 << 16, 1, 0, True, dev)
+    assert abs(gn.mean().item() - 0.5772) < 2e-2 and abs(gn.var().item() - 1.6449) < 6e-2
+
+
+def test_llama_stack_top2(dev):
+    """3-layer MoE stack with k = 2 (the argparse default of train_ds_medplib.py:124-136: E=3, k=2), Gumbel draws injected on both
+    sides; tokens whose expert pair differs from the fp32 oracle's (bf16 near-ties) are excluded from the hidden comparison."""
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=3, num_experts=3, top_k_experts=2, capacity_factor=1.0)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W)
+    g = torch.Generator().manual_seed(6)
+    B, S = 2, 150
+    T, E = B * S, cfg.num_experts
+    emb = (torch.randn(B, S, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16)
+    noise = {i: -torch.log(-torch.log(torch.rand(T, E, generator=g).clamp_(1e-6, 1 - 1e-6))) for i in range(3)}
+    coll = []
+    ref, aux_ref = OL.llama_forward(emb.float(), None, W, cfg, training=True, rts=noise, collect=coll)
+    m.model.llm.rts_uniform_provider = lambda i, T_, E_: noise[i].to(dev)
+    out, aux, routing = m.model.llm.forward(emb.to(dev), None, collect_routing=True)
+    flipped = torch.zeros(T, dtype=torch.bool)
+    for li, (((i1, i2), (s1, s2), c_ref), (e, s_, c)) in enumerate(zip(coll, routing)):
+        e, s_ = e.cpu().long(), s_.cpu().long()
+        # a flipped token also shifts the queue positions behind it, so tokens at the capacity boundary can be kept on one side
+        # and dropped on the other: identical routing = same expert pair AND same kept/dropped state of both choices
+        same = (e[:T] == i1) & (e[T:] == i2)
+        flipped |= ~(same & ((s_[:T] >= 0) == (s1 >= 0)) & ((s_[T:] >= 0) == (s2 >= 0)))
+        print(f"layer {li}: expert-pair agreement {same.float().mean().item():.4f}, counts ref {c_ref.tolist()} got {c.cpu().tolist()}")
+        if same.all():
+            assert torch.equal(s_[:T], s1) and torch.equal(s_[T:], s2) and torch.equal(c.cpu(), c_ref)
+    assert flipped.float().mean().item() < 0.05
+    keep = ~flipped
+    _stat("llama hidden top-2 moe (tokens with identical routing)", out.view(T, -1).cpu()[keep], ref.view(T, -1)[keep], atol=0.0, rtol=12 * 2 ** -8)
+    for a, b in zip(aux, aux_ref):
+        _stat("l_aux top-2", a, b.view(1), atol=5e-3)
