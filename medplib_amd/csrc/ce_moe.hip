@@ -123,32 +123,79 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     for (int e = 0; e < E; ++e) exp_counts[e] = cnt_sh[e];
   }
   __syncthreads();
-  // keep decision (global memory `slot` temporarily holds the keep flag)
-  for (int s = tid; s < T; s += 1024) {
-    const int e = expert[s];
-    int keep = 1;
-    if (cnt_sh[e] > capacity) {
-      if (rts) {
-        int rank = 0;
-        const float u = rts[(int64_t)s * E + e];
-        for (int t = 0; t < T; ++t) {
-          if (expert[t] != e) continue;
-          const float ut = rts[(int64_t)t * E + e];
-          rank += (ut > u) || (ut == u && t < s);
-        }
-        keep = rank < capacity;
+  // keep decision (global memory `slot` temporarily holds the keep flag).  Without RTS draws the selection is first-come: the
+  // rank is the token-order prefix count computed by the scan below, so every token stays flagged and slots >= capacity are
+  // dropped after the scan.  With draws (DeepSpeed use_rts): an over-capacity expert keeps its `capacity` LARGEST draws (ties:
+  // lower token index first, the order torch.topk's stable sort yields) -- found by an 8-bit-per-pass radix select over the
+  // order-preserving integer image of the fp32 draws (4 histogram passes over T values instead of an O(T^2) rank count).
+  const int chunk = (T + 1023) / 1024;
+  const int s0 = min(T, tid * chunk), s1 = min(T, s0 + chunk);
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int s = tid; s < T; s += 1024) slot[s] = 1;
+  __syncthreads();
+  if (rts) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_bin, sel_need;
+    __shared__ int eq_scan[16];
+    for (int e = 0; e < E; ++e) {
+      if (cnt_sh[e] <= capacity) continue;                 // block-uniform
+      unsigned prefix = 0, pmask = 0, need = (unsigned)capacity;
+      if (capacity == 0) {
+        for (int s = tid; s < T; s += 1024) if (expert[s] == e) slot[s] = 0;
+        __syncthreads();
+        continue;
       }
-      // without RTS draws the selection is first-come: rank == the token-order prefix count computed by the scan below, so
-      // every token stays flagged here and the slots >= capacity are dropped after the scan (no O(T^2) pass)
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int s = tid; s < T; s += 1024) {
+          if (expert[s] != e) continue;
+          const unsigned b = __float_as_uint(rts[(int64_t)s * E + e]);
+          const unsigned key = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+          if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned cum = 0; int b = 255;
+          for (; b > 0; --b) { if (cum + hist[b] >= need) break; cum += hist[b]; }
+          sel_bin = (unsigned)b; sel_need = need - cum;
+        }
+        __syncthreads();
+        prefix |= sel_bin << shift; pmask |= 0xffu << shift; need = sel_need;
+        __syncthreads();
+      }
+      // prefix = key of the capacity-th largest draw; `need` of the tokens holding exactly that key are kept, in token order
+      int eq = 0;
+      for (int s = s0; s < s1; ++s) {
+        if (expert[s] != e) continue;
+        const unsigned b = __float_as_uint(rts[(int64_t)s * E + e]);
+        eq += ((b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) == prefix);
+      }
+      int v = eq;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+      }
+      if (lane == 63) eq_scan[wv] = v;
+      __syncthreads();
+      int rank = v - eq;
+      for (int w = 0; w < wv; ++w) rank += eq_scan[w];
+      for (int s = s0; s < s1; ++s) {
+        if (expert[s] != e) continue;
+        const unsigned b = __float_as_uint(rts[(int64_t)s * E + e]);
+        const unsigned key = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+        int keep = key > prefix;
+        if (key == prefix) { keep = rank < (int)need; ++rank; }
+        slot[s] = keep;
+      }
+      __syncthreads();
     }
-    slot[s] = keep;
   }
   __syncthreads();
   // exclusive scan of kept tokens per expert in token order: thread `tid` owns a contiguous chunk; wave-level shuffle scan of
   // the per-thread totals, then the 16 wave totals are combined through LDS
-  const int chunk = (T + 1023) / 1024;
-  const int s0 = tid * chunk, s1 = min(T, s0 + chunk);
-  const int lane = tid & 63, wv = tid >> 6;
   int loc[MAXE];
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) loc[e] = 0;

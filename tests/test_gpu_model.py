@@ -320,6 +320,34 @@ def test_model_forward_icl_separate_mode(dev):
         _stat(f"icl loss[{k}]", out[k], ref[k], atol=3e-2)
 
 
+def test_moe_rts_radix_select_with_tied_draws(dev):
+    """Random-token-selection over capacity with heavily tied draws (torch.topk's tie order is unspecified, so no oracle here):
+    exactly `capacity` tokens of the overflowing expert survive, every kept draw >= every dropped draw, and among the draws equal
+    to the threshold the lowest token indices are the ones kept."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(8)
+    T, E = 5112, 2
+    gates = torch.softmax(torch.randn(T, E, generator=g) + torch.tensor([1.5, 0.0]), 1)
+    for cap, levels in ((3834, 16), (1000, 3), (2556, 1 << 20), (0, 4)):
+        u = torch.floor(torch.rand(T, E, generator=g) * levels) / levels + 0.01
+        e, s, w, kept, c, la = ops.moe_route_top1(gates.to(dev), cap, u.to(dev))
+        e, s = e.cpu().long(), s.cpu().long()
+        for k in range(E):
+            mine = e == k
+            n_k = int(mine.sum())
+            keep = mine & (s >= 0)
+            assert int(keep.sum()) == min(n_k, cap) == int(kept[k])
+            if n_k > cap and cap > 0:
+                uk = u[:, k]
+                thr = uk[keep].min()
+                assert uk[mine & ~keep].max() <= thr
+                tied = mine & (uk == thr)
+                n_tied_kept = int((tied & keep).sum())
+                assert torch.equal(torch.nonzero(tied & keep).flatten(), torch.nonzero(tied).flatten()[:n_tied_kept])
+            # slots are the token-order ranks of the kept tokens
+            assert torch.equal(s[keep], torch.arange(int(keep.sum())))
+
+
 def test_moe_top2_routing_bit_exact_on_identical_gates(dev):
     """DeepSpeed top2gating: with the same fp32 logits / gate probabilities and the same injected Gumbel draws on both
     sides, both expert ids, both slots, counts and l_aux are exact, including second choices queued behind all first choices and
