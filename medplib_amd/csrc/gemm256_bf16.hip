@@ -556,6 +556,8 @@ extern "C" int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, i
   return MP_OK;
 }
 
+void mp_gemm_split_workspace(float** ws, int** tickets, int64_t* bytes) { *ws = g_split_ws; *tickets = g_split_tickets; *bytes = g_split_ws_bytes; }
+
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   static int abl = -1;
   if (abl < 0) {

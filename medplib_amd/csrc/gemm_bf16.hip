@@ -12,6 +12,7 @@
 #include "common.h"
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -37,8 +38,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
+  // split-K (host-chosen, g.max_split > 1 only for launches with few tiles and a long K, e.g. the SAM adapter convolutions:
+  // 24 tiles x 108 K-tiles): unit = split * nwg + tile; partial sums meet in the workspace exactly like the 256x256 kernel's
+  // tail split (gemm256_bf16.hip): register-order fp32 partials by agent-scope stores, a ticket per tile, the last arriver sums
+  // the S partials in ascending split order and runs the epilogue.
+  const int S = g.max_split > 1 ? g.max_split : 1;
+  const int split = blockIdx.x / nwg;
   // bijective XCD remap: blocks that land on the same XCD (bid % 8) get a contiguous range of tile ids
-  int bid = blockIdx.x;
+  int bid = blockIdx.x - split * nwg;
+  const int tile_id = bid;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -64,7 +72,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = K / BK;
+  int kt0 = 0, nt = K / BK;
+  if (S > 1) {
+    const int base = nt / S, extra = nt % S;
+    kt0 = split * base + min(split, extra);
+    nt = base + (split < extra ? 1 : 0);
+  }
   const int fr = lane & 15;   // fragment row (A) / col (W) within 16
   const int fq = lane >> 4;   // k-chunk selector 0..3
 
@@ -103,8 +116,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (wave * 4 + i) * 8 + sub_row;
-      a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
-      w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
+      a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8 + (int64_t)kt0 * BK;
+      w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8 + (int64_t)kt0 * BK;
     }
     auto issue = [&](int t, int buf) {
 #pragma unroll
@@ -130,8 +143,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     const bf16_t* w_ptr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      a_ptr[i] = A + (int64_t)min(m0 + ld_row + 32 * i, M - 1) * g.lda + ld_c * 8;
-      w_ptr[i] = W + (int64_t)min(n0 + ld_row + 32 * i, N - 1) * g.ldw + ld_c * 8;
+      a_ptr[i] = A + (int64_t)min(m0 + ld_row + 32 * i, M - 1) * g.lda + ld_c * 8 + (int64_t)kt0 * BK;
+      w_ptr[i] = W + (int64_t)min(n0 + ld_row + 32 * i, N - 1) * g.ldw + ld_c * 8 + (int64_t)kt0 * BK;
     }
     bf16x8 ra[4], rw[4];
     auto gload = [&](int t) {
@@ -160,6 +173,46 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     }
   }
 
+  if (S > 1) {
+    __syncthreads();                                     // all LDS reads of the main loop are done: smem[0] becomes the flag
+    unsigned long long* wsu = reinterpret_cast<unsigned long long*>(g.ws) + ((int64_t)(batch * nwg + tile_id) * S) * (BM * BN / 2);
+    unsigned long long* mine = wsu + (int64_t)split * (BM * BN / 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned long long v = (unsigned long long)__float_as_uint(acc[i][j][2 * h]) |
+                                       ((unsigned long long)__float_as_uint(acc[i][j][2 * h + 1]) << 32);
+          __hip_atomic_store(mine + ((i * 4 + j) * 2 + h) * NT + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    int* ticket_p = g.tickets + batch * nwg + tile_id;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *flag;
+    if (ticket != S - 1) return;
+    if (tid == 0) __hip_atomic_store(ticket_p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; ++sp) {
+      const unsigned long long* part = wsu + (int64_t)sp * (BM * BN / 2);
+      unsigned long long t[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t[q] = __hip_atomic_load(part + q * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int i = q >> 3, j = (q >> 1) & 3, h = q & 1;
+        acc[i][j][2 * h] += __uint_as_float((unsigned)(t[q] & 0xffffffffull));
+        acc[i][j][2 * h + 1] += __uint_as_float((unsigned)(t[q] >> 32));
+      }
+    }
+  }
   // epilogue: D layout col = lane&15, row = (lane>>4)*4 + r
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
@@ -212,7 +265,34 @@ static bool use_256(const GemmArgs& g, int batch) {
   if (g.act == ACT_SWIGLU_PAIR) return true;          // the paired epilogue exists in the 256x256 kernel only
   if (gemm_variant() != 2) return false;
   const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
-  return g.M >= 1024 && g.N >= 1024 && tiles >= 128;
+  static int min_tiles = -1, min_n = -1;
+  if (min_tiles < 0) {
+    const char* e = getenv("MP_GEMM256_MIN_TILES");
+    min_tiles = (e && atoi(e) >= 1) ? atoi(e) : 128;
+    const char* f = getenv("MP_GEMM256_MIN_N");
+    min_n = (f && atoi(f) >= 1) ? atoi(f) : 1024;
+  }
+  return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
+}
+
+// implemented in gemm256_bf16.hip: the registered split-K scratch (mp_gemm_set_workspace)
+void mp_gemm_split_workspace(float** ws, int** tickets, int64_t* bytes);
+
+// split-K factor of a 128x128 launch: only when the tile count leaves most of the machine idle, K is long enough to amortise the
+// partial-sum round trip, the row count is known on the host and the scratch is registered
+static int split128(const GemmArgs& g, int batch, float** ws, int** tickets) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("MP_GEMM_MAX_SPLIT"); enabled = (e && atoi(e) == 1) ? 0 : 1; }
+  if (!enabled || g.m_dev) return 1;
+  int64_t bytes = 0;
+  mp_gemm_split_workspace(ws, tickets, &bytes);
+  if (!*ws) return 1;
+  const int64_t tiles = mp_cdiv(g.M, BM) * mp_cdiv(g.N, BN) * batch;
+  const int nt = g.K / BK;
+  if (tiles > 128 || nt < 8) return 1;
+  int S = (int)std::min<int64_t>(std::min<int64_t>(256 / tiles, nt / 4), 16);
+  while (S > 1 && tiles * S * (int64_t)BM * BN * 4 > bytes) --S;
+  return S < 2 ? 1 : S;
 }
 
 static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
@@ -245,7 +325,8 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
-  launch_gemm(g, dim3(tiles, 1), stream);
+  g.max_split = split128(g, 1, &g.ws, &g.tickets);
+  launch_gemm(g, dim3(tiles * g.max_split, 1), stream);
   return mp_check_launch("mp_gemm_bf16_nt");
 }
 

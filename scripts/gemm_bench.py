@@ -7,7 +7,10 @@ import sys
 SHAPES = [  # (name, M, N, K)
     ("llama qkv", 5112, 12288, 4096), ("llama o", 5112, 4096, 4096), ("expert gate|up (E=1 slice)", 2556, 22016, 4096),
     ("expert down", 2556, 4096, 11008), ("dense gate|up", 5112, 22016, 4096), ("dense down", 5112, 4096, 11008),
-    ("clip fc1", 4616, 4096, 1024), ("clip qkv", 4616, 3072, 1024), ("sam qkv win", 6272, 2304, 768), ("square 4096", 4096, 4096, 4096),
+    ("clip fc1", 4616, 4096, 1024), ("clip qkv", 4616, 3072, 1024), ("clip o", 4616, 1024, 1024), ("clip fc2", 4616, 1024, 4096),
+    ("projector 0", 4608, 4096, 1024), ("projector 2", 4608, 4096, 4096),
+    ("sam qkv win", 6272, 2304, 768), ("sam proj", 2048, 768, 768), ("sam fc1", 2048, 3072, 768), ("sam fc2", 2048, 768, 3072),
+    ("sam adapter conv", 512, 768, 6912), ("square 4096", 4096, 4096, 4096),
     ("square 8192", 8192, 8192, 8192),
 ]
 EXPERT = ("experts gate|up (E=2, cap 3834, 2556 routed)", 3834, 22016, 4096, 2556)

@@ -68,6 +68,24 @@ def test_gemm_epilogues(dev):
     assert (outb[130:].float() == 7.0).all(), "rows beyond the device-side count must stay untouched"
 
 
+def test_gemm_128_split_k(dev):
+    """Few tiles + long K (the SAM adapter convolutions as GEMMs: 512 x 768 x 6912 = 24 tiles of 128x128, 108 K-tiles): the
+    128x128 kernel runs split-K units that meet in the registered workspace; fused bias / activation / residual are applied once
+    by the last arriver; the result is bit-reproducible."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for (M, N, K) in [(512, 768, 6912), (512, 768, 3072), (2048, 768, 3072), (130, 200, 1024)]:
+        a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.05)
+        bias = torch.randn(N, generator=g); res = _bf(torch.randn(M, N, generator=g))
+        ref = torch.relu(O.linear(a.float(), w.float(), bias)) + res.float()
+        out = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), act=ops.ACT_RELU)
+        _report(f"gemm128 split-K {M}x{N}x{K}", out, ref, rtol=3 * BF16_EPS, atol=1e-3 * math.sqrt(K))
+        for _ in range(3):
+            assert torch.equal(ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), act=ops.ACT_RELU), out)
+        outf = ops.gemm(a.to(dev), w.to(dev), out_dtype=torch.float32)
+        _report(f"gemm128 split-K f32 out {M}x{N}x{K}", outf, O.linear(a.float(), w.float()), rtol=1e-4, atol=2e-3)
+
+
 def test_gemm_batched_experts(dev):
     from medplib_amd import ops
     g = torch.Generator().manual_seed(9)
