@@ -101,9 +101,11 @@ def test_gemm_batched_experts(dev):
         assert (out[e, c:].float() == 0).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("B,S,H,D,causal,ragged", [(2, 639, 4, 128, True, True), (1, 64, 2, 128, True, False),
-                                                   (2, 577, 3, 64, False, False), (1, 200, 2, 64, False, True)])
+                                                   (2, 577, 3, 64, False, False), (1, 200, 2, 64, False, True),
+                                                   (2, 639, 2, 128, True, False), (1, 1316, 2, 128, True, False),
+                                                   (3, 130, 2, 64, True, True)])
 def test_attention(dev, variant, B, S, H, D, causal, ragged):
     from medplib_amd import ops
     g = torch.Generator().manual_seed(S + D + variant)
