@@ -158,14 +158,28 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const bf16_t* __rest
   }
 }
 
-// ---- adapter: per-image token mean (bf16 -> fp32) and channel gate
-__global__ void token_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)B * C) return;
-  const int c = (int)(idx % C), b = (int)(idx / C);
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += (float)x[((int64_t)b * T + t) * C + c];
-  out[idx] = s / (float)T;
+// ---- adapter: per-image token mean (bf16 -> fp32) and channel gate.  One block per (image, 64 channels); the tokens are striped
+//      over 16 waves and combined in a fixed order (a thread per (image, channel) walking all tokens took 61 us on 6144 threads)
+__global__ __launch_bounds__(1024) void token_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
+  __shared__ float part[16][64];
+  const int cb = (C + 63) / 64;
+  const int b = blockIdx.x / cb;
+  const int c = (blockIdx.x % cb) * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    int t = w;
+    for (; t + 16 < T; t += 32) { s0 += (float)x[((int64_t)b * T + t) * C + c]; s1 += (float)x[((int64_t)b * T + t + 16) * C + c]; }
+    for (; t < T; t += 16) s0 += (float)x[((int64_t)b * T + t) * C + c];
+  }
+  part[w][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    float tsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tsum += part[k][threadIdx.x];
+    out[(int64_t)b * C + c] = tsum / (float)T;
+  }
 }
 __global__ void scale_channels_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate, bf16_t* __restrict__ y, int B,
                                       int T, int C) {
@@ -354,7 +368,7 @@ extern "C" int mp_relpos_tables_bf16(const void* qkv, int64_t ld, const float* r
 extern "C" int mp_token_mean_bf16(const void* x, float* out, int B, int T, int C, hipStream_t stream) {
   const int64_t n = (int64_t)B * C;
   if (n == 0) return MP_OK;
-  hipLaunchKernelGGL(token_mean_kernel, GRID1D(n), (const bf16_t*)x, out, B, T, C);
+  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)(B * ((C + 63) / 64))), dim3(1024), 0, stream, (const bf16_t*)x, out, B, T, C);
   return mp_check_launch("mp_token_mean_bf16");
 }
 

@@ -45,6 +45,57 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bf16_kernel(const bf16_t*
   }
 }
 
+// LayerNorm with one WAVE per row (dim <= 2048: CLIP 1024, SAM 768 / 256): the two reductions are wave shuffles, no LDS and no
+// workgroup barrier; four rows per 256-thread block.  Same arithmetic order per lane as the block version (two-pass variance).
+__global__ __launch_bounds__(256) void layernorm_bf16_wave_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, bf16_t* __restrict__ y, int64_t rows,
+                                                                  int dim, float eps, int64_t ldx, int64_t ldy) {
+  constexpr int WC = 4;                                   // chunks of 64 lanes x 8 elements
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  bf16_t* yr = y + row * ldy;
+  bf16x8 v[WC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < WC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < dim) {
+      v[c] = *reinterpret_cast<const bf16x8*>(xr + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[c][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < WC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < dim) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[c][j] - mean; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+  for (int c = 0; c < WC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < dim) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + i), w1 = *reinterpret_cast<const f32x4*>(w + i + 4);
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (b) { b0 = *reinterpret_cast<const f32x4*>(b + i); b1 = *reinterpret_cast<const f32x4*>(b + i + 4); }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (bf16_t)(((float)v[c][j] - mean) * rs * w0[j] + b0[j]);
+        o[4 + j] = (bf16_t)(((float)v[c][4 + j] - mean) * rs * w1[j] + b1[j]);
+      }
+      *reinterpret_cast<bf16x8*>(yr + i) = o;
+    }
+  }
+}
+
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ b, bf16_t* __restrict__ y,
                                                                      int dim, float eps, int64_t ldx, int64_t ldy) {
@@ -228,6 +279,11 @@ extern "C" int mp_layernorm_bf16(const void* x, int64_t ldx, const float* w, con
   MP_REQUIRE(dim % 8 == 0 && dim <= ROW_THREADS * 8 * MAXC && ldx % 8 == 0 && ldy % 8 == 0, MP_ERR_SHAPE,
              "mp_layernorm_bf16: dim=%d unsupported", dim);
   if (rows == 0) return MP_OK;
+  if (dim <= 2048) {
+    hipLaunchKernelGGL(layernorm_bf16_wave_kernel, dim3((unsigned)mp_cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, w, b,
+                       (bf16_t*)y, rows, dim, eps, ldx, ldy);
+    return mp_check_launch("mp_layernorm_bf16");
+  }
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, stream, (const bf16_t*)x, w, b,
                      (bf16_t*)y, dim, eps, ldx, ldy);
   return mp_check_launch("mp_layernorm_bf16");

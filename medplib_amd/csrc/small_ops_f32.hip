@@ -105,19 +105,28 @@ __global__ void act_bwd_f32_kernel(const float* __restrict__ dy, const float* __
   else if (act == 2) dx[i] = dy[i] * gelu_erf_grad(x[i]);
   else { const float s = x[i]; dx[i] = dy[i] * s * (1.f - s); }  // act==3: x holds the sigmoid OUTPUT
 }
-// out[c] (+)= sum_r x[r, c]   (bias gradients); one block per 64 columns, rows striped over 4 waves
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
-                                                         int cols, int accumulate) {
-  __shared__ float part[4][64];
+// out[c] (+)= sum_r x[r, c]   (bias gradients); one block per 64 columns, rows striped over 16 waves with four independent
+// accumulators per thread (the launches are latency-bound: 4 waves walking 2048 rows one dependent add at a time took 17 us);
+// the 16 partials are combined in a fixed order, so the result does not depend on scheduling
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                          int cols, int accumulate) {
+  __shared__ float part[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < cols)
-    for (int64_t r = w; r < rows; r += 4) s += x[r * cols + c];
-  part[w][threadIdx.x & 63] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int64_t r = w;
+    for (; r + 48 < rows; r += 64) {
+      s0 += x[r * cols + c]; s1 += x[(r + 16) * cols + c]; s2 += x[(r + 32) * cols + c]; s3 += x[(r + 48) * cols + c];
+    }
+    for (; r < rows; r += 16) s0 += x[r * cols + c];
+  }
+  part[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w == 0 && c < cols) {
-    const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
     out[c] = accumulate ? out[c] + t : t;
   }
 }
@@ -226,7 +235,7 @@ extern "C" int mp_act_bwd_f32(const float* dy, const float* x, float* dx, int64_
 }
 extern "C" int mp_colsum_f32(const float* x, float* out, int64_t rows, int cols, int accumulate, hipStream_t stream) {
   if (cols == 0) return MP_OK;
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)mp_cdiv(cols, 64)), dim3(256), 0, stream, x, out, rows, cols,
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)mp_cdiv(cols, 64)), dim3(1024), 0, stream, x, out, rows, cols,
                      accumulate);
   return mp_check_launch("mp_colsum_f32");
 }
