@@ -63,6 +63,8 @@ int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const v
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
  * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */
 int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
+/* A stream that issues GEMMs concurrently with others gets its own scratch (up to 4 streams); other streams use the default. */
+int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
 
 /* Fused attention forward; variant 0 = hardware transpose-read V path, 1 = scalar-transposed V (cross-check).
  * Llama causal + key padding (HF-4.31 eager), CLIP (A.2), SAM window/global attention with decomposed

@@ -545,18 +545,35 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
-// tail split-K workspace, registered by the host (mp_gemm_set_workspace): >= n_cu * 256 KiB of fp32 partials + n_cu tickets
-static float* g_split_ws = nullptr;
-static int* g_split_tickets = nullptr;
-static int64_t g_split_ws_bytes = 0;
+// split-K workspaces, registered by the host: >= n_cu * 256 KiB of fp32 partials + >= 256 tickets each.  One workspace serves
+// one stream at a time, so a stream that runs GEMMs concurrently with the default one registers its own
+// (mp_gemm_set_stream_workspace); launches on any other stream use the default entry.
+struct SplitWs { hipStream_t stream; float* ws; int* tickets; int64_t bytes; };
+static SplitWs g_split_default = {nullptr, nullptr, nullptr, 0};
+static SplitWs g_split_streams[4] = {};
+static int g_split_n_streams = 0;
 
 extern "C" int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
   MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_workspace: need >= 256 zeroed int tickets");
-  g_split_ws = (float*)ws; g_split_tickets = tickets; g_split_ws_bytes = ws ? ws_bytes : 0;
+  g_split_default = SplitWs{nullptr, (float*)ws, tickets, ws ? ws_bytes : 0};
   return MP_OK;
 }
 
-void mp_gemm_split_workspace(float** ws, int** tickets, int64_t* bytes) { *ws = g_split_ws; *tickets = g_split_tickets; *bytes = g_split_ws_bytes; }
+extern "C" int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
+  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_stream_workspace: need >= 256 zeroed int tickets");
+  for (int i = 0; i < g_split_n_streams; ++i)
+    if (g_split_streams[i].stream == stream) { g_split_streams[i] = SplitWs{stream, (float*)ws, tickets, ws ? ws_bytes : 0}; return MP_OK; }
+  MP_REQUIRE(g_split_n_streams < 4, MP_ERR_ARG, "mp_gemm_set_stream_workspace: at most 4 per-stream workspaces");
+  g_split_streams[g_split_n_streams++] = SplitWs{stream, (float*)ws, tickets, ws ? ws_bytes : 0};
+  return MP_OK;
+}
+
+void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes) {
+  const SplitWs* e = &g_split_default;
+  for (int i = 0; i < g_split_n_streams; ++i)
+    if (g_split_streams[i].stream == stream) e = &g_split_streams[i];
+  *ws = e->ws; *tickets = e->tickets; *bytes = e->bytes;
+}
 
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   static int abl = -1;
@@ -592,8 +609,9 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
     }
     GemmArgs gf = g;
     gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split;
-    gf.ws = g_split_ws; gf.tickets = g_split_tickets;
-    if (!gf.ws || g_split_ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
+    int64_t ws_bytes = 0;
+    mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
+    if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
     const dim3 fgrid(tiles * batch + n_cu);
     if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
     else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);

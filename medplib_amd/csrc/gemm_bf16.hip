@@ -276,16 +276,16 @@ static bool use_256(const GemmArgs& g, int batch) {
 }
 
 // implemented in gemm256_bf16.hip: the registered split-K scratch (mp_gemm_set_workspace)
-void mp_gemm_split_workspace(float** ws, int** tickets, int64_t* bytes);
+void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
 
 // split-K factor of a 128x128 launch: only when the tile count leaves most of the machine idle, K is long enough to amortise the
 // partial-sum round trip, the row count is known on the host and the scratch is registered
-static int split128(const GemmArgs& g, int batch, float** ws, int** tickets) {
+static int split128(const GemmArgs& g, int batch, hipStream_t stream, float** ws, int** tickets) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("MP_GEMM_MAX_SPLIT"); enabled = (e && atoi(e) == 1) ? 0 : 1; }
   if (!enabled || g.m_dev) return 1;
   int64_t bytes = 0;
-  mp_gemm_split_workspace(ws, tickets, &bytes);
+  mp_gemm_split_workspace(stream, ws, tickets, &bytes);
   if (!*ws) return 1;
   const int64_t tiles = mp_cdiv(g.M, BM) * mp_cdiv(g.N, BN) * batch;
   const int nt = g.K / BK;
@@ -325,7 +325,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
-  g.max_split = split128(g, 1, &g.ws, &g.tickets);
+  g.max_split = split128(g, 1, stream, &g.ws, &g.tickets);
   launch_gemm(g, dim3(tiles * g.max_split, 1), stream);
   return mp_check_launch("mp_gemm_bf16_nt");
 }

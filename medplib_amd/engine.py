@@ -13,6 +13,8 @@ reduce-scatter + all-gather collapses to this when optimizer state is replicated
 import math
 import os
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -106,6 +108,14 @@ class Engine:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = None
+        # When every trainable tensor lives in the fp32 mask tail (stage-III "LoRA off": mask_decoder + text_hidden_fcs), the model
+        # may run that tail on its own stream so it overlaps the next step's frozen trunk (MedPLIBForCausalLM.tail_side_stream);
+        # backward / step then follow it onto that stream.
+        if torch.cuda.is_available() and hasattr(model, "tail_side_stream") and int(config.get("overlap_mask_tail", 1)):
+            names = {id(p): n for n, p in model.named_parameters()}
+            tail_only = all(("mask_decoder" in names.get(id(p), "") or "text_hidden_fcs" in names.get(id(p), ""))
+                            for p in self.optimizer.params)
+            model.tail_side_stream = bool(tail_only)
         self.training_dataloader = None
         if training_data is not None:
             sampler = None
@@ -131,11 +141,21 @@ class Engine:
     def backward(self, loss):
         """autograd backward (grads accumulate straight into the flat buffer), then — at an accumulation boundary — one
         bucketed all-reduce of the flat gradient on the communication stream (collective C1)."""
-        if self.grad_accum > 1:
-            loss = loss / self.grad_accum
-        loss.backward()
-        if self.is_gradient_accumulation_boundary():
-            self.launch_grad_reduce()
+        with self._tail_ctx():
+            if self.grad_accum > 1:
+                loss = loss / self.grad_accum
+            loss.backward()
+            if self.is_gradient_accumulation_boundary():
+                self.launch_grad_reduce()
+
+    def _tail_ctx(self):
+        """The stream the model put the trainable tail on for this step (or the caller's stream)."""
+        st = getattr(self.module, "active_tail_stream", None)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
+    def sync_side_streams(self):
+        if hasattr(self.module, "sync_side_streams") and torch.cuda.is_available():
+            self.module.sync_side_streams()
 
     def launch_grad_reduce(self):
         """SUM all-reduce of the flat gradient bucket (averaged by grad_scale = 1/world inside the AdamW kernel)."""
@@ -160,14 +180,15 @@ class Engine:
         self.micro_steps += 1
         if not boundary:
             return
-        self.wait_grad_reduce()
         if self.scheduler is not None:
             self.scheduler.step()
             lr = self.scheduler.get_last_lr()[0]
         else:
             lr = self.optimizer.lr
-        self.optimizer.step(lr=lr, grad_scale=1.0 / self.world)         # SUM all-reduce -> mean
-        self.optimizer.zero_grad()
+        with self._tail_ctx():
+            self.wait_grad_reduce()
+            self.optimizer.step(lr=lr, grad_scale=1.0 / self.world)         # SUM all-reduce -> mean
+            self.optimizer.zero_grad()
         self.global_steps += 1
 
     def get_lr(self):
@@ -176,6 +197,7 @@ class Engine:
     # checkpoints: <dir>/latest holds "global_step<N>" like DeepSpeed (train_ds_medplib.py:453-470) -------------------
     def save_checkpoint(self, save_dir, client_state=None):
         tag = f"global_step{self.global_steps}"
+        self.sync_side_streams()
         if self.rank == 0:
             os.makedirs(os.path.join(save_dir, tag), exist_ok=True)
             module_sd = {n: p.detach().cpu() for n, p in self.module.named_parameters() if p.requires_grad}
@@ -190,6 +212,7 @@ class Engine:
             dist.barrier()
 
     def load_checkpoint(self, load_dir):
+        self.sync_side_streams()
         latest = os.path.join(load_dir, "latest")
         if not os.path.exists(latest):
             return None, None

@@ -97,10 +97,37 @@ class MedPLIBForCausalLM(nn.Module):
         self.to_device()
         self.seg_token_idx = cfg.seg_token_idx
         self.inference_threshold = 0.1
+        self.sam_side_stream = True             # run the SAM encoder beside the LLM stack (model_forward)
+        self._sam_stream = None
+        # Training only, switched on by engine.initialize(): the fp32 mask tail (forward, and through autograd its backward; the
+        # engine adds the optimizer) runs on its own stream, so its ~700 tiny launches overlap the NEXT step's CLIP tower / LLM
+        # instead of holding the machine at a few percent occupancy.  The calling stream waits for the tail FORWARD before
+        # model_forward returns (the loss dict is safe to read); backward and optimizer stay asynchronous to it and are ordered
+        # against the next tail by the tail stream itself.  Anything else that touches trainable state calls sync_side_streams().
+        self.tail_side_stream = False
+        self._tail_stream_obj = None
+        self.active_tail_stream = None
         self.capture_intermediates = False      # tests: keep the trunk outputs that feed the trainable tail
         self.captured = {}
 
     # ------------------------------------------------------------------ plumbing
+    def _side_stream(self):
+        if self._sam_stream is None:
+            self._sam_stream = ops.side_stream(self.device_, "sam_encoder", with_gemm_workspace=True)   # own split-K scratch
+        return self._sam_stream
+
+    def _tail_stream(self):
+        if self._tail_stream_obj is None:
+            self._tail_stream_obj = ops.side_stream(self.device_, "mask_tail")      # fp32 tail: no bf16 GEMMs, no scratch needed
+        return self._tail_stream_obj
+
+    def sync_side_streams(self):
+        """Order the calling stream behind everything the side streams have been given (tail backward / optimizer, SAM encoder)."""
+        cur = torch.cuda.current_stream()
+        for st in (self._tail_stream_obj, self._sam_stream):
+            if st is not None:
+                cur.wait_stream(st)
+
     def to_device(self):
         nn.Module.to(self, self.device_)
         return self
@@ -122,6 +149,7 @@ class MedPLIBForCausalLM(nn.Module):
 
     # ------------------------------------------------------------------ checkpoint layout
     def load_hf_state_dict(self, sd):
+        self.sync_side_streams()
         m = self.model
         m.llm.load_hf(sd)
         m.vision_tower.load_hf(sd)
@@ -226,6 +254,16 @@ class MedPLIBForCausalLM(nn.Module):
         att_np = _np_ids(attention_mask).astype(bool) if attention_mask is not None else None
         B = ids_np.shape[0]
         m = self.model
+        # The frozen SAM-Med2D encoder does not depend on the LLM: it runs on a side stream so its ~350 short, low-occupancy
+        # launches (windowed attention, adapter convolutions on 64-token maps) fill in beside the LLM's GEMMs instead of
+        # occupying the machine alone.  Joined again before the mask tail.
+        image_tokens = None
+        if seg_flag and self.sam_side_stream:
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
         with torch.no_grad():
             plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, kwargs.get("mask_images"),
                                                 kwargs.get("image_token_types"), kwargs.get("image_token_lengths"))
@@ -253,9 +291,39 @@ class MedPLIBForCausalLM(nn.Module):
             out["loss"] = out["ce_loss"] = ce_w[0]
             return out
 
-        # ---- <SEG> rows -> text_hidden_fcs -> prompt + mask decoder (MedPLIB.py:456-502), batched over all masks
+        # ---- <SEG> rows -> text_hidden_fcs -> prompt + mask decoder -> losses (MedPLIB.py:456-572), batched over all masks
+        main = torch.cuda.current_stream()
+        if image_tokens is None:
+            with torch.no_grad():
+                image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
+        else:
+            main.wait_stream(self._side_stream())
+            image_tokens.record_stream(main)
+        use_tail = self.tail_side_stream and self.training and not inference and torch.is_grad_enabled()
+        if not use_tail:
+            self.active_tail_stream = None
+            if self._tail_stream_obj is not None:
+                main.wait_stream(self._tail_stream_obj)           # parameters may still be in an optimizer step over there
+            return self._mask_tail(plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list,
+                                   inference, B)
+        tail = self._tail_stream()
+        tail.wait_stream(main)
+        for t in (last_hidden, ce, image_tokens, seg_rows_d, exp_d):
+            if t is not None:
+                t.record_stream(tail)
+        for g_ in (masks_list or []):
+            if torch.is_tensor(g_) and g_.is_cuda:
+                g_.record_stream(tail)
+        with torch.cuda.stream(tail):
+            out = self._mask_tail(plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list,
+                                  inference, B)
+        main.wait_event(tail.record_event())                        # the loss dict is complete for the caller's stream
+        self.active_tail_stream = tail
+        return out
+
+    def _mask_tail(self, plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list, inference, B):
+        cfg, dev, m = self.config, self.device_, self.model
         with torch.no_grad():
-            image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
             if self.capture_intermediates:
                 self.captured = {"last_hidden": last_hidden, "image_tokens": image_tokens, "ce": ce}
             assert image_tokens.shape[0] == B
@@ -299,6 +367,7 @@ class MedPLIBForCausalLM(nn.Module):
         tokens (the last generated token is never fed back), i.e. one position FEWER than build_seg_token_mask(output_ids)
         yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
         cfg, dev, m = self.config, self.device_, self.model
+        self.sync_side_streams()
         if region_masks:
             raise NotImplementedError("region prompts are outside the built path (SURVEY §8f)")
         ids = _np_ids(input_ids).astype(np.int64)

@@ -82,6 +82,34 @@ def _ensure_gemm_workspace(device):
         _GEMM_WS = (ws, tickets)
 
 
+_STREAM_WS = {}
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, name, with_gemm_workspace=False):
+    """Process-wide side streams (one per device and role): models share them, so the library's small per-stream workspace table
+    is not exhausted by short-lived model instances."""
+    key = (torch.device(device).index or 0, name)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    st = _SIDE_STREAMS[key]
+    if with_gemm_workspace:
+        register_stream_workspace(st)
+    return st
+
+
+
+def register_stream_workspace(stream):
+    """Give `stream` (a torch.cuda.Stream that runs GEMMs concurrently with the default stream) its own split-K scratch."""
+    key = stream.cuda_stream
+    if key not in _STREAM_WS:
+        import ctypes
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=stream.device)
+        tickets = torch.zeros(256, dtype=torch.int32, device=stream.device)
+        lib().call("mp_gemm_set_stream_workspace", ctypes.c_void_p(key), _p(ws), ws.numel(), _p(tickets), tickets.numel())
+        _STREAM_WS[key] = (ws, tickets)
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, out=None, alpha=1.0, m_dev=None):
     """out[M,N] = act(alpha * a[M,K] @ w[N,K]^T + bias) + residual.  a/w bf16 with unit inner stride."""
     _chk(a, torch.bfloat16, "gemm.a"); _chk(w, torch.bfloat16, "gemm.w")
