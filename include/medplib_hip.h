@@ -135,14 +135,16 @@ int mp_bilinear_resize_fwd(const void* in, int in_dtype, float* out, int n, int 
 int mp_bilinear_resize_bwd(const float* dout, float* din_zeroed, int n, int in_h, int in_w, int crop_y0, int crop_x0,
                            int crop_h, int crop_w, int out_h, int out_w, hipStream_t stream);
 /* BCE + Dice + IoU-MSE + Focal and their weighted combination (MedPLIB.py:26-124, 515-572); out10 in the
- * reference's dict order; stats[n,8] feeds the backward. */
+ * reference's dict order; stats[n,8] feeds the backward.  `offsets` (device int64 [n_masks+1], element offsets into the flat
+ * pred / gt buffers) makes the batch ragged — masks of different H x W, which the reference handles by looping; NULL = n_masks
+ * masks of `hw` elements each. */
 size_t mp_mask_losses_workspace(int n_masks);
 int mp_mask_losses_fwd(const float* pred, const float* gt, const float* pred_iou, const float* ce_loss, int n_masks, int64_t hw,
-                       float w_ce, float w_bce, float w_dice, float w_iou, float w_focal, float* stats, float* out10,
-                       void* workspace, size_t workspace_bytes, hipStream_t stream);
+                       const int64_t* offsets, float w_ce, float w_bce, float w_dice, float w_iou, float w_focal, float* stats,
+                       float* out10, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int mp_mask_losses_bwd(const float* pred, const float* gt, const float* stats, const float* grad_scale, float* dpred,
-                       float* dpred_iou, int n_masks, int64_t hw, float w_bce, float w_dice, float w_iou, float w_focal,
-                       hipStream_t stream);
+                       float* dpred_iou, int n_masks, int64_t hw, const int64_t* offsets, float w_bce, float w_dice, float w_iou,
+                       float w_focal, hipStream_t stream);
 /* (sigmoid(x) > thr) and |pred|,|gt|,|and|,|or| counts (train_ds_medplib.py:702-719,750; vqa_infer.py:565-588). */
 int mp_mask_threshold_iou(const void* pred, int pred_dtype, const float* gt, uint8_t* bin_out,
                           unsigned long long* counts_zeroed, int n_masks, int64_t hw, float threshold, hipStream_t stream);

@@ -73,12 +73,17 @@ __device__ __forceinline__ void loss_terms(float x, float g, float* t) {
   t[5] = -(1.f - FOCAL_ALPHA) * (1.f - g) * p * p * logf(omp + 1e-12f);
 }
 
+// offsets (optional, [n+1] element offsets into the flat pred / gt buffers) make the batch ragged: masks of different H x W
+// in one launch (the reference loops over masks, MedPLIB.py:515-559); null = n masks of HW elements each
 __global__ __launch_bounds__(256) void mask_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                                float* __restrict__ partial, int64_t HW) {
+                                                                float* __restrict__ partial, int64_t HW,
+                                                                const int64_t* __restrict__ offsets) {
   __shared__ float red[16];
   const int m = blockIdx.y;
-  const float* x = pred + (int64_t)m * HW;
-  const float* g = gt + (int64_t)m * HW;
+  const int64_t base = offsets ? offsets[m] : (int64_t)m * HW;
+  if (offsets) HW = offsets[m + 1] - base;
+  const float* x = pred + base;
+  const float* g = gt + base;
   float acc[NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)LOSS_BLOCKS * 256) {
     float t[NSUM];
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(256) void mask_loss_partial_kernel(const float* __r
 __global__ __launch_bounds__(256) void mask_loss_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ pred_iou,
                                                                  const float* __restrict__ ce_loss, float* __restrict__ stats,
                                                                  float* __restrict__ out, int n, int64_t HW, float w_ce, float w_bce,
-                                                                 float w_dice, float w_iou, float w_focal) {
+                                                                 float w_dice, float w_iou, float w_focal,
+                                                                 const int64_t* __restrict__ offsets) {
   __shared__ float red[16];
   float l_bce = 0.f, l_dice = 0.f, l_iou = 0.f, l_focal = 0.f;
   for (int m = threadIdx.x; m < n; m += 256) {
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void mask_loss_finalize_kernel(const float* __
     for (int b = 0; b < LOSS_BLOCKS; ++b)
 #pragma unroll
       for (int k = 0; k < NSUM; ++k) s[k] += partial[((int64_t)m * LOSS_BLOCKS + b) * NSUM + k];
-    const float N = (float)HW;
+    const float N = offsets ? (float)(offsets[m + 1] - offsets[m]) : (float)HW;
     const float bce = (s[0] / N) / (1.f + 1e-8f);
     const float dice = 1.f - (2.f * s[3] + 1e-6f) / (s[1] + s[2] + 1e-6f);
     const float J = (s[3] + 1e-7f) / (s[1] + s[2] - s[3] + 1e-7f);
@@ -136,8 +142,11 @@ __global__ __launch_bounds__(256) void mask_loss_finalize_kernel(const float* __
 // d(loss)/d(pred) for upstream gradient *gscale (device scalar) on out[0]; also d(loss)/d(pred_iou)
 __global__ void mask_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ stats,
                                      const float* __restrict__ gscale, float* __restrict__ dpred, float* __restrict__ dpred_iou,
-                                     int n, int64_t HW, float w_bce, float w_dice, float w_iou, float w_focal) {
+                                     int n, int64_t HW, float w_bce, float w_dice, float w_iou, float w_focal,
+                                     const int64_t* __restrict__ offsets) {
   const int m = blockIdx.y;
+  const int64_t base = offsets ? offsets[m] : (int64_t)m * HW;
+  if (offsets) HW = offsets[m + 1] - base;
   const float gs = gscale ? gscale[0] : 1.f;
   const float cn = gs / ((float)n + 1e-8f);
   const float* st = stats + (int64_t)m * 8;
@@ -151,7 +160,7 @@ __global__ void mask_loss_bwd_kernel(const float* __restrict__ pred, const float
   const float c_iou = cn * w_iou * 2.f * (J - q);
   const float c_focal = cn * w_focal / (N + 1e-12f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
-    const float x = pred[(int64_t)m * HW + i], g = gt[(int64_t)m * HW + i];
+    const float x = pred[base + i], g = gt[base + i];
     const float p = 1.f / (1.f + expf(-x));
     const float omp = 1.f - p;
     const float dp_dx = p * omp;
@@ -164,7 +173,7 @@ __global__ void mask_loss_bwd_kernel(const float* __restrict__ pred, const float
     const float dpos = -FOCAL_ALPHA * g * (-2.f * omp * logf(p + 1e-12f) + omp * omp / (p + 1e-12f));
     const float dneg = -(1.f - FOCAL_ALPHA) * (1.f - g) * (2.f * p * logf(omp + 1e-12f) - p * p / (omp + 1e-12f));
     d += c_focal * (dpos + dneg) * dp_dx;
-    dpred[(int64_t)m * HW + i] = d;
+    dpred[base + i] = d;
   }
 }
 
@@ -226,24 +235,24 @@ extern "C" int mp_bilinear_resize_bwd(const float* dout, float* din_zeroed, int 
 extern "C" size_t mp_mask_losses_workspace(int n_masks) { return (size_t)n_masks * LOSS_BLOCKS * NSUM * sizeof(float); }
 
 extern "C" int mp_mask_losses_fwd(const float* pred, const float* gt, const float* pred_iou, const float* ce_loss, int n_masks,
-                                  int64_t hw, float w_ce, float w_bce, float w_dice, float w_iou, float w_focal, float* stats,
-                                  float* out10, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  MP_REQUIRE(n_masks > 0 && hw > 0, MP_ERR_SHAPE, "mp_mask_losses_fwd: need at least one mask (n=%d)", n_masks);
+                                  int64_t hw, const int64_t* offsets, float w_ce, float w_bce, float w_dice, float w_iou, float w_focal,
+                                  float* stats, float* out10, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  MP_REQUIRE(n_masks > 0 && (hw > 0 || offsets), MP_ERR_SHAPE, "mp_mask_losses_fwd: need at least one mask (n=%d)", n_masks);
   MP_REQUIRE(workspace_bytes >= mp_mask_losses_workspace(n_masks), MP_ERR_WORKSPACE, "mp_mask_losses_fwd: workspace too small");
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(mask_loss_partial_kernel, dim3(LOSS_BLOCKS, n_masks), dim3(256), 0, stream, pred, gt, partial, hw);
+  hipLaunchKernelGGL(mask_loss_partial_kernel, dim3(LOSS_BLOCKS, n_masks), dim3(256), 0, stream, pred, gt, partial, hw, offsets);
   hipLaunchKernelGGL(mask_loss_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, pred_iou, ce_loss, stats, out10, n_masks,
-                     hw, w_ce, w_bce, w_dice, w_iou, w_focal);
+                     hw, w_ce, w_bce, w_dice, w_iou, w_focal, offsets);
   return mp_check_launch("mp_mask_losses_fwd");
 }
 
 extern "C" int mp_mask_losses_bwd(const float* pred, const float* gt, const float* stats, const float* grad_scale, float* dpred,
-                                  float* dpred_iou, int n_masks, int64_t hw, float w_bce, float w_dice, float w_iou, float w_focal,
-                                  hipStream_t stream) {
-  MP_REQUIRE(n_masks > 0 && hw > 0, MP_ERR_SHAPE, "mp_mask_losses_bwd: bad shape");
-  const int bx = (int)(mp_cdiv(hw, 256) < 128 ? mp_cdiv(hw, 256) : 128);
+                                  float* dpred_iou, int n_masks, int64_t hw, const int64_t* offsets, float w_bce, float w_dice,
+                                  float w_iou, float w_focal, hipStream_t stream) {
+  MP_REQUIRE(n_masks > 0 && (hw > 0 || offsets), MP_ERR_SHAPE, "mp_mask_losses_bwd: bad shape");
+  const int bx = offsets ? 128 : (int)(mp_cdiv(hw, 256) < 128 ? mp_cdiv(hw, 256) : 128);
   hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(bx, n_masks), dim3(256), 0, stream, pred, gt, stats, grad_scale, dpred,
-                     dpred_iou, n_masks, hw, w_bce, w_dice, w_iou, w_focal);
+                     dpred_iou, n_masks, hw, w_bce, w_dice, w_iou, w_focal, offsets);
   return mp_check_launch("mp_mask_losses_bwd");
 }
 

@@ -185,19 +185,19 @@ class MaskLossFn(torch.autograd.Function):
     reference's output dict as one tensor; only out[0] ('loss') is differentiable."""
 
     @staticmethod
-    def forward(ctx, pred, gt, pred_iou, ce_loss, weights):
+    def forward(ctx, pred, gt, pred_iou, ce_loss, weights, offsets=None):
         pred, gt, pred_iou = pred.contiguous(), gt.contiguous(), pred_iou.contiguous()
-        out, stats = ops.mask_losses_fwd(pred, gt, pred_iou, ce_loss, weights)
+        out, stats = ops.mask_losses_fwd(pred, gt, pred_iou, ce_loss, weights, offsets)
         ctx.save_for_backward(pred, gt, stats)
-        ctx.weights = weights
+        ctx.weights, ctx.offsets = weights, offsets
         return out
 
     @staticmethod
     def backward(ctx, dout):
         pred, gt, stats = ctx.saved_tensors
         gscale = dout[0:1].contiguous()
-        dpred, dq = ops.mask_losses_bwd(pred, gt, stats, gscale, ctx.weights)
-        return dpred, None, dq, None, None
+        dpred, dq = ops.mask_losses_bwd(pred, gt, stats, gscale, ctx.weights, ctx.offsets)
+        return dpred, None, dq, None, None, None
 
 
 class BuildTokensFn(torch.autograd.Function):

@@ -345,12 +345,21 @@ class MedPLIBForCausalLM(nn.Module):
             return {"pred_masks": pred_masks, "gt_masks": masks_list}
 
         # ---- fused mask losses (MedPLIB.py:515-572)
-        if full is None:
-            raise NotImplementedError("mask losses over masks of different sizes in one step are not built yet (DESIGN.md)")
-        H, W = full.shape[-2:]
-        gt = torch.stack([g.reshape(H, W) for g in masks_list[:n]]).to(device=dev, dtype=torch.float32).view(n, H * W)
         weights = (cfg.ce_loss_weight, cfg.bce_loss_weight, cfg.dice_loss_weight, cfg.iou_loss_weight, cfg.focal_loss_weight)
-        out10 = A.MaskLossFn.apply(full.view(n, H * W), gt, iou_pred, ce, weights)
+        if full is not None:
+            H, W = full.shape[-2:]
+            gt = torch.stack([g.reshape(H, W) for g in masks_list[:n]]).to(device=dev, dtype=torch.float32).view(n, H * W)
+            out10 = A.MaskLossFn.apply(full.view(n, H * W), gt, iou_pred, ce, weights)
+        else:
+            # masks of different sizes in one step: one ragged launch over the flat concatenation (the reference loops per mask)
+            for i in range(n):
+                assert tuple(masks_list[i].shape[-2:]) == tuple(pred_masks[i].shape[-2:]), \
+                    f"gt_mask.shape: {tuple(masks_list[i].shape)}, pred_mask.shape: {tuple(pred_masks[i].shape)}"   # MedPLIB.py:527-531
+            sizes = [int(pm.shape[-2] * pm.shape[-1]) for pm in pred_masks]
+            offsets = _h2d(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64), dev)
+            pred_flat = torch.cat([pm.reshape(-1) for pm in pred_masks])
+            gt_flat = torch.cat([g.reshape(-1).to(device=dev, dtype=torch.float32) for g in masks_list[:n]])
+            out10 = A.MaskLossFn.apply(pred_flat, gt_flat, iou_pred, ce, weights, offsets)
         return {k: out10[i] for i, k in enumerate(LOSS_KEYS)}
 
 

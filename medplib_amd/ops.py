@@ -477,26 +477,30 @@ def bilinear_resize_bwd(dout, in_hw, crop):
     return din
 
 
-def mask_losses_fwd(pred, gt, pred_iou, ce_loss, weights):
-    """pred/gt [n, HW] f32, pred_iou [n] f32, ce_loss 1-elem f32 or None; weights = (ce, bce, dice, iou, focal).
-    Returns (out10, stats)."""
+def mask_losses_fwd(pred, gt, pred_iou, ce_loss, weights, offsets=None):
+    """pred/gt [n, HW] f32 (or flat [sum HW_i] with int64 device `offsets` [n+1] for masks of different sizes), pred_iou [n] f32,
+    ce_loss 1-elem f32 or None; weights = (ce, bce, dice, iou, focal).  Returns (out10, stats)."""
     _chk(pred, torch.float32, "mask_losses.pred"); _chk(gt, torch.float32, "mask_losses.gt")
     assert pred.is_contiguous() and gt.is_contiguous() and pred_iou.is_contiguous()
-    n, hw = pred.shape
+    if offsets is not None:
+        _chk(offsets, torch.int64, "mask_losses.offsets")
+        n, hw = offsets.numel() - 1, 0
+    else:
+        n, hw = pred.shape
     ws = lib().raw("mp_mask_losses_workspace")(n)
     work = torch.empty(ws, dtype=torch.uint8, device=pred.device)
     stats = torch.zeros((n, 8), dtype=torch.float32, device=pred.device)
     out = torch.empty(10, dtype=torch.float32, device=pred.device)
-    lib().call("mp_mask_losses_fwd", _p(pred), _p(gt), _p(pred_iou), _p(ce_loss), n, hw, *[float(w) for w in weights], _p(stats),
+    lib().call("mp_mask_losses_fwd", _p(pred), _p(gt), _p(pred_iou), _p(ce_loss), n, hw, _p(offsets), *[float(w) for w in weights], _p(stats),
                _p(out), _p(work), ws, _stream())
     return out, stats
 
 
-def mask_losses_bwd(pred, gt, stats, grad_scale, weights):
-    n, hw = pred.shape
+def mask_losses_bwd(pred, gt, stats, grad_scale, weights, offsets=None):
+    n, hw = (offsets.numel() - 1, 0) if offsets is not None else pred.shape
     dpred = torch.empty_like(pred)
     dq = torch.empty(n, dtype=torch.float32, device=pred.device)
-    lib().call("mp_mask_losses_bwd", _p(pred), _p(gt), _p(stats), _p(grad_scale), _p(dpred), _p(dq), n, hw,
+    lib().call("mp_mask_losses_bwd", _p(pred), _p(gt), _p(stats), _p(grad_scale), _p(dpred), _p(dq), n, hw, _p(offsets),
                *[float(w) for w in weights[1:]], _stream())
     return dpred, dq
 

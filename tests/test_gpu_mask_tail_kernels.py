@@ -158,6 +158,31 @@ def test_mask_losses_fwd_bwd(dev, golden_dir):
     _close("dloss/dpred_iou", dq, q.grad.view(-1), rtol=1e-4, atol=1e-7)
 
 
+def test_mask_losses_ragged_sizes(dev):
+    """Masks of different H x W in one launch (flat buffers + offsets) vs the oracle's per-mask loop (MedPLIB.py:515-559)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(17)
+    shapes = [(96, 80), (40, 131), (336, 336), (7, 5)]
+    preds = [(torch.randn(1, h, w, generator=g) * 3).requires_grad_() for h, w in shapes]
+    gts = [(torch.rand(h, w, generator=g) > 0.6).float() for h, w in shapes]
+    qs = [torch.rand(1, generator=g).requires_grad_() for _ in shapes]
+    weights = dict(ce=1.0, bce=2.0, dice=0.5, iou=1.5, focal=3.0)
+    wl = (1.0, 2.0, 0.5, 1.5, 3.0)
+    ce = torch.tensor([0.21])
+    ref = O.combine_mask_losses(preds, gts, qs, ce[0], weights)
+    ref["loss"].backward()
+    sizes = [h * w for h, w in shapes]
+    off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64, device=dev)
+    pf = torch.cat([p.detach().reshape(-1) for p in preds]).to(dev); gf = torch.cat([x.reshape(-1) for x in gts]).to(dev)
+    qd = torch.cat([q.detach() for q in qs]).to(dev)
+    out, stats = ops.mask_losses_fwd(pf, gf, qd, ce.to(dev), wl, offsets=off)
+    for i, k in enumerate(O.LOSS_KEYS):
+        _close(f"ragged loss[{k}]", out[i], ref[k].detach(), rtol=2e-5, atol=1e-6)
+    dpred, dq = ops.mask_losses_bwd(pf, gf, stats, None, wl, offsets=off)
+    _close("ragged dloss/dpred", dpred, torch.cat([p.grad.reshape(-1) for p in preds]), rtol=1e-3, atol=1e-8)
+    _close("ragged dloss/dpred_iou", dq, torch.cat([q.grad for q in qs]), rtol=1e-4, atol=1e-7)
+
+
 def test_threshold_iou_bit_exact(dev, golden_dir):
     from medplib_amd import ops
     gz = np.load(os.path.join(golden_dir, "mask_head_reference.npz"))

@@ -461,3 +461,29 @@ def test_engine_side_streams_do_not_change_results(dev):
         assert torch.equal(l[0], ref_l[0]), (l, ref_l)
         assert (g - ref_g).abs().max().item() <= 1e-6 * max(1.0, ref_g.abs().max().item())
         assert ((l - ref_l).abs() / ref_l.abs()).max().item() < 2e-3, (l, ref_l)
+
+
+def test_model_forward_mixed_mask_sizes(dev):
+    """Labels / GT masks of different H x W (and different resize_list entries) in one batch: grouped bilinear resizes + one
+    ragged loss launch vs the oracle's per-mask loop."""
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, iou_loss_weight=0.5)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    batch = OM.make_batch(cfg, 3)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(96, 80), (120, 64), (96, 80)]
+    batch["masks_list"] = [(torch.rand(h, w, generator=g) > 0.5).float() for h, w in shapes]
+    batch["label_list"] = [torch.full((h, w), 255.0) for h, w in shapes]
+    batch["resize_list"] = [(256, 256), (256, 136), (256, 256)]
+    bq = dict(batch)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = OM.model_forward(bq, W, cfg, training=True)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    out = m(**gb)
+    for k in O.LOSS_KEYS:
+        _stat(f"mixed-size loss[{k}]", out[k], ref[k], atol=3e-2)
+    out["loss"].backward()
+    grads = [p.grad for p in m.trainable_parameters() if p.grad is not None]      # hypernets 1-3 / their tokens get none
+    assert len(grads) > 20 and all(torch.isfinite(g_).all() for g_ in grads)
