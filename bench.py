@@ -173,6 +173,18 @@ def main():
                     "avg_launch_us": round(ms * 1e3 / max(sampled, 1), 2),
                     "gemm_tflop_per_step": round(all_flops / args.steps / 1e12, 2),
                     "gemm_ms_per_step": round(all_flops / args.steps / (achieved * 1e12) * 1e3, 2)}
+            # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
+            # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
+            # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath)).get("gemm256v3")
+                if tj:
+                    roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
+                    roof["traffic_detail"] = {"kernel": "gemm256v3_bf16_nt_kernel", "read_bytes_per_launch": tj["read_bytes_per_launch"],
+                                              "write_bytes_per_launch": tj["write_bytes_per_launch"],
+                                              "source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, "
+                                                        "read = 2 x FETCH_SIZE per the gfx950 correction)"}
         res = {
             "metric": "train samples/sec (img+64tok)", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
