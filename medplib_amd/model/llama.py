@@ -48,6 +48,17 @@ class LlamaStack:
         self.training = True
         self.rts_uniform_provider = None   # callable(layer_idx, T, E) -> fp32 [T,E] gate draws (RTS uniforms / top-2 Gumbel) or None
         self.gate_pass = 0                 # forward passes so far: part of the key of the stateless gate-draw generator
+        self.ep = None                     # ExpertParallel (expert_parallel.py) once enable_expert_parallel() sharded the experts
+
+    def enable_expert_parallel(self, ep):
+        """Shard the experts over an expert-parallel group (DeepSpeed `ep_size`, medplib_moe_llama.py:604-614): every rank keeps the
+        weights of its E/ep experts only; the gate `wg` stays replicated.  Call after the weights are loaded."""
+        ids = ep.local_expert_ids()
+        for i in self.moe_layers:
+            lw = self.layers[i]
+            lw["gu"] = lw["gu"][ids[0]:ids[-1] + 1].contiguous()
+            lw["down"] = lw["down"][ids[0]:ids[-1] + 1].contiguous()
+        self.ep = ep
 
     # ------------------------------------------------------------------ HF checkpoint layout
     def load_hf(self, sd, prefix=""):
@@ -133,14 +144,33 @@ class LlamaStack:
         else:
             expert, slot, weight, kept, counts, l_aux = ops.moe_route_top2(gates, logits, cap, self._gate_draws(i, T, E, gumbel=True))
         buf = ops.moe_dispatch(h, expert, slot, E, cap, top_k=k)
-        act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
-        if ops.GEMM_TIMER is not None:
-            ops.GEMM_TIMER.batched_rows = k * T      # algorithmic rows of the expert GEMMs: every token visits k experts
-        ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
-        y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
-        ops.gemm_batched(act, lw["down"], y, m_dev=kept)
+        if self.ep is not None:
+            y = self._experts_parallel(lw, buf, kept, cap)
+        else:
+            act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
+            if ops.GEMM_TIMER is not None:
+                ops.GEMM_TIMER.batched_rows = k * T      # algorithmic rows of the expert GEMMs: every token visits k experts
+            ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
+            y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
+            ops.gemm_batched(act, lw["down"], y, m_dev=kept)
         out = ops.moe_combine(y, expert, slot, weight, x, cap, top_k=k)
         return out, l_aux, (expert, slot, counts)
+
+    def _experts_parallel(self, lw, buf, kept, cap):
+        """MOELayer with ep_size > 1: all-to-all the routed rows to the ranks that own the experts, run each local expert over the
+        [ep] capacity slabs it received (one batched GEMM pair per local expert, the slab row counts travel with the rows), and
+        all-to-all the outputs back (sharded_moe.py MOELayer.forward; collectives C3 of SURVEY §2.5)."""
+        cfg, ep = self.cfg, self.ep
+        ff, d = cfg.intermediate_size, cfg.hidden_size
+        recv, counts = ep.dispatch(buf, kept)                      # [ep, E_local, cap, d], [ep, E_local]
+        counts_t = counts.t().contiguous()                         # [E_local, ep]: per local expert, rows from each source rank
+        y = torch.empty_like(recv)
+        for e in range(ep.E_local):
+            a = recv[:, e]                                         # [ep, cap, d] view, batch stride E_local*cap*d
+            act = torch.empty((ep.ep, cap, ff), dtype=torch.bfloat16, device=buf.device)
+            ops.gemm_batched(a, lw["gu"][e].unsqueeze(0).expand(ep.ep, -1, -1), act, m_dev=counts_t[e], act=ops.ACT_SWIGLU_PAIR)
+            ops.gemm_batched(act, lw["down"][e].unsqueeze(0).expand(ep.ep, -1, -1), y[:, e], m_dev=counts_t[e])
+        return ep.combine(y)
 
     def new_kv_cache(self, batch, max_len):
         """KV cache for `evaluate()`'s greedy decode (HF `use_cache=True`, MedPLIB.py:592-606): post-RoPE K and V per layer."""

@@ -487,3 +487,28 @@ def test_model_forward_mixed_mask_sizes(dev):
     out["loss"].backward()
     grads = [p.grad for p in m.trainable_parameters() if p.grad is not None]      # hypernets 1-3 / their tokens get none
     assert len(grads) > 20 and all(torch.isfinite(g_).all() for g_ in grads)
+
+
+def test_expert_parallel_path_single_rank_rccl(dev):
+    """The ep_size > 1 code path of the MoE layer (all-to-all dispatch over RCCL, per-local-expert batched GEMMs over the received
+    capacity slabs with the exchanged row counts, all-to-all combine) on a one-rank process group: must reproduce the replicated-
+    experts path bit for bit.  (The 2-rank exchange itself is covered on gloo in tests/test_host_logic.py.)"""
+    import torch.distributed as dist
+    from medplib_amd.expert_parallel import ExpertParallel
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, num_experts=3, capacity_factor=1.0)
+    W = OM.init_hf_weights(cfg)
+    g = torch.Generator().manual_seed(12)
+    emb = (torch.randn(2, 90, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    ref, _, _ = _model(cfg, dev, W).model.llm.forward(emb, None)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        m = _model(cfg, dev, W)
+        m.model.llm.enable_expert_parallel(ExpertParallel(dist.group.WORLD, 1, cfg.num_experts))
+        out, _, _ = m.model.llm.forward(emb, None)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -179,3 +179,62 @@ def test_splice_plan_matches_executed_reference(golden_dir, tag):
         if cc != splice.SPLICE_PAD:
             out[r] = embed[cc] if cc >= 0 else feats[-1 - cc]
     assert np.abs(out.view(plan.src_code.shape[0], -1, embed.shape[1]).numpy() - g[f"{tag}_embeds"]).max() < 1e-6
+
+
+_EP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from medplib_amd import expert_parallel as EP
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['PORT']}", rank=rank, world_size=2)
+ep_groups, edp_groups = EP.group_ranks(8, 2)
+assert ep_groups == [[0, 1], [2, 3], [4, 5], [6, 7]] and edp_groups == [[0, 2, 4, 6], [1, 3, 5, 7]]
+group, _ = EP.build_groups(2)
+E, cap, d = 4, 6, 5
+ep = EP.ExpertParallel(group, 2, E)
+assert ep.local_expert_ids() == [2 * rank, 2 * rank + 1]
+g = torch.Generator().manual_seed(100 + rank)
+T = 11
+x = torch.randn(T, d, generator=g)
+expert = torch.randint(0, E, (T,), generator=g)
+slot = torch.full((T,), -1, dtype=torch.long); kept = torch.zeros(E, dtype=torch.int32)
+for t in range(T):                                   # first-come slots, capacity drop (what moe_route_top1 produces)
+    e = int(expert[t])
+    if kept[e] < cap:
+        slot[t] = int(kept[e]); kept[e] += 1
+buf = torch.zeros(E, cap, d)
+for t in range(T):
+    if slot[t] >= 0:
+        buf[expert[t], slot[t]] = x[t]
+recv, counts = ep.dispatch(buf, kept)                # [ep, E_local, cap, d], [ep, E_local]
+assert recv.shape == (2, 2, cap, d) and counts.shape == (2, 2)
+f = lambda e, v: v * (e + 2.0) + e                   # expert e (global id)
+y = torch.zeros_like(recv)
+for s in range(2):
+    for el in range(2):
+        n = int(counts[s, el])
+        y[s, el, :n] = f(2 * rank + el, recv[s, el, :n])
+        assert recv[s, el, n:].abs().sum() == 0      # rows beyond the count are padding
+out = ep.combine(y)                                  # [E, cap, d]: outputs of every global expert for MY tokens
+for t in range(T):
+    if slot[t] >= 0:
+        assert torch.allclose(out[expert[t], slot[t]], f(int(expert[t]), x[t])), (t, int(expert[t]))
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_expert_parallel_all_to_all_two_ranks_gloo(tmp_path):
+    """MOELayer's two all-to-alls (dispatch / combine) with E = 4 experts sharded over ep = 2 ranks: every routed row reaches the
+    rank that owns its expert together with the per-(source, expert) row counts, and comes back to its token's slot."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ep_worker.py"
+    script.write_text(_EP_WORKER)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
