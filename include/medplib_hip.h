@@ -179,6 +179,11 @@ int mp_adaptive_avgpool_tokens_bf16(const void* x, void* out, int n, int len_in,
  * reference's cast, medplib_arch.py:103-104) -> NHWC [n, OH, OW, CO] bf16; w [CO, 9] f32, bias [CO] f32 (medplib_arch.py:84-85). */
 int mp_conv3x3s2_c1_gelu_bf16(const void* img, int img_dtype, const float* w, const float* bias, void* out, int n, int H, int W,
                               int CO, hipStream_t stream);
+/* extract_region_feature (medplib_arch.py:580-613): out[m, :] = mean over the points offsets[m]..offsets[m+1] of the bilinear
+ * (grid_sample align_corners=True, zero padding) read-out of feature map `map_index[m]` ([h, w, C] token-major) at the
+ * normalised (x, y) pairs in `xy`; each sample rounded to bf16 before the fp32 mean, like the reference's dtype round trip. */
+int mp_region_point_mean_bf16(const void* fmap, const float* xy, const int64_t* offsets, const int* map_index, void* out,
+                              int n_masks, int h, int w, int C, hipStream_t stream);
 /* Adapter_Layer channel gate: global average pool and per-channel scale (image_encoder.py:43-47). */
 int mp_token_mean_bf16(const void* x, float* out, int B, int T, int C, hipStream_t stream);
 int mp_scale_channels_bf16(const void* x, const float* gate, void* y, int B, int T, int C, hipStream_t stream);

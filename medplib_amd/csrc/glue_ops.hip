@@ -287,6 +287,50 @@ __global__ void conv3x3s2_c1_gelu_kernel(const TIN* __restrict__ img, const floa
   *reinterpret_cast<bf16x8*>(out + pix * CO + co) = o;
 }
 
+
+// ---- region prompts: extract_region_feature (medplib_arch.py:580-613).  For mask m: mean over its sampled points of the bilinear
+//      (grid_sample, align_corners=True, zero padding) read-out of the sample's [h, w, C] feature map at normalised (x, y).
+//      Mirrors the reference's rounding points: the sample is computed in fp32, rounded to the model dtype (bf16), the mean is
+//      accumulated in fp32 and rounded once.  One thread per (mask, 8 channels).
+__global__ void region_point_mean_kernel(const bf16_t* __restrict__ fmap, const float* __restrict__ xy, const int64_t* __restrict__ offsets,
+                                         const int* __restrict__ map_index, bf16_t* __restrict__ out, int n_masks, int h, int w, int C) {
+  const int per_row = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_masks * per_row) return;
+  const int c = (int)(idx % per_row) * 8;
+  const int m = (int)(idx / per_row);
+  const bf16_t* fm = fmap + (int64_t)map_index[m] * h * w * C;
+  const int64_t p0 = offsets[m], p1 = offsets[m + 1];
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int64_t p = p0; p < p1; ++p) {
+    // grid = 2 * coord - 1; align_corners=True unnormalisation ((g + 1) / 2) * (size - 1)
+    const float gx = 2.f * xy[2 * p] - 1.f, gy = 2.f * xy[2 * p + 1] - 1.f;
+    const float ix = ((gx + 1.f) * 0.5f) * (float)(w - 1), iy = ((gy + 1.f) * 0.5f) * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    auto corner = [&](int yy, int xx, float wt) {
+      if (yy < 0 || yy >= h || xx < 0 || xx >= w) return;
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(fm + ((int64_t)yy * w + xx) * C + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += (float)t[j] * wt;
+    };
+    corner(y0, x0, wy0 * wx0); corner(y0, x1, wy0 * wx1); corner(y1, x0, wy1 * wx0); corner(y1, x1, wy1 * wx1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)(bf16_t)v[j];
+  }
+  const float inv = p1 > p0 ? 1.f / (float)(p1 - p0) : 0.f;        // empty mask: mean of nothing = NaN -> nan_to_num -> 0
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j] * inv);
+  *reinterpret_cast<bf16x8*>(out + (int64_t)m * C + c) = o;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -420,4 +464,14 @@ extern "C" int mp_conv3x3s2_c1_gelu_bf16(const void* img, int img_dtype, const f
   else
     hipLaunchKernelGGL(conv3x3s2_c1_gelu_kernel<bf16_t>, grid, blk, 0, stream, (const bf16_t*)img, w, bias, (bf16_t*)out, n, H, W, OH, OW, CO);
   return mp_check_launch("mp_conv3x3s2_c1_gelu_bf16");
+}
+
+extern "C" int mp_region_point_mean_bf16(const void* fmap, const float* xy, const int64_t* offsets, const int* map_index, void* out,
+                                         int n_masks, int h, int w, int C, hipStream_t stream) {
+  MP_REQUIRE(n_masks >= 0 && h > 0 && w > 0 && C % 8 == 0, MP_ERR_SHAPE, "mp_region_point_mean_bf16: bad shape");
+  if (n_masks == 0) return MP_OK;
+  const int64_t total = (int64_t)n_masks * (C / 8);
+  hipLaunchKernelGGL(region_point_mean_kernel, dim3((unsigned)mp_cdiv(total, 256)), dim3(256), 0, stream, (const bf16_t*)fmap, xy,
+                     offsets, map_index, (bf16_t*)out, n_masks, h, w, C);
+  return mp_check_launch("mp_region_point_mean_bf16");
 }

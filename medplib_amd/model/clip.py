@@ -40,6 +40,8 @@ class ClipTower:
                                 "fc2_w": rn(C, I), "fc2_b": rn(C, dtype=torch.float32)})
         d = cfg.hidden_size
         self.proj = {"w0": rn(d, C), "b0": rn(d, dtype=torch.float32), "w2": rn(d, d), "b2": rn(d, dtype=torch.float32)}
+        # region_fea_adapter = nn.Linear(mm_hidden_size, hidden_size) on the RAW tower features (medplib_arch.py:131, 204-208)
+        self.region_adapter = {"w": rn(d, C), "b": rn(d, dtype=torch.float32)}
 
     def n_run_layers(self):
         sel, L = self.cfg.mm_vision_select_layer, self.cfg.clip_num_layers
@@ -70,6 +72,8 @@ class ClipTower:
             put(lw["fc2_w"], sd[lp + "mlp.fc2.weight"]); put(lw["fc2_b"], sd[lp + "mlp.fc2.bias"])
         put(self.proj["w0"], sd[proj_prefix + "0.weight"]); put(self.proj["b0"], sd[proj_prefix + "0.bias"])
         put(self.proj["w2"], sd[proj_prefix + "2.weight"]); put(self.proj["b2"], sd[proj_prefix + "2.bias"])
+        if "model.region_fea_adapter.weight" in sd:
+            put(self.region_adapter["w"], sd["model.region_fea_adapter.weight"]); put(self.region_adapter["b"], sd["model.region_fea_adapter.bias"])
 
     def export_hf(self, tower_prefix="model.vision_tower.vision_tower.vision_model.", proj_prefix="model.mm_projector."):
         cfg = self.cfg
@@ -91,12 +95,14 @@ class ClipTower:
             sd[lp + "mlp.fc2.weight"] = lw["fc2_w"]; sd[lp + "mlp.fc2.bias"] = lw["fc2_b"].to(bf)
         sd[proj_prefix + "0.weight"] = self.proj["w0"]; sd[proj_prefix + "0.bias"] = self.proj["b0"].to(bf)
         sd[proj_prefix + "2.weight"] = self.proj["w2"]; sd[proj_prefix + "2.bias"] = self.proj["b2"].to(bf)
+        sd["model.region_fea_adapter.weight"] = self.region_adapter["w"]; sd["model.region_fea_adapter.bias"] = self.region_adapter["b"].to(bf)
         return sd
 
     # ------------------------------------------------------------------ forward
-    def encode_images(self, images):
+    def encode_images(self, images, return_raw=False):
         """images [n,3,336,336] (bf16 or f32) -> projected features [n*576, hidden] bf16 (encode_images,
-        medplib_arch.py:198-212, without compressor)."""
+        medplib_arch.py:198-212, without compressor); with return_raw also the tower features [n*576, C] the region adapter
+        reads."""
         cfg = self.cfg
         n = images.shape[0]
         C, NP, H = cfg.clip_hidden_size, cfg.clip_num_patches, cfg.clip_num_heads
@@ -116,4 +122,9 @@ class ClipTower:
             x = ops.gemm(h, lw["fc2_w"], bias=lw["fc2_b"], residual=x)
         feats = ops.copy_rows(x, n * NP, C, NP, S, 1)            # drop CLS (clip_encoder.py:33-34)
         h = ops.gemm(feats, self.proj["w0"], bias=self.proj["b0"], act=ops.ACT_GELU)
-        return ops.gemm(h, self.proj["w2"], bias=self.proj["b2"])
+        out = ops.gemm(h, self.proj["w2"], bias=self.proj["b2"])
+        return (out, feats) if return_raw else out
+
+    def region_feature_map(self, raw_rows):
+        """region_fea_adapter over raw tower features [rows, C] -> [rows, hidden] (medplib_arch.py:207)."""
+        return ops.gemm(raw_rows, self.region_adapter["w"], bias=self.region_adapter["b"])

@@ -38,6 +38,7 @@ class MedPLIBConfig:
     clip_ln_eps: float = 1e-5
     mm_vision_select_layer: int = -2
     mm_use_im_start_end: bool = True
+    max_sample_point: int = 512             # region prompts: points sampled per region mask (train_ds_medplib.py:120)
     # ICL front end (medplib_arch.py:67-131; scripts/train_medplib_icl.sh)
     mm_token_compress: bool = False
     mm_compressed_token_count: int = 256

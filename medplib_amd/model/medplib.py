@@ -9,6 +9,7 @@ per-sample splice loop, per-mask decoder loop) is replaced by batched kernels.
 Dead work the reference performs but never consumes is not executed (results are identical — row-wise ops):
 full-vocabulary fp32 logits for unsupervised rows, text_hidden_fcs on non-<SEG> rows, the 32 intermediate hidden
 states, CLIP's last layer, mask tokens 1-3."""
+import math
 from typing import List, Optional
 
 import numpy as np
@@ -22,7 +23,7 @@ from .config import MedPLIBConfig
 from .llama import LlamaStack
 from .sam import MaskDecoder, PromptEncoderText, SamImageEncoder
 from .icl import MaskTokenEncoder, TokenCompressor
-from .splice import IMAGE_TOKEN_INDEX, icl_feature_layout, plan_splice
+from .splice import IMAGE_TOKEN_INDEX, REGION_TOKEN_INDEX, icl_feature_layout, plan_splice
 
 LOSS_KEYS = ["loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", "unscale_mask_bce_loss",
              "unscale_mask_dice_loss", "unscale_mask_loss", "unscale_mask_iou_loss", "unscale_mask_focal_loss"]
@@ -207,8 +208,43 @@ class MedPLIBForCausalLM(nn.Module):
                 outs[i] = r[j:j + 1]
         return None, outs
 
+    def _region_features(self, raw_feats, n_images, region_masks, valid_region_masks_bool):
+        """extract_region_feature (medplib_arch.py:283-295, 580-613) for the samples that carry region masks: region_fea_adapter on
+        their raw tower features, then per mask the mean of the feature map sampled at (a random subset of) its non-zero pixels.
+        The pixel lists are built on the host (`nonzero` has a data-dependent size; the reference synchronises here too) and the
+        subset is drawn with torch.randperm from the global generator exactly where the reference draws it.
+        Returns (features [n_region_masks, hidden] bf16, per-sample first row or None)."""
+        cfg = self.config
+        valid = [any(v) for v in valid_region_masks_bool]
+        vidx = [i for i, v in enumerate(valid) if v]
+        assert len(vidx) == len(region_masks), f"{len(vidx)}, {len(region_masks)}"              # medplib_arch.py:582
+        NP, C = cfg.clip_num_patches, cfg.clip_hidden_size
+        hw = int(math.isqrt(NP))
+        raw = raw_feats.view(n_images, NP, C)
+        sel = raw if vidx == list(range(n_images)) else raw[torch.as_tensor(vidx, device=raw.device)]
+        fmap = self.model.vision_tower.region_feature_map(sel.reshape(-1, C)).view(len(vidx), NP, cfg.hidden_size)
+        xy, offsets, map_index, bases, n_rows = [], [0], [], [None] * n_images, 0
+        for j, (b, masks) in enumerate(zip(vidx, region_masks)):
+            if len(masks) == 0:
+                continue
+            bases[b] = n_rows
+            H, W = masks[0].shape[0], masks[0].shape[1]
+            for mk in masks:
+                pts = torch.as_tensor(mk).detach().cpu().nonzero()                                  # (y, x)
+                if pts.shape[0] > cfg.max_sample_point:
+                    pts = pts[torch.randperm(pts.shape[0])[:cfg.max_sample_point], :]               # rand_sample, :33-39
+                p = pts.to(torch.float32) / torch.tensor([float(H), float(W)])
+                xy.append(p.flip(1).numpy())                                                        # (x, y) for grid_sample
+                offsets.append(offsets[-1] + pts.shape[0])
+                map_index.append(j)
+                n_rows += 1
+        dev = self.device_
+        feats = ops.region_point_mean(fmap.contiguous(), _h2d(np.concatenate(xy).astype(np.float32).reshape(-1, 2), dev),
+                                      _h2d(np.asarray(offsets, dtype=np.int64), dev), _h2d(np.asarray(map_index, dtype=np.int32), dev), hw, hw)
+        return feats, bases
+
     def _encode_and_plan(self, ids_np, lab_np, att_np, images_clip, mask_images=None, image_token_types=None,
-                         image_token_lengths=None, with_seg=True):
+                         image_token_lengths=None, with_seg=True, region_masks=None, valid_region_masks_bool=None):
         """encode_images (+ TokenCompressor) / encode_masks and the splice plan for the three image layouts of
         prepare_inputs_labels_for_multimodal (medplib_arch.py:246-279): 4-D tensor = one image per sample; list / 5-D =
         several images per sample; list + mask_images + image_token_types = ICL separate mode with the mask encoder.
@@ -219,9 +255,20 @@ class MedPLIBForCausalLM(nn.Module):
         seg_lens = image_token_lengths if image_token_lengths is not None else tok
         multi = isinstance(images_clip, (list, tuple)) or images_clip.dim() == 5
         clip_in = torch.cat([im for im in images_clip], 0) if multi else images_clip
-        feats = m.vision_tower.encode_images(clip_in)
+        region_flag = region_masks is not None and len(region_masks) > 0                        # medplib_arch.py:221-227
+        if region_flag:
+            assert not multi, "region prompts come with one image per sample"                     # medplib_arch.py:248, 269
+            feats, raw = m.vision_tower.encode_images(clip_in, return_raw=True)
+        else:
+            feats = m.vision_tower.encode_images(clip_in)
         if m.mm_token_compressor is not None:
             feats = m.mm_token_compressor.forward(feats, clip_in.shape[0], cfg.clip_num_patches)
+        if region_flag:
+            rfeats, rbases = self._region_features(raw, clip_in.shape[0], region_masks, valid_region_masks_bool)
+            n_img_rows = feats.shape[0]
+            plan = plan_splice(ids_np, lab_np, att_np, tok, seg_token_idx=seg_idx, seg_feature_lengths=seg_lens,
+                               region_bases=[None if b is None else n_img_rows + b for b in rbases])
+            return plan, torch.cat([feats, rfeats], 0)
         if image_token_types is not None and mask_images is not None and len(mask_images) > 0:
             assert multi, "ICL separate mode expects a list (or 5-D tensor) of images"     # medplib_arch.py:247
             if m.mask_encoder is None:
@@ -246,8 +293,6 @@ class MedPLIBForCausalLM(nn.Module):
         cfg = self.config
         if attention_mask is None:
             attention_mask = attention_masks            # LISA.model_forward spells it `attention_masks` (LISA.py:267)
-        if region_masks:
-            raise NotImplementedError("region prompts (extract_region_feature) are outside the built path (SURVEY §8f)")
         dev = self.device_
         ids_np = _np_ids(input_ids)
         lab_np = _np_ids(labels) if labels is not None else None
@@ -266,7 +311,8 @@ class MedPLIBForCausalLM(nn.Module):
                 image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
         with torch.no_grad():
             plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, kwargs.get("mask_images"),
-                                                kwargs.get("image_token_types"), kwargs.get("image_token_lengths"))
+                                                kwargs.get("image_token_types"), kwargs.get("image_token_lengths"),
+                                                region_masks=region_masks, valid_region_masks_bool=valid_region_masks_bool)
             # every host-built index tensor of the step goes to the device NOW (see _h2d)
             src = _h2d(plan.src_code.reshape(-1), dev)
             key_valid = None
@@ -377,15 +423,14 @@ class MedPLIBForCausalLM(nn.Module):
         yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
         cfg, dev, m = self.config, self.device_, self.model
         self.sync_side_streams()
-        if region_masks:
-            raise NotImplementedError("region prompts are outside the built path (SURVEY §8f)")
         ids = _np_ids(input_ids).astype(np.int64)
         assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
         was_training = self.training
         self.train(False)
         nfeat = cfg.image_token_len
         plan, feats = self._encode_and_plan(ids, None, None, images_clip, mask_images, image_token_types, image_token_lengths,
-                                            with_seg=False)
+                                            with_seg=False, region_masks=region_masks if region_masks else None,
+                                            valid_region_masks_bool=valid_region_masks_bool)
         src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev)
         S = plan.seq_len
         embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(1, S, cfg.hidden_size)
@@ -409,8 +454,10 @@ class MedPLIBForCausalLM(nn.Module):
             self.train(was_training)
             return torch.from_numpy(output_ids), []
         n_ph = int((output_ids == IMAGE_TOKEN_INDEX).sum())
+        has_region = bool((output_ids == REGION_TOKEN_INDEX).any())          # region ids expand 1:1, any base will do for the mask
         seg_plan = plan_splice(output_ids, None, None, nfeat if n_ph <= 1 else [nfeat] * n_ph, seg_token_idx=self.seg_token_idx,
-                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else nfeat)
+                               seg_feature_lengths=image_token_lengths if image_token_lengths is not None else nfeat,
+                               region_bases=[0] * output_ids.shape[0] if has_region else None)
         seg_rows = np.flatnonzero(seg_plan.seg_mask[0, :n_hidden])
         if seg_rows.size >= 1:
             row = int(seg_rows[0])                                          # first <SEG> when several (MedPLIB.py:639-641)

@@ -42,7 +42,8 @@ class SplicePlan:
 
 def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_mask: Optional[np.ndarray],
                 feature_lengths, images_per_sample: Optional[Sequence[int]] = None, seg_token_idx: Optional[int] = None,
-                seg_feature_lengths=None, feature_bases: Optional[Sequence[int]] = None) -> SplicePlan:
+                seg_feature_lengths=None, feature_bases: Optional[Sequence[int]] = None,
+                region_bases: Optional[Sequence[Optional[int]]] = None) -> SplicePlan:
     """input_ids [B, L] int64 with IMAGE_TOKEN_INDEX placeholders.
 
     feature_lengths: int (every image expands to that many rows; one image per sample, consumed in batch order even by
@@ -52,10 +53,13 @@ def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_m
       MedPLIB.py:318-341); defaults to feature_lengths.
     feature_bases: first feature row of each placeholder (flat, with per-placeholder feature_lengths) when the feature
       buffer is not laid out in placeholder order — ICL separate mode keeps all image blocks first and the mask-encoder
-      blocks after them (medplib_arch.py:246-267 interleaves them by `image_token_types`)."""
+      blocks after them (medplib_arch.py:246-267 interleaves them by `image_token_types`).
+    region_bases: per sample, the feature row of its first region feature (or None): the k-th REGION_TOKEN_INDEX after the
+      sample's last image placeholder is replaced by row region_bases[b] + k (medplib_arch.py:409-433; labels keep those
+      positions).  Region tokens anywhere else are rejected, like the reference's assert (:323-324)."""
     ids = np.asarray(input_ids, dtype=np.int64)
     B, L = ids.shape
-    assert not (ids == REGION_TOKEN_INDEX).any(), "region prompts (REGION_TOKEN_INDEX) are outside this path"
+    assert region_bases is not None or not (ids == REGION_TOKEN_INDEX).any(), "REGION_TOKEN_INDEX ids need region features"
     per_token = not np.isscalar(feature_lengths)
     assert feature_bases is None or per_token, "feature_bases needs per-placeholder feature_lengths"
     flat_lengths = list(feature_lengths) if per_token else None
@@ -97,7 +101,15 @@ def plan_splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_m
             prev = p + 1
             if not per_token and k == 0 and pos.size > 1:
                 raise ValueError("several image placeholders in one sample need per-placeholder feature_lengths")
-        src_parts.append(cur[prev:])
+        tail = cur[prev:]
+        rpos = np.flatnonzero(tail == REGION_TOKEN_INDEX)
+        assert not (cur[:prev] == REGION_TOKEN_INDEX).any(), "region tokens must follow the sample's last image placeholder"
+        if rpos.size:
+            assert pos.size > 0 and region_bases is not None and region_bases[b] is not None, \
+                "REGION_TOKEN_INDEX in a sample without image / region features"
+            tail = tail.copy()
+            tail[rpos] = -1 - (int(region_bases[b]) + np.arange(rpos.size, dtype=np.int64))
+        src_parts.append(tail)
         if labels is not None:
             lab_parts.append(labels[b, prev:])
         if seg_shift is not None:

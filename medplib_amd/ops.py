@@ -622,6 +622,18 @@ def conv3x3s2_c1_gelu(img, w, bias):
     return out
 
 
+def region_point_mean(fmap, xy, offsets, map_index, h, w):
+    """fmap [n_maps, h*w, C] bf16, xy [n_pts, 2] f32 (x, y in [0,1]), offsets int64 [n_masks+1], map_index int32 [n_masks]
+    -> [n_masks, C] bf16 (extract_region_feature)."""
+    _chk(fmap, torch.bfloat16, "region_point_mean.fmap"); _chk(xy, torch.float32, "region_point_mean.xy")
+    _chk(offsets, torch.int64, "region_point_mean.offsets"); _chk(map_index, torch.int32, "region_point_mean.map_index")
+    assert fmap.is_contiguous() and xy.is_contiguous()
+    n, C = map_index.numel(), fmap.shape[-1]
+    out = torch.empty((n, C), dtype=torch.bfloat16, device=fmap.device)
+    lib().call("mp_region_point_mean_bf16", _p(fmap), _p(xy), _p(offsets), _p(map_index), _p(out), n, h, w, C, _stream())
+    return out
+
+
 def copy_rows(src, rows, dim, rows_per_batch, src_batch_rows, src_row0):
     dst = torch.empty((rows, dim), dtype=torch.bfloat16, device=src.device)
     lib().call("mp_copy_rows_bf16", _p(src), _p(dst), rows, dim, rows_per_batch, src_batch_rows, src_row0, _stream())

@@ -18,6 +18,8 @@ import torch.nn.functional as F
 from . import ops
 from .ops import IGNORE_INDEX, IMAGE_TOKEN_INDEX
 
+REGION_TOKEN_INDEX = -300          # utils/utils.py:9
+
 
 # ----------------------------------------------------------------------------------------------- CLIP + projector
 def clip_features(images, W, cfg, prefix="model.vision_tower.vision_tower.vision_model."):
@@ -107,11 +109,44 @@ def combine_icl_features(image_features, mask_features, image_token_types):
     return out
 
 
+def extract_region_feature(region_feature_map, region_masks, max_sample_point, return_dtype=torch.float32):
+    """medplib_arch.py:580-613 restated literally (+ rand_sample :33-39, point_sample :41-65).  region_feature_map [n, h*w, C]
+    (region_fea_adapter output of the samples that have region masks), region_masks: per sample a list of [H, W] masks.
+    Per mask: normalised (y, x) of the non-zero pixels (a random subset via torch.randperm when there are more than
+    max_sample_point), bilinear grid_sample (align_corners=True) of the [C, h, w] map at those points, mean over the points."""
+    out = []
+    assert len(region_feature_map) == len(region_masks)
+    for fmap, masks in zip(region_feature_map, region_masks):
+        if len(masks) == 0:
+            out.append(None)
+            continue
+        wh = torch.tensor([masks[0].shape[0], masks[0].shape[1]])[None,]
+        pos = []
+        for m in masks:
+            x = m.nonzero() / wh
+            if x.shape[0] > max_sample_point:
+                x = x[torch.randperm(x.shape[0])[:max_sample_point], :]
+            pos.append(x)
+        pos = torch.nn.utils.rnn.pad_sequence(pos, padding_value=-1, batch_first=True)
+        valid = ~(pos.sum(dim=-1) < 0)
+        h = w = int(math.sqrt(fmap.shape[0]))
+        c = fmap.shape[-1]
+        dup = fmap.reshape(h, w, c).permute(2, 0, 1).unsqueeze(0).repeat(pos.shape[0], 1, 1, 1)
+        grid = (2.0 * pos.flip(dims=(2,)).unsqueeze(2) - 1.0).float()
+        samp = F.grid_sample(dup.float(), grid, align_corners=True).to(return_dtype).squeeze(3)      # [n_mask, C, P]
+        samp = samp.to(dup.dtype)
+        out.append(torch.stack([x[m].mean(dim=0) for x, m in zip(samp.transpose(1, 2), valid)]).nan_to_num())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- splice + seg mask
-def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, embed_tokens, per_token=False):
-    """medplib_arch.py:296-527 restated literally (mm_use_im_start_end branch; region prompts excluded).
+def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, embed_tokens, per_token=False,
+                                         region_features=None, valid_region_masks_bool=None):
+    """medplib_arch.py:296-527 restated literally (mm_use_im_start_end branch).
     image_features: [n_img, n_feat, d] (4-D images layout: one per sample, consumed per sample) or a flat list with one
-    entry per placeholder (multi-image layouts).  Returns (attention_mask, inputs_embeds, labels)."""
+    entry per placeholder (multi-image layouts).  region_features (optional): extract_region_feature's list over the samples
+    with valid_region_masks_bool (bool per sample); REGION_TOKEN_INDEX ids after the last image are replaced by them (:409-433).
+    Returns (attention_mask, inputs_embeds, labels)."""
     new_embeds, new_labels = [], [] if labels is not None else None
     cur_image_idx = 0
     for b, cur_ids in enumerate(input_ids):
@@ -140,9 +175,16 @@ def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, imag
             cur_ids = cur_ids[s + 2:]
             idx = torch.where(cur_ids == IMAGE_TOKEN_INDEX)[0]
         if cur_ids.numel() > 0:
-            cur_e.append(embed_tokens[cur_ids])
+            region_indices = (cur_ids == REGION_TOKEN_INDEX).nonzero(as_tuple=True)[0].tolist()
+            cur_ids = cur_ids[cur_ids != REGION_TOKEN_INDEX]
+            text = embed_tokens[cur_ids]
             if labels is not None:
-                cur_l.append(cur_labels)
+                cur_l.append(cur_labels)                       # labels keep the region positions (:420-421)
+            if region_features is not None and valid_region_masks_bool[b] is not None:
+                for k, indice in enumerate(region_indices):
+                    ridx = int(torch.as_tensor(valid_region_masks_bool[:b + 1]).sum().item()) - 1
+                    text = torch.cat((text[:indice], region_features[ridx][k].unsqueeze(0), text[indice:]))
+            cur_e.append(text)
         new_embeds.append(torch.cat(cur_e, 0))
         if labels is not None:
             new_labels.append(torch.cat(cur_l, 0))

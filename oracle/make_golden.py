@@ -121,22 +121,27 @@ def golden_glue():
     g = torch.Generator().manual_seed(11)
 
     class Tower(torch.nn.Module):
-        num_patches = P
         hidden_size = Cv
 
+        def __init__(self, n_patches=P):
+            super().__init__()
+            self.num_patches = n_patches
+
         def forward(self, images):
-            return images.flatten(1)[:, :P * Cv].reshape(images.shape[0], P, Cv)
+            n = self.num_patches
+            return images.flatten(1)[:, :n * Cv].reshape(images.shape[0], n, Cv)
 
         @property
         def dummy_feature(self):
             return torch.zeros(1, Cv)
 
     class Inner(torch.nn.Module):
-        def __init__(self, compress, mask_enc):
+        def __init__(self, compress, mask_enc, n_patches=P):
             super().__init__()
             self.embed_tokens = torch.nn.Embedding(V, d)
             self.mm_projector = torch.nn.Linear(Cv, d)
-            self.vision_tower = Tower()
+            self.vision_tower = Tower(n_patches)
+            self.max_sample_point = 20
             self.region_fea_adapter = torch.nn.Linear(Cv, d)
             if compress:
                 self.mm_token_compressor = A.TokenCompressor(d, compress)
@@ -147,11 +152,12 @@ def golden_glue():
             return self.vision_tower
 
     class Host(torch.nn.Module, A.LlavaMetaForCausalLM):
-        def __init__(self, compress=0, mask_enc=0):
+        def __init__(self, compress=0, mask_enc=0, n_patches=P):
             torch.nn.Module.__init__(self)
-            self.inner = Inner(compress, mask_enc)
+            self.inner = Inner(compress, mask_enc, n_patches)
             self.config = types.SimpleNamespace(mm_use_im_start_end=True, tune_mm_mlp_adapter=False, mm_token_compress=bool(compress),
-                                                mm_compressed_token_count=compress, icl_mask_encoder=bool(mask_enc))
+                                                mm_compressed_token_count=compress, icl_mask_encoder=bool(mask_enc),
+                                                region_geo_sampler=False)
             self.seg_token_idx = SEG
             self.device = torch.device("cpu")
 
@@ -266,6 +272,46 @@ def golden_glue():
     types_ = [["image", "mask", "image", "mask", "image"]] * 2
     lengths = [[4, 3, 4, 3, 4]] * 2
     run_case("C", host, ids, labels, att, images, mask_images, types_, lengths, default_len=4)
+
+    # ---- case D: region prompts (medplib_arch.py:283-295, 409-433, 580-613): 9 patches (3 x 3 feature map), region tokens after
+    #      the image; sample 1 has no region; one mask has more non-zero pixels than max_sample_point (20) -> torch.randperm
+    host = Host(n_patches=9); seed_params(host, 4)
+    L = 18
+    ids = torch.stack([ids_row(L, [3], [15]), ids_row(L, [3], [14]), ids_row(L, [5], [16])])
+    ids[0, 8] = -300; ids[0, 11] = -300; ids[2, 9] = -300
+    att = torch.ones(3, L, dtype=torch.bool)
+    labels = ids.clone(); labels[:, :12] = -100
+    images = torch.randn(3, 3, 4, 4, generator=g)
+    def blob(h, w, n):
+        m = torch.zeros(h, w)
+        idx = torch.randperm(h * w, generator=g)[:n]
+        m.view(-1)[idx] = 1.0
+        return m
+    region_masks = [[blob(12, 10, 7), blob(12, 10, 45)], [blob(12, 10, 13)]]
+    vrb = [[True, True], [False], [True]]
+    host.eval()
+    torch.manual_seed(123)
+    with torch.no_grad():
+        _, new_att, _, emb, new_lab = host.prepare_inputs_labels_for_multimodal(ids, att, None, labels, images, region_masks, vrb)
+    Wd = weights_of(host)
+    with torch.no_grad():
+        raw = host.inner.vision_tower(images)
+        feats = torch.nn.functional.linear(raw, Wd["model.mm_projector.weight"], Wd["model.mm_projector.bias"])
+        rmap = torch.nn.functional.linear(raw, Wd["model.region_fea_adapter.weight"], Wd["model.region_fea_adapter.bias"])
+        valid = torch.tensor([any(v) for v in vrb])
+        torch.manual_seed(123)
+        rfeat = llm.extract_region_feature(rmap[valid], region_masks, 20)
+        o_att, o_emb, o_lab = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feats, Wd["model.embed_tokens.weight"], False,
+                                                                       region_features=rfeat, valid_region_masks_bool=valid)
+    assert torch.equal(o_lab, new_lab) and torch.equal(o_att, new_att)
+    assert torch.allclose(o_emb, emb, rtol=0, atol=1e-6), (o_emb - emb).abs().max()
+    out.update(D_ids=ids.numpy(), D_labels=labels.numpy(), D_att=att.numpy(), D_images=images.numpy(), D_new_labels=new_lab.numpy(),
+               D_new_att=new_att.numpy(), D_embeds=emb.numpy(), D_valid=valid.numpy(), D_seed=np.int64(123), D_max_sample_point=np.int64(20),
+               D_region_masks=np.stack([m.numpy() for ms in region_masks for m in ms]), D_region_counts=np.array([len(ms) for ms in region_masks]),
+               D_region_features=torch.cat(rfeat).numpy())
+    for k, v in Wd.items():
+        out[f"D_W_{k}"] = v.numpy()
+    print("glue case D (region prompts) S =", emb.shape[1], "ok")
 
     # ---- the two modules at the real token counts (576 -> 256; 336x336 mask -> 441 -> 64); weights come from
     #      llm.init_icl_weights(seed) on both sides, so only inputs and expected outputs are stored

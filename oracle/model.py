@@ -54,6 +54,7 @@ def init_hf_weights(cfg, seed=0, sam_seed=1234):
         W[lp + "mlp.fc2.weight"] = rn(C, I, s=1.0 / I ** 0.5); W[lp + "mlp.fc2.bias"] = rn(C, s=0.05)
     W["model.mm_projector.0.weight"] = rn(d, C, s=1.0 / C ** 0.5); W["model.mm_projector.0.bias"] = rn(d, s=0.05)
     W["model.mm_projector.2.weight"] = rn(d, d, s=1.0 / d ** 0.5); W["model.mm_projector.2.bias"] = rn(d, s=0.05)
+    W["model.region_fea_adapter.weight"] = rn(d, C, s=1.0 / C ** 0.5); W["model.region_fea_adapter.bias"] = rn(d, s=0.05)
     W["model.text_hidden_fcs.0.0.weight"] = rn(d, d, s=1.0 / d ** 0.5, bf=False); W["model.text_hidden_fcs.0.0.bias"] = rn(d, s=0.05, bf=False)
     W["model.text_hidden_fcs.0.2.weight"] = rn(cfg.out_dim, d, s=1.0 / d ** 0.5, bf=False)
     W["model.text_hidden_fcs.0.2.bias"] = rn(cfg.out_dim, s=0.05, bf=False)
@@ -144,7 +145,8 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
                                                         if k.startswith("model.visual_model.")}, depth=cfg.sam_depth)
         clip_in = batch["images_clip"]
         multi = isinstance(clip_in, (list, tuple)) or clip_in.dim() == 5
-        feats = llm.mm_projector(llm.clip_features(torch.cat(list(clip_in), 0) if multi else clip_in, W, cfg), W)
+        raw_feats = llm.clip_features(torch.cat(list(clip_in), 0) if multi else clip_in, W, cfg)
+        feats = llm.mm_projector(raw_feats, W)
         tok = cfg.clip_num_patches
         if getattr(cfg, "mm_token_compress", False):                    # encode_images, medplib_arch.py:198-202
             tok = cfg.mm_compressed_token_count
@@ -155,7 +157,13 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
             feat_list, per_token = llm.combine_icl_features(list(feats), list(mf), batch["image_token_types"]), True
         elif multi:
             feat_list, per_token = list(feats), True
-        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token)
+        region_features = valid = None
+        if batch.get("region_masks") is not None and len(batch["region_masks"]) > 0:        # medplib_arch.py:221-227, 283-295
+            valid = torch.tensor([any(v) for v in batch["valid_region_masks_bool"]])
+            rmap = F.linear(raw_feats, W["model.region_fea_adapter.weight"], W["model.region_fea_adapter.bias"])[valid]
+            region_features = llm.extract_region_feature(rmap, batch["region_masks"], cfg.max_sample_point)
+        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token,
+                                                                      region_features=region_features, valid_region_masks_bool=valid)
         kv = None if att2.all() else att2
         hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
         ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)

@@ -512,3 +512,51 @@ def test_expert_parallel_path_single_rank_rccl(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_region_prompts_forward(dev):
+    """Region-VQA layout (medplib_arch.py:283-295, 409-433, 580-613): region_fea_adapter on the raw CLIP features, point-sampled
+    region features (one mask with more pixels than max_sample_point -> torch.randperm drawn in the reference's order) spliced at
+    the REGION_TOKEN_INDEX positions; CE-only batch (seg_flag False).  Kernel vs the oracle's extract_region_feature, then the
+    whole forward."""
+    from medplib_amd import ops
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, max_sample_point=40)
+    W = OM.init_hf_weights(cfg)
+    g = torch.Generator().manual_seed(9)
+    # ---- kernel: 2 feature maps (4 x 4 patches), 3 masks
+    NP, d = cfg.clip_num_patches, cfg.hidden_size
+    hw = int(NP ** 0.5)
+    fmap = (torch.randn(2, NP, d, generator=g)).to(torch.bfloat16)
+    masks = [[(torch.rand(30, 22, generator=g) > 0.97).float(), (torch.rand(30, 22, generator=g) > 0.5).float()], [(torch.rand(30, 22, generator=g) > 0.9).float()]]
+    torch.manual_seed(77)
+    ref = OL.extract_region_feature(fmap.float(), masks, cfg.max_sample_point, return_dtype=torch.bfloat16)
+    torch.manual_seed(77)
+    xy, off, mi = [], [0], []
+    for j, ms in enumerate(masks):
+        for mk in ms:
+            pts = mk.nonzero()
+            if pts.shape[0] > cfg.max_sample_point:
+                pts = pts[torch.randperm(pts.shape[0])[:cfg.max_sample_point]]
+            xy.append((pts.float() / torch.tensor([30.0, 22.0])).flip(1)); off.append(off[-1] + pts.shape[0]); mi.append(j)
+    got = ops.region_point_mean(fmap.to(dev), torch.cat(xy).contiguous().to(dev), torch.tensor(off, dtype=torch.int64, device=dev),
+                                torch.tensor(mi, dtype=torch.int32, device=dev), hw, hw)
+    _stat("region_point_mean vs oracle", got, torch.cat(ref), atol=2e-2)
+    # ---- whole forward: sample 0 has two regions, sample 1 none, sample 2 one
+    m = _model(cfg, dev, W).train()
+    batch = OM.make_batch(cfg, 3)
+    ids = batch["input_ids"]
+    ids[0, 40] = -300; ids[0, 44] = -300; ids[2, 42] = -300
+    batch["region_masks"] = [[masks[0][0], masks[0][1]], [masks[1][0]]]
+    batch["valid_region_masks_bool"] = [[True, True], [False], [True]]
+    batch["seg_flag"] = False
+    bq = dict(batch)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        _, inter = OM.model_forward(bq, W, cfg, training=True, return_intermediates=True)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    torch.manual_seed(5)
+    out = m(**gb)
+    _stat("region-prompt ce_loss", out["ce_loss"], inter["ce"] * cfg.ce_loss_weight, atol=3e-2)
+    assert float(out["mask_loss"]) == 0.0 and inter["embeds"].shape[1] == ids.shape[1] + NP - 1

@@ -238,3 +238,44 @@ def test_expert_parallel_all_to_all_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_region_prompt_splice_matches_executed_reference(golden_dir):
+    """Region prompts: the oracle's extract_region_feature (incl. the torch.randperm subsample) and plan_splice's REGION_TOKEN_INDEX
+    handling vs the reference's own prepare_inputs_labels_for_multimodal run with region_masks (glue_reference.npz case D)."""
+    g = np.load(os.path.join(golden_dir, "glue_reference.npz"))
+    W = {k[len("D_W_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("D_W_")}
+    ids, labels, att = (g[f"D_{k}"] for k in ("ids", "labels", "att"))
+    images = torch.from_numpy(g["D_images"])
+    P, Cv = 9, 4
+    raw = images.flatten(1)[:, :P * Cv].reshape(images.shape[0], P, Cv)
+    feats = torch.nn.functional.linear(raw, W["model.mm_projector.weight"], W["model.mm_projector.bias"])
+    rmap = torch.nn.functional.linear(raw, W["model.region_fea_adapter.weight"], W["model.region_fea_adapter.bias"])
+    valid = torch.from_numpy(g["D_valid"])
+    masks, k = [], 0
+    for c in g["D_region_counts"]:
+        masks.append([torch.from_numpy(g["D_region_masks"][k + j]) for j in range(int(c))]); k += int(c)
+    torch.manual_seed(int(g["D_seed"]))
+    rfeat = OL.extract_region_feature(rmap[valid], masks, int(g["D_max_sample_point"]))
+    assert np.abs(torch.cat(rfeat).numpy() - g["D_region_features"]).max() < 1e-6
+    # plan: image rows first, region rows behind them
+    bases, n = [], 0
+    vi = 0
+    for b in range(ids.shape[0]):
+        if bool(valid[b]):
+            bases.append(P * ids.shape[0] + n); n += len(masks[vi]); vi += 1
+        else:
+            bases.append(None)
+    plan = splice.plan_splice(ids, labels, att, P, seg_token_idx=33, region_bases=bases)
+    assert np.array_equal(plan.labels, g["D_new_labels"]) and np.array_equal(plan.attention_mask, g["D_new_att"])
+    allf = torch.cat([feats.reshape(-1, feats.shape[-1]), torch.cat(rfeat)])
+    embed = W["model.embed_tokens.weight"]
+    code = plan.src_code.reshape(-1)
+    out = torch.zeros(code.shape[0], embed.shape[1])
+    for r, cc in enumerate(code):
+        if cc != splice.SPLICE_PAD:
+            out[r] = embed[cc] if cc >= 0 else allf[-1 - cc]
+    assert np.abs(out.view(ids.shape[0], -1, embed.shape[1]).numpy() - g["D_embeds"]).max() < 1e-6
+    with pytest.raises(AssertionError):
+        bad = ids.copy(); bad[0, 1] = splice.REGION_TOKEN_INDEX           # before the image placeholder: the reference asserts too
+        splice.plan_splice(bad, labels, att, P, region_bases=bases)
