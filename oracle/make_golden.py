@@ -374,6 +374,25 @@ def golden_mask_head():
     # calculate_iou / threshold (train_ds_medplib.py:702-719) restated in ops.threshold_iou; pin the counts
     b, counts, iou, dice = ops.threshold_iou(pred[0, 0], gt[0])
     out.update(thr_mask=b.numpy(), thr_counts=np.array(counts, np.int64), thr_iou=np.float64(iou), thr_dice=np.float64(dice))
+    # validate()'s per-sample metrics (train_ds_medplib.py:745-772) from the reference's own intersectionAndUnionGPU
+    # (utils/utils.py:92-104): intersection / union per class (K = 2), acc_iou with the "no-object target" rule
+    import utils.utils as RU
+    vm = []
+    for i in range(n):
+        output_i = (torch.sigmoid(pred[i]) > 0.1).int()                       # [1, H, W]
+        mask_i = gt[i].int().unsqueeze(0)
+        # (CPU histc has no int kernel: same values as float)
+        inter_i, union_i, _ = RU.intersectionAndUnionGPU(output_i.float().contiguous().clone(), mask_i.float().contiguous(), 2, ignore_index=255)
+        acc = inter_i / (union_i + 1e-5)
+        acc[union_i == 0] += 1.0
+        b = output_i.bool(); gm = mask_i.bool()
+        u = torch.logical_or(b, gm).sum()
+        iou = 0.0 if u == 0 else (torch.logical_and(b, gm).sum().float() / u.float()).item()
+        vm.append(np.concatenate([inter_i.numpy(), union_i.numpy(), acc.numpy(), [iou, 2 * iou / (1 + iou)]]))
+        o_b, o_counts, o_iou, o_dice = ops.threshold_iou(pred[i, 0], gt[i])
+        om = ops.validate_metrics(o_counts, H * Wd)
+        assert np.allclose(np.concatenate([om["intersection"], om["union"], om["acc_iou"], [om["iou"], om["dice"]]]), vm[-1], rtol=1e-6, atol=0), (om, vm[-1])
+    out["validate_metrics"] = np.stack(vm)
     np.savez_compressed(os.path.join(OUT, "mask_head_reference.npz"), **out)
     print("mask head goldens ok")
 

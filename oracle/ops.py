@@ -193,6 +193,21 @@ def threshold_iou(pred_logits, gt, thr=0.1):
     return b, (int(b.sum()), int(g.sum()), inter, union), iou, 2 * iou / (1 + iou)
 
 
+def validate_metrics(counts, n_pixels):
+    """Per-sample metrics of validate() (train_ds_medplib.py:745-772) from the four integer counts of threshold_iou
+    (|pred|, |gt|, |pred & gt|, |pred | gt|) for a binary target without ignore pixels: intersectionAndUnionGPU (utils/utils.py:
+    92-104) with K = 2 gives intersection = [N - |or|, |and|], union = [N - |and|, |or|]; acc_iou = I / (U + 1e-5), +1 where the
+    union is empty; IoU = |and| / |or| (0 when empty, calculate_iou :702-719); Dice = 2 IoU / (1 + IoU)."""
+    import numpy as np
+    _, _, inter, union = (int(c) for c in counts)
+    I = np.array([n_pixels - union, inter], dtype=np.float32)
+    U = np.array([n_pixels - inter, union], dtype=np.float32)
+    acc = I / (U + np.float32(1e-5))
+    acc[U == 0] += 1.0
+    iou = 0.0 if union == 0 else float(np.float32(inter) / np.float32(union))
+    return {"intersection": I, "union": U, "acc_iou": acc, "iou": iou, "dice": 2 * iou / (1 + iou)}
+
+
 def cross_entropy_filtered(logits, labels):
     """medplib_moe_llama.py:392-408: shift, drop batch rows whose shifted labels are all -100, mean CE over the rest.
     logits [B,S,V] fp32, labels [B,S]."""

@@ -560,3 +560,23 @@ def test_region_prompts_forward(dev):
     out = m(**gb)
     _stat("region-prompt ce_loss", out["ce_loss"], inter["ce"] * cfg.ce_loss_weight, atol=3e-2)
     assert float(out["mask_loss"]) == 0.0 and inter["embeds"].shape[1] == ids.shape[1] + NP - 1
+
+
+def test_validate_batch_metrics(dev):
+    """validate()'s loop body: inference forward -> GPU threshold + counts -> host metrics.  The counts are integers: on the masks
+    the HIP path produced they must equal the oracle's threshold_iou exactly, and the metrics follow."""
+    from medplib_amd import metrics
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).eval()
+    batch = OM.make_batch(cfg, 1)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    meters = metrics.SegMeters()
+    got = metrics.validate_batch(m, gb, meters)
+    with torch.no_grad():
+        pm = m(**dict(gb, inference=True))["pred_masks"][0].float().cpu()
+    _, counts, iou, dice = O.threshold_iou(pm[0], batch["masks_list"][0])
+    ref = O.validate_metrics(counts, pm[0].numel())
+    assert np.array_equal(got["intersection"], ref["intersection"]) and np.array_equal(got["union"], ref["union"])
+    assert got["iou"] == ref["iou"] and abs(got["dice"] - dice) < 1e-12 and meters.count == 1

@@ -42,6 +42,26 @@ def test_mask_head_oracle_matches_reference_golden(golden_dir):
     assert abs(iou - float(g["thr_iou"])) < 1e-12 and abs(dice - float(g["thr_dice"])) < 1e-12
 
 
+def test_validate_metrics_match_reference_functions(golden_dir):
+    """validate()'s per-sample numbers from the four threshold counts vs the reference's intersectionAndUnionGPU / calculate_iou
+    run on the same masks (mask_head_reference.npz: validate_metrics); the product's host function must agree too."""
+    from medplib_amd import metrics
+    g = np.load(os.path.join(golden_dir, "mask_head_reference.npz"))
+    pred, gt = torch.from_numpy(g["loss_pred"]), torch.from_numpy(g["loss_gt"])
+    meters = metrics.SegMeters()
+    for i in range(pred.shape[0]):
+        _, counts, _, _ = ops.threshold_iou(pred[i, 0], gt[i])
+        for fn in (ops.validate_metrics, metrics.metrics_from_counts):
+            m = fn(counts, gt[i].numel())
+            got = np.concatenate([m["intersection"], m["union"], m["acc_iou"], [m["iou"], m["dice"]]])
+            assert np.allclose(got, g["validate_metrics"][i], rtol=1e-6, atol=0), (i, got, g["validate_metrics"][i])
+        meters.update(m)
+    s = meters.summary()
+    vm = g["validate_metrics"]
+    assert abs(s["giou"] - vm[:, 5].mean()) < 1e-6 and abs(s["dice"] - vm[:, 7].mean()) < 1e-6
+    assert abs(s["ciou"] - vm[:, 1].sum() / (vm[:, 3].sum() + 1e-10)) < 1e-6
+
+
 def _glue_case(g, tag):
     from oracle import llm
     W = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_W_")}
