@@ -295,6 +295,123 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
 
 
 
+// Epilogue for TRANSPOSED accumulators (v3): the MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] is
+// C[row = i*16 + fr, col = j*16 + fq*4 + r] of the wave tile — a lane owns FOUR CONSECUTIVE COLUMNS of one row per fragment.
+// Outputs leave straight from registers as 8-byte (bf16) / 16-byte (fp32) pieces, four fragments completing each 128-byte row
+// segment; bias / activation / residual / SwiGLU pairing are per-lane register work with the same rounding points as the LDS
+// epilogue (activation result rounded to bf16 before the residual add or the silu(gate)*up product).  No LDS, no barrier: the
+// operand ring is free for whatever comes next.
+__device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&acc)[8][4], int batch, int M, int N, int m0, int n0,
+                                                   int wr, int wc, int fr, int fq) {
+  const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
+  const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
+  const int cw = n0 + wc * 64;                                  // first column of the wave tile
+  // ---- pass 1: alpha, bias (in place)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int col = cw + j * 16 + fq * 4 + r; bv[r] = col < N ? bias0[col] : 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i][j] = acc[i][j] * g.alpha + bv;
+  }
+  // ---- pass 2: activation (one fully unrolled sweep per activation kind; the switch stays outside the sweeps)
+#define MP_ACT_SWEEP(EXPR)                                                          \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                    \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = (EXPR); }         \
+    __builtin_amdgcn_sched_barrier(0); /* one fragment's temporaries at a time (erff is register hungry) */         \
+  }
+  switch (g.act) {
+    case ACT_RELU: MP_ACT_SWEEP(fmaxf(v, 0.f)) break;
+    case ACT_GELU: MP_ACT_SWEEP(gelu_erf_fast(v)) break;
+    case ACT_QUICK_GELU: MP_ACT_SWEEP(v / (1.f + __expf(-1.702f * v))) break;
+    case ACT_SILU: MP_ACT_SWEEP(v / (1.f + __expf(-v))) break;
+    default: break;
+  }
+#undef MP_ACT_SWEEP
+  // ---- pass 3: stores
+  if (g.out_f32) {
+    float* Cf = reinterpret_cast<float*>(g.C) + batch * g.sC;
+    const bool vec = (g.ldc & 3) == 0 && (!R || (g.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = cw + j * 16 + fq * 4;
+        f32x4 v = acc[i][j];
+        if (row < M && col < N) {
+          if (vec && col + 4 <= N) {
+            if (R) {
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + (int64_t)row * g.ldr + col);
+              v += f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+            }
+            *reinterpret_cast<f32x4*>(Cf + (int64_t)row * g.ldc + col) = v;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (col + r < N) Cf[(int64_t)row * g.ldc + col + r] = v[r] + (R ? (float)R[(int64_t)row * g.ldr + col + r] : 0.f);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);            // one row of fragments at a time: keeps the address / residual registers bounded
+    }
+    return;
+  }
+  bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
+  if (g.act == ACT_SWIGLU_PAIR) {
+    // W rows are [gate 0..31 | up 0..31 | gate 32..63 | ...]: fragments j = 0,1 are gate columns, j = 2,3 the matching up columns;
+    // gate and up are rounded to bf16 first, like the unfused GEMM + SwiGLU kernel pair
+    const int half_n = N >> 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (cw >> 1) + j * 16 + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gf = (float)(bf16_t)acc[i][j][r];
+          const float uf = (float)(bf16_t)acc[i][j + 2][r];
+          o[r] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+        }
+        if (row < M && col + 4 <= half_n) *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + col) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  const bool vec = (g.ldc & 3) == 0 && (!R || (g.ldr & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = cw + j * 16 + fq * 4;
+      // the activation result is rounded to bf16 before the residual add (HF's own order: act(x) is a bf16 tensor)
+      f32x4 v = {(float)(bf16_t)acc[i][j][0], (float)(bf16_t)acc[i][j][1], (float)(bf16_t)acc[i][j][2], (float)(bf16_t)acc[i][j][3]};
+      if (row < M && col < N) {
+        if (vec && col + 4 <= N) {
+          if (R) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + (int64_t)row * g.ldr + col);
+            v += f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+          }
+          *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + col) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < N) Cb[(int64_t)row * g.ldc + col + r] = (bf16_t)(v[r] + (R ? (float)R[(int64_t)row * g.ldr + col + r] : 0.f));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+
 // =====================================================================================================================
 // v3: v1's geometry (BK = 64, 128-B rows = whole cache lines per DMA row, 2 stages) with a CONTINUOUS DMA stream: the stage
 // is recycled region by region as soon as its last reader phase has retired, two DMA instructions per wave in EVERY phase,
@@ -437,7 +554,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
           if constexpr (ABL == 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(FB[j][kk])); }                   \
           else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                            \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], FB[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                          \
   } while (0)
 #define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -539,7 +656,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
       }
     }
   }
-  gemm256_epilogue(g, acc, smem, batch, M, N, m0, n0, wave, wr, wc, lane, fr, fq);
+  gemm256_epilogue_t(g, acc, batch, M, N, m0, n0, wr, wc, fr, fq);
 }
 
 
