@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // (W, A): transposed accumulators
     }
   };
 
@@ -213,27 +213,44 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
       }
     }
   }
-  // epilogue: D layout col = lane&15, row = (lane>>4)*4 + r
+  // epilogue.  The MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] = C[row = i*16 + fr, col = j*16 + fq*4 + r] of the
+  // wave tile: a lane owns four consecutive columns of one row per fragment and stores them as one 8-byte (bf16) / 16-byte (fp32)
+  // piece.  Same rounding points as before: activation result rounded to the output type, residual added after.
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
   bf16_t* Cb = g.out_f32 ? nullptr : reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
   float* Cf = g.out_f32 ? reinterpret_cast<float*>(g.C) + batch * g.sC : nullptr;
+  const bool vec = (g.ldc & 3) == 0 && (!R || (g.ldr & 3) == 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wn * 64 + j * 16 + fr;
+    const int col = n0 + wn * 64 + j * 16 + fq * 4;
     if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (bias && col + r < N) ? bias[col + r] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + fr;
+      if (row >= M) continue;
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
-        if (row >= M) continue;
-        float v = acc[i][j][r] * g.alpha + bv;
-        v = apply_act(v, g.act);
-        if (R) v += (float)R[(int64_t)row * g.ldr + col];
-        if (Cf) Cf[(int64_t)row * g.ldc + col] = v;
-        else Cb[(int64_t)row * g.ldc + col] = (bf16_t)v;
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * g.alpha + bv[r], g.act);
+      if (vec && col + 4 <= N) {
+        if (R) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + (int64_t)row * g.ldr + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (Cf) *reinterpret_cast<f32x4*>(Cf + (int64_t)row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+        else *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + col) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (col + r >= N) continue;
+          const float f = v[r] + (R ? (float)R[(int64_t)row * g.ldr + col + r] : 0.f);
+          if (Cf) Cf[(int64_t)row * g.ldc + col + r] = f;
+          else Cb[(int64_t)row * g.ldc + col + r] = (bf16_t)f;
+        }
       }
     }
   }

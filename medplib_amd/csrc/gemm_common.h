@@ -48,7 +48,7 @@ static __device__ __forceinline__ float gelu_erf_fast(float x) {
 static __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_GELU: return gelu_erf(v);
+    case ACT_GELU: return gelu_erf_fast(v);
     case ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));
     case ACT_SILU: return v / (1.f + __expf(-v));
     default: return v;
