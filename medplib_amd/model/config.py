@@ -61,6 +61,9 @@ class MedPLIBConfig:
     focal_loss_weight: float = 1.0
     seg_token_idx: int = 32000
     train_mask_decoder: bool = True
+    # inference only: run the mask decoder's upsampler + hypernetwork product as the single fused bf16 kernel (what the reference
+    # computes under --precision bf16) instead of the fp32 tail that training differentiates through
+    fused_bf16_upsampler: bool = False
 
     @property
     def head_dim(self):

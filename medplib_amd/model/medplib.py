@@ -52,6 +52,7 @@ class _VisualModel(nn.Module):
         self.image_encoder = SamImageEncoder(cfg, device)          # frozen bf16 kernel-layout weights
         self.prompt_encoder = PromptEncoderText(cfg.sam_out_chans, cfg.sam_grid)
         self.mask_decoder = MaskDecoder(cfg.sam_out_chans, cfg.sam_grid)
+        self.mask_decoder.fused_bf16_upsampler = bool(cfg.fused_bf16_upsampler)
 
 
 class _Inner(nn.Module):

@@ -284,6 +284,12 @@ class MaskDecoder(nn.Module):
                                               nn.ConvTranspose2d(dim // 4, dim // 8, 2, 2), nn.GELU())
         self.output_hypernetworks_mlps = nn.ModuleList([_MLP(dim, dim, dim // 8, 3) for _ in range(4)])
         self.iou_prediction_head = _MLP(dim, 256, 4, 3)
+        self.fused_bf16_upsampler = False       # opt-in inference path (config.fused_bf16_upsampler); packed weights cached
+        self._packed = None
+
+    def train(self, mode=True):
+        self._packed = None                     # weights may change while training: re-pack on the next inference call
+        return super().train(mode)
 
     def forward(self, image_tokens, dense_pe_tokens, no_mask_embed, text_embeds):
         """image_tokens [n, h*w, C] fp32 (NHWC order), dense_pe_tokens [h*w, C], no_mask_embed [1, C], text_embeds [n,1,C]
@@ -294,6 +300,19 @@ class MaskDecoder(nn.Module):
         src = A.add(image_tokens, no_mask_embed.view(-1))                 # src = image_embeddings + dense (broadcast over tokens)
         hs, src = self.transformer(src, dense_pe_tokens, tokens)
         iou_tok, mask_tok0 = hs[:, 0, :], hs[:, 1, :]
+        if self.fused_bf16_upsampler and not torch.is_grad_enabled() and g % 16 == 0:
+            # inference: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hypernetwork product in ONE bf16 pass over HBM
+            # (mp_mask_upsample_fused_bf16), the arithmetic the reference itself runs under `--precision bf16`
+            hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)
+            if self._packed is None:
+                ct1, ln, ct2 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
+                w1p, w2p = ops.pack_upsampler_weights(ct1.weight.detach(), ct2.weight.detach())
+                self._packed = (w1p, ct1.bias.detach().float().contiguous(), ln.weight.detach().float().contiguous(),
+                                ln.bias.detach().float().contiguous(), w2p, ct2.bias.detach().float().contiguous(), float(ln.eps))
+            w1p, b1, lw, lb, w2p, b2, eps = self._packed
+            _, masks = ops.mask_upsample_fused(ops.cast_to_bf16(src.contiguous()).view(n, g * g, C), w1p, b1, lw, lb, w2p, b2, g, g,
+                                               hyper=hyper0.contiguous(), want_up=False, eps=eps)
+            return masks, self.iou_prediction_head(iou_tok)[:, 0]
         up = A.ConvT2x2Fn.apply(src.view(n, g, g, C), self.output_upscaling[0].weight, self.output_upscaling[0].bias)
         ln = self.output_upscaling[1]
         up = A.GeluFn.apply(A.layernorm(up, ln.weight, ln.bias, ln.eps))

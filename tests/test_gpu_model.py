@@ -581,3 +581,34 @@ def test_validate_batch_metrics(dev):
     assert np.array_equal(got["intersection"], ref["intersection"]) and np.array_equal(got["union"], ref["union"])
     # (the reference divides in fp32 — intersection.float() / union.float() — so IoU is an fp32 value; threshold_iou's is double)
     assert got["iou"] == ref["iou"] and got["dice"] == ref["dice"] and abs(got["dice"] - dice) < 1e-7 and meters.count == 1
+
+
+def test_inference_with_fused_bf16_upsampler(dev):
+    """config.fused_bf16_upsampler: inference masks through the single fused bf16 upsampler kernel vs the fp32 tail on the same
+    model: logits agree to bf16 noise, the thresholded masks' Dice agrees within 1e-3 (the BASELINE target), training is untouched
+    (the fp32 autograd path is used whenever gradients are enabled)."""
+    from medplib_amd import ops
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2)
+    W = OM.init_hf_weights(cfg)
+    batch = OM.make_batch(cfg, 3)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    m32 = _model(cfg, dev, W).eval()
+    cfg2 = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, fused_bf16_upsampler=True)
+    mbf = _model(cfg2, dev, W).eval()
+    with torch.no_grad():
+        a = m32(**dict(gb, inference=True))["pred_masks"]
+        b = mbf(**dict(gb, inference=True))["pred_masks"]
+    for i in range(3):
+        _stat(f"fused-bf16 vs fp32 mask logits [{i}]", b[i], a[i], atol=0.0, rtol=2e-2)
+        gt = gb["masks_list"][i].reshape(1, -1)
+        _, ca = ops.mask_threshold_iou(a[i].reshape(1, -1).contiguous(), gt, 0.1)
+        _, cb = ops.mask_threshold_iou(b[i].reshape(1, -1).contiguous(), gt, 0.1)
+        dice = lambda c: 2.0 * c[2] / max(c[0] + c[1], 1)
+        da, db = dice(ca[0].tolist()), dice(cb[0].tolist())
+        print(f"dice fp32 {da:.5f} fused-bf16 {db:.5f}")
+        assert abs(da - db) < 1e-3
+    # training path of the bf16-flagged model still differentiates through the fp32 tail
+    out = mbf.train()(**gb)
+    out["loss"].backward()
+    assert all(torch.isfinite(p.grad).all() for p in mbf.trainable_parameters() if p.grad is not None)
