@@ -612,3 +612,51 @@ def test_inference_with_fused_bf16_upsampler(dev):
     out = mbf.train()(**gb)
     out["loss"].backward()
     assert all(torch.isfinite(p.grad).all() for p in mbf.trainable_parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("moe", [True, False])
+def test_llama_layer_at_true_dims(dev, moe):
+    """One decoder layer at the 7B dimensions of the benchmark (d = 4096, ff = 11008, 32 heads x 128, S = 639, E = 2 top-1 with the
+    stage-IV capacity factor) against the fp32 oracle: the kernels' large-shape paths (256x256 GEMM tiles incl. tail split-K and
+    the SwiGLU-pair epilogue, batched expert GEMMs with device-side counts, D = 128 causal attention over 10 key tiles) at the
+    sizes bench.py runs.  Error bound: bf16 storage of ~10 intermediate tensors on O(1) activations."""
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=1, vocab_size=1024, moe_enable=moe, moe_gate_sampling=False)
+    g = torch.Generator().manual_seed(3)
+    d, ff, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
+
+    def rn(*shape, s):
+        return (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).float()
+    W = {"model.embed_tokens.weight": rn(cfg.vocab_size, d, s=0.5), "lm_head.weight": rn(cfg.vocab_size, d, s=0.05),
+         "model.norm.weight": 1 + rn(d, s=0.1)}
+    p = "model.layers.0."
+    for n in ("q", "k", "v", "o"):
+        W[p + f"self_attn.{n}_proj.weight"] = rn(d, d, s=d ** -0.5)
+    W[p + "input_layernorm.weight"] = 1 + rn(d, s=0.1); W[p + "post_attention_layernorm.weight"] = 1 + rn(d, s=0.1)
+    if moe:
+        W[p + "mlp.deepspeed_moe.gate.wg.weight"] = torch.randn(E, d, generator=g) * 0.05
+        for e in range(E):
+            ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+            W[ep + "gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[ep + "up_proj.weight"] = rn(ff, d, s=d ** -0.5)
+            W[ep + "down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
+    else:
+        W[p + "mlp.gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[p + "mlp.up_proj.weight"] = rn(ff, d, s=d ** -0.5)
+        W[p + "mlp.down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
+    from medplib_amd.model.llama import LlamaStack
+    llm = LlamaStack(cfg, dev)
+    llm.load_hf(W)
+    B, S = 2, 639
+    emb = (torch.randn(B, S, d, generator=g) * 0.5).to(torch.bfloat16)
+    kv = torch.ones(B, S, dtype=torch.bool); kv[1, 600:] = False
+    torch.set_num_threads(min(32, os.cpu_count()))
+    coll = []
+    with torch.no_grad():
+        ref, _ = OL.llama_forward(emb.float(), kv, W, cfg, training=True, collect=coll)
+    out, _, routing = llm.forward(emb.to(dev), kv.to(torch.uint8).to(dev), collect_routing=True)
+    keep = torch.ones(B * S, dtype=torch.bool)
+    if moe:
+        e_ref = coll[0][0]
+        e = routing[0][0].cpu().long()
+        keep = e == e_ref
+        print(f"true-dims routing agreement {keep.float().mean().item():.4f}; counts ref {coll[0][2].tolist()} got {routing[0][2].cpu().tolist()}")
+        assert keep.float().mean().item() > 0.98
+    _stat(f"7B-dims layer (moe={moe}) final-norm hidden", out.view(B * S, -1).cpu()[keep], ref.view(B * S, -1)[keep], atol=0.0, rtol=8 * 2 ** -8)
