@@ -59,6 +59,15 @@ int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const v
                             void* C, int64_t ldc, int64_t strideC, const float* bias, int64_t strideBias, int batch,
                             int M, int N, int K, int act, int out_dtype, const int* m_dev, hipStream_t stream);
 
+/* The same expert GEMMs with the MOELayer's dispatch / combine einsums folded in (top-1 routing): A rows are GATHERED from the shared
+ * [tokens, K] activations by a_rows[b * rows_stride + r] (= mp_moe_route_top1's slot_token), and with c_rows the C rows are SCATTERED
+ * to the shared [tokens, N] output as residual[row] + c_scale[row] * bf16(acc) — the combine weights and the decoder layer's residual
+ * add (sharded_moe.py MOELayer.forward; medplib_moe_llama.py:144-147).  act: MP_ACT_NONE or MP_ACT_SWIGLU_PAIR (no scatter). */
+int mp_gemm_bf16_nt_batched_rows(const void* A, int64_t lda, int64_t strideA, const int* a_rows, const void* W, int64_t ldw,
+                                 int64_t strideW, void* C, int64_t ldc, int64_t strideC, const int* c_rows, const float* c_scale,
+                                 const void* residual, int64_t ldr, int rows_stride, int batch, int M, int N, int K, int act,
+                                 const int* m_dev, hipStream_t stream);
+
 /* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
  * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */
@@ -207,7 +216,12 @@ int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, float* logits,
                      int n_experts, hipStream_t stream);
 /* DeepSpeed top1gating: argmax expert, capacity, random-token-selection from injected uniforms, slots, l_aux. */
 int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,
-                      int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream);
+                      int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, int* slot_token,
+                      hipStream_t stream);
+/* (slot_token, optional: [n_experts * capacity], slot_token[e * capacity + s] = token in slot s of expert e — the row index the
+ * expert GEMMs gather their A rows and scatter their C rows by, mp_gemm_bf16_nt_batched_rows.)
+ * out[t] = x[t] for the tokens no expert took: the residual-only rows when the combine is fused into the down projection. */
+int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t tokens, int dim, hipStream_t stream);
 /* DeepSpeed top2gating (sharded_moe.py, deepspeed==0.13.1): first choice = argmax gates, second = argmax of
  * logits + noise (Gumbel draws, or NULL) with the first masked; locations by cumsum in token order, second choices behind all
  * first choices; choices at location >= capacity dropped; surviving gate pair renormalised.  Entry layout of

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __restrict__ gates, const float* __restrict__ rts, int T,
                                                               int E, int capacity, int* __restrict__ expert, int* __restrict__ slot,
                                                               float* __restrict__ weight, int* __restrict__ kept_counts,
-                                                              long long* __restrict__ exp_counts, float* __restrict__ l_aux) {
+                                                              long long* __restrict__ exp_counts, float* __restrict__ l_aux,
+                                                              int* __restrict__ slot_token) {
   __shared__ float red[16];
   __shared__ int cnt_sh[MAXE];
   __shared__ int scan[16][MAXE];     // per-wave kept totals
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
 #pragma unroll
       for (int k = 0; k < MAXE; ++k) if (k == e) { v = base[k]; base[k] += 1; }
       slot[s] = (v < capacity) ? v : -1;
+      if (slot_token && v < capacity) slot_token[(int64_t)e * capacity + v] = s;      // inverse map: the expert GEMMs gather / scatter by it
     } else {
       slot[s] = -1;
     }
@@ -285,6 +287,19 @@ __global__ void moe_combine_kernel(const bf16_t* __restrict__ y, const int* __re
     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
   }
   *reinterpret_cast<bf16x8*>(out + s * d + c) = o;
+}
+
+// out[s, :] = x[s, :] for the tokens no expert took (slot < 0): the residual-only rows when combine is fused into the expert
+// down-projection's epilogue (which writes every routed token's row exactly once)
+__global__ void moe_fill_dropped_kernel(const bf16_t* __restrict__ x, const int* __restrict__ slot, bf16_t* __restrict__ out, int64_t T,
+                                        int d) {
+  const int per_row = d / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * per_row) return;
+  const int64_t s = idx / per_row;
+  if (slot[s] >= 0) return;
+  const int c = (int)(idx % per_row) * 8;
+  *reinterpret_cast<bf16x8*>(out + s * d + c) = *reinterpret_cast<const bf16x8*>(x + s * d + c);
 }
 
 // ---------------- top-2 routing (single block, 1024 threads) ----------------
@@ -430,11 +445,21 @@ extern "C" int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, flo
 }
 
 extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,
-                                 int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream) {
+                                 int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, int* slot_token,
+                                 hipStream_t stream) {
   MP_REQUIRE(n_experts >= 1 && n_experts <= MAXE && tokens > 0 && capacity >= 0, MP_ERR_SHAPE, "mp_moe_route_top1: bad shape");
   hipLaunchKernelGGL(moe_route_top1_kernel, dim3(1), dim3(1024), 0, stream, gates, rts_uniform, tokens, n_experts, capacity, expert,
-                     slot, weight, kept_counts, exp_counts, l_aux);
+                     slot, weight, kept_counts, exp_counts, l_aux, slot_token);
   return mp_check_launch("mp_moe_route_top1");
+}
+
+extern "C" int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t tokens, int dim, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0, MP_ERR_SHAPE, "mp_moe_fill_dropped_bf16: bad shape");
+  const int64_t n = tokens * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(moe_fill_dropped_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, slot, (bf16_t*)out,
+                     tokens, dim);
+  return mp_check_launch("mp_moe_fill_dropped_bf16");
 }
 
 extern "C" int mp_moe_route_top2(const float* gates, const float* logits, const float* noise, int tokens, int n_experts, int capacity,

@@ -303,6 +303,33 @@ __global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
 // operand ring is free for whatever comes next.
 __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&acc)[8][4], int batch, int M, int N, int m0, int n0,
                                                    int wr, int wc, int fr, int fq) {
+  if (g.c_rows) {
+    // combine folded into the epilogue (top-1 MoE down projection): out[token] = residual[token] + weight[token] * bf16(acc) with
+    // the same rounding points as the separate combine kernel (expert output rounded to bf16 first)
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+    const int cw = n0 + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + wr * 128 + i * 16 + fr;
+      const int orow = row < M ? g.c_rows[batch * g.rows_stride + row] : 0;
+      const float sc = (row < M && g.c_scale) ? g.c_scale[orow] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = cw + j * 16 + fq * 4;
+        if (row < M && col + 4 <= N) {
+          f32x4 v = {(float)(bf16_t)acc[i][j][0], (float)(bf16_t)acc[i][j][1], (float)(bf16_t)acc[i][j][2], (float)(bf16_t)acc[i][j][3]};
+          v *= sc;
+          if (g.residual) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(g.residual + (int64_t)orow * g.ldr + col);
+            v += f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+          }
+          *reinterpret_cast<bf16x4*>(Cb + (int64_t)orow * g.ldc + col) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
   const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
   const int cw = n0 + wc * 64;                                  // first column of the wave tile
@@ -503,7 +530,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   for (int i = 0; i < 4; ++i) {
     const int arow = (wave + 8 * i) * 8 + sub_row;
     const int wrow = (wave * 4 + i) * 8 + sub_row;
-    a_src[i] = A + (int64_t)min(m0 + arow, M - 1) * g.lda + src_c * 8 + (int64_t)kt0 * BK2;
+    int ar = min(m0 + arow, M - 1);
+    if (g.a_rows) ar = g.a_rows[batch * g.rows_stride + ar];        // gather: the dispatch is folded into the operand fetch
+    a_src[i] = A + (int64_t)ar * g.lda + src_c * 8 + (int64_t)kt0 * BK2;
     w_src[i] = W + (int64_t)min(n0 + wrow, N - 1) * g.ldw + src_c * 8 + (int64_t)kt0 * BK2;
   }
   auto dma_a = [&](int i, int t) {

@@ -116,7 +116,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (wave * 4 + i) * 8 + sub_row;
-      a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8 + (int64_t)kt0 * BK;
+      int ar = min(m0 + row, M - 1);
+      if (g.a_rows) ar = g.a_rows[batch * g.rows_stride + ar];
+      a_src[i] = A + (int64_t)ar * g.lda + src_c * 8 + (int64_t)kt0 * BK;
       w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8 + (int64_t)kt0 * BK;
     }
     auto issue = [&](int t, int buf) {
@@ -143,7 +145,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     const bf16_t* w_ptr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      a_ptr[i] = A + (int64_t)min(m0 + ld_row + 32 * i, M - 1) * g.lda + ld_c * 8 + (int64_t)kt0 * BK;
+      int ar = min(m0 + ld_row + 32 * i, M - 1);
+      if (g.a_rows) ar = g.a_rows[batch * g.rows_stride + ar];
+      a_ptr[i] = A + (int64_t)ar * g.lda + ld_c * 8 + (int64_t)kt0 * BK;
       w_ptr[i] = W + (int64_t)min(n0 + ld_row + 32 * i, N - 1) * g.ldw + ld_c * 8 + (int64_t)kt0 * BK;
     }
     bf16x8 ra[4], rw[4];
@@ -216,6 +220,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   // epilogue.  The MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] = C[row = i*16 + fr, col = j*16 + fq*4 + r] of the
   // wave tile: a lane owns four consecutive columns of one row per fragment and stores them as one 8-byte (bf16) / 16-byte (fp32)
   // piece.  Same rounding points as before: activation result rounded to the output type, residual added after.
+  if (g.c_rows) {      // combine folded into the epilogue (see gemm256_bf16.hip): out[token] = residual[token] + weight[token] * bf16(acc)
+    bf16_t* Co = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + fr;
+      if (row >= M) continue;
+      const int orow = g.c_rows[batch * g.rows_stride + row];
+      const float sc = g.c_scale ? g.c_scale[orow] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fq * 4;
+        if (col + 4 > N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sc * (float)(bf16_t)acc[i][j][r];
+        if (g.residual) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(g.residual + (int64_t)orow * g.ldr + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        *reinterpret_cast<bf16x4*>(Co + (int64_t)orow * g.ldc + col) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      }
+    }
+    return;
+  }
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
   bf16_t* Cb = g.out_f32 ? nullptr : reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
@@ -371,4 +400,31 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);
   return mp_check_launch("mp_gemm_bf16_nt_batched");
+}
+
+// Expert GEMMs with the MoE dispatch / combine folded in (top-1 routing): per expert b, A row r comes from row a_rows[b*rows_stride+r]
+// of the shared [tokens, K] activation matrix (a_rows null = A is [batch, M, K] as in the plain batched call), and — when c_rows is
+// given — C row r goes to row c_rows[b*rows_stride+r] of the shared [tokens, N] output as residual[row] + c_scale[row] * bf16(acc).
+extern "C" int mp_gemm_bf16_nt_batched_rows(const void* A, int64_t lda, int64_t strideA, const int* a_rows, const void* W, int64_t ldw,
+                                            int64_t strideW, void* C, int64_t ldc, int64_t strideC, const int* c_rows,
+                                            const float* c_scale, const void* residual, int64_t ldr, int rows_stride, int batch, int M,
+                                            int N, int K, int act, const int* m_dev, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched_rows: bad shape");
+  MP_REQUIRE(K % BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && strideW % 8 == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched_rows: K %% 64, strides %% 8");
+  MP_REQUIRE(act == ACT_NONE || act == ACT_SWIGLU_PAIR, MP_ERR_ARG, "mp_gemm_bf16_nt_batched_rows: activation must be none or SWIGLU_PAIR");
+  MP_REQUIRE(act != ACT_SWIGLU_PAIR || (N % 64 == 0 && ldc % 8 == 0 && !c_rows), MP_ERR_ARG, "mp_gemm_bf16_nt_batched_rows: bad SWIGLU_PAIR use");
+  MP_REQUIRE(!c_rows || (N % 4 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0)), MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched_rows: scatter needs N, ldc, ldr %% 4 == 0");
+  MP_REQUIRE(c_rows || (!c_scale && !residual), MP_ERR_ARG, "mp_gemm_bf16_nt_batched_rows: c_scale / residual come with c_rows");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.bias = nullptr; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.out_f32 = 0; g.alpha = 1.f;
+  g.sA = a_rows ? 0 : strideA; g.sW = strideW; g.sC = c_rows ? 0 : strideC; g.sR = 0; g.sBias = 0; g.m_dev_stride = 1;
+  g.group_m = gemm_group_m();
+  g.a_rows = a_rows; g.c_rows = c_rows; g.c_scale = c_scale; g.rows_stride = rows_stride;
+  if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
+  const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
+  launch_gemm(g, dim3(tiles, batch), stream);
+  return mp_check_launch("mp_gemm_bf16_nt_batched_rows");
 }

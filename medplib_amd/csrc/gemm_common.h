@@ -29,6 +29,11 @@ struct GemmArgs {
   int n_cu;                   // compute units the tile waves are counted against
   int nbatch;                 // batch count (the flat work decode walks all batches)
   int max_split;              // upper bound on the tail split factor (1 = off)
+  // MoE expert GEMMs fused with dispatch / combine (mp_gemm_bf16_nt_batched_rows): per batch b, A row r is read from row
+  // a_rows[b * rows_stride + r] of the (shared) A matrix; C row r is written to row c_rows[b * rows_stride + r] of the (shared) C
+  // matrix, scaled by c_scale[that row] before the residual (indexed by the same destination row) is added.  null = identity.
+  const int* a_rows; const int* c_rows; const float* c_scale;
+  int rows_stride;
 };
 
 // GELU(erf) without erff: gelu(x) = relu(x) - a Phi(-a), a = |x|, log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute

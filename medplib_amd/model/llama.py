@@ -49,6 +49,7 @@ class LlamaStack:
         self.rts_uniform_provider = None   # callable(layer_idx, T, E) -> fp32 [T,E] gate draws (RTS uniforms / top-2 Gumbel) or None
         self.gate_pass = 0                 # forward passes so far: part of the key of the stateless gate-draw generator
         self.ep = None                     # ExpertParallel (expert_parallel.py) once enable_expert_parallel() sharded the experts
+        self.fuse_moe_gather_scatter = True   # top-1, one rank: dispatch / combine folded into the expert GEMMs
 
     def enable_expert_parallel(self, ep):
         """Shard the experts over an expert-parallel group (DeepSpeed `ep_size`, medplib_moe_llama.py:604-614): every rank keeps the
@@ -139,6 +140,20 @@ class LlamaStack:
         cap = self.capacity(T)
         k = cfg.top_k_experts
         logits, gates = ops.moe_gate(h, lw["wg"])
+        if k == 1 and self.ep is None and self.fuse_moe_gather_scatter:
+            # top-1 on one rank: the dispatch is a row gather in the gate|up GEMM's operand fetch and the combine (gate weight and
+            # the layer's residual add) a row scatter in the down GEMM's epilogue; every routed token's row is written exactly once,
+            # the capacity-dropped ones get the residual stream from a fill kernel
+            expert, slot, weight, kept, counts, l_aux, slot_token = ops.moe_route_top1(
+                gates, cap, self._gate_draws(i, T, E, gumbel=False), want_slot_token=True)
+            act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
+            if ops.GEMM_TIMER is not None:
+                ops.GEMM_TIMER.batched_rows = T
+            ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
+            out = torch.empty((T, d), dtype=torch.bfloat16, device=h.device)
+            ops.gemm_batched_rows(act, lw["down"], out, kept, c_rows=slot_token, c_scale=weight, residual=x, rows_stride=cap)
+            ops.moe_fill_dropped(x, slot, out)
+            return out, l_aux, (expert, slot, counts)
         if k == 1:
             expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
         else:

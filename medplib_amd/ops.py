@@ -666,16 +666,47 @@ def moe_gate(x, wg):
     return logits, gates
 
 
-def moe_route_top1(gates, capacity, rts_uniform=None):
+def moe_route_top1(gates, capacity, rts_uniform=None, want_slot_token=False):
+    """-> (expert, slot, weight, kept, counts, l_aux[, slot_token [E, capacity] int32: token held by each slot])."""
     T, E = gates.shape
     dev = gates.device
+    slot_token = torch.empty((E, int(capacity)), dtype=torch.int32, device=dev) if want_slot_token else None
     expert = torch.empty(T, dtype=torch.int32, device=dev); slot = torch.empty(T, dtype=torch.int32, device=dev)
     weight = torch.empty(T, dtype=torch.float32, device=dev)
     kept = torch.empty(E, dtype=torch.int32, device=dev); counts = torch.empty(E, dtype=torch.int64, device=dev)
     l_aux = torch.empty(1, dtype=torch.float32, device=dev)
     lib().call("mp_moe_route_top1", _p(gates), _p(rts_uniform), T, E, int(capacity), _p(expert), _p(slot), _p(weight), _p(kept),
-               _p(counts), _p(l_aux), _stream())
+               _p(counts), _p(l_aux), _p(slot_token), _stream())
+    if want_slot_token:
+        return expert, slot, weight, kept, counts, l_aux, slot_token
     return expert, slot, weight, kept, counts, l_aux
+
+
+def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, residual=None, act=ACT_NONE, rows_stride=0):
+    """Expert GEMMs with dispatch / combine folded in.  With a_rows: a is the shared [tokens, K] matrix and expert b reads rows
+    a_rows[b*rows_stride + r]; else a is [E, M, K].  With c_rows: out is the shared [tokens, N] matrix, row c_rows[...] receives
+    residual[row] + c_scale[row] * bf16(acc); else out is [E, M, N(/2 for SWIGLU_PAIR)].  w [E, N, K]; m_dev int32 [E]."""
+    _chk(a, torch.bfloat16, "gemm_batched_rows.a"); _chk(w, torch.bfloat16, "gemm_batched_rows.w")
+    E, N, K = w.shape
+    M = int(rows_stride) if a_rows is not None else a.shape[1]          # rows per expert slab (the capacity)
+    lda, sa = (a.stride(0), 0) if a_rows is not None else (a.stride(1), a.stride(0))
+    ldc, sc = (out.stride(0), 0) if c_rows is not None else (out.stride(1), out.stride(0))
+    _ensure_gemm_workspace(a.device)
+    t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
+    lib().call("mp_gemm_bf16_nt_batched_rows", _p(a), lda, sa, _p(a_rows), _p(w), w.stride(1), w.stride(0), _p(out), ldc, sc, _p(c_rows),
+               _p(c_scale), _p(residual), residual.stride(0) if residual is not None else 0, int(rows_stride), E, int(M), N, K, act,
+               _p(m_dev), _stream())
+    if GEMM_TIMER is not None:
+        rows = getattr(GEMM_TIMER, "batched_rows", None) or E * M
+        GEMM_TIMER.end(2.0 * rows * N * K, t0)
+    return out
+
+
+def moe_fill_dropped(x, slot, out):
+    """out[t] = x[t] where slot[t] < 0 (tokens dropped by the capacity limit keep the residual stream only)."""
+    T, d = x.shape
+    lib().call("mp_moe_fill_dropped_bf16", _p(x), _p(slot), _p(out), T, d, _stream())
+    return out
 
 
 def moe_route_top2(gates, logits, capacity, noise=None):

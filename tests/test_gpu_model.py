@@ -660,3 +660,24 @@ def test_llama_layer_at_true_dims(dev, moe):
         print(f"true-dims routing agreement {keep.float().mean().item():.4f}; counts ref {coll[0][2].tolist()} got {routing[0][2].cpu().tolist()}")
         assert keep.float().mean().item() > 0.98
     _stat(f"7B-dims layer (moe={moe}) final-norm hidden", out.view(B * S, -1).cpu()[keep], ref.view(B * S, -1)[keep], atol=0.0, rtol=8 * 2 ** -8)
+
+
+@pytest.mark.parametrize("cf", [1.5, 0.6])
+def test_moe_gather_scatter_fusion_is_bit_identical(dev, cf):
+    """Top-1 MoE layer with the dispatch folded into the gate|up GEMM's operand fetch and the combine (+ residual) into the down
+    GEMM's epilogue vs the separate dispatch / combine kernels: same rounding points, so the stack output must be bit-identical —
+    including capacity-dropped tokens (cf = 0.6 drops ~40 % of one expert's tokens), which only keep the residual stream."""
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, num_experts=2, capacity_factor=cf)
+    W = OM.init_hf_weights(cfg)
+    g = torch.Generator().manual_seed(21)
+    emb = (torch.randn(3, 171, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    kv = torch.ones(3, 171, dtype=torch.uint8, device=dev); kv[2, 150:] = 0
+    outs = []
+    for fused in (True, False):
+        m = _model(cfg, dev, W)
+        m.model.llm.fuse_moe_gather_scatter = fused
+        out, aux, routing = m.model.llm.forward(emb, kv, collect_routing=True)
+        outs.append((out, routing))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if cf < 1:
+        assert (outs[0][1][0][1] < 0).any(), "the small capacity factor must actually drop tokens"
