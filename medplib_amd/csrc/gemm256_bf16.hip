@@ -9,14 +9,18 @@
 //   group 1:   B  |  LOAD(p) | B | MFMA(p) | B | LOAD(p+1) | B | MFMA(p+1) ...
 //
 // A K-tile (64 deep) is four phases = the four 64x32 quadrants of the wave tile, ordered (0,0) (0,1) (1,1) (1,0) so that
-// consecutive phases reuse either the A or the B fragments already in registers (12/4/8/4 ds_read_b128 per phase).
-// Operands arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear LDS image, XOR swizzle applied on the SOURCE address);
-// the 8 DMA instructions per wave per K-tile are issued in the LOAD segments of phases 0-2 of the previous tile and retired
-// with one counted wait (vmcnt(0)) at the end of phase 3's LOAD segment, one barrier before anybody reads that stage.
-// Hazards: RAW — vmcnt(0) by the issuing wave, then >= 1 barrier, then the ds_reads; WAR — the last reads of a stage are
-// retired (lgkmcnt(0)) before the barrier that precedes the first DMA into that stage.
-// Epilogue: accumulators -> LDS (per-wave 128x64 bf16 image) -> 16-byte row-contiguous global stores with fused
-// bias / activation / residual.
+// consecutive phases reuse either the A or the B fragments already in registers (12/4/8/0 ds_read_b128 per phase).
+// Operands arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear LDS image, XOR swizzle applied on the SOURCE address) as a
+// continuous stream: a stage is recycled region by region as soon as its last reader phase has retired (details at the kernel).
+// The MFMAs are issued as (W fragment, A fragment), which transposes the accumulator fragments: a lane ends up owning four
+// CONSECUTIVE COLUMNS of a row, so the epilogue (bias / activation / residual / SwiGLU pairing / MoE row scatter) stores 8- or
+// 16-byte row pieces straight from registers — no LDS round trip.
+// Work decode: a flat unit id over all batches with XCD chunking and a grouped tile order, plus tail split-K (at the kernel).
+// Tried and dropped: BK = 32 with 4 stages (half cache lines per DMA row), 32x32x16 MFMAs (dependent-accumulator distance 2),
+// per-tile DMA bursts with vmcnt(0) (the "v1" schedule this file started with), an LDS-transposed epilogue with 16-byte stores
+// (slower than the register-direct one by 5-20 % depending on K), and persistent workgroups with the next tile's prologue
+// issued before the epilogue (+2-4 % on multi-wave shapes in isolation, -2.3 % on the training step: workgroups that never
+// leave the CUs starve the concurrent SAM-encoder and mask-tail streams).
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -38,262 +42,6 @@ __device__ __forceinline__ int lds_off2(int r, int c) { return r * 128 + ((c ^ (
     __builtin_amdgcn_sched_barrier(0);     \
     asm volatile("" ::: "memory");         \
   } while (0)
-
-// Accumulators -> per-wave LDS image -> 16-byte row-contiguous global stores with fused bias / activation / residual /
-// SwiGLU pairing (bf16 output), or direct fp32 stores.
-__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], char* smem, int batch, int M, int N, int m0,
-                                                 int n0, int wave, int wr, int wc, int lane, int fr, int fq) {
-  constexpr int EP_LD = 144;
-  const bool via_lds = !g.out_f32;
-  const bool swiglu = (g.act == ACT_SWIGLU_PAIR);
-  if (via_lds) {
-    char* ep = smem + wave * 16384;
-    const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
-    float bias_v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + fr;
-      bias_v[j] = (bias0 && col < N) ? bias0[col] : 0.f;
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const int i = half * 4 + ii;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<bf16_t*>(ep + (ii * 16 + fq * 4 + r) * EP_LD + (j * 16 + fr) * 2) =
-                (bf16_t)apply_act(acc[i][j][r] * g.alpha + bias_v[j], swiglu ? ACT_NONE : g.act);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
-      bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
-      if (swiglu) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int idx = it * 64 + lane;
-          const int lr = idx >> 2, q = idx & 3;
-          const int row = m0 + wr * 128 + half * 64 + lr;
-          const int col = ((n0 + wc * 64) >> 1) + q * 8;
-          const bf16x8 gv = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + q * 16);
-          const bf16x8 uv = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + 64 + q * 16);
-          if (row < M && col + 8 <= (N >> 1)) {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float gf = (float)gv[e];
-              o[e] = (bf16_t)(gf / (1.f + __expf(-gf)) * (float)uv[e]);
-            }
-            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = o;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
-        const int row = m0 + wr * 128 + half * 64 + lr;
-        const int col = n0 + wc * 64 + lc;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + lr * EP_LD + lc * 2);
-        if (row < M && col < N) {
-          if (col + 8 <= N && ((g.ldc & 7) == 0) && (!R || (g.ldr & 7) == 0)) {
-            if (R) {
-              const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rv[e]);
-            }
-            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = v;
-          } else {
-            for (int e = 0; e < 8 && col + e < N; ++e) {
-              float f = (float)v[e];
-              if (R) f += (float)R[(int64_t)row * g.ldr + col + e];
-              Cb[(int64_t)row * g.ldc + col + e] = (bf16_t)f;
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-    const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
-    const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
-    float* Cf = reinterpret_cast<float*>(g.C) + batch * g.sC;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + fr;
-      if (col >= N) continue;
-      const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wr * 128 + i * 16 + fq * 4 + r;
-          if (row >= M) continue;
-          float v = apply_act(acc[i][j][r] * g.alpha + bv, g.act);
-          if (R) v += (float)R[(int64_t)row * g.ldr + col];
-          Cf[(int64_t)row * g.ldc + col] = v;
-        }
-    }
-  }
-}
-
-
-// ABL (ablation builds for scripts/gemm_bench.py only): 0 = product kernel, 1 = no MFMA, 2 = no LDS fragment reads, 3 = no DMA
-template <int ABL>
-__global__ __launch_bounds__(NT2, 1) void gemm256_bf16_nt_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int batch = blockIdx.y;
-  const bf16_t* __restrict__ A = g.A + batch * g.sA;
-  const bf16_t* __restrict__ W = g.W + batch * g.sW;
-  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
-  const int N = g.N, K = g.K;
-
-  // tile space from the EFFECTIVE row count (device-side expert counts): surplus workgroups of the capacity-sized grid exit
-  // here, and the XCD remap below stays balanced over the tiles that really exist
-  const int tiles_m = (M + BM2 - 1) / BM2;
-  const int tiles_n = (N + BN2 - 1) / BN2;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (bid >= nwg) return;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  // grouped order: ids walk GROUP_M consecutive M-tiles before stepping N, so the ~32-64 workgroups that are co-resident on
-  // one XCD cover a GROUP_M x (32/GROUP_M) block of tiles and share both their A and their W panels through that XCD's L2
-  const int GROUP_M = g.group_m;
-  const int per_group = GROUP_M * tiles_n;
-  const int grp = bid / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-  if (m0 >= M) return;                       // whole workgroup exits together (block-uniform)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  // ---- DMA source pointers: instruction j (0..31) of an operand covers rows 8j..8j+7; this wave issues j = wave*4 + i
-  const int sub_row = lane >> 3;
-  const int src_c = (lane & 7) ^ sub_row;
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + sub_row;
-    a_src[i] = A + (int64_t)min(m0 + row, M - 1) * g.lda + src_c * 8;
-    w_src[i] = W + (int64_t)min(n0 + row, N - 1) * g.ldw + src_c * 8;
-  }
-  auto dma_a = [&](int i, int t, int stage) {
-    if constexpr (ABL == 3) return;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
-                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + (wave * 4 + i) * 1024),
-                                     16, 0, 0);
-  };
-  auto dma_w = [&](int i, int t, int stage) {
-    if constexpr (ABL == 3) return;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
-                                     (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024),
-                                     16, 0, 0);
-  };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  bf16x8 fa[4][2];   // A fragments of the current M-quadrant: [m-frag within quadrant][kk]
-  bf16x8 fb[2][2];   // B fragments of the current N-quadrant: [n-frag within quadrant][kk]
-  if constexpr (ABL == 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) for (int kk = 0; kk < 2; ++kk) for (int e = 0; e < 8; ++e) { fa[i][kk][e] = (bf16_t)(float)(lane + i); if (i < 2) fb[i][kk][e] = (bf16_t)(float)(lane - i); }
-  }
-
-  auto load_a = [&](int qm, const char* st) {
-    if constexpr (ABL == 2) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fa[i][kk] = *reinterpret_cast<const bf16x8*>(st + lds_off2(wr * 128 + (qm * 4 + i) * 16 + fr, kk * 4 + fq));
-  };
-  auto load_b = [&](int qn, const char* st) {
-    if constexpr (ABL == 2) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fb[j][kk] = *reinterpret_cast<const bf16x8*>(st + OP_BYTES + lds_off2(wc * 64 + (qn * 2 + j) * 16 + fr, kk * 4 + fq));
-  };
-#define MP_MFMA_Q(QM, QN)                                                                                  \
-  do {                                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          if constexpr (ABL == 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(fb[j][kk])); }                   \
-          else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                            \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], fb[j][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                          \
-  } while (0)
-
-  const int nt = K / BK2;
-
-  // ---- prologue: tile 0 into stage 0
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { dma_a(i, 0, 0); dma_w(i, 0, 0); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MP_BAR();
-  if (wr == 1) MP_BAR();                     // stagger group 1 by one barrier
-
-  for (int t = 0; t < nt; ++t) {
-    const int stage = t & 1;
-    const char* st = smem + stage * STAGE_BYTES;
-    const bool more = (t + 1 < nt);
-    // ---------------- phase 0: quadrant (0,0) ----------------
-    if (more) { dma_a(0, t + 1, stage ^ 1); dma_a(1, t + 1, stage ^ 1); dma_w(0, t + 1, stage ^ 1); }
-    load_b(0, st);
-    load_a(0, st);
-    MP_BAR();
-    MP_MFMA_Q(0, 0);
-    MP_BAR();
-    // ---------------- phase 1: quadrant (0,1) ----------------
-    if (more) { dma_a(2, t + 1, stage ^ 1); dma_a(3, t + 1, stage ^ 1); dma_w(1, t + 1, stage ^ 1); }
-    load_b(1, st);
-    MP_BAR();
-    MP_MFMA_Q(0, 1);
-    MP_BAR();
-    // ---------------- phase 2: quadrant (1,1) ----------------
-    if (more) { dma_w(2, t + 1, stage ^ 1); dma_w(3, t + 1, stage ^ 1); }
-    load_a(1, st);
-    MP_BAR();
-    MP_MFMA_Q(1, 1);
-    MP_BAR();
-    // ---------------- phase 3: quadrant (1,0) ----------------
-    load_b(0, st);
-    // retire this tile's last LDS reads (WAR vs the DMA into this stage two phases from now) and the next tile's DMA
-    // (RAW: landed before the barrier that precedes its first read)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    MP_BAR();
-    MP_MFMA_Q(1, 0);
-    MP_BAR();
-  }
-  if (wr == 0) MP_BAR();                     // balance the stagger barrier of group 1
-
-  gemm256_epilogue(g, acc, smem, batch, M, N, m0, n0, wave, wr, wc, lane, fr, fq);
-}
-
-
 
 // Epilogue for TRANSPOSED accumulators (v3): the MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] is
 // C[row = i*16 + fr, col = j*16 + fq*4 + r] of the wave tile — a lane owns FOUR CONSECUTIVE COLUMNS of one row per fragment.
@@ -440,8 +188,8 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
 
 
 // =====================================================================================================================
-// v3: v1's geometry (BK = 64, 128-B rows = whole cache lines per DMA row, 2 stages) with a CONTINUOUS DMA stream: the stage
-// is recycled region by region as soon as its last reader phase has retired, two DMA instructions per wave in EVERY phase,
+// The kernel ("v3" keeps the name it had among the variants that were tried): BK = 64, 128-B rows = whole cache lines per DMA
+// row, 2 stages, with a CONTINUOUS DMA stream: the stage is recycled region by region as soon as its last reader phase has retired, two DMA instructions per wave in EVERY phase,
 // retired by one counted wait (vmcnt(6)) per K-tile — the memory pipe never drains.
 //   reads:  P0 A-q0 + B-q0 (kept in fb0 for P3)   P1 B-q1   P2 A-q1   P3 none
 //   DMA  :  P0 A-q1 of tile t+1 | P1 A-q0 of tile t+2 | P2 B[0,1] of tile t+2 | P3 B[2,3] of tile t+2
@@ -724,50 +472,34 @@ void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int6
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   static int abl = -1;
   if (abl < 0) {
-    const char* e = getenv("MP_GEMM_ABLATE");
+    const char* e = getenv("MP_GEMM_ABLATE");          // scripts/gemm_bench.py only: 1 = no MFMA, 2 = no LDS fragment reads, 3 = no DMA
     abl = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 0;
-    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-  }
-  static int ver = -1;
-  if (ver < 0) {
-    // 3 (default) = continuous LDS-DMA stream with region-level stage recycling; 1 = per-tile DMA bursts (A/B reference)
-    const char* e = getenv("MP_GEMM256_VERSION");
-    ver = (e && e[0] == '1') ? 1 : 3;
     (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   }
+  MP_REQUIRE(batch <= MAX_FLAT_BATCH, MP_ERR_SHAPE, "256x256 GEMM: at most %d batches per launch (got %d)", MAX_FLAT_BATCH, batch);
   const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
-  const dim3 grid(tiles, batch), blk(NT2);
-  if (ver == 3 && batch <= MAX_FLAT_BATCH) {
-    static int n_cu = 0, max_split = -1;
-    if (!n_cu) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-      n_cu = std::min(n_cu, 256);                      // workspace / ticket sizing
-      const char* e = getenv("MP_GEMM_MAX_SPLIT");     // 1 = no tail split (A/B), default 8
-      max_split = (e && atoi(e) >= 1) ? atoi(e) : 8;
-    }
-    GemmArgs gf = g;
-    gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split;
-    int64_t ws_bytes = 0;
-    mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
-    if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
-    const dim3 fgrid(tiles * batch + n_cu);
-    if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-    else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-    else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-    else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-    return mp_check_launch("mp_gemm_bf16_nt(256v3)");
+  const dim3 blk(NT2);
+  static int n_cu = 0, max_split = -1;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    n_cu = std::min(n_cu, 256);                      // workspace / ticket sizing
+    const char* e = getenv("MP_GEMM_MAX_SPLIT");     // 1 = no tail split (A/B), default 8
+    max_split = (e && atoi(e) >= 1) ? atoi(e) : 8;
   }
-  if (abl == 1) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<1>, grid, blk, 2 * STAGE_BYTES, stream, g);
-  else if (abl == 2) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<2>, grid, blk, 2 * STAGE_BYTES, stream, g);
-  else if (abl == 3) hipLaunchKernelGGL(gemm256_bf16_nt_kernel<3>, grid, blk, 2 * STAGE_BYTES, stream, g);
-  else hipLaunchKernelGGL(gemm256_bf16_nt_kernel<0>, grid, blk, 2 * STAGE_BYTES, stream, g);
+  GemmArgs gf = g;
+  gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split;
+  int64_t ws_bytes = 0;
+  mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
+  if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
+  const dim3 fgrid(tiles * batch + n_cu);             // surplus workgroups (device-side row counts, unsplit tails) exit at once
+  if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+  else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+  else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+  else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
   return mp_check_launch("mp_gemm_bf16_nt(256)");
 }

@@ -309,6 +309,7 @@ static int gemm_group_m() {
 
 static bool use_256(const GemmArgs& g, int batch) {
   if (g.act == ACT_SWIGLU_PAIR) return true;          // the paired epilogue exists in the 256x256 kernel only
+  if (batch > 8) return false;                        // its flat work decode walks at most 8 batches
   if (gemm_variant() != 2) return false;
   const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
   static int min_tiles = -1, min_n = -1;
