@@ -106,6 +106,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # the GPU leg's host work is index planning on 8 x 64 ids: a handful of threads per rank (N ranks x every core would
+    # oversubscribe the host with spinning OpenMP pools); the cpu_baseline leg sets its own thread count
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl")
