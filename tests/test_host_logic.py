@@ -279,3 +279,35 @@ def test_region_prompt_splice_matches_executed_reference(golden_dir):
     with pytest.raises(AssertionError):
         bad = ids.copy(); bad[0, 1] = splice.REGION_TOKEN_INDEX           # before the image placeholder: the reference asserts too
         splice.plan_splice(bad, labels, att, P, region_bases=bases)
+
+
+def test_lora_merge_state_dict_matches_adapter_forward():
+    """merge_and_unload as a state-dict transformation: y = W x + (alpha / r) B A x must equal the merged Linear; peft key layout
+    (base_model.model. prefix, .base_layer., lora_A/B.default) is stripped back to the HF layout; untargeted tensors pass through."""
+    from medplib_amd import lora
+    g = torch.Generator().manual_seed(0)
+    d, r, alpha = 24, 4, 16.0
+    base = {"model.layers.0.self_attn.q_proj.weight": torch.randn(d, d, generator=g), "model.layers.0.self_attn.k_proj.weight": torch.randn(d, d, generator=g),
+            "model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.1.up_proj.weight": torch.randn(2 * d, d, generator=g),
+            "model.mm_projector.0.weight": torch.randn(d, d, generator=g), "model.norm.weight": torch.randn(d, generator=g)}
+    assert lora.find_lora_targets(base, ["q_proj", "up_proj", "mm_projector"]) == [
+        "model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.1.up_proj", "model.layers.0.self_attn.q_proj"]
+    peft_sd = {}
+    for k, v in base.items():
+        name = k[:-len(".weight")]
+        if "q_proj" in k or "up_proj" in k:
+            peft_sd["base_model.model." + name + ".base_layer.weight"] = v
+            peft_sd["base_model.model." + name + ".lora_A.default.weight"] = torch.randn(r, v.shape[1], generator=g)
+            peft_sd["base_model.model." + name + ".lora_B.default.weight"] = torch.randn(v.shape[0], r, generator=g)
+        else:
+            peft_sd["base_model.model." + k] = v
+    merged = lora.merge_lora_state_dict(peft_sd, lora_alpha=alpha)
+    assert set(merged) == set(base)
+    x = torch.randn(5, d, generator=g)
+    for k in base:
+        if "q_proj" in k or "up_proj" in k:
+            n = "base_model.model." + k[:-len(".weight")]
+            y = x @ base[k].t() + (alpha / r) * (x @ peft_sd[n + ".lora_A.default.weight"].t()) @ peft_sd[n + ".lora_B.default.weight"].t()
+            assert torch.allclose(x @ merged[k].t(), y, atol=1e-4)
+        else:
+            assert torch.equal(merged[k], base[k])
