@@ -319,6 +319,9 @@ static bool use_256(const GemmArgs& g, int batch) {
     const char* f = getenv("MP_GEMM256_MIN_N");
     min_n = (f && atoi(f) >= 1) ? atoi(f) : 1024;
   }
+  // short K with a small second tile wave (CLIP fc1 / mm_projector.0: 304 / 288 tiles, 16 K-tiles): the tail split leaves 4-K-tile
+  // units that are all prologue and epilogue; the 128x128 kernel measured 67 vs 79 us there
+  if (g.K <= 1024 && tiles > 256 && (tiles % 256) > 0 && (tiles % 256) < 128) return false;
   return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
 }
 
