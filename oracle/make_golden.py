@@ -336,6 +336,40 @@ def golden_glue():
     print("glue goldens ok")
 
 
+def check_collate_contract():
+    """Not a fixture: runs the reference's own DataCollatorForSupervisedDataset (datasets/DataCollatorForSupervisedDataset.py) on
+    seeded per-sample dicts next to medplib_amd.collate.collate and requires identical batches key by key (tensors bit-equal,
+    lists equal).  The CPU test tests/test_host_logic.py::test_collate_contract checks the same cases against expectations
+    derived here (printed as literals)."""
+    import importlib.util
+    import types
+    _import_reference_medplib()                        # puts REF on sys.path with the empty stand-ins registered
+    spec = importlib.util.spec_from_file_location("ref_collator", os.path.join(REF, "datasets", "DataCollatorForSupervisedDataset.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    from medplib_amd.collate import collate
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))          # tests/ (not a package)
+    from collate_cases import make_cases
+    for name, samples in make_cases().items():
+        for inf in (False, True):
+            a = mod.DataCollatorForSupervisedDataset(samples, inference=inf)
+            b = collate(samples, inference=inf)
+            assert set(a) == set(b), (name, set(a) ^ set(b))
+            for k in a:
+                _same(a[k], b[k], f"{name}.{k}")
+        print("collate case", name, "identical to the reference collator; input_ids", tuple(a["input_ids"].shape))
+
+
+def _same(x, y, tag):
+    if torch.is_tensor(x):
+        assert torch.is_tensor(y) and x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), tag
+    elif isinstance(x, (list, tuple)):
+        assert isinstance(y, (list, tuple)) and len(x) == len(y), tag
+        for i, (p, q) in enumerate(zip(x, y)):
+            _same(p, q, f"{tag}[{i}]")
+    else:
+        assert x == y, (tag, x, y)
+
+
 def golden_mask_head():
     """postprocess_masks / losses / metrics: run the reference functions from model/MedPLIB.py.  That module imports
     deepspeed/transformers at import time, so the four loss callables and postprocess_masks are exercised through a
@@ -406,3 +440,5 @@ if __name__ == "__main__":
         golden_mask_head()
     if "glue" in which:
         golden_glue()
+    if "collate" in which:
+        check_collate_contract()

@@ -311,3 +311,27 @@ def test_lora_merge_state_dict_matches_adapter_forward():
             assert torch.allclose(x @ merged[k].t(), y, atol=1e-4)
         else:
             assert torch.equal(merged[k], base[k])
+
+
+def test_collate_contract():
+    """medplib_amd.collate.collate on the shared cases (oracle/make_golden.py `collate` runs the REFERENCE collator on the same dicts
+    and requires key-by-key identity): padding / truncation to model_max_length, attention mask, flat mask lists with per-sample
+    validity, region bookkeeping, ICL list layout, conversation offsets."""
+    from collate_cases import make_cases
+    from medplib_amd.collate import collate
+    cases = make_cases()
+    b = collate(cases["seg_ragged_truncated"])
+    assert b["input_ids"].shape == (3, 20) and b["labels"].shape == (3, 20)
+    assert b["attention_mask"].sum(1).tolist() == [9, 20, 14] and (b["labels"][0, 9:] == -100).all() and (b["input_ids"][0, 9:] == 0).all()
+    assert b["seg_flag"] and len(b["masks_list"]) == 3 and b["valid_mask_bool"] == [[True], [True, True], []] and len(b["resize_list"]) == 3
+    assert b["offset"].tolist() == [0, 2, 3, 4] and b["images"].shape == (3, 3, 8, 8) and b["images_clip"].shape == (3, 3, 6, 6)
+    assert b["icl_image_counts"] == [1, 1, 1] and b["image_token_types"] == [["image"]] * 3 and b["mask_images"] == []
+    b = collate(cases["vqa_only_with_regions"], inference=True)
+    assert not b["seg_flag"] and b["rp_flag"] and b["inference"] and len(b["region_masks"]) == 1 and b["region_masks"][0].shape == (2, 12, 10)
+    assert [[bool(v) for v in row] for row in b["valid_region_masks_bool"]] == [[True], [False]] and b["valid_mask_bool"] == []
+    b = collate(cases["icl"])
+    assert isinstance(b["images_clip"], list) and b["images_clip"][0].shape == (2, 3, 6, 6) and len(b["mask_images"]) == 2
+    assert b["image_token_lengths"] == [[4, 2, 4]] * 2 and b["icl_image_counts"] == [2, 2]
+    # the batch dict is what the model's host-side planning consumes
+    lengths, bases = splice.icl_feature_layout(b["image_token_types"], 4, 2)
+    assert lengths == [4, 2, 4, 4, 2, 4] and bases == [0, 16, 4, 8, 18, 12]
