@@ -258,6 +258,15 @@ class AverageMeterPack:
         self.buf[i] += float(value) * n
         self.buf[len(self.names) + i] += n
 
+    def update_many(self, values, n=1):
+        """values: {name: 0-dim device tensor}.  Accumulates on the device — no host synchronisation per step (the reference's
+        AverageMeter.update(loss.item()) stalls the host on every micro-batch)."""
+        k = len(self.names)
+        idx = [self.names.index(name) for name in values]
+        vals = torch.stack([values[name].detach().reshape(()).to(self.buf.device, torch.float64) for name in values])
+        self.buf[idx] += vals * n
+        self.buf[[k + i for i in idx]] += n
+
     def all_reduce(self):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)

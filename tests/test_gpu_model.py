@@ -681,3 +681,18 @@ def test_moe_gather_scatter_fusion_is_bit_identical(dev, cf):
     assert torch.equal(outs[0][0], outs[1][0])
     if cf < 1:
         assert (outs[0][1][0][1] < 0).any(), "the small capacity factor must actually drop tokens"
+
+
+def test_training_entry_point_runs_and_resumes(dev, tmp_path):
+    """medplib_amd.train.main (train_ds_medplib.py control flow) at tiny dims: 2 epochs x 3 steps with a checkpoint, validation
+    metrics, then a second invocation that auto-resumes from <log_dir>/ckpt_model/latest and continues at the saved global step."""
+    from medplib_amd import train
+    argv = ["--model_size", "tiny", "--batch_size", "2", "--epochs", "2", "--steps_per_epoch", "3", "--save_steps", "2", "--lr", "1e-3",
+            "--log_dir", str(tmp_path)]
+    hist = train.main(argv)
+    assert len(hist) == 6 and all(np.isfinite(hist))
+    latest = open(os.path.join(str(tmp_path), "ckpt_model", "latest")).read().strip()
+    assert latest == "global_step6"
+    hist2 = train.main(argv + ["--epochs", "3"])          # resumes at epoch 2 (global step 6) and runs one more epoch
+    assert len(hist2) == 3
+    assert open(os.path.join(str(tmp_path), "ckpt_model", "latest")).read().strip() == "global_step9"
