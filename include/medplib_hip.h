@@ -68,6 +68,14 @@ int mp_gemm_bf16_nt_batched_rows(const void* A, int64_t lda, int64_t strideA, co
                                  const void* residual, int64_t ldr, int rows_stride, int batch, int M, int N, int K, int act,
                                  const int* m_dev, hipStream_t stream);
 
+/* y[m, n] = epilogue(x[m, :] . W[n, :]) for M <= 8 rows: the single-token decode steps of evaluate() (HF generate with a KV cache,
+ * MedPLIB.py:592-606), bound by the HBM stream of W.  Same epilogues as mp_gemm_bf16_nt (incl. SWIGLU_PAIR).
+ * MoE decode: w_index[m] (device int) picks the expert's matrix (W + w_index[m] * strideW) per row; then the output is
+ * residual + row_scale[m] * bf16(acc), with scale 0 for rows whose row_keep[m] < 0 (capacity-dropped tokens). */
+int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, int64_t strideW, void* y, int64_t ldy, const float* bias,
+                 const void* residual, int64_t ldr, const int* w_index, const float* row_scale, const int* row_keep, int M, int N, int K,
+                 int act, int out_dtype, float alpha, hipStream_t stream);
+
 /* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
  * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */

@@ -1,0 +1,218 @@
+// bf16 GEMV for the single-token decode steps of evaluate() (HF generate with a KV cache, MedPLIB.py:592-606): y[m, n] = x[m, :] . W[n, :]
+// for M <= 8 rows.  One decode step reads every LLM weight once, so this kernel is bound by the HBM stream of W (13.2 GB per
+// token at 7B): a wave owns four consecutive output columns (four W rows of K bf16), streams them with 16-byte loads — eight in
+// flight per lane — against the x chunk it holds in registers, reduces across the wave, and applies the same fused epilogues as the
+// GEMM (bias, activation, residual, SwiGLU pairing over the interleaved gate|up rows).  MoE decode: `w_index[m]` (device) selects
+// the expert's weight matrix per row and `row_scale[m]` / `row_keep[m]` carry the top-1 gate probability and the capacity drop.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int GV_MAXM = 8;
+
+struct GemvArgs {
+  const bf16_t* x; int64_t ldx;
+  const bf16_t* W; int64_t ldw; int64_t strideW;
+  void* y; int64_t ldy;
+  const float* bias; const bf16_t* residual; int64_t ldr;
+  const int* w_index;        // [M] device: weight matrix per row (null = one shared matrix)
+  const float* row_scale;    // [M] device or null
+  const int* row_keep;       // [M] device or null: rows with row_keep[m] < 0 get scale 0 (capacity-dropped tokens)
+  int M, N, K, act, out_f32;
+  float alpha;
+};
+
+__device__ __forceinline__ float gv_dot8(const bf16x8 a, const bf16x8 b, float acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = fmaf((float)a[j], (float)b[j], acc);
+  return acc;
+}
+
+// SHARED: all M rows use the same W (W rows are loaded once and reused for every x row)
+template <int M, bool SWIGLU>
+__global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // columns of this wave: plain = 4 consecutive; SWIGLU = gate rows {g0, g0+1} and their up rows {g0+32, g0+33}
+  int rows[4];
+  if (SWIGLU) {
+    const int pair = wid * 2;                               // output column pair index
+    const int blk = pair >> 5, j = pair & 31;
+    rows[0] = blk * 64 + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + 32; rows[3] = rows[0] + 33;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+  }
+  if (rows[0] >= g.N) return;
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)min(rows[r], g.N - 1) * g.ldw;
+  float acc[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+  const int iters = g.K / 512;                              // 64 lanes x 8 elements per step
+  int k = lane * 8;
+  for (int it = 0; it + 1 < iters; it += 2, k += 1024) {    // two steps per trip: 8 weight loads in flight per lane
+    bf16x8 w0[4], w1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k + 512); }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
+      const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k + 512);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+    }
+  }
+  if (iters & 1) {
+    bf16x8 w0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, w0[r], acc[m][r]);
+    }
+  }
+  k = iters * 512 + lane * 8;                                // K tail (K % 512 != 0; K % 8 == 0)
+  if (k < g.K) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + k), acc[m][r]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+  if (lane != 0) return;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (SWIGLU) {
+      bf16_t* yo = reinterpret_cast<bf16_t*>(g.y) + (int64_t)m * g.ldy;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float gf = (float)(bf16_t)(acc[m][p] * g.alpha), uf = (float)(bf16_t)(acc[m][2 + p] * g.alpha);
+        const int col = (rows[p] >> 6) * 32 + (rows[p] & 31);
+        if (rows[p] < g.N) yo[col] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = rows[r];
+        if (n >= g.N) continue;
+        float v = apply_act(acc[m][r] * g.alpha + (g.bias ? g.bias[n] : 0.f), g.act);
+        if (g.out_f32) {
+          if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+          reinterpret_cast<float*>(g.y)[(int64_t)m * g.ldy + n] = v;
+        } else {
+          v = (float)(bf16_t)v;                              // same rounding points as the 256x256 GEMM epilogue
+          if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+          reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+        }
+      }
+    }
+  }
+}
+
+// INDEXED: every row picks its own weight matrix (MoE experts); rows are processed one after the other
+template <bool SWIGLU>
+__global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int rows[4];
+  if (SWIGLU) {
+    const int pair = wid * 2;
+    const int blk = pair >> 5, j = pair & 31;
+    rows[0] = blk * 64 + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + 32; rows[3] = rows[0] + 33;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+  }
+  if (rows[0] >= g.N) return;
+  for (int m = 0; m < g.M; ++m) {
+    const bf16_t* Wm = g.W + (int64_t)g.w_index[m] * g.strideW;
+    float scale = g.row_scale ? g.row_scale[m] : 1.f;
+    if (g.row_keep && g.row_keep[m] < 0) scale = 0.f;
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wp[r] = Wm + (int64_t)min(rows[r], g.N - 1) * g.ldw;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 8; k < g.K; k += 512) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + k), acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane != 0) continue;
+    bf16_t* yo = reinterpret_cast<bf16_t*>(g.y) + (int64_t)m * g.ldy;
+    if (SWIGLU) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float gf = (float)(bf16_t)acc[p], uf = (float)(bf16_t)acc[2 + p];
+        const int col = (rows[p] >> 6) * 32 + (rows[p] & 31);
+        if (rows[p] < g.N) yo[col] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = rows[r];
+        if (n >= g.N) continue;
+        float v = scale * (float)(bf16_t)acc[r];            // combine: gate weight on the bf16-rounded expert output, then the residual
+        if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+        yo[n] = (bf16_t)v;
+      }
+    }
+  }
+}
+
+template <int M>
+void launch_shared(const GemvArgs& g, dim3 grid, hipStream_t s) {
+  if (g.act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL((gemv_shared_kernel<M, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemv_shared_kernel<M, false>), grid, dim3(256), 0, s, g);
+}
+
+}  // namespace
+
+extern "C" int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, int64_t strideW, void* y, int64_t ldy, const float* bias,
+                            const void* residual, int64_t ldr, const int* w_index, const float* row_scale, const int* row_keep, int M, int N,
+                            int K, int act, int out_dtype, float alpha, hipStream_t stream) {
+  MP_REQUIRE(M >= 1 && M <= GV_MAXM && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, MP_ERR_SHAPE,
+             "mp_gemv_bf16: 1 <= M <= 8, K %% 8 == 0 (M=%d N=%d K=%d)", M, N, K);
+  MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemv_bf16: bad out dtype");
+  MP_REQUIRE(act >= 0 && act <= 5, MP_ERR_ARG, "mp_gemv_bf16: bad activation %d", act);
+  MP_REQUIRE(act != ACT_SWIGLU_PAIR || (N % 64 == 0 && out_dtype == MP_BF16 && !bias && !residual), MP_ERR_ARG,
+             "mp_gemv_bf16: SWIGLU_PAIR needs N %% 64 == 0, bf16 output, no bias / residual");
+  MP_REQUIRE(!w_index || (out_dtype == MP_BF16 && !bias && (act == ACT_NONE || act == ACT_SWIGLU_PAIR)), MP_ERR_ARG,
+             "mp_gemv_bf16: the indexed (expert) form takes no bias and only NONE / SWIGLU_PAIR");
+  GemvArgs g{(const bf16_t*)x, ldx, (const bf16_t*)W, ldw, strideW, y, ldy, bias, (const bf16_t*)residual, ldr, w_index, row_scale, row_keep,
+             M, N, K, act, out_dtype == MP_F32, alpha};
+  const int waves = act == ACT_SWIGLU_PAIR ? N / 4 : (int)mp_cdiv(N, 4);
+  const dim3 grid((unsigned)mp_cdiv(waves, 4));
+  if (w_index) {
+    if (act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL(gemv_indexed_kernel<true>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gemv_indexed_kernel<false>, grid, dim3(256), 0, stream, g);
+    return mp_check_launch("mp_gemv_bf16(indexed)");
+  }
+  switch (M) {
+    case 1: launch_shared<1>(g, grid, stream); break;
+    case 2: launch_shared<2>(g, grid, stream); break;
+    case 3: launch_shared<3>(g, grid, stream); break;
+    case 4: launch_shared<4>(g, grid, stream); break;
+    default: {      // 5..8 rows: two passes of <= 4 over the same weights
+      GemvArgs a = g; a.M = 4; launch_shared<4>(a, grid, stream);
+      GemvArgs b = g; b.M = M - 4; b.x = g.x + 4 * ldx;
+      b.y = g.out_f32 ? (void*)(reinterpret_cast<float*>(y) + 4 * ldy) : (void*)(reinterpret_cast<bf16_t*>(y) + 4 * ldy);
+      if (g.residual) b.residual = g.residual + 4 * ldr;
+      switch (b.M) { case 1: launch_shared<1>(b, grid, stream); break; case 2: launch_shared<2>(b, grid, stream); break;
+                     case 3: launch_shared<3>(b, grid, stream); break; default: launch_shared<4>(b, grid, stream); }
+    }
+  }
+  return mp_check_launch("mp_gemv_bf16");
+}

@@ -134,12 +134,21 @@ class LlamaStack:
         cfg = self.cfg
         T = h.shape[0]
         if i not in self.moe_layers:
+            if T <= 8:
+                return ops.gemv(ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR), lw["down"], residual=x), None, None
             act = ops.gemm(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR)       # silu(gate)*up fused into the GEMM epilogue
             return ops.gemm(act, lw["down"], residual=x), None, None
         E, ff, d = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
         cap = self.capacity(T)
         k = cfg.top_k_experts
         logits, gates = ops.moe_gate(h, lw["wg"])
+        if k == 1 and self.ep is None and T <= 8:
+            # decode rows: each row streams its own expert's matrices (GEMV with a device-side expert index); the combine weight,
+            # the capacity drop and the residual ride in the down projection's epilogue
+            expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
+            act = ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR, w_index=expert)
+            out = ops.gemv(act, lw["down"], residual=x, w_index=expert, row_scale=weight, row_keep=slot)
+            return out, l_aux, (expert, slot, counts)
         if k == 1 and self.ep is None and self.fuse_moe_gather_scatter:
             # top-1 on one rank: the dispatch is a row gather in the gate|up GEMM's operand fetch and the combine (gate weight and
             # the layer's residual add) a row scatter in the down GEMM's epilogue; every routed token's row is written exactly once,
@@ -206,9 +215,11 @@ class LlamaStack:
         aux, routing = [], []
         self.gate_pass += 1
         pos0 = kv_cache["len"] if kv_cache is not None else 0
+        # a handful of rows (the single-token decode steps): the projections are weight streams -> GEMV kernel (HBM-bound)
+        lin = (lambda a, w, **kw: ops.gemv(a, w, **kw)) if B * S <= 8 else (lambda a, w, **kw: ops.gemm(a, w, **kw))
         for i, lw in enumerate(self.layers):
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
-            qkv = ops.gemm(h, lw["qkv"])
+            qkv = lin(h, lw["qkv"])
             ops.rope_qk_(qkv, self.cos, self.sin, S, H, D, pos_offset=pos0)
             q5 = qkv.view(B, S, 3, H, D)
             if kv_cache is not None:
@@ -219,7 +230,7 @@ class LlamaStack:
                 attn = ops.attention(q5[:, :, 0], kv_cache["k"][i][:, :pos0 + 1], kv_cache["v"][i][:, :pos0 + 1], causal=False)
             else:
                 attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
-            x = ops.gemm(attn.view(B * S, d), lw["o"], residual=x)
+            x = lin(attn.view(B * S, d), lw["o"], residual=x)
             h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
             x, l_aux, r = self._mlp(i, lw, h, x)
             if l_aux is not None:
@@ -233,7 +244,10 @@ class LlamaStack:
 
     def next_token_logits(self, hidden_row):
         """fp32 logits of one position: lm_head(hidden).float() (medplib_moe_llama.py:388-389).  hidden_row [n, d] bf16."""
-        return ops.gemm(hidden_row.contiguous(), self.lm_head, out_dtype=torch.float32)
+        h = hidden_row.contiguous()
+        if h.shape[0] <= 8:
+            return ops.gemv(h, self.lm_head, out_dtype=torch.float32)
+        return ops.gemm(h, self.lm_head, out_dtype=torch.float32)
 
     def cross_entropy(self, last_hidden, sup_rows, sup_labels, aux):
         """CE over supervised rows only (row-wise op; unsupervised rows never reach the loss — SURVEY B.8):

@@ -134,6 +134,20 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
     return out
 
 
+def gemv(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, alpha=1.0, w_index=None, row_scale=None, row_keep=None):
+    """x [M <= 8, K] bf16; w [N, K] bf16 or, with w_index (int32 [M] device), [E, N, K] with row m using w[w_index[m]].
+    Decode-step projections (HBM-bound weight stream)."""
+    _chk(x, torch.bfloat16, "gemv.x"); _chk(w, torch.bfloat16, "gemv.w")
+    M, K = x.shape
+    N = w.shape[-2]
+    assert x.stride(1) == 1 and w.stride(-1) == 1
+    out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
+    lib().call("mp_gemv_bf16", _p(x), x.stride(0), _p(w), w.stride(-2), w.stride(0) if w.dim() == 3 else 0, _p(out), out.stride(0), _p(bias),
+               _p(residual), residual.stride(0) if residual is not None else 0, _p(w_index), _p(row_scale), _p(row_keep), M, N, K, act,
+               _dt(out_dtype), float(alpha), _stream())
+    return out
+
+
 def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
     """a [E,M,K], w [E,N,K], out [E,M,N] (bf16 or f32); m_dev int32 [E] device row counts."""
     _chk(a, torch.bfloat16, "gemm_batched.a"); _chk(w, torch.bfloat16, "gemm_batched.w")

@@ -257,3 +257,33 @@ def test_gemm_swiglu_pair_epilogue(dev):
         ref = O.swiglu(ab[e, :c].float() @ wgs[e].float().T, ab[e, :c].float() @ wus[e].float().T)
         _report(f"swiglu-pair expert {e}", out[e, :c], ref, rtol=3 * BF16_EPS, atol=2e-2)
         assert (out[e, c:].float() == 0).all()
+
+
+def test_gemv_decode_projections(dev):
+    """mp_gemv_bf16 (decode-step projections) vs the oracle and vs the GEMM path: plain / residual / fp32-out with a ragged N /
+    K not a multiple of 512 / SwiGLU pairing over interleaved gate|up rows / per-row expert selection with gate scale and drop."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(41)
+    for M, N, K in ((1, 768, 512), (3, 1000, 1024), (1, 515, 4096), (2, 256, 1408), (6, 192, 640)):
+        x = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.05)
+        res = _bf(torch.randn(M, N, generator=g)); bias = torch.randn(N, generator=g)
+        ref = O.linear(x.float(), w.float())
+        _report(f"gemv {M}x{N}x{K}", ops.gemv(x.to(dev), w.to(dev)), ref, rtol=2 * BF16_EPS, atol=1e-3 * math.sqrt(K))
+        _report(f"gemv f32 out {M}x{N}x{K}", ops.gemv(x.to(dev), w.to(dev), out_dtype=torch.float32), ref, rtol=1e-4, atol=2e-3)
+        out = ops.gemv(x.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), act=ops.ACT_SILU)
+        _report(f"gemv epilogue {M}x{N}x{K}", out, torch.nn.functional.silu(ref + bias) + res.float(), rtol=3 * BF16_EPS, atol=3e-2)
+    # SwiGLU pair: must equal the fused GEMM epilogue's result on the same interleaved weights (same rounding points)
+    M, ff, K = 2, 320, 1024
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    wg = _bf(torch.randn(ff, K, generator=g) * 0.1).to(dev); wu = _bf(torch.randn(ff, K, generator=g) * 0.1).to(dev)
+    wi = ops.swiglu_interleave(wg, wu)
+    ref = O.swiglu(O.linear(x.float().cpu(), wg.float().cpu()), O.linear(x.float().cpu(), wu.float().cpu()))
+    _report("gemv swiglu pair", ops.gemv(x, wi, act=ops.ACT_SWIGLU_PAIR), ref, rtol=3 * BF16_EPS, atol=2e-2)
+    # experts: row m uses w[idx[m]]; combine scale, capacity drop (keep < 0) and residual
+    E, N, K, M = 3, 256, 512, 4
+    x = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(E, N, K, generator=g) * 0.05); res = _bf(torch.randn(M, N, generator=g))
+    idx = torch.tensor([2, 0, 1, 2], dtype=torch.int32); scale = torch.tensor([0.7, 0.9, 0.55, 0.6]); keep = torch.tensor([0, 3, -1, 1], dtype=torch.int32)
+    out = ops.gemv(x.to(dev), w.to(dev), residual=res.to(dev), w_index=idx.to(dev), row_scale=scale.to(dev), row_keep=keep.to(dev))
+    ref = torch.stack([res[m].float() + (0.0 if keep[m] < 0 else scale[m]) * (x[m].float() @ w[idx[m]].float().t()).to(torch.bfloat16).float() for m in range(M)])
+    _report("gemv experts", out, ref, rtol=2 * BF16_EPS, atol=2e-2)
+    assert torch.equal(out[2].cpu(), res[2]), "a capacity-dropped row keeps the residual stream exactly"
