@@ -212,6 +212,12 @@ def test_model_forward_losses_and_grads(dev, moe, ragged):
         res = m(**gb)
     assert len(res["pred_masks"]) == 3 and res["pred_masks"][0].shape == (1, 96, 80)
     _stat("pred_mask[0]", res["pred_masks"][0], inter["pred_masks"][0], atol=0.15)
+    # BASELINE target: segmentation Dice of the thresholded masks (sigmoid > 0.1) within 1e-3 of the reference CPU path
+    for i in range(3):
+        _, _, _, dice_ref = O.threshold_iou(inter["pred_masks"][i][0], batch["masks_list"][i])
+        _, _, _, dice_hip = O.threshold_iou(res["pred_masks"][i][0].float().cpu(), batch["masks_list"][i])
+        print(f"dice[{i}] oracle {dice_ref:.5f} hip {dice_hip:.5f}")
+        assert abs(dice_ref - dice_hip) <= 1e-3
 
 
 def test_engine_step_matches_reference_adamw(dev):
