@@ -89,7 +89,9 @@ int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes,
 int mp_attention_fwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss,
                           const void* V, int64_t v_sb, int64_t v_ss, void* O, int64_t o_sb, int64_t o_ss,
                           const uint8_t* key_valid, const float* rel_h, const float* rel_w, int kh, int kw, int B, int H,
-                          int Sq, int Sk, int D, int causal, float scale, int variant, hipStream_t stream);
+                          int Sq, int Sk, int D, int causal, float scale, int variant, const int* sk_dev, hipStream_t stream);
+/* (sk_dev, optional: the number of valid keys, <= Sk, read from device memory — the KV-cache length of a decode step that lives in
+ * a HIP graph, where launch arguments cannot change from token to token.) */
 
 /* LlamaRMSNorm (HF 4.31; medplib_moe_llama.py:121,138,286). */
 int mp_rmsnorm_bf16(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy, int64_t rows, int dim, float eps,
@@ -100,6 +102,13 @@ int mp_layernorm_bf16(const void* x, int64_t ldx, const float* w, const float* b
 /* Half-split RoPE on the q and k thirds of a fused [tokens, 3*H*D] buffer. */
 int mp_rope_qk_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
                     int head_dim, int pos_offset, hipStream_t stream);
+/* One decode step of the KV-cache path (prepare_inputs_for_generation + LlamaAttention with past_key_value, medplib_moe_llama.py:
+ * 451-485; HF 4.31): RoPE of the single new token of each sequence at position *pos_dev (device), q rotated in place inside the
+ * fused qkv row, rotated k and v appended to the caches at that position.  mp_advance_ints bumps the device-side counters. */
+int mp_decode_rope_append_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, void* cache_k, void* cache_v,
+                               const int* pos_dev, int B, int heads, int head_dim, int64_t cache_batch_stride, int64_t cache_seq_stride,
+                               hipStream_t stream);
+int mp_advance_ints(int* p, int n, int delta, hipStream_t stream);
 /* greedy next-token pick over fp32 logits (HF generate do_sample=False, MedPLIB.py:592-606). */
 int mp_argmax_rows_f32(const float* x, int64_t ld, int64_t rows, int cols, int64_t* out, hipStream_t stream);
 /* out = silu(gu[:, :ff]) * gu[:, ff:]  (LlamaMLP). */

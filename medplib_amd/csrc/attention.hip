@@ -34,6 +34,7 @@ struct AttnArgs {
   int B, H, Sq, Sk;
   int causal;
   float scale;
+  const int* sk_dev;         // optional: number of valid keys read from device memory (<= Sk); decode steps inside a HIP graph
 };
 
 template <int D>
@@ -43,6 +44,7 @@ __device__ __forceinline__ int k_off(int r, int c) {  // byte offset of 16-B chu
 
 template <int D, bool VT_SCALAR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
   constexpr int KT = 64;            // keys per tile
   constexpr int CH = D / 8;         // 16-B chunks per row
   constexpr int NF = D / 16;        // output fragments along D
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // (no causal diagonal, no padding, no bias) skip every mask test.
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
+  if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
   constexpr int KT = 64, CH = D / 8, NF = D / 16, KS = D / 32;
   constexpr int TILE_BYTES = KT * D * 2;          // one operand, one stage
   constexpr int RPI = 1024 / (D * 2);             // rows per 1-KiB DMA instruction
@@ -435,6 +438,143 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }
 
+}  // namespace
+
+// =====================================================================================================================
+// Decode attention (one query per sequence against the KV cache): no MFMA tile fits a single row, and the 128-query kernel
+// walks the key tiles of a head serially on one CU (~25 us at 700 keys, 32 CUs busy).  Flash-decoding layout instead: the keys of
+// a (sequence, head) are split over NS workgroups (all 256 CUs stream K / V); inside a workgroup CH = D/8 lanes share a key row
+// (16-byte loads, partial dot, shuffle reduction), scores sit in LDS, a block-wide max / sum, then the same lanes accumulate
+// p * V.  Every split leaves (max, sum, unnormalised o[D]) in the workspace, takes a ticket, and the last arriver of the head
+// merges the NS partials in split order.  fp32 throughout, P rounded to bf16 before the PV product like the tiled kernels.
+// Workspace / tickets: the registered split-K scratch of the GEMM (mp_gemm_set_workspace); without it NS = 1.
+void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
+
+namespace {
+
+constexpr int DEC_MAX_CHUNK = 2048;         // keys per split held in LDS
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, float* __restrict__ ws, int* __restrict__ tickets, int NS) {
+  constexpr int CH = D / 8;               // lanes per key row
+  constexpr int KPB = 256 / CH;           // keys per block-iteration
+  __shared__ float sc[DEC_MAX_CHUNK];
+  __shared__ float red[16];
+  __shared__ float part[KPB][D];
+  __shared__ int s_ticket;
+  const int Sk = a.sk_dev ? min(a.Sk, a.sk_dev[0]) : a.Sk;
+  const int tid = threadIdx.x;
+  const int c = tid % CH, kg = tid / CH;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int split = blockIdx.y;
+  int chunk = (Sk + NS - 1) / NS;
+  chunk = ((chunk + KPB - 1) / KPB) * KPB;
+  const int k_lo = min(Sk, split * chunk), k_hi = min(Sk, k_lo + chunk);
+  const bf16_t* Kb = a.K + b * a.k_sb + (int64_t)h * D;
+  const bf16_t* Vb = a.V + b * a.v_sb + (int64_t)h * D;
+  const bf16x8 qv = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_sb + (int64_t)h * D + c * 8);
+  float q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (float)qv[j];
+  // ---- scores of this split's keys (two key rows in flight per lane)
+  float mx = -INFINITY;
+  for (int k0 = k_lo; k0 < k_hi; k0 += 2 * KPB) {
+    const int key0 = k0 + kg, key1 = k0 + KPB + kg;
+    bf16x8 kv0 = {}, kv1 = {};
+    if (key0 < k_hi) kv0 = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)key0 * a.k_ss + c * 8);
+    if (key1 < k_hi) kv1 = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)key1 * a.k_ss + c * 8);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d0 = fmaf(q[j], (float)kv0[j], d0); d1 = fmaf(q[j], (float)kv1[j], d1); }
+#pragma unroll
+    for (int off = 1; off < CH; off <<= 1) { d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); }
+    if (key0 < k_hi) { d0 *= a.scale; if (c == 0) sc[key0 - k_lo] = d0; mx = fmaxf(mx, d0); }
+    if (key1 < k_hi) { d1 *= a.scale; if (c == 0) sc[key1 - k_lo] = d1; mx = fmaxf(mx, d1); }
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = tid; k < k_hi - k_lo; k += 256) {
+    const float p = __expf(sc[k] - mx);
+    sum += p;
+    sc[k] = (float)(bf16_t)p;               // P is rounded to bf16 before PV (HF: softmax(...).to(q.dtype))
+  }
+  sum = block_sum(sum, red);                // (also orders the sc[] writes before the reads below)
+  // ---- unnormalised o = P V over this split
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  for (int key = k_lo + kg; key < k_hi; key += 2 * KPB) {
+    const int key1 = key + KPB;
+    const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)key * a.v_ss + c * 8);
+    bf16x8 v1 = {};
+    float p1 = 0.f;
+    if (key1 < k_hi) { v1 = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)key1 * a.v_ss + c * 8); p1 = sc[key1 - k_lo]; }
+    const float p0 = sc[key - k_lo];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fmaf(p1, (float)v1[j], fmaf(p0, (float)v0[j], o[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[kg][c * 8 + j] = o[j];
+  __syncthreads();
+  float t = 0.f;
+  if (tid < D) {
+#pragma unroll 4
+    for (int g2 = 0; g2 < KPB; ++g2) t += part[g2][tid];
+  }
+  bf16_t* Op = a.O + b * a.o_sb + (int64_t)h * D;
+  if (NS == 1) {
+    if (tid < D) Op[tid] = (bf16_t)(sum > 0.f ? t / sum : 0.f);
+    return;
+  }
+  // ---- partial (max, sum, o[D]) to the workspace; last arriver of the head merges in split order
+  float* wsh = ws + (int64_t)bh * NS * (D + 2);
+  float* mine = wsh + split * (D + 2);
+  if (tid < D) __hip_atomic_store(mine + 2 + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) { __hip_atomic_store(mine, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(mine + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(tickets + bh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != NS - 1) return;
+  if (tid == 0) __hip_atomic_store(tickets + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < D) {
+    float M = -INFINITY;
+    for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, __hip_atomic_load(wsh + sp * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float L = 0.f, acc = 0.f;
+    for (int sp = 0; sp < NS; ++sp) {
+      const float ms = __hip_atomic_load(wsh + sp * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+      L += w * __hip_atomic_load(wsh + sp * (D + 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc += w * __hip_atomic_load(wsh + sp * (D + 2) + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    Op[tid] = (bf16_t)(L > 0.f ? acc / L : 0.f);
+  }
+}
+
+template <int D>
+int launch_attn_decode(const AttnArgs& a, hipStream_t stream) {
+  float* ws = nullptr; int* tickets = nullptr; int64_t bytes = 0;
+  mp_gemm_split_workspace(stream, &ws, &tickets, &bytes);
+  int NS = 1;
+  if (ws && a.B * a.H <= 256) {
+    NS = 256 / (a.B * a.H);
+    NS = NS < 1 ? 1 : (NS > 16 ? 16 : NS);
+    while (NS > 1 && (int64_t)a.B * a.H * NS * (D + 2) * 4 > bytes) --NS;
+  }
+  while ((a.Sk + NS - 1) / NS + 64 > DEC_MAX_CHUNK) ++NS;               // a split's scores must fit the LDS array
+  if (NS > 1 && !ws) return -1;
+  hipLaunchKernelGGL((attn_decode_kernel<D>), dim3(a.B * a.H, NS), dim3(256), 0, stream, a, ws, tickets, NS);
+  return mp_check_launch("mp_attention_fwd_bf16(decode)");
+}
+
+}  // namespace
+
+namespace {
+
 template <int D, bool VT_SCALAR>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
   constexpr int KT = 64, VT_LD = KT + 8;
@@ -451,7 +591,7 @@ extern "C" int mp_attention_fwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, 
                                      const void* V, int64_t v_sb, int64_t v_ss, void* O, int64_t o_sb, int64_t o_ss,
                                      const uint8_t* key_valid, const float* rel_h, const float* rel_w, int kh, int kw,
                                      int B, int H, int Sq, int Sk, int D, int causal, float scale, int variant,
-                                     hipStream_t stream) {
+                                     const int* sk_dev, hipStream_t stream) {
   MP_REQUIRE(D == 64 || D == 128, MP_ERR_SHAPE, "mp_attention_fwd_bf16: head_dim %d unsupported (64/128)", D);
   MP_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, MP_ERR_SHAPE, "mp_attention_fwd_bf16: bad shape");
   MP_REQUIRE((q_ss % 8 == 0) && (k_ss % 8 == 0) && (v_ss % 8 == 0), MP_ERR_SHAPE,
@@ -459,10 +599,14 @@ extern "C" int mp_attention_fwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, 
   MP_REQUIRE((rel_h == nullptr) == (rel_w == nullptr), MP_ERR_ARG, "mp_attention_fwd_bf16: rel_h/rel_w must come together");
   MP_REQUIRE(!rel_h || (kh > 0 && kw > 0 && kh * kw == Sk), MP_ERR_SHAPE, "mp_attention_fwd_bf16: kh*kw must equal Sk");
   AttnArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss,
-             o_sb, o_ss, key_valid, rel_h, rel_w, kh, kw, B, H, Sq, Sk, causal, scale};
+             o_sb, o_ss, key_valid, rel_h, rel_w, kh, kw, B, H, Sq, Sk, causal, scale, sk_dev};
   MP_REQUIRE(o_ss % 4 == 0, MP_ERR_SHAPE, "mp_attention_fwd_bf16: output sequence stride must be a multiple of 4 elements");
   // variant 0 = transposed-formulation kernel (default); 1 = first-generation kernel with scalar-transposed V; 2 = first-generation
   // kernel with the hardware transpose read (both kept as cross-checks)
+  if (variant == 0 && Sq == 1 && !causal && !key_valid && !rel_h && Sk <= 16 * (DEC_MAX_CHUNK - 64)) {   // single-query decode step
+    const int rc = D == 64 ? launch_attn_decode<64>(a, stream) : launch_attn_decode<128>(a, stream);
+    if (rc >= 0) return rc;                                                           // (-1: needs the workspace -> tiled kernel)
+  }
   // (short rel-pos attention — SAM windows / global blocks, S <= 256 — stays on the 64-query-row kernel: more workgroups for the
   // same work and a per-row bias lookup; measured 24 vs 37 us on the global blocks)
   if (variant == 0 && !(rel_h && Sq <= 256)) return D == 64 ? launch_attn2<64>(a, stream) : launch_attn2<128>(a, stream);

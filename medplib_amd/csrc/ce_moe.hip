@@ -242,6 +242,65 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
     for (int e = 0; e < E; ++e) kept_counts[e] = min(base[e], capacity);
 }
 
+// ---------------- top-1 routing for a handful of tokens (T <= 64: the decode steps): one wave, lane = token ----------------
+// Same outputs as moe_route_top1_kernel; the 1024-thread kernel spends ~25 us in block-wide reductions, which at 32 layers is a
+// fifth of a decode step.
+__global__ __launch_bounds__(64) void moe_route_top1_small_kernel(const float* __restrict__ gates, const float* __restrict__ rts, int T,
+                                                                  int E, int capacity, int* __restrict__ expert, int* __restrict__ slot,
+                                                                  float* __restrict__ weight, int* __restrict__ kept_counts,
+                                                                  long long* __restrict__ exp_counts, float* __restrict__ l_aux,
+                                                                  int* __restrict__ slot_token) {
+  const int s = threadIdx.x;
+  const bool live = s < T;
+  int best = 0;
+  float bv = live ? gates[(int64_t)s * E] : 0.f;
+  float aux = 0.f;
+  for (int e = 1; e < E; ++e) {
+    const float g = live ? gates[(int64_t)s * E + e] : 0.f;
+    if (g > bv) { bv = g; best = e; }
+  }
+  for (int e = 0; e < E; ++e) {
+    const float me = wave_sum(live ? gates[(int64_t)s * E + e] : 0.f) / (float)T;
+    const unsigned long long m = __ballot(live && best == e);
+    aux += me * ((float)__popcll(m) / (float)T);
+    if (s == 0) exp_counts[e] = __popcll(m);
+  }
+  if (s == 0) l_aux[0] = aux * (float)E;
+  // keep decision: over-capacity experts keep their `capacity` largest draws (ties: lower token first) or, without draws, the
+  // first `capacity` tokens
+  int keep = live ? 1 : 0;
+  unsigned long long same = 0;                      // the live tokens that chose this lane's expert
+  for (int e = 0; e < E; ++e) {
+    const unsigned long long m = __ballot(live && best == e);
+    if (best == e) same = m;
+  }
+  if (live && __popcll(same) > capacity) {
+    int rank = 0;
+    if (rts) {
+      const float u = rts[(int64_t)s * E + best];
+      for (int t = 0; t < T; ++t) {
+        if (!((same >> t) & 1ull)) continue;
+        const float ut = rts[(int64_t)t * E + best];
+        rank += (ut > u) || (ut == u && t < s);
+      }
+    } else {
+      rank = __popcll(same & ((1ull << s) - 1ull));
+    }
+    keep = rank < capacity;
+  }
+  // slots = rank among the KEPT tokens of the same expert in token order
+  int my_slot = -1;
+  for (int e = 0; e < E; ++e) {
+    const unsigned long long km = __ballot(live && keep && best == e);
+    if (live && keep && best == e) my_slot = __popcll(km & ((1ull << s) - 1ull));
+    if (s == 0) kept_counts[e] = min(__popcll(km), capacity);
+  }
+  if (live) {
+    expert[s] = best; weight[s] = bv; slot[s] = my_slot;
+    if (slot_token && my_slot >= 0) slot_token[(int64_t)best * capacity + my_slot] = s;
+  }
+}
+
 // buf[expert[j*T + s], slot[j*T + s], :] = x[s, :]   for the top_k choices j of token s
 __global__ void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int* __restrict__ expert, const int* __restrict__ slot,
                                     bf16_t* __restrict__ buf, int64_t T, int d, int capacity, int top_k) {
@@ -448,6 +507,11 @@ extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, i
                                  int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, int* slot_token,
                                  hipStream_t stream) {
   MP_REQUIRE(n_experts >= 1 && n_experts <= MAXE && tokens > 0 && capacity >= 0, MP_ERR_SHAPE, "mp_moe_route_top1: bad shape");
+  if (tokens <= 64) {
+    hipLaunchKernelGGL(moe_route_top1_small_kernel, dim3(1), dim3(64), 0, stream, gates, rts_uniform, tokens, n_experts, capacity, expert,
+                       slot, weight, kept_counts, exp_counts, l_aux, slot_token);
+    return mp_check_launch("mp_moe_route_top1(small)");
+  }
   hipLaunchKernelGGL(moe_route_top1_kernel, dim3(1), dim3(1024), 0, stream, gates, rts_uniform, tokens, n_experts, capacity, expert,
                      slot, weight, kept_counts, exp_counts, l_aux, slot_token);
   return mp_check_launch("mp_moe_route_top1");

@@ -168,6 +168,42 @@ __global__ void rope_qk_bf16_kernel(bf16_t* __restrict__ qkv, const float* __res
   *reinterpret_cast<bf16x8*>(base + half + c) = ohi;
 }
 
+// Decode step (one new token per sequence): RoPE at the cached length read from DEVICE memory (so the launch arguments do not
+// change from token to token and the step can live in a HIP graph), q rotated in place, the rotated k and the v appended to the
+// KV cache at that position.  One thread per (sequence, head, 8 rotary pairs).
+__global__ void decode_rope_append_kernel(bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ cos_t,
+                                          const float* __restrict__ sin_t, bf16_t* __restrict__ ck, bf16_t* __restrict__ cv,
+                                          const int* __restrict__ pos_dev, int B, int H, int D, int64_t c_sb, int64_t c_ss) {
+  const int half = D / 2, per_head = half / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H * per_head) return;
+  const int c = (idx % per_head) * 8, h = (idx / per_head) % H, b = idx / (per_head * H);
+  const int pos = pos_dev[0];
+  const float* cs = cos_t + (int64_t)pos * half + c;
+  const float* sn = sin_t + (int64_t)pos * half + c;
+  bf16_t* q = qkv + (int64_t)b * ld + (int64_t)h * D;
+  bf16_t* k = q + (int64_t)H * D;
+  const bf16_t* v = k + (int64_t)H * D;
+  bf16_t* kd = ck + b * c_sb + (int64_t)pos * c_ss + (int64_t)h * D;
+  bf16_t* vd = cv + b * c_sb + (int64_t)pos * c_ss + (int64_t)h * D;
+  const bf16x8 qlo = *reinterpret_cast<const bf16x8*>(q + c), qhi = *reinterpret_cast<const bf16x8*>(q + half + c);
+  const bf16x8 klo = *reinterpret_cast<const bf16x8*>(k + c), khi = *reinterpret_cast<const bf16x8*>(k + half + c);
+  bf16x8 oql, oqh, okl, okh;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = (float)qlo[j], bq = (float)qhi[j], ka = (float)klo[j], kb = (float)khi[j];
+    oql[j] = (bf16_t)(a * cs[j] - bq * sn[j]); oqh[j] = (bf16_t)(bq * cs[j] + a * sn[j]);
+    okl[j] = (bf16_t)(ka * cs[j] - kb * sn[j]); okh[j] = (bf16_t)(kb * cs[j] + ka * sn[j]);
+  }
+  *reinterpret_cast<bf16x8*>(q + c) = oql; *reinterpret_cast<bf16x8*>(q + half + c) = oqh;
+  *reinterpret_cast<bf16x8*>(kd + c) = okl; *reinterpret_cast<bf16x8*>(kd + half + c) = okh;
+  *reinterpret_cast<bf16x8*>(vd + c) = *reinterpret_cast<const bf16x8*>(v + c);
+  *reinterpret_cast<bf16x8*>(vd + half + c) = *reinterpret_cast<const bf16x8*>(v + half + c);
+}
+__global__ void advance_ints_kernel(int* p, int n, int delta) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] += delta;
+}
+
 // out[T, F] = silu(gu[T, 0:F]) * gu[T, F:2F]
 __global__ void swiglu_bf16_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int64_t T, int F, int64_t ldgu,
                                    int64_t ldo) {
@@ -297,6 +333,24 @@ extern "C" int mp_rope_qk_bf16(void* qkv, int64_t ld, const float* cos_t, const 
   hipLaunchKernelGGL(rope_qk_bf16_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (bf16_t*)qkv, cos_t, sin_t,
                      tokens, seq, heads, head_dim, ld, pos_offset);
   return mp_check_launch("mp_rope_qk_bf16");
+}
+
+extern "C" int mp_decode_rope_append_bf16(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, void* cache_k, void* cache_v,
+                                          const int* pos_dev, int B, int heads, int head_dim, int64_t cache_batch_stride,
+                                          int64_t cache_seq_stride, hipStream_t stream) {
+  MP_REQUIRE(head_dim % 16 == 0 && ld % 8 == 0 && pos_dev != nullptr, MP_ERR_SHAPE, "mp_decode_rope_append_bf16: bad shape");
+  const int n = B * heads * (head_dim / 16);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(decode_rope_append_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (bf16_t*)qkv, ld, cos_t, sin_t,
+                     (bf16_t*)cache_k, (bf16_t*)cache_v, pos_dev, B, heads, head_dim, cache_batch_stride, cache_seq_stride);
+  return mp_check_launch("mp_decode_rope_append_bf16");
+}
+
+extern "C" int mp_advance_ints(int* p, int n, int delta, hipStream_t stream) {
+  MP_REQUIRE(n >= 0 && n <= 64, MP_ERR_SHAPE, "mp_advance_ints: n <= 64");
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(advance_ints_kernel, dim3(1), dim3(64), 0, stream, p, n, delta);
+  return mp_check_launch("mp_advance_ints");
 }
 
 extern "C" int mp_swiglu_bf16(const void* gu, int64_t ldgu, void* out, int64_t ldo, int64_t rows, int ff,

@@ -145,7 +145,10 @@ class LlamaStack:
         if k == 1 and self.ep is None and T <= 8:
             # decode rows: each row streams its own expert's matrices (GEMV with a device-side expert index); the combine weight,
             # the capacity drop and the residual ride in the down projection's epilogue
-            expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
+            # (no gate draws: random token selection only acts when an expert is over capacity, and capacity >= T for these rows
+            #  only when cap >= T; otherwise the draws are generated as usual)
+            draws = None if cap >= T else self._gate_draws(i, T, E, gumbel=False)
+            expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, draws)
             act = ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR, w_index=expert)
             out = ops.gemv(act, lw["down"], residual=x, w_index=expert, row_scale=weight, row_keep=slot)
             return out, l_aux, (expert, slot, counts)
@@ -241,6 +244,27 @@ class LlamaStack:
             kv_cache["len"] = pos0 + S
         out = ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps)
         return out.view(B, S, d), aux, (routing if collect_routing else None)
+
+    def decode_step(self, emb, kv_cache, counters):
+        """One token per sequence against the KV cache with the cache length held ON THE DEVICE (`counters` int32 [2] =
+        [position of the new token, number of valid keys after appending it]): no launch argument depends on the step, so the
+        whole step can be captured once into a HIP graph and replayed per token (evaluate()).  emb [B, 1, d] -> hidden [B, 1, d].
+        The caller advances `counters` (ops.advance_ints) after the step."""
+        cfg = self.cfg
+        B, _, d = emb.shape
+        H, D = cfg.num_attention_heads, cfg.head_dim
+        x = emb.reshape(B, d)
+        self.gate_pass += 1
+        for i, lw in enumerate(self.layers):
+            h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
+            qkv = ops.gemv(h, lw["qkv"])
+            ops.decode_rope_append(qkv, self.cos, self.sin, kv_cache["k"][i], kv_cache["v"][i], counters[0:1], H, D)
+            q4 = qkv.view(B, 1, 3, H, D)[:, :, 0]
+            attn = ops.attention(q4, kv_cache["k"][i], kv_cache["v"][i], causal=False, sk_dev=counters[1:2])
+            x = ops.gemv(attn.view(B, d), lw["o"], residual=x)
+            h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
+            x, _, _ = self._mlp(i, lw, h, x)
+        return ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps).view(B, 1, d)
 
     def next_token_logits(self, hidden_row):
         """fp32 logits of one position: lm_head(hidden).float() (medplib_moe_llama.py:388-389).  hidden_row [n, d] bf16."""

@@ -106,6 +106,7 @@ class MedPLIBForCausalLM(nn.Module):
         # instead of holding the machine at a few percent occupancy.  The calling stream waits for the tail FORWARD before
         # model_forward returns (the loss dict is safe to read); backward and optimizer stay asynchronous to it and are ordered
         # against the next tail by the tail stream itself.  Anything else that touches trainable state calls sync_side_streams().
+        self.decode_with_graph = True            # evaluate(): replay one captured HIP graph per generated token
         self.tail_side_stream = False
         self._tail_stream_obj = None
         self.active_tail_stream = None
@@ -410,6 +411,51 @@ class MedPLIBForCausalLM(nn.Module):
         return {k: out10[i] for i, k in enumerate(LOSS_KEYS)}
 
 
+    def _decode_graph(self, prefill_hidden, cache, S, max_new_tokens, eos_token_id, check_every=16):
+        """Greedy decode with ONE captured HIP graph per call: embed(token) -> 32 decode layers (GEMV projections, RoPE + KV append
+        and attention at the device-side cache length) -> final norm -> lm_head -> argmax -> next token, all on the device; the host
+        replays the graph once per token (~450 kernel launches otherwise) and only looks at the generated ids every `check_every`
+        tokens to stop at EOS.  Tokens after the first EOS are discarded, so the result equals the token-by-token loop.
+        Returns (generated ids, [hidden of each fed token])."""
+        cfg, dev, llm = self.config, self.device_, self.model.llm
+        d = cfg.hidden_size
+        tok = ops.argmax_rows(llm.next_token_logits(prefill_hidden[0, -1:]))              # first generated token, int64 [1] on the device
+        counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
+        toks = torch.empty(max_new_tokens, dtype=torch.int64, device=dev)
+        hid_all = torch.empty((max_new_tokens, d), dtype=torch.bfloat16, device=dev)
+        toks[0:1].copy_(tok)
+        h_static = torch.empty((1, 1, d), dtype=torch.bfloat16, device=dev)
+
+        def step():
+            emb = ops.splice_rows(llm.embed_tokens, None, tok, d)
+            h = llm.decode_step(emb.view(1, 1, d), cache, counters)
+            h_static.copy_(h)
+            tok.copy_(ops.argmax_rows(llm.next_token_logits(h[0, -1:])))
+            ops.advance_ints(counters, 1)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        n, done = 1, False
+        while n < max_new_tokens and not done:
+            upto = min(max_new_tokens, n + check_every)
+            for i in range(n, upto):
+                graph.replay()                                   # feeds token i-1, produces token i
+                hid_all[i - 1:i].copy_(h_static.view(1, d))
+                toks[i:i + 1].copy_(tok)
+            got = toks[:upto].cpu().tolist()                     # the only host synchronisation of the loop
+            n = upto
+            if eos_token_id in got:
+                n = got.index(eos_token_id) + 1
+                done = True
+        generated = toks[:n].cpu().tolist()
+        step_hiddens = [hid_all[i:i + 1].view(1, 1, d) for i in range(n - 1)]
+        return generated, step_hiddens
+
     # ------------------------------------------------------------------ evaluate (MedPLIB.py:574-680)
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, region_masks=(), valid_region_masks_bool=(),
@@ -437,17 +483,22 @@ class MedPLIBForCausalLM(nn.Module):
         embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(1, S, cfg.hidden_size)
         cache = m.llm.new_kv_cache(1, S + max_new_tokens)
         hidden, _, _ = m.llm.forward(embeds, None, kv_cache=cache)
-        hiddens = [hidden]
-        generated = []
-        for _ in range(max_new_tokens):
-            logits = m.llm.next_token_logits(hiddens[-1][0, -1:])
-            tok = int(ops.argmax_rows(logits)[0])
-            generated.append(tok)
-            if tok == eos_token_id or len(generated) == max_new_tokens:
-                break
-            emb = ops.splice_rows(m.llm.embed_tokens, None, torch.tensor([tok], dtype=torch.int64, device=dev), cfg.hidden_size)
-            h, _, _ = m.llm.forward(emb.view(1, 1, -1), None, kv_cache=cache)
-            hiddens.append(h)
+        if self.decode_with_graph and max_new_tokens > 2 and cfg.top_k_experts == 1:
+            generated, step_hiddens = self._decode_graph(hidden, cache, S, max_new_tokens, eos_token_id)
+        else:
+            generated, step_hiddens = [], []
+            last = hidden[0, -1:]
+            for _ in range(max_new_tokens):
+                logits = m.llm.next_token_logits(last)
+                tok = int(ops.argmax_rows(logits)[0])
+                generated.append(tok)
+                if tok == eos_token_id or len(generated) == max_new_tokens:
+                    break
+                emb = ops.splice_rows(m.llm.embed_tokens, None, torch.tensor([tok], dtype=torch.int64, device=dev), cfg.hidden_size)
+                h, _, _ = m.llm.forward(emb.view(1, 1, -1), None, kv_cache=cache)
+                step_hiddens.append(h)
+                last = h[0, -1:]
+        hiddens = [hidden] + step_hiddens
         output_ids = np.concatenate([ids, np.asarray(generated, dtype=np.int64)[None]], 1)
         all_hidden = torch.cat(hiddens, 1)                                  # [1, S + n_gen - 1, d]
         n_hidden = all_hidden.shape[1]

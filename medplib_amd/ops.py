@@ -166,7 +166,7 @@ def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
     return out
 
 
-def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w=None, scale=None, variant=0):
+def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w=None, scale=None, variant=0, sk_dev=None):
     """q,k,v: [B,S,H,D] bf16 views (stride(3)==1, stride(2)==D); returns [B,Sq,H*D] bf16."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, torch.bfloat16, "attention." + n)
@@ -185,10 +185,25 @@ def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w
         kh, kw = rel_h.shape[-1], rel_w.shape[-1]
     if key_valid is not None:
         _chk(key_valid, torch.uint8, "attention.key_valid"); assert key_valid.is_contiguous()
+    if Sq == 1:
+        _ensure_gemm_workspace(q.device)          # the decode kernel splits a head's keys over workgroups through this scratch
     lib().call("mp_attention_fwd_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0),
                v.stride(1), _p(out), out.stride(0), out.stride(1), _p(key_valid), _p(rel_h), _p(rel_w), kh, kw, B, H, Sq, Sk,
-               D, int(causal), float(scale), variant, _stream())
+               D, int(causal), float(scale), variant, _p(sk_dev), _stream())
     return out
+
+
+def decode_rope_append(qkv, cos_t, sin_t, cache_k, cache_v, pos_dev, heads, head_dim):
+    """qkv [B, 3*H*D] (one new token per sequence): q rotated in place, rotated k / v written to the caches [B, max_len, H, D] at
+    position pos_dev[0] (int32 on the device)."""
+    _chk(qkv, torch.bfloat16, "decode_rope_append.qkv"); _chk(pos_dev, torch.int32, "decode_rope_append.pos")
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and cache_k.stride(3) == 1 and cache_k.stride(2) == head_dim
+    lib().call("mp_decode_rope_append_bf16", _p(qkv), qkv.stride(0), _p(cos_t), _p(sin_t), _p(cache_k), _p(cache_v), _p(pos_dev), qkv.shape[0],
+               heads, head_dim, cache_k.stride(0), cache_k.stride(1), _stream())
+
+
+def advance_ints(t, delta=1):
+    lib().call("mp_advance_ints", _p(t), t.numel(), int(delta), _stream())
 
 
 def rmsnorm(x, w, eps, out=None):

@@ -24,7 +24,7 @@ def test_loader_signatures_and_error_plumbing():
     rc = L.raw("mp_gemm_bf16_nt")(None, 64, None, 64, None, 64, None, None, 0, 4, 4, 65, 0, 0, 1.0, None, None)
     assert rc == -1 and "multiple of 64" in L.last_error()
     rc = L.raw("mp_attention_fwd_bf16")(None, 0, 0, None, 0, 0, None, 0, 0, None, 0, 0, None, None, None, 0, 0, 1, 1, 1, 1, 48,
-                                        0, 1.0, 0, None)
+                                        0, 1.0, 0, None, None)
     assert rc == -1 and "head_dim" in L.last_error()
 
 

@@ -326,6 +326,26 @@ def test_model_forward_icl_separate_mode(dev):
         _stat(f"icl loss[{k}]", out[k], ref[k], atol=3e-2)
 
 
+def test_moe_routing_small_token_counts(dev):
+    """The one-wave routing kernel of the decode steps (T <= 64) against the oracle: expert ids, slots, counts, l_aux, with and
+    without capacity overflow and injected RTS draws."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(19)
+    for T, E, cap, use_rts in ((1, 2, 1, False), (7, 3, 2, True), (64, 2, 20, True), (33, 4, 5, False), (64, 8, 64, False)):
+        x = torch.randn(T, 32, generator=g); wg = torch.randn(E, 32, generator=g) * 0.4
+        u = torch.rand(T, E, generator=g) if use_rts else None
+        _, l_aux, counts, idx, slot = OL.moe_top1(x, wg, [lambda t: t] * E, cap, u)
+        gates = torch.softmax(x @ wg.t(), 1)
+        e, s, w, kept, c, la, st = ops.moe_route_top1(gates.to(dev), cap, None if u is None else u.to(dev), want_slot_token=True)
+        assert torch.equal(e.cpu().long(), idx) and torch.equal(s.cpu().long(), slot) and torch.equal(c.cpu(), counts), (T, E, cap)
+        assert abs(la.item() - l_aux.item()) < 1e-6
+        assert torch.equal(w.cpu(), gates.max(1).values)
+        for t in range(T):
+            if slot[t] >= 0:
+                assert int(st[idx[t], slot[t]]) == t
+        assert kept.cpu().tolist() == [int(((idx == k) & (slot >= 0)).sum()) for k in range(E)]
+
+
 def test_moe_rts_radix_select_with_tied_draws(dev):
     """Random-token-selection over capacity with heavily tied draws (torch.topk's tie order is unspecified, so no oracle here):
     exactly `capacity` tokens of the overflowing expert survive, every kept draw >= every dropped draw, and among the draws equal

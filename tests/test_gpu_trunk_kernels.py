@@ -287,3 +287,19 @@ def test_gemv_decode_projections(dev):
     ref = torch.stack([res[m].float() + (0.0 if keep[m] < 0 else scale[m]) * (x[m].float() @ w[idx[m]].float().t()).to(torch.bfloat16).float() for m in range(M)])
     _report("gemv experts", out, ref, rtol=2 * BF16_EPS, atol=2e-2)
     assert torch.equal(out[2].cpu(), res[2]), "a capacity-dropped row keeps the residual stream exactly"
+
+
+@pytest.mark.parametrize("D,H", [(128, 4), (64, 3)])
+def test_attention_decode_single_query(dev, D, H):
+    """One query per sequence against a KV cache whose valid length lives in device memory (the decode steps of evaluate()):
+    the decode kernel vs the oracle on the valid prefix, for cache lengths that are not multiples of anything."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(D + H)
+    B, max_len = 2, 900
+    q = _bf(torch.randn(B, 1, H, D, generator=g)); k = _bf(torch.randn(B, max_len, H, D, generator=g)); v = _bf(torch.randn(B, max_len, H, D, generator=g))
+    for n in (1, 17, 640, 899):
+        ref = O.attention(q.float(), k[:, :n].float(), v[:, :n].float())
+        out = ops.attention(q.to(dev), k.to(dev), v.to(dev), causal=False, sk_dev=torch.tensor([n], dtype=torch.int32, device=dev))
+        _report(f"decode attention D={D} Sk={n}", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
+        out2 = ops.attention(q.to(dev), k[:, :n].contiguous().to(dev), v[:, :n].contiguous().to(dev), causal=False, variant=2)
+        _report(f"decode attention vs tiled kernel D={D} Sk={n}", out, out2.float().cpu(), rtol=3 * BF16_EPS, atol=2e-2)
