@@ -257,6 +257,8 @@ int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const
                         int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
 
 /* ---- optimizer (train_ds_medplib.py:383-420: AdamW betas (0.9,0.95), wd 0, clip 1.0) ------------------------------ */
+/* out_accum[0] += sum(x^2); out_accum must hold 1 + 256 floats (out_accum[1..256] = per-block partials, summed in index order: the
+ * result is bit-reproducible). */
 int mp_sumsq_accum_f32(const float* x, int64_t n, float* out_accum, hipStream_t stream);
 int mp_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_sumsq,

@@ -39,22 +39,52 @@ __global__ void bilinear_fwd_kernel(const TIN* __restrict__ in, float* __restric
   out[idx] = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
 }
 
-// d_in (zero-initialised) += scatter of d_out through the same four taps
+// d_in = transpose of the resize as a GATHER: one thread per input pixel of the crop window walks the (few) output rows / columns
+// whose two taps can touch it, tests them with the same src_index() the forward uses, and adds in a fixed (oy, ox) order — no float
+// atomics, so the gradient is bit-reproducible (PyTorch's upsample_bilinear2d_backward scatters with atomicAdd).
+__device__ __forceinline__ void tap_range(int i, float scale, int out_size, int* lo, int* hi) {
+  // outputs o with floor(src(o)) in {i-1, i}: src(o) = scale*(o+0.5)-0.5 in [i-1, i+1)  ->  o in [(i-0.5)/scale-0.5, (i+1.5)/scale-0.5)
+  const float inv = 1.f / scale;
+  int a = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  int b = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  *lo = a < 0 ? 0 : a;
+  *hi = b > out_size - 1 ? out_size - 1 : b;
+}
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int n, int IH, int IW, int y0,
                                     int x0, int ch, int cw, int OH, int OW) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)n * OH * OW) return;
-  const int ox = (int)(idx % OW);
-  const int oy = (int)((idx / OW) % OH);
-  const int m = (int)(idx / ((int64_t)OW * OH));
+  if (idx >= (int64_t)n * ch * cw) return;
+  const int ix = (int)(idx % cw);
+  const int iy = (int)((idx / cw) % ch);
+  const int m = (int)(idx / ((int64_t)cw * ch));
   const float sh = (float)ch / (float)OH, sw = (float)cw / (float)OW;
-  const Lerp ly = src_index(oy, sh, ch), lx = src_index(ox, sw, cw);
-  float* p = din + (int64_t)m * IH * IW;
-  const float g = dout[idx];
-  atomicAdd(p + (int64_t)(y0 + ly.i0) * IW + x0 + lx.i0, g * ly.w0 * lx.w0);
-  atomicAdd(p + (int64_t)(y0 + ly.i0) * IW + x0 + lx.i1, g * ly.w0 * lx.w1);
-  atomicAdd(p + (int64_t)(y0 + ly.i1) * IW + x0 + lx.i0, g * ly.w1 * lx.w0);
-  atomicAdd(p + (int64_t)(y0 + ly.i1) * IW + x0 + lx.i1, g * ly.w1 * lx.w1);
+  int oy0, oy1, ox0, ox1;
+  tap_range(iy, sh, OH, &oy0, &oy1);
+  tap_range(ix, sw, OW, &ox0, &ox1);
+  // the first / last input row also collect the clamped outputs (src < 0 -> 0, i0 clamped to in_size - 1)
+  if (iy == 0) oy0 = 0;
+  if (iy == ch - 1) oy1 = OH - 1;
+  if (ix == 0) ox0 = 0;
+  if (ix == cw - 1) ox1 = OW - 1;
+  const float* g = dout + (int64_t)m * OH * OW;
+  float acc = 0.f;
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    const Lerp ly = src_index(oy, sh, ch);
+    float wy = 0.f;
+    if (ly.i0 == iy) wy += ly.w0;
+    if (ly.i1 == iy) wy += ly.w1;                 // i1 == i0 at the last row: both taps land on it, like the scatter
+    if (ly.i0 != iy && ly.i1 != iy) continue;
+    float row = 0.f;
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const Lerp lx = src_index(ox, sw, cw);
+      float wx = 0.f;
+      if (lx.i0 == ix) wx += lx.w0;
+      if (lx.i1 == ix) wx += lx.w1;
+      if (lx.i0 == ix || lx.i1 == ix) row += g[(int64_t)oy * OW + ox] * wx;
+    }
+    acc += wy * row;
+  }
+  din[(int64_t)m * IH * IW + (int64_t)(y0 + iy) * IW + x0 + ix] += acc;      // each input pixel has exactly one owner thread
 }
 
 // ---------------- fused mask losses ----------------
@@ -225,8 +255,8 @@ extern "C" int mp_bilinear_resize_bwd(const float* dout, float* din_zeroed, int 
                                       int crop_h, int crop_w, int out_h, int out_w, hipStream_t stream) {
   MP_REQUIRE(crop_y0 >= 0 && crop_x0 >= 0 && crop_y0 + crop_h <= in_h && crop_x0 + crop_w <= in_w && crop_h > 0 && crop_w > 0,
              MP_ERR_SHAPE, "mp_bilinear_resize_bwd: crop window outside the input");
-  const int64_t total = (int64_t)n * out_h * out_w;
-  if (total == 0) return MP_OK;
+  const int64_t total = (int64_t)n * crop_h * crop_w;            // one thread per input pixel of the crop window (gather)
+  if (total == 0 || out_h == 0 || out_w == 0) return MP_OK;
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)mp_cdiv(total, 256)), dim3(256), 0, stream, dout, din_zeroed, n, in_h,
                      in_w, crop_y0, crop_x0, crop_h, crop_w, out_h, out_w);
   return mp_check_launch("mp_bilinear_resize_bwd");

@@ -6,12 +6,23 @@
 
 namespace {
 
+// sum of squares in two stages with a FIXED reduction order (a float atomicAdd across blocks made the clip factor, hence every
+// parameter, differ from run to run in the last bits): SUMSQ_BLOCKS partials into out[1 .. SUMSQ_BLOCKS], then one block adds them
+// in index order onto out[0]
+constexpr int SUMSQ_BLOCKS = 256;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(float* __restrict__ out, int blocks) {
+  if (threadIdx.x == 0) {
+    float s = out[0];
+    for (int i = 0; i < blocks; ++i) s += out[1 + i];
+    out[0] = s;
+  }
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -38,8 +49,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 extern "C" int mp_sumsq_accum_f32(const float* x, int64_t n, float* out_accum, hipStream_t stream) {
   if (n == 0) return MP_OK;
-  const int blocks = (int)(mp_cdiv(n, 256) < 1024 ? mp_cdiv(n, 256) : 1024);
+  const int blocks = (int)(mp_cdiv(n, 256) < SUMSQ_BLOCKS ? mp_cdiv(n, 256) : SUMSQ_BLOCKS);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, x, n, out_accum);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, out_accum, blocks);
   return mp_check_launch("mp_sumsq_accum_f32");
 }
 

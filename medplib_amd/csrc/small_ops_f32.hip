@@ -28,8 +28,7 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w ; per-row partial dw/db go to [rows_blocks, dim] scratch-free
-// path: dw/db accumulated with atomics into zero-initialised buffers.
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w ; dw / db come from ln_bwd_wb_f32_kernel below.
 __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ dx,
@@ -51,8 +50,31 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
   for (int i = lane; i < dim; i += 64) {
     const float xh = (xr[i] - mu) * rs, g = dyr[i] * w[i];
     dx[row * dim + i] = rs * (g - sg - xh * sgx);
-    if (dw) atomicAdd(dw + i, dyr[i] * xh);
-    if (db) atomicAdd(db + i, dyr[i]);
+  }
+}
+// dw[c] += sum_r dy[r,c] * xhat[r,c];  db[c] += sum_r dy[r,c]: one block per 64 columns, rows striped over 16 waves, partials
+// combined in wave order (float atomics from every row made LayerNorm weight gradients irreproducible)
+__global__ __launch_bounds__(1024) void ln_bwd_wb_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dw, float* __restrict__ db, int64_t rows, int dim) {
+  __shared__ float pw[16][64], pb[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float sw = 0.f, sb = 0.f;
+  if (c < dim)
+    for (int64_t r = w; r < rows; r += 16) {
+      const float d = dy[r * dim + c];
+      sw += d * ((x[r * dim + c] - mean[r]) * rstd[r]);
+      sb += d;
+    }
+  pw[w][threadIdx.x & 63] = sw; pb[w][threadIdx.x & 63] = sb;
+  __syncthreads();
+  if (w == 0 && c < dim) {
+    float tw = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tw += pw[k][threadIdx.x]; tb += pb[k][threadIdx.x]; }
+    if (dw) dw[c] += tw;
+    if (db) db[c] += tb;
   }
 }
 
@@ -201,6 +223,9 @@ extern "C" int mp_layernorm_bwd_f32(const float* dy, const float* x, const float
   if (rows == 0) return MP_OK;
   hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3((unsigned)mp_cdiv(rows, 4)), dim3(256), 0, stream, dy, x, w, mean, rstd, dx,
                      dw_accum, db_accum, rows, dim);
+  if (dw_accum || db_accum)
+    hipLaunchKernelGGL(ln_bwd_wb_f32_kernel, dim3((unsigned)mp_cdiv(dim, 64)), dim3(1024), 0, stream, dy, x, mean, rstd, dw_accum, db_accum,
+                       rows, dim);
   return mp_check_launch("mp_layernorm_bwd_f32");
 }
 extern "C" int mp_softmax_fwd_f32(const float* x, float* y, int64_t rows, int cols, float scale, hipStream_t stream) {

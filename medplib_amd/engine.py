@@ -63,7 +63,7 @@ class FlatAdamW:
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1 + 256, dtype=torch.float32, device=dev)      # [0] = the norm^2, [1:] = block partials
         off = 0
         for p in self.params:                                   # re-home every parameter (and its grad) into the flat buffers
             k = p.numel()
