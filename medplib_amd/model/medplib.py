@@ -456,29 +456,16 @@ class MedPLIBForCausalLM(nn.Module):
         step_hiddens = [hid_all[i:i + 1].view(1, 1, d) for i in range(n - 1)]
         return generated, step_hiddens
 
-    # ------------------------------------------------------------------ evaluate (MedPLIB.py:574-680)
-    @torch.no_grad()
-    def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, region_masks=(), valid_region_masks_bool=(),
-                 max_new_tokens=512, tokenizer=None, attention_mask=None, inference_demo=False, mask_images=None,
-                 image_token_types=None, image_token_lengths=None, eos_token_id=2):
-        """Greedy generation with a KV cache (prefill + single-token decode steps), then one mask per sample from the hidden
-        state that predicts the first <SEG> (or position -2 when no <SEG> was generated) — MedPLIB.py:574-680.
-        Returns (output_ids [1, L + n_generated] int64 on the host, [pred_mask [1,H,W]]).
-
-        Reference quirk kept: the concatenated per-step hidden states cover the spliced prompt and the first n-1 generated
-        tokens (the last generated token is never fed back), i.e. one position FEWER than build_seg_token_mask(output_ids)
-        yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
+    def _greedy(self, ids, images_clip, max_new_tokens, eos_token_id, mask_images=None, image_token_types=None, image_token_lengths=None,
+                region_masks=None, valid_region_masks_bool=None):
+        """HF `generate(do_sample=False, use_cache=True)` on one sample (MedPLIB.py:592-606; prepare_inputs_for_generation,
+        medplib_moe_llama.py:451-485): prefill of the spliced prompt, then single-token decode steps against the KV cache.
+        Returns (output_ids [1, L + n] on the host, [hidden states of the prompt, of each fed token])."""
         cfg, dev, m = self.config, self.device_, self.model
-        self.sync_side_streams()
-        ids = _np_ids(input_ids).astype(np.int64)
-        assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
-        was_training = self.training
-        self.train(False)
-        nfeat = cfg.image_token_len
         plan, feats = self._encode_and_plan(ids, None, None, images_clip, mask_images, image_token_types, image_token_lengths,
                                             with_seg=False, region_masks=region_masks if region_masks else None,
                                             valid_region_masks_bool=valid_region_masks_bool)
-        src = torch.from_numpy(plan.src_code.reshape(-1)).to(dev)
+        src = _h2d(plan.src_code.reshape(-1), dev)
         S = plan.seq_len
         embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(1, S, cfg.hidden_size)
         cache = m.llm.new_kv_cache(1, S + max_new_tokens)
@@ -498,8 +485,53 @@ class MedPLIBForCausalLM(nn.Module):
                 h, _, _ = m.llm.forward(emb.view(1, 1, -1), None, kv_cache=cache)
                 step_hiddens.append(h)
                 last = h[0, -1:]
-        hiddens = [hidden] + step_hiddens
-        output_ids = np.concatenate([ids, np.asarray(generated, dtype=np.int64)[None]], 1)
+        return np.concatenate([ids, np.asarray(generated, dtype=np.int64)[None]], 1), [hidden] + step_hiddens
+
+    @torch.no_grad()
+    def generate(self, input_ids, images=None, attention_mask=None, max_new_tokens=512, eos_token_id=2, **kwargs):
+        """The VQA entry the drivers use (`model.generate(input_ids, images=images_clip, attention_mask=..., max_new_tokens=...,
+        do_sample=False)`, vqa_infer.py:430-442): greedy decoding, one sample per call like the reference's loop (batch rows are
+        decoded one after the other).  Returns output ids [B, L + n_max] (right-padded with eos), prompt included, as HF does."""
+        self.sync_side_streams()
+        ids = _np_ids(input_ids).astype(np.int64)
+        was_training = self.training
+        self.train(False)
+        rows = []
+        for b in range(ids.shape[0]):
+            row = ids[b:b + 1]
+            if attention_mask is not None:
+                row = row[:, _np_ids(attention_mask)[b].astype(bool)]               # drop this row's padding
+            img = images[b] if isinstance(images, (list, tuple)) else images[b:b + 1]
+            if isinstance(images, (list, tuple)):
+                img = [img]
+            out, _ = self._greedy(row, img, max_new_tokens, eos_token_id, kwargs.get("mask_images"), kwargs.get("image_token_types"),
+                                  kwargs.get("image_token_lengths"))
+            rows.append(out[0])
+        self.train(was_training)
+        n = max(r.shape[0] for r in rows)
+        return torch.from_numpy(np.stack([np.concatenate([r, np.full(n - r.shape[0], eos_token_id, np.int64)]) for r in rows]))
+
+    # ------------------------------------------------------------------ evaluate (MedPLIB.py:574-680)
+    @torch.no_grad()
+    def evaluate(self, images_clip, images, input_ids, resize_list, original_size_list, region_masks=(), valid_region_masks_bool=(),
+                 max_new_tokens=512, tokenizer=None, attention_mask=None, inference_demo=False, mask_images=None,
+                 image_token_types=None, image_token_lengths=None, eos_token_id=2):
+        """Greedy generation with a KV cache (prefill + single-token decode steps), then one mask per sample from the hidden
+        state that predicts the first <SEG> (or position -2 when no <SEG> was generated) — MedPLIB.py:574-680.
+        Returns (output_ids [1, L + n_generated] int64 on the host, [pred_mask [1,H,W]]).
+
+        Reference quirk kept: the concatenated per-step hidden states cover the spliced prompt and the first n-1 generated
+        tokens (the last generated token is never fed back), i.e. one position FEWER than build_seg_token_mask(output_ids)
+        yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
+        cfg, dev, m = self.config, self.device_, self.model
+        self.sync_side_streams()
+        ids = _np_ids(input_ids).astype(np.int64)
+        assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
+        was_training = self.training
+        self.train(False)
+        nfeat = cfg.image_token_len
+        output_ids, hiddens = self._greedy(ids, images_clip, max_new_tokens, eos_token_id, mask_images, image_token_types, image_token_lengths,
+                                           region_masks, valid_region_masks_bool)
         all_hidden = torch.cat(hiddens, 1)                                  # [1, S + n_gen - 1, d]
         n_hidden = all_hidden.shape[1]
         if (output_ids[:, 1:] == self.seg_token_idx).sum() == 0 and inference_demo:

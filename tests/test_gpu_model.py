@@ -717,3 +717,22 @@ def test_training_entry_point_runs_and_resumes(dev, tmp_path):
     hist2 = train.main(argv + ["--epochs", "3"])          # resumes at epoch 2 (global step 6) and runs one more epoch
     assert len(hist2) == 3
     assert open(os.path.join(str(tmp_path), "ckpt_model", "latest")).read().strip() == "global_step9"
+
+
+def test_generate_matches_evaluate_tokens(dev):
+    """model.generate (the VQA entry, vqa_infer.py:430-442) on a 2-row batch with right padding: each row's ids equal evaluate()'s
+    (which are bit-exact vs the oracle in test_evaluate_greedy_decode_and_mask); graph-replayed and token-by-token decoding agree."""
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).eval()
+    b = OM.make_batch(cfg, 2, ragged=True)
+    ids, att = b["input_ids"], b["attention_mask"]
+    clip = b["images_clip"].to(dev).to(torch.bfloat16)
+    out = m.generate(ids, images=clip, attention_mask=att, max_new_tokens=6, eos_token_id=-1)
+    m.decode_with_graph = False
+    out_loop = m.generate(ids, images=clip, attention_mask=att, max_new_tokens=6, eos_token_id=-1)
+    assert torch.equal(out, out_loop)
+    for r in range(2):
+        n = int(att[r].sum())
+        o_ids, _ = m.evaluate(clip[r:r + 1], b["images"][r:r + 1].to(dev), ids[r:r + 1, :n], [(256, 256)], [(96, 80)], max_new_tokens=6, eos_token_id=-1)
+        assert torch.equal(out[r, :n + 6], o_ids[0])
