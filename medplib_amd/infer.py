@@ -1,0 +1,103 @@
+"""Inference / evaluation entry point with the control flow of the reference's `model/eval/vqa_infer.py`: `validate_seg` (:488-633 —
+per sample: prompt cut after the last "ASSISTANT:" colon, `model.evaluate(...)` = greedy decode + one mask, threshold 0.1, IoU /
+Dice meters, per-modality breakdown) and the VQA loop (:430-442 — `model.generate`).  Tokenizer, datasets and string metrics are the
+reference's (out of scope): `--dataset package.module:factory` plugs them in; `synthetic` runs the seeded generator the
+tests and benchmarks use."""
+import argparse
+import importlib
+import os
+
+import torch
+
+from . import metrics, ops
+from .train import SyntheticDataset, build_model, dict_to_device
+
+COLON_ID = 29901          # the ':' that ends "ASSISTANT:" in the llava_v1 prompt (vqa_infer.py:521-523)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="MedPLIB segmentation / VQA inference on MI355X")
+    p.add_argument("--version", default="")
+    p.add_argument("--vision_pretrained", default="")
+    p.add_argument("--model_size", default="7b", choices=["7b", "tiny"])
+    p.add_argument("--dataset", default="synthetic")
+    p.add_argument("--eval_seg", action="store_true", default=True)
+    p.add_argument("--eval_vqa", action="store_true", default=False)
+    p.add_argument("--max_new_tokens", default=64, type=int)
+    p.add_argument("--n_samples", default=4, type=int)
+    p.add_argument("--lisa", action="store_true")
+    p.add_argument("--seed", default=42, type=int)
+    # the model flags build_model reads (train.py)
+    for name, typ, dv in (("moe_enable", lambda s: s.lower() in ("1", "true"), True), ("num_experts", int, 2), ("top_k_experts", int, 1),
+                          ("capacity_factor", float, 1.5), ("eval_capacity_factor", float, 2.0), ("min_capacity", int, 0),
+                          ("router_aux_loss_coef", float, 0.0), ("ce_loss_weight", float, 1.0), ("dice_loss_weight", float, 0.5),
+                          ("bce_loss_weight", float, 2.0), ("iou_loss_weight", float, 2.0), ("focal_loss_weight", float, 2.0), ("ep_size", int, 1)):
+        p.add_argument("--" + name, type=typ, default=dv)
+    p.add_argument("--train_mask_decoder", action="store_true", default=True)
+    return p.parse_args(argv)
+
+
+@torch.no_grad()
+def validate_seg(val, model, device, max_new_tokens=64):
+    """-> (mIoU, mDice, per-modality dict) over `val` (items = collated single-sample batches)."""
+    model.eval()
+    ious, dices, by_mod = [], [], {}
+    for i in range(len(val)):
+        b = dict_to_device(val[i], device)
+        ids, att = b["input_ids"], b["attention_mask"]
+        colon = (torch.as_tensor(ids) == COLON_ID).nonzero(as_tuple=True)
+        cut = int(colon[1][-1]) + 1 if colon[1].numel() else ids.shape[1]               # vqa_infer.py:521-523
+        output_ids, pred_masks = model.evaluate(b["images_clip"], b["images"], ids[:, :cut], b["resize_list"], b["label_list"],
+                                                max_new_tokens=max_new_tokens, attention_mask=att[:, :cut],
+                                                mask_images=b.get("mask_images"), image_token_types=b.get("image_token_types"),
+                                                image_token_lengths=b.get("image_token_lengths"))
+        iou = 0.0
+        if len(pred_masks) > 0:
+            gt = b["masks_list"][0].reshape(1, -1).to(device=device, dtype=torch.float32).contiguous()
+            _, counts = ops.mask_threshold_iou(pred_masks[0].reshape(1, -1).contiguous(), gt, 0.1)
+            iou = metrics.metrics_from_counts(counts[0].cpu().tolist(), gt.numel())["iou"]
+        dice = 2 * iou / (1 + iou)
+        ious.append(iou); dices.append(dice)
+        path = (b.get("image_paths") or [None])[0]
+        mod = os.path.basename(path).split("_")[0] if path else "synthetic"
+        by_mod.setdefault(mod, {"iou": [], "dice": []})
+        by_mod[mod]["iou"].append(iou); by_mod[mod]["dice"].append(dice)
+    miou, mdice = sum(ious) / max(len(ious), 1), sum(dices) / max(len(dices), 1)
+    print("miou: {:.6f}, mDice: {:.6f}".format(miou, mdice))
+    res = {m: {k: round(sum(v) / len(v), 6) for k, v in d.items()} for m, d in by_mod.items()}
+    print(res)
+    return miou, mdice, res
+
+
+@torch.no_grad()
+def run_vqa(val, model, device, max_new_tokens=64):
+    """-> list of generated id tensors (detokenisation and the string metrics are the reference's)."""
+    model.eval()
+    outs = []
+    for i in range(len(val)):
+        b = dict_to_device(val[i], device)
+        outs.append(model.generate(b["input_ids"], images=b["images_clip"], attention_mask=b["attention_mask"], max_new_tokens=max_new_tokens))
+    return outs
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    torch.manual_seed(args.seed)
+    cfg, model = build_model(args, device)
+    if args.dataset == "synthetic":
+        val = SyntheticDataset(cfg, 1, args.n_samples, args.seed + 7, args.model_size == "tiny")
+    else:
+        mod, _, fn = args.dataset.partition(":")
+        val = getattr(importlib.import_module(mod), fn)(args, cfg)
+    out = {}
+    if args.eval_vqa:
+        out["vqa_output_ids"] = run_vqa(val, model, device, args.max_new_tokens)
+    if args.eval_seg:
+        out["miou"], out["mdice"], out["per_modality"] = validate_seg(val, model, device, args.max_new_tokens)
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -736,3 +736,13 @@ def test_generate_matches_evaluate_tokens(dev):
         n = int(att[r].sum())
         o_ids, _ = m.evaluate(clip[r:r + 1], b["images"][r:r + 1].to(dev), ids[r:r + 1, :n], [(256, 256)], [(96, 80)], max_new_tokens=6, eos_token_id=-1)
         assert torch.equal(out[r, :n + 6], o_ids[0])
+
+
+def test_inference_entry_point(dev):
+    """medplib_amd.infer.main (model/eval/vqa_infer.py control flow) at tiny dims: validate_seg over synthetic samples (evaluate() +
+    threshold + IoU / Dice) and the VQA generate loop."""
+    from medplib_amd import infer
+    out = infer.main(["--model_size", "tiny", "--n_samples", "3", "--max_new_tokens", "5", "--eval_vqa"])
+    assert 0.0 <= out["miou"] <= 1.0 and abs(out["mdice"] - 2 * out["miou"] / (1 + out["miou"])) < 0.2
+    assert len(out["vqa_output_ids"]) == 3 and out["vqa_output_ids"][0].shape == (1, 64 + 5)
+    assert set(out["per_modality"]) == {"synthetic"}
