@@ -108,6 +108,9 @@ class Engine:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = None
+        # "reduce_single_rank": run the gradient collective even on a one-rank group (SUM over one rank is the identity), so the
+        # communication-stream ordering can be exercised on a single GPU (tests/test_gpu_model.py)
+        self.reduce_single_rank = bool(config.get("reduce_single_rank", False)) and dist.is_initialized()
         # When every trainable tensor lives in the fp32 mask tail (stage-III "LoRA off": mask_decoder + text_hidden_fcs), the model
         # may run that tail on its own stream so it overlaps the next step's frozen trunk (MedPLIBForCausalLM.tail_side_stream);
         # backward / step then follow it onto that stream.
@@ -159,7 +162,7 @@ class Engine:
 
     def launch_grad_reduce(self):
         """SUM all-reduce of the flat gradient bucket (averaged by grad_scale = 1/world inside the AdamW kernel)."""
-        if self.world == 1:
+        if self.world == 1 and not self.reduce_single_rank:
             return
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())

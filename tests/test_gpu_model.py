@@ -484,6 +484,52 @@ def test_engine_side_streams_do_not_change_results(dev):
         assert torch.equal(p, ref_p), (p - ref_p).abs().max()
 
 
+def test_engine_gradient_allreduce_on_rccl_single_rank(dev):
+    """The data-parallel exchange (engine.launch_grad_reduce: SUM all-reduce of the flat fp32 gradient bucket over RCCL on the
+    communication stream, waited for by the tail stream before AdamW) on a one-rank RCCL group with `reduce_single_rank`: the sum
+    over one rank is the identity, so three steps must reproduce the no-collective run bit for bit; the packed meter all-reduce
+    runs on the same group.  (The 2-rank arithmetic is covered on gloo in tests/test_host_logic.py.)"""
+    import torch.distributed as dist
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2)
+    W = OM.init_hf_weights(cfg)
+    batches = [OM.make_batch(cfg, 3, seed=s) for s in range(3)]
+
+    def run(reduce):
+        m = _model(cfg, dev, W).train()
+        ds = {"optimizer": {"type": "AdamW", "params": {"lr": 1e-3, "weight_decay": 0.0, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0,
+              "reduce_single_rank": reduce}
+        eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(), config=ds)
+        assert eng.reduce_single_rank == bool(reduce)
+        losses = []
+        for b in batches:
+            gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+            gb["masks_list"] = [x.to(dev) for x in b["masks_list"]]
+            out = eng(**gb)
+            eng.backward(out["loss"])
+            eng.step()
+            losses.append(out["loss"].detach())
+        eng.sync_side_streams()
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), eng.optimizer.flat_param.detach().cpu().clone()
+
+    ref_l, ref_p = run(False)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29618", rank=0, world_size=1)
+    try:
+        l, p = run(True)
+        pack = engine.AverageMeterPack(["a", "b"], device=dev)
+        pack.update_many({"a": torch.tensor(2.0, device=dev), "b": torch.tensor(4.0, device=dev)}, 3)
+        pack.all_reduce()
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(l, ref_l), (l, ref_l)
+    assert torch.equal(p, ref_p), (p - ref_p).abs().max()
+
+
 def test_model_forward_mixed_mask_sizes(dev):
     """Labels / GT masks of different H x W (and different resize_list entries) in one batch: grouped bilinear resizes + one
     ragged loss launch vs the oracle's per-mask loop."""
