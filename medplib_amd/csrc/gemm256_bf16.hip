@@ -3,13 +3,15 @@
 // 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128x64 output tile = 8x4 fragments of
 // v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  One workgroup per CU (128 KiB LDS: 2 stages x (A 32 KiB + B 32 KiB)),
 // two waves per SIMD: waves w and w+4 share a SIMD, and the two M-halves (wave groups) run ONE BARRIER OUT OF PHASE, so on
-// every SIMD one wave is in a 16-MFMA segment while its partner is in its LDS-read / DMA-issue segment:
+// every SIMD one wave is in a 32-MFMA segment while its partner is in its LDS-read / DMA-issue segment:
 //
-//   group 0:        LOAD(p) | B | MFMA(p) | B | LOAD(p+1) | B | MFMA(p+1) | B ...
-//   group 1:   B  |  LOAD(p) | B | MFMA(p) | B | LOAD(p+1) | B | MFMA(p+1) ...
+//   group 0:        LOAD(h) | B | MFMA(h) | B | LOAD(h+1) | B | MFMA(h+1) | B ...
+//   group 1:   B  |  LOAD(h) | B | MFMA(h) | B | LOAD(h+1) | B | MFMA(h+1) ...
 //
-// A K-tile (64 deep) is four phases = the four 64x32 quadrants of the wave tile, ordered (0,0) (0,1) (1,1) (1,0) so that
-// consecutive phases reuse either the A or the B fragments already in registers (12/4/8/0 ds_read_b128 per phase).
+// A K-tile (64 deep) is two segments = the two 64x64 halves of the wave tile (rows 0-63, then 64-127; the B fragments stay
+// in registers for both): 16 + 8 ds_read_b128 and 4 barriers per K-tile.  (Four 16-MFMA quadrant segments with 8 barriers
+// per K-tile, the schedule this kernel had first, measured 6-7 % slower on every Llama shape: the segment hand-off, not the
+// barrier count of the skeleton, is what costs.)
 // Operands arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear LDS image, XOR swizzle applied on the SOURCE address) as a
 // continuous stream: a stage is recycled region by region as soon as its last reader phase has retired (details at the kernel).
 // The MFMAs are issued as (W fragment, A fragment), which transposes the accumulator fragments: a lane ends up owning four
@@ -189,13 +191,18 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
 
 // =====================================================================================================================
 // The kernel ("v3" keeps the name it had among the variants that were tried): BK = 64, 128-B rows = whole cache lines per DMA
-// row, 2 stages, with a CONTINUOUS DMA stream: the stage is recycled region by region as soon as its last reader phase has retired, two DMA instructions per wave in EVERY phase,
-// retired by one counted wait (vmcnt(6)) per K-tile — the memory pipe never drains.
-//   reads:  P0 A-q0 + B-q0 (kept in fb0 for P3)   P1 B-q1   P2 A-q1   P3 none
-//   DMA  :  P0 A-q1 of tile t+1 | P1 A-q0 of tile t+2 | P2 B[0,1] of tile t+2 | P3 B[2,3] of tile t+2
-// (A-q0 rows are free after P0, B after P1, A-q1 rows after P2.)  Every LOAD segment ends with lgkmcnt(0) before its barrier,
-// so a region's reads are retired by all waves before the barrier that precedes the first DMA into it.
-//
+// row, 2 stages, with a CONTINUOUS DMA stream: a stage is recycled region by region as soon as its last reader segment has
+// retired, and one counted wait (vmcnt(6)) per K-tile retires it -- the memory pipe never drains.
+//   reads:  H0  B (all 64 columns) + A rows 0-63        H1  A rows 64-127
+//   DMA  :  H0  A rows 64-127 of tile t+1 (2 pieces)     H1  A rows 0-63 + B of tile t+2 (6 pieces)
+// (B and the A rows 0-63 are free after H0's reads, the A rows 64-127 after H1's.)  Every LOAD segment ends with lgkmcnt(0)
+// before its barrier, so a region's reads are retired by all waves before the barrier that precedes the first DMA into it;
+// within a segment the fragment reads are issued first and the DMA pieces behind them (+2 %).
+// Where the time goes (8192^3, one box, scripts/gemm_ab.py with MP_GEMM_ABLATE): everything 750 us; skeleton + epilogue alone
+// 99; + MFMA only 498; + fragment reads only 297; + DMA only 549 (380 when every workgroup fetches the same tile, 295 when it
+// is also the same K-tile: the LDS-DMA path tops out at ~64 B/clk/CU and the real L2 access pattern delivers ~31); MFMA +
+// reads 579, MFMA + DMA 588, reads + DMA 568.  The L2 -> LDS stream is the longest single leg; leading-dimension padding
+// (channel conflicts), more DMA in flight (80 KiB), a second counted wait and a 4 + 4 split of the DMA issue changed nothing.
 // Work decode (flat 1-D grid over all batches) and TAIL SPLIT-K.  T = tiles of all batches (from the effective, device-side row
 // counts).  The first full = floor(T / CUs) * CUs tiles are whole-K units, XCD-chunked so that the units co-resident on one XCD
 // cover neighbouring tiles.  The remaining rem = T - full tiles would occupy rem of the CUs for a whole tile-time (Llama's
@@ -284,12 +291,12 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     w_src[i] = W + (int64_t)min(n0 + wrow, N - 1) * g.ldw + src_c * 8 + (int64_t)kt0 * BK2;
   }
   auto dma_a = [&](int i, int t) {
-    if constexpr (ABL == 3) return;
+    if constexpr (ABL & 4) return;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)t * BK2),
                                      (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
   };
   auto dma_w = [&](int i, int t) {
-    if constexpr (ABL == 3) return;
+    if constexpr (ABL & 4) return;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (int64_t)t * BK2),
                                      (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE_BYTES + OP_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
   };
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-  if constexpr (ABL == 2) {
+  if constexpr (ABL & 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) for (int kk = 0; kk < 2; ++kk) for (int e = 0; e < 8; ++e) {
       fa[i][kk][e] = (bf16_t)(float)(lane + i);
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     }
   }
   auto load_a = [&](int qm, const char* st) {
-    if constexpr (ABL == 2) return;
+    if constexpr (ABL & 2) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -317,26 +324,30 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   };
 #define MP_LOAD_B(FB, QN, ST)                                                                                \
   do {                                                                                                      \
-    if constexpr (ABL != 2) {                                                                               \
+    if constexpr (!(ABL & 2)) {                                                                             \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
           FB[j][kk] = *reinterpret_cast<const bf16x8*>((ST) + OP_BYTES + lds_off2(wc * 64 + ((QN) * 2 + j) * 16 + fr, kk * 4 + fq)); \
     }                                                                                                       \
   } while (0)
-#define MP_MFMA_Q3(QM, QN, FB)                                                                             \
+// one MFMA segment: the 64 x 64 half QM of the wave tile, K = 64 (32 MFMAs; column half QN0 first)
+#define MP_MFMA_HALF(QM, QN, FB)                                                                           \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+        if constexpr (ABL & 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(FB[j][kk])); }                       \
+        else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                              \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0);
+#define MP_MFMA_32(QM, QNX, FBX, QNY, FBY)                                                                  \
   do {                                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-          if constexpr (ABL == 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(FB[j][kk])); }                   \
-          else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                            \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0); \
+    MP_MFMA_HALF(QM, QNX, FBX)                                                                              \
+    MP_MFMA_HALF(QM, QNY, FBY)                                                                              \
     __builtin_amdgcn_s_setprio(0);                                                                          \
   } while (0)
 #define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-  // ---- prologue: all of tile 0, and tile 1 except its A-q1 rows (those are issued in P0 of tile 0)
+  // ---- prologue: all of tile 0 and what the (virtual) tile -1 would have issued for tile 1
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dma_a(i, 0); dma_w(i, 0); }
   if (nt > 1) {
@@ -353,34 +364,30 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
     const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
-    // ---------------- P0: quadrant (0,0) ----------------
-    if (n1) { dma_a(1, t + 1); dma_a(3, t + 1); }
+    // ---------------- H0: rows 0-63 of the wave tile x all 64 columns (32 MFMAs) ----------------
     MP_LOAD_B(fb0, 0, st);
-    load_a(0, st);
-    MP_LGKM0();
-    MP_BAR();
-    MP_MFMA_Q3(0, 0, fb0);
-    MP_BAR();
-    // ---------------- P1: quadrant (0,1) ----------------
-    if (n2) { dma_a(0, t + 2); dma_a(2, t + 2); }
     MP_LOAD_B(fb1, 1, st);
+    load_a(0, st);
+    __builtin_amdgcn_sched_barrier(0);                 // fragment reads first: the DMA issue then overlaps their latency
+    if (n1) { dma_a(1, t + 1); dma_a(3, t + 1); }
     MP_LGKM0();
     MP_BAR();
-    MP_MFMA_Q3(0, 1, fb1);
+    MP_MFMA_32(0, 0, fb0, 1, fb1);
     MP_BAR();
-    // ---------------- P2: quadrant (1,1) ----------------
-    if (n2) { dma_w(0, t + 2); dma_w(1, t + 2); }
+    // ---------------- H1: rows 64-127 (32 MFMAs) ----------------
     load_a(1, st);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) {
+      dma_a(0, t + 2); dma_a(2, t + 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_w(i, t + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // everything up to the A rows 64-127 of tile t+1 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     MP_LGKM0();
     MP_BAR();
-    MP_MFMA_Q3(1, 1, fb1);
-    MP_BAR();
-    // ---------------- P3: quadrant (1,0) ----------------
-    if (n2) { dma_w(2, t + 2); dma_w(3, t + 2); }
-    if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything up to A-q1 of tile t+1 has landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MP_BAR();
-    MP_MFMA_Q3(1, 0, fb0);
+    MP_MFMA_32(1, 1, fb1, 0, fb0);
     MP_BAR();
   }
   if (wr == 0) MP_BAR();
@@ -472,12 +479,12 @@ void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int6
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   static int abl = -1;
   if (abl < 0) {
-    const char* e = getenv("MP_GEMM_ABLATE");          // scripts/gemm_bench.py only: 1 = no MFMA, 2 = no LDS fragment reads, 3 = no DMA
-    abl = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 0;
-    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    const char* e = getenv("MP_GEMM_ABLATE");          // scripts/gemm_ab.py only: 1 = no MFMA, 2 = no LDS fragment reads, 4 = no DMA
+    abl = e ? atoi(e) : 0;
+    if (abl != 1 && abl != 2 && abl != 4) abl = 0;
+#define MP_ATTR(A) (void)hipFuncSetAttribute((const void*)gemm256v3_bf16_nt_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES)
+    MP_ATTR(0); MP_ATTR(1); MP_ATTR(2); MP_ATTR(4);
+#undef MP_ATTR
   }
   MP_REQUIRE(batch <= MAX_FLAT_BATCH, MP_ERR_SHAPE, "256x256 GEMM: at most %d batches per launch (got %d)", MAX_FLAT_BATCH, batch);
   const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
@@ -497,9 +504,13 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
   if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
   const dim3 fgrid(tiles * batch + n_cu);             // surplus workgroups (device-side row counts, unsplit tails) exit at once
-  if (abl == 1) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<1>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-  else if (abl == 2) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<2>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-  else if (abl == 3) hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<3>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
-  else hipLaunchKernelGGL(gemm256v3_bf16_nt_kernel<0>, fgrid, blk, 2 * STAGE_BYTES, stream, gf);
+#define MP_GO(A) hipLaunchKernelGGL((gemm256v3_bf16_nt_kernel<A>), fgrid, blk, 2 * STAGE_BYTES, stream, gf)
+  switch (abl) {
+    case 1: MP_GO(1); break;
+    case 2: MP_GO(2); break;
+    case 4: MP_GO(4); break;
+    default: MP_GO(0);
+  }
+#undef MP_GO
   return mp_check_launch("mp_gemm_bf16_nt(256)");
 }
