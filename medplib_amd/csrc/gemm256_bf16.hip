@@ -202,7 +202,9 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
 // 99; + MFMA only 498; + fragment reads only 297; + DMA only 549 (380 when every workgroup fetches the same tile, 295 when it
 // is also the same K-tile: the LDS-DMA path tops out at ~64 B/clk/CU and the real L2 access pattern delivers ~31); MFMA +
 // reads 579, MFMA + DMA 588, reads + DMA 568.  The L2 -> LDS stream is the longest single leg; leading-dimension padding
-// (channel conflicts), more DMA in flight (80 KiB), a second counted wait and a 4 + 4 split of the DMA issue changed nothing.
+// (channel conflicts), more DMA in flight (80 KiB), a second counted wait and a 4 + 4 split of the DMA issue changed nothing;
+// anything placed inside the MFMA segments costs: closing the segment's barrier 2-8 MFMAs early (so the partner starts while
+// this wave finishes) -12 %, two of the six DMA pieces interleaved with the MFMAs -4 %.
 // Work decode (flat 1-D grid over all batches) and TAIL SPLIT-K.  T = tiles of all batches (from the effective, device-side row
 // counts).  The first full = floor(T / CUs) * CUs tiles are whole-K units, XCD-chunked so that the units co-resident on one XCD
 // cover neighbouring tiles.  The remaining rem = T - full tiles would occupy rem of the CUs for a whole tile-time (Llama's
@@ -330,20 +332,22 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
           FB[j][kk] = *reinterpret_cast<const bf16x8*>((ST) + OP_BYTES + lds_off2(wc * 64 + ((QN) * 2 + j) * 16 + fr, kk * 4 + fq)); \
     }                                                                                                       \
   } while (0)
-// one MFMA segment: the 64 x 64 half QM of the wave tile, K = 64 (32 MFMAs; column half QN0 first)
-#define MP_MFMA_HALF(QM, QN, FB)                                                                           \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-        if constexpr (ABL & 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(FB[j][kk])); }                       \
-        else acc[(QM) * 4 + i][(QN) * 2 + j] =                                                              \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(QM) * 4 + i][(QN) * 2 + j], 0, 0, 0);
+// MFMAs [LO, HI) of a 32-MFMA segment: the 64 x 64 half QM of the wave tile, K = 64; column half QNX (fragments FBX) first
+#define MP_MFMA_RANGE(QM, QNX, FBX, QNY, FBY, LO, HI)                                                       \
+  _Pragma("unroll") for (int idx = (LO); idx < (HI); ++idx) {                                               \
+    const int h = idx >> 4, kk = (idx >> 3) & 1, i = (idx >> 1) & 3, j = idx & 1;                           \
+    const int qn = h ? (QNY) : (QNX);                                                                       \
+    const bf16x8 bfrag = h ? FBY[j][kk] : FBX[j][kk];                                                       \
+    if constexpr (ABL & 1) { asm volatile("" :: "v"(fa[i][kk]), "v"(bfrag)); }                              \
+    else acc[(QM) * 4 + i][qn * 2 + j] =                                                                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, fa[i][kk], acc[(QM) * 4 + i][qn * 2 + j], 0, 0, 0);  \
+  }
 #define MP_MFMA_32(QM, QNX, FBX, QNY, FBY)                                                                  \
   do {                                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    MP_MFMA_HALF(QM, QNX, FBX)                                                                              \
-    MP_MFMA_HALF(QM, QNY, FBY)                                                                              \
+    MP_MFMA_RANGE(QM, QNX, FBX, QNY, FBY, 0, 32)                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                          \
+    MP_BAR();                                                                                               \
   } while (0)
 #define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -373,7 +377,6 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     MP_LGKM0();
     MP_BAR();
     MP_MFMA_32(0, 0, fb0, 1, fb1);
-    MP_BAR();
     // ---------------- H1: rows 64-127 (32 MFMAs) ----------------
     load_a(1, st);
     __builtin_amdgcn_sched_barrier(0);
@@ -388,7 +391,6 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     MP_LGKM0();
     MP_BAR();
     MP_MFMA_32(1, 1, fb1, 0, fb0);
-    MP_BAR();
   }
   if (wr == 0) MP_BAR();
   if (is_split) {
