@@ -321,7 +321,9 @@ static bool use_256(const GemmArgs& g, int batch) {
   }
   // short K with a small second tile wave (CLIP fc1 / mm_projector.0: 304 / 288 tiles, 16 K-tiles): the tail split leaves 4-K-tile
   // units that are all prologue and epilogue; the 128x128 kernel measured 67 vs 79 us there
-  if (g.K <= 1024 && tiles > 256 && (tiles % 256) > 0 && (tiles % 256) < 128) return false;
+  static int shortk = -1;
+  if (shortk < 0) { const char* e = getenv("MP_GEMM_SHORTK_RULE"); shortk = (e && atoi(e) == 0) ? 0 : 1; }
+  if (shortk && g.K <= 1024 && tiles > 256 && (tiles % 256) > 0 && (tiles % 256) < 128) return false;
   return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
 }
 
