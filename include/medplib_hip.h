@@ -256,6 +256,24 @@ int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const in
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,
                         int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
 
+/* ---- image preprocessing in front of the path (datasets/LazySupervisedDataset.py:535-556) -------- */
+/* Window bounds + 22-bit fixed-point coefficients of one axis of PIL's bilinear ImagingResample (Pillow Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc), which is what ResizeLongestSide.apply_image ends in
+ * (model/segment_anything/utils/transforms.py:25-34).  HOST function (no GPU): bounds int[out_size][2] = (first, count), coefs
+ * int[out_size][ksize], ksize = mp_pil_bilinear_ksize(in_size, out_size). */
+int mp_pil_bilinear_ksize(int in_size, int out_size);
+int mp_pil_bilinear_coeffs(int in_size, int out_size, int* bounds, int* coefs, int ksize);
+/* One 8-bits-per-channel resampling pass over a device uint8 array viewed as [outer, in_len, inner] -> [outer, out_len, inner]
+ * (horizontal pass of an HWC image: outer = H, inner = C; vertical: outer = 1, inner = W*C); bounds / coefs on the device.
+ * Bit-exact with PIL. */
+int mp_resample_axis_u8(const void* src, void* dst, int64_t outer, int in_len, int out_len, int64_t inner, const int* bounds,
+                        const int* coefs, int ksize, hipStream_t stream);
+/* uint8 HWC [h, w, C] -> float / bf16 CHW [C, size_h, size_w]: dst[c, top + y, left + x] = table[c][src[y, x, c]], pad[c] outside.
+ * With the host-built 256-entry tables this is LazySupervisedDataset.preprocess (:480-505) + pad_tensor_channelwise (:446-477):
+ * SAM `(x - pixel_mean) / pixel_std` then zero pad; CLIP integer-mean pad then CLIPImageProcessor rescale + normalise. */
+int mp_image_table_pad_chw(const void* src, int h, int w, int C, const float* table, const float* pad, void* dst, int size_h,
+                           int size_w, int top, int left, int out_dtype, hipStream_t stream);
+
 /* ---- optimizer (train_ds_medplib.py:383-420: AdamW betas (0.9,0.95), wd 0, clip 1.0) ------------------------------ */
 /* out_accum[0] += sum(x^2); out_accum must hold 1 + 256 floats (out_accum[1..256] = per-block partials, summed in index order: the
  * result is bit-reproducible). */

@@ -431,6 +431,67 @@ def golden_mask_head():
     print("mask head goldens ok")
 
 
+def golden_preprocess():
+    """Image preprocessing.  Executed here: the reference's `ResizeLongestSide.get_preprocess_shape`
+    (transforms.py:98-108), `LazySupervisedDataset.preprocess` + `pad_tensor_channelwise` (LazySupervisedDataset.py:446-505,
+    called unbound on a holder carrying the class constants), the real PIL resize that `ResizeLongestSide.apply_image` ends in
+    (torchvision is absent: its one-line glue `resize(to_pil_image(img), (h, w))` is written out as
+    `Image.fromarray(img).resize((w, h), BILINEAR)`), and the installed CLIPImageProcessor (transformers 5.15, PIL backend) for
+    the rescale + normalise leg."""
+    import importlib.util
+    import types
+    from PIL import Image
+    _import_reference_medplib()
+    spec = importlib.util.spec_from_file_location("ref_lazy_dataset", os.path.join(REF, "datasets", "LazySupervisedDataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    DS = mod.LazySupervisedDataset
+    RLS = mod.ResizeLongestSide
+    holder = types.SimpleNamespace(pixel_mean=DS.pixel_mean, pixel_std=DS.pixel_std, clip_pixel_mean=DS.clip_pixel_mean,
+                                   clip_pixel_std=DS.clip_pixel_std)
+    holder.pad_tensor_channelwise = lambda *a, **k: DS.pad_tensor_channelwise(holder, *a, **k)
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336})
+    rng = np.random.default_rng(7)
+    out = {}
+    shapes = [(97, 143), (160, 120), (64, 64), (300, 451)]
+    out["n_cases"] = np.int64(len(shapes))
+    for i, (h, w) in enumerate(shapes):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        # smooth half of the cases so the resampler sees gradients as well as noise
+        if i % 2 == 1:
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.stack([(yy * 255 // max(h - 1, 1)), (xx * 255 // max(w - 1, 1)), ((yy + xx) % 256)], -1).astype(np.uint8)
+        mask = (rng.random((h, w)) > 0.6).astype(np.uint8)
+        out[f"img{i}"] = img
+        out[f"mask{i}"] = mask
+        for tag, size in (("sam", 256), ("clip", 336)):
+            nh, nw = RLS.get_preprocess_shape(h, w, size)
+            resized = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+            out[f"{tag}_resized{i}"] = resized
+            x = torch.from_numpy(resized).permute(2, 0, 1).contiguous()
+            if tag == "sam":
+                out[f"sam_out{i}"] = DS.preprocess(holder, x, size).numpy()
+            else:
+                padded = DS.preprocess(holder, x, size, normalize=False)
+                assert padded.dtype == torch.uint8
+                out[f"clip_padded{i}"] = padded.numpy()
+                out[f"clip_out{i}"] = proc.preprocess(padded, return_tensors="pt")["pixel_values"][0].numpy()
+        nh, nw = RLS.get_preprocess_shape(h, w, 336)
+        rm = np.array(Image.fromarray(mask).resize((nw, nh), Image.BILINEAR))
+        out[f"region_mask{i}"] = DS.preprocess(holder, torch.from_numpy(rm).contiguous(), 336, normalize=False, is_mask=True).numpy()
+    # the restatement against what was just executed
+    from . import preprocess as P
+    for i, (h, w) in enumerate(shapes):
+        img, mask = out[f"img{i}"], out[f"mask{i}"]
+        s, rs = P.preprocess_sam(img)
+        assert np.array_equal(s, out[f"sam_out{i}"]) and tuple(rs) == out[f"sam_resized{i}"].shape[:2]
+        assert np.array_equal(P.preprocess_clip(img), out[f"clip_out{i}"])
+        assert np.array_equal(P.preprocess_region_mask(mask), out[f"region_mask{i}"])
+    np.savez_compressed(os.path.join(OUT, "preprocess_reference.npz"), **out)
+    print("preprocess goldens ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["sam", "mask_head", "glue"]
@@ -442,3 +503,5 @@ if __name__ == "__main__":
         golden_glue()
     if "collate" in which:
         check_collate_contract()
+    if "preprocess" in which:
+        golden_preprocess()
