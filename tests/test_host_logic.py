@@ -335,3 +335,72 @@ def test_collate_contract():
     # the batch dict is what the model's host-side planning consumes
     lengths, bases = splice.icl_feature_layout(b["image_token_types"], 4, 2)
     assert lengths == [4, 2, 4, 4, 2, 4] and bases == [0, 16, 4, 8, 18, 12]
+
+
+def test_deepspeed_checkpoint_merge_matches_executed_reference(tmp_path):
+    """merge_deepspeed_states vs the reference's own `params_bf16_to_f32.load_model_parameters`, executed on the same synthetic
+    DeepSpeed directory when /root/reference is present (this container); the fixed expectations below hold everywhere."""
+    import importlib.util
+    from medplib_amd import checkpoint as C
+    g = torch.Generator().manual_seed(0)
+    d = tmp_path / "global_step7"
+    d.mkdir()
+    dense = {"model.embed_tokens.weight": torch.randn(10, 4, generator=g).to(torch.bfloat16),
+             "model.layers.0.self_attn.q_proj.weight": torch.randn(4, 4, generator=g).to(torch.bfloat16),
+             "model.layers.0.mlp.deepspeed_moe.gate.wg.weight": torch.randn(2, 4, generator=g)}
+    torch.save({"module": dense, "global_steps": 7}, d / "mp_rank_00_model_states.pt")
+    for e in range(2):
+        torch.save({f"model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.{e}.up_proj.weight": torch.randn(8, 4, generator=g).to(torch.bfloat16)},
+                   d / f"layer_0_expert_{e}_mp_rank_00_model_states.pt")
+    torch.save({"x": 1}, d / "bf16_zero_pp_rank_0_mp_rank_00_optim_states.pt")            # not a *model_states.pt file: ignored
+    merged = C.merge_deepspeed_states(str(d))
+    assert len(merged) == 5 and all(v.dtype == torch.float32 for v in merged.values())
+    assert torch.equal(merged["model.layers.0.self_attn.q_proj.weight"], dense["model.layers.0.self_attn.q_proj.weight"].float())
+    ref_path = "/root/reference/params_bf16_to_f32.py"
+    if os.path.exists(ref_path):
+        spec = importlib.util.spec_from_file_location("ref_params_bf16_to_f32", ref_path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ref = mod.load_model_parameters(str(d), "cpu")
+        assert set(ref) == set(merged) and all(torch.equal(ref[k], merged[k]) for k in ref)
+    # a key present in two files is an error, like the reference
+    torch.save({"model.embed_tokens.weight": torch.zeros(1)}, d / "layer_0_expert_9_mp_rank_00_model_states.pt")
+    with pytest.raises(ValueError):
+        C.merge_deepspeed_states(str(d))
+
+
+def test_seed_experts_from_dense_checkpoints():
+    """initialize_moe_modules (medplib_moe_llama.py:572-638) as a state-dict transformation: layer choice by moe_mode, expert e <-
+    dense MLP of source e, dense MLP keys of MoE layers removed, fp32 gate added; the result loads into the MoE stack."""
+    from medplib_amd import checkpoint as C
+    assert C.moe_layer_indices(8, "first_half") == [0, 1, 2, 3] and C.moe_layer_indices(8, "second_half") == [4, 5, 6, 7]
+    assert C.moe_layer_indices(8, "sparse") == [0, 2, 4, 6] and C.moe_layer_indices(4, "dense") == [0, 1, 2, 3]
+    assert C.moe_layer_indices(8, "dense", [1, 5]) == [1, 5]
+    with pytest.raises(NotImplementedError):
+        C.moe_layer_indices(8, "other")
+    g = torch.Generator().manual_seed(1)
+    d, ff, nl = 8, 16, 4
+
+    def dense_ckpt():
+        sd = {"model.norm.weight": torch.randn(d, generator=g)}
+        for L in range(nl):
+            sd[f"model.layers.{L}.self_attn.q_proj.weight"] = torch.randn(d, d, generator=g)
+            for p, shp in (("gate_proj", (ff, d)), ("up_proj", (ff, d)), ("down_proj", (d, ff))):
+                sd[f"model.layers.{L}.mlp.{p}.weight"] = torch.randn(*shp, generator=g)
+        return sd
+    base, s0, s1 = dense_ckpt(), dense_ckpt(), dense_ckpt()
+    layers = C.moe_layer_indices(nl, "sparse")
+    out = C.seed_experts_from_dense(base, [s0, s1], [2], layers, d)
+    for L in range(nl):
+        for p in ("gate_proj", "up_proj", "down_proj"):
+            dense_key = f"model.layers.{L}.mlp.{p}.weight"
+            if L in layers:
+                assert dense_key not in out
+                for e, src in enumerate((s0, s1)):
+                    assert torch.equal(out[f"model.layers.{L}.mlp.deepspeed_moe.experts.deepspeed_experts.{e}.{p}.weight"], src[dense_key])
+            else:
+                assert torch.equal(out[dense_key], base[dense_key])
+        if L in layers:
+            wg = out[f"model.layers.{L}.mlp.deepspeed_moe.gate.wg.weight"]
+            assert wg.shape == (2, d) and wg.dtype == torch.float32 and float(wg.abs().max()) <= 1.0 / d ** 0.5
+    assert torch.equal(out["model.layers.1.self_attn.q_proj.weight"], base["model.layers.1.self_attn.q_proj.weight"])
