@@ -239,6 +239,12 @@ int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, 
  * expert GEMMs gather their A rows and scatter their C rows by, mp_gemm_bf16_nt_batched_rows.)
  * out[t] = x[t] for the tokens no expert took: the residual-only rows when the combine is fused into the down projection. */
 int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t tokens, int dim, hipStream_t stream);
+/* Decode rows (tokens <= 8): the post-attention LlamaRMSNorm, the TopKGate logits / softmax and top1gating in one launch —
+ * bit-identical with mp_rmsnorm_bf16 + mp_moe_gate_bf16 + mp_moe_route_top1 (the three launches cost 21 us per layer of a decode
+ * step, nearly all latency).  h [tokens, dim] receives the normed rows; gates (optional) [tokens, n_experts]. */
+int mp_decode_norm_gate_route(const void* x, int64_t ldx, const float* ln_w, float eps, const float* wg, void* h, int64_t ldh,
+                              const float* rts_uniform, int tokens, int dim, int n_experts, int capacity, float* gates, int* expert,
+                              int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream);
 /* DeepSpeed top2gating (sharded_moe.py, deepspeed==0.13.1): first choice = argmax gates, second = argmax of
  * logits + noise (Gumbel draws, or NULL) with the first masked; locations by cumsum in token order, second choices behind all
  * first choices; choices at location >= capacity dropped; surviving gate pair renormalised.  Entry layout of

@@ -40,15 +40,12 @@ __global__ __launch_bounds__(256) void mean_plus_kernel(const float* __restrict_
 }
 
 // ---------------- MoE gate: logits = x.float() @ wg.float()^T ; gates = softmax(logits) ----------------
-__global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wg,
-                                                       float* __restrict__ logits, float* __restrict__ gates, int64_t T, int d, int E) {
-  const int lane = threadIdx.x & 63;
-  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= T) return;
+// one token's gate by one wave: fp32 logits and their softmax (lane 0 writes them)
+__device__ __forceinline__ void moe_gate_token(const bf16_t* __restrict__ xr, const float* __restrict__ wg, int d, int E, int lane,
+                                               float* __restrict__ logits_out, float* __restrict__ gates_out) {
   float acc[MAXE];
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
-  const bf16_t* xr = x + tok * ldx;
   for (int i = lane * 8; i < d; i += 64 * 8) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + i);
 #pragma unroll
@@ -71,8 +68,19 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
       if (e < E) { p[e] = expf(acc[e] - mx); s += p[e]; }
 #pragma unroll
     for (int e = 0; e < MAXE; ++e)
-      if (e < E) { logits[tok * E + e] = acc[e]; gates[tok * E + e] = p[e] / s; }
+      if (e < E) {
+        if (logits_out) logits_out[e] = acc[e];
+        gates_out[e] = p[e] / s;
+      }
   }
+}
+
+__global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wg,
+                                                       float* __restrict__ logits, float* __restrict__ gates, int64_t T, int d, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  moe_gate_token(x + tok * ldx, wg, d, E, lane, logits + tok * E, gates + tok * E);
 }
 
 // ---------------- top-1 routing (single block, 1024 threads) ----------------
@@ -245,12 +253,11 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
 // ---------------- top-1 routing for a handful of tokens (T <= 64: the decode steps): one wave, lane = token ----------------
 // Same outputs as moe_route_top1_kernel; the 1024-thread kernel spends ~25 us in block-wide reductions, which at 32 layers is a
 // fifth of a decode step.
-__global__ __launch_bounds__(64) void moe_route_top1_small_kernel(const float* __restrict__ gates, const float* __restrict__ rts, int T,
-                                                                  int E, int capacity, int* __restrict__ expert, int* __restrict__ slot,
+__device__ __forceinline__ void moe_route_top1_small_body(const float* __restrict__ gates, const float* __restrict__ rts, int T,
+                                                               int E, int capacity, int* __restrict__ expert, int* __restrict__ slot,
                                                                   float* __restrict__ weight, int* __restrict__ kept_counts,
                                                                   long long* __restrict__ exp_counts, float* __restrict__ l_aux,
-                                                                  int* __restrict__ slot_token) {
-  const int s = threadIdx.x;
+                                                                  int* __restrict__ slot_token, int s) {
   const bool live = s < T;
   int best = 0;
   float bv = live ? gates[(int64_t)s * E] : 0.f;
@@ -299,6 +306,68 @@ __global__ __launch_bounds__(64) void moe_route_top1_small_kernel(const float* _
     expert[s] = best; weight[s] = bv; slot[s] = my_slot;
     if (slot_token && my_slot >= 0) slot_token[(int64_t)best * capacity + my_slot] = s;
   }
+}
+
+__global__ __launch_bounds__(64) void moe_route_top1_small_kernel(const float* __restrict__ gates, const float* __restrict__ rts, int T,
+                                                                  int E, int capacity, int* __restrict__ expert, int* __restrict__ slot,
+                                                                  float* __restrict__ weight, int* __restrict__ kept_counts,
+                                                                  long long* __restrict__ exp_counts, float* __restrict__ l_aux,
+                                                                  int* __restrict__ slot_token) {
+  moe_route_top1_small_body(gates, rts, T, E, capacity, expert, slot, weight, kept_counts, exp_counts, l_aux, slot_token, threadIdx.x);
+}
+
+// ---------------- decode rows (T <= 8): post-attention RMSNorm + gate + top-1 routing in ONE launch ----------------
+// The three kernels it replaces cost 4.8 + 11.6 + 4.9 us per layer of a decode step, almost all of it launch latency.  Same
+// arithmetic, same order: the norm is rmsnorm_bf16_kernel's 256-thread row (norm_elementwise.hip), the gate moe_gate_token, the
+// routing moe_route_top1_small_body -- the fused and the separate path produce identical bits.
+__global__ __launch_bounds__(256) void decode_norm_gate_route_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ ln_w,
+                                                                     float eps, const float* __restrict__ wg, bf16_t* __restrict__ h,
+                                                                     int64_t ldh, const float* __restrict__ rts, int T, int d, int E,
+                                                                     int capacity, float* __restrict__ gates_out, int* __restrict__ expert,
+                                                                     int* __restrict__ slot, float* __restrict__ weight,
+                                                                     int* __restrict__ kept_counts, long long* __restrict__ exp_counts,
+                                                                     float* __restrict__ l_aux) {
+  __shared__ float red[16];
+  __shared__ float gates_sh[8 * MAXE];
+  constexpr int NC = 4;                                // dim <= 256 * 8 * 4
+  for (int row = 0; row < T; ++row) {
+    const bf16_t* xr = x + row * ldx;
+    bf16_t* hr = h + row * ldh;
+    bf16x8 v[NC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = (c * 256 + threadIdx.x) * 8;
+      if (i < d) {
+        v[c] = *reinterpret_cast<const bf16x8*>(xr + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[c][j]; ss += f * f; }
+      }
+    }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = (c * 256 + threadIdx.x) * 8;
+      if (i < d) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16_t t = (bf16_t)((float)v[c][j] * rs);
+          o[j] = (bf16_t)(ln_w[i + j] * (float)t);
+        }
+        *reinterpret_cast<bf16x8*>(hr + i) = o;
+      }
+    }
+  }
+  __syncthreads();                                     // the normed rows (global) are visible to the whole workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = wave; row < T; row += 4) moe_gate_token(h + row * ldh, wg, d, E, lane, nullptr, gates_sh + row * E);
+  __syncthreads();
+  if (gates_out)
+    for (int i = threadIdx.x; i < T * E; i += 256) gates_out[i] = gates_sh[i];
+  if (wave == 0)
+    moe_route_top1_small_body(gates_sh, rts, T, E, capacity, expert, slot, weight, kept_counts, exp_counts, l_aux, nullptr, lane);
 }
 
 // buf[expert[j*T + s], slot[j*T + s], :] = x[s, :]   for the top_k choices j of token s
@@ -515,6 +584,18 @@ extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, i
   hipLaunchKernelGGL(moe_route_top1_kernel, dim3(1), dim3(1024), 0, stream, gates, rts_uniform, tokens, n_experts, capacity, expert,
                      slot, weight, kept_counts, exp_counts, l_aux, slot_token);
   return mp_check_launch("mp_moe_route_top1");
+}
+
+extern "C" int mp_decode_norm_gate_route(const void* x, int64_t ldx, const float* ln_w, float eps, const float* wg, void* h, int64_t ldh,
+                                        const float* rts_uniform, int tokens, int dim, int n_experts, int capacity, float* gates,
+                                        int* expert, int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux,
+                                        hipStream_t stream) {
+  MP_REQUIRE(tokens >= 1 && tokens <= 8 && n_experts >= 1 && n_experts <= MAXE && dim % 8 == 0 && dim <= 8192 && ldx % 8 == 0 &&
+                 ldh % 8 == 0 && capacity >= 0,
+             MP_ERR_SHAPE, "mp_decode_norm_gate_route: tokens <= 8, experts <= %d, dim %% 8 == 0 and <= 8192", MAXE);
+  hipLaunchKernelGGL(decode_norm_gate_route_kernel, dim3(1), dim3(256), 0, stream, (const bf16_t*)x, ldx, ln_w, eps, wg, (bf16_t*)h, ldh,
+                     rts_uniform, tokens, dim, n_experts, capacity, gates, expert, slot, weight, kept_counts, exp_counts, l_aux);
+  return mp_check_launch("mp_decode_norm_gate_route");
 }
 
 extern "C" int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t tokens, int dim, hipStream_t stream) {

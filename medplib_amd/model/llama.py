@@ -50,6 +50,7 @@ class LlamaStack:
         self.gate_pass = 0                 # forward passes so far: part of the key of the stateless gate-draw generator
         self.ep = None                     # ExpertParallel (expert_parallel.py) once enable_expert_parallel() sharded the experts
         self.fuse_moe_gather_scatter = True   # top-1, one rank: dispatch / combine folded into the expert GEMMs
+        self.fuse_decode_routing = True       # decode rows: post-attention norm + gate + routing in one launch
 
     def enable_expert_parallel(self, ep):
         """Shard the experts over an expert-parallel group (DeepSpeed `ep_size`, medplib_moe_llama.py:604-614): every rank keeps the
@@ -262,8 +263,16 @@ class LlamaStack:
             q4 = qkv.view(B, 1, 3, H, D)[:, :, 0]
             attn = ops.attention(q4, kv_cache["k"][i], kv_cache["v"][i], causal=False, sk_dev=counters[1:2])
             x = ops.gemv(attn.view(B, d), lw["o"], residual=x)
-            h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
-            x, _, _ = self._mlp(i, lw, h, x)
+            if i in self.moe_layers and cfg.top_k_experts == 1 and self.ep is None and B <= 8 and self.fuse_decode_routing:
+                # post-attention norm + gate + routing in one launch, then the two expert GEMVs (same bits as the separate kernels)
+                E, cap = cfg.num_experts, self.capacity(B)
+                draws = None if cap >= B else self._gate_draws(i, B, E, gumbel=False)
+                h, expert, slot, weight, _, _, _ = ops.decode_norm_gate_route(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"], cap, draws)
+                act = ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR, w_index=expert)
+                x = ops.gemv(act, lw["down"], residual=x, w_index=expert, row_scale=weight, row_keep=slot)
+            else:
+                h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
+                x, _, _ = self._mlp(i, lw, h, x)
         return ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps).view(B, 1, d)
 
     def next_token_logits(self, hidden_row):

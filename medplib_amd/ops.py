@@ -711,6 +711,24 @@ def moe_route_top1(gates, capacity, rts_uniform=None, want_slot_token=False):
     return expert, slot, weight, kept, counts, l_aux
 
 
+def decode_norm_gate_route(x, ln_w, eps, wg, capacity, rts_uniform=None):
+    """Decode rows (T <= 8): post-attention RMSNorm + gate + top-1 routing in one launch (bit-identical with rmsnorm + moe_gate +
+    moe_route_top1).  -> (h [T, d] bf16, expert, slot, weight, kept, counts, l_aux)."""
+    _chk(x, torch.bfloat16, "decode_norm_gate_route.x"); _chk(ln_w, torch.float32, "decode_norm_gate_route.ln_w")
+    _chk(wg, torch.float32, "decode_norm_gate_route.wg")
+    T, d = x.shape
+    E = wg.shape[0]
+    dev = x.device
+    h = torch.empty((T, d), dtype=torch.bfloat16, device=dev)
+    expert = torch.empty(T, dtype=torch.int32, device=dev); slot = torch.empty(T, dtype=torch.int32, device=dev)
+    weight = torch.empty(T, dtype=torch.float32, device=dev)
+    kept = torch.empty(E, dtype=torch.int32, device=dev); counts = torch.empty(E, dtype=torch.int64, device=dev)
+    l_aux = torch.empty(1, dtype=torch.float32, device=dev)
+    lib().call("mp_decode_norm_gate_route", _p(x), x.stride(0), _p(ln_w), float(eps), _p(wg), _p(h), h.stride(0), _p(rts_uniform), T, d, E,
+               int(capacity), None, _p(expert), _p(slot), _p(weight), _p(kept), _p(counts), _p(l_aux), _stream())
+    return h, expert, slot, weight, kept, counts, l_aux
+
+
 def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, residual=None, act=ACT_NONE, rows_stride=0):
     """Expert GEMMs with dispatch / combine folded in.  With a_rows: a is the shared [tokens, K] matrix and expert b reads rows
     a_rows[b*rows_stride + r]; else a is [E, M, K].  With c_rows: out is the shared [tokens, N] matrix, row c_rows[...] receives

@@ -16,10 +16,13 @@ from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
 ap = argparse.ArgumentParser()
 ap.add_argument("--new", type=int, default=32)
 ap.add_argument("--dense", action="store_true")
+ap.add_argument("--no-fuse-routing", action="store_true", help="A/B: separate rmsnorm / gate / route launches in the decode step")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = MedPLIBConfig.medplib_7b(moe_enable=not args.dense)
 model = (LISAForCausalLM if args.dense else MedPLIBForCausalLM)(cfg, device=dev).eval()
+if args.no_fuse_routing:
+    model.model.llm.fuse_decode_routing = False
 g = torch.Generator().manual_seed(0)
 L, V = 64, cfg.vocab_size
 ids = torch.randint(3, 31999, (1, L), generator=g)

@@ -303,3 +303,24 @@ def test_attention_decode_single_query(dev, D, H):
         _report(f"decode attention D={D} Sk={n}", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
         out2 = ops.attention(q.to(dev), k[:, :n].contiguous().to(dev), v[:, :n].contiguous().to(dev), causal=False, variant=2)
         _report(f"decode attention vs tiled kernel D={D} Sk={n}", out, out2.float().cpu(), rtol=3 * BF16_EPS, atol=2e-2)
+
+
+def test_decode_norm_gate_route_equals_separate_kernels(dev):
+    """mp_decode_norm_gate_route (one launch per layer of a decode step) vs mp_rmsnorm_bf16 + mp_moe_gate_bf16 + mp_moe_route_top1:
+    identical bits for the normed rows, the expert / slot indices, the combine weights, the counts and l_aux — including an
+    over-capacity case with RTS draws."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for T, E, d, cap, with_draws in [(1, 2, 4096, 4, False), (5, 3, 4096, 8, False), (8, 2, 1024, 2, True), (3, 4, 512, 1, True)]:
+        x = (torch.randn(T, d, generator=g) * 2).to(torch.bfloat16).to(dev)
+        ln_w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
+        wg = (torch.randn(E, d, generator=g) * 0.05).to(dev)
+        draws = torch.rand(T, E, generator=g).to(dev) if with_draws else None
+        h_ref = ops.rmsnorm(x, ln_w, 1e-5)
+        _, gates = ops.moe_gate(h_ref, wg)
+        ref = ops.moe_route_top1(gates, cap, draws)
+        got = ops.decode_norm_gate_route(x, ln_w, 1e-5, wg, cap, draws)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], h_ref), (T, E, d)
+        for a, b, name in zip(got[1:], ref, ["expert", "slot", "weight", "kept", "counts", "l_aux"]):
+            assert torch.equal(a, b), (name, T, E, d, a, b)
