@@ -202,7 +202,8 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
 // 99; + MFMA only 498; + fragment reads only 297; + DMA only 549 (380 when every workgroup fetches the same tile, 295 when it
 // is also the same K-tile: the LDS-DMA path tops out at ~64 B/clk/CU and the real L2 access pattern delivers ~31); MFMA +
 // reads 579, MFMA + DMA 588, reads + DMA 568.  The L2 -> LDS stream is the longest single leg; leading-dimension padding
-// (channel conflicts), more DMA in flight (80 KiB), a second counted wait and a 4 + 4 split of the DMA issue changed nothing;
+// (channel conflicts), more DMA in flight (80 KiB) and a second counted wait changed nothing; other splits of the eight DMA
+// pieces over the two load segments are slower than 2 + 6 (4 + 4: -3.5 %, 0 + 8: -1...-4 %);
 // anything placed inside the MFMA segments costs: closing the segment's barrier 2-8 MFMAs early (so the partner starts while
 // this wave finishes) -12 %, two of the six DMA pieces interleaved with the MFMAs -4 %.
 // Work decode (flat 1-D grid over all batches) and TAIL SPLIT-K.  T = tiles of all batches (from the effective, device-side row
