@@ -245,6 +245,11 @@ int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t 
 int mp_decode_norm_gate_route(const void* x, int64_t ldx, const float* ln_w, float eps, const float* wg, void* h, int64_t ldh,
                               const float* rts_uniform, int tokens, int dim, int n_experts, int capacity, float* gates, int* expert,
                               int* slot, float* weight, int* kept_counts, long long* exp_counts, float* l_aux, hipStream_t stream);
+/* DeepSpeed residual MoE (MoE(use_residual=True).forward, deepspeed/moe/layer.py; off in the shipped scripts,
+ * train_ds_medplib.py:131): out = x + (moe * c0 + mlp * c1), (c0, c1) = softmax of the two `coefficient` logits of the row
+ * (coef [tokens, ldcoef >= 2] bf16), with the bf16 module's rounding points. */
+int mp_moe_residual_mix_bf16(const void* x, const void* moe, const void* mlp, const void* coef, int64_t ldcoef, void* out,
+                             int64_t tokens, int dim, hipStream_t stream);
 /* DeepSpeed top2gating (sharded_moe.py, deepspeed==0.13.1): first choice = argmax gates, second = argmax of
  * logits + noise (Gumbel draws, or NULL) with the first masked; locations by cumsum in token order, second choices behind all
  * first choices; choices at location >= capacity dropped; surviving gate pair renormalised.  Entry layout of

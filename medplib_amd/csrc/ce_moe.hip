@@ -370,6 +370,32 @@ __global__ __launch_bounds__(256) void decode_norm_gate_route_kernel(const bf16_
     moe_route_top1_small_body(gates_sh, rts, T, E, capacity, expert, slot, weight, kept_counts, exp_counts, l_aux, nullptr, lane);
 }
 
+// DeepSpeed "residual MoE" (MoE(use_residual=True), deepspeed/moe/layer.py forward): out = x + (moe * c0 + mlp * c1) with
+// c = softmax(coefficient(h)) over two logits; bf16 rounding points of the bf16 module: the softmax result, each product, their sum,
+// the decoder layer's residual add.
+__global__ void moe_residual_mix_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ moe, const bf16_t* __restrict__ mlp,
+                                        const bf16_t* __restrict__ coef, int64_t ldcoef, bf16_t* __restrict__ out, int64_t T, int d) {
+  const int per_row = d / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * per_row) return;
+  const int64_t s = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;
+  const float l0 = (float)coef[s * ldcoef], l1 = (float)coef[s * ldcoef + 1];
+  const float mx = fmaxf(l0, l1);
+  const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+  const float c0 = (float)(bf16_t)(e0 / (e0 + e1)), c1 = (float)(bf16_t)(e1 / (e0 + e1));
+  const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + s * d + c);
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(moe + s * d + c);
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(mlp + s * d + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t0 = (float)(bf16_t)((float)a[j] * c0), t1 = (float)(bf16_t)((float)b[j] * c1);
+    o[j] = (bf16_t)((float)xv[j] + (float)(bf16_t)(t0 + t1));
+  }
+  *reinterpret_cast<bf16x8*>(out + s * d + c) = o;
+}
+
 // buf[expert[j*T + s], slot[j*T + s], :] = x[s, :]   for the top_k choices j of token s
 __global__ void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int* __restrict__ expert, const int* __restrict__ slot,
                                     bf16_t* __restrict__ buf, int64_t T, int d, int capacity, int top_k) {
@@ -596,6 +622,16 @@ extern "C" int mp_decode_norm_gate_route(const void* x, int64_t ldx, const float
   hipLaunchKernelGGL(decode_norm_gate_route_kernel, dim3(1), dim3(256), 0, stream, (const bf16_t*)x, ldx, ln_w, eps, wg, (bf16_t*)h, ldh,
                      rts_uniform, tokens, dim, n_experts, capacity, gates, expert, slot, weight, kept_counts, exp_counts, l_aux);
   return mp_check_launch("mp_decode_norm_gate_route");
+}
+
+extern "C" int mp_moe_residual_mix_bf16(const void* x, const void* moe, const void* mlp, const void* coef, int64_t ldcoef, void* out,
+                                       int64_t tokens, int dim, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && ldcoef >= 2, MP_ERR_SHAPE, "mp_moe_residual_mix_bf16: bad shape");
+  const int64_t n = tokens * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(moe_residual_mix_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)moe,
+                     (const bf16_t*)mlp, (const bf16_t*)coef, ldcoef, (bf16_t*)out, tokens, dim);
+  return mp_check_launch("mp_moe_residual_mix_bf16");
 }
 
 extern "C" int mp_moe_fill_dropped_bf16(const void* x, const int* slot, void* out, int64_t tokens, int dim, hipStream_t stream) {

@@ -19,6 +19,7 @@ class MedPLIBConfig:
     moe_enable: bool = True
     num_experts: int = 2
     top_k_experts: int = 1
+    use_residual: bool = False        # DeepSpeed residual MoE: out * c0 + mlp(x) * c1 (train_ds_medplib.py:131, off in the shipped scripts)
     capacity_factor: float = 1.5
     eval_capacity_factor: float = 2.0
     min_capacity: int = 0

@@ -40,6 +40,12 @@ class LlamaStack:
                 lw["wg"] = rn(E, d, dtype=torch.float32)
                 lw["gu"] = rn(E, 2 * ff, d)
                 lw["down"] = rn(E, d, ff)
+                if cfg.use_residual:              # MoE.mlp (a dense copy of the expert) + MoE.coefficient = Linear(hidden, 2)
+                    lw["res_gu"] = rn(2 * ff, d)
+                    lw["res_down"] = rn(d, ff)
+                    lw["coef_w"] = torch.zeros(8, d, dtype=torch.bfloat16, device=device)     # rows 2..7 are padding
+                    lw["coef_w"][:2] = rn(2, d)
+                    lw["coef_b"] = torch.zeros(8, dtype=torch.float32, device=device)
             else:
                 lw["gu"] = rn(2 * ff, d)
                 lw["down"] = rn(d, ff)
@@ -85,6 +91,11 @@ class LlamaStack:
                     ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
                     put(lw["gu"][e], ops.swiglu_interleave(sd[ep + "gate_proj.weight"], sd[ep + "up_proj.weight"]))
                     put(lw["down"][e], sd[ep + "down_proj.weight"])
+                if self.cfg.use_residual:
+                    put(lw["res_gu"], ops.swiglu_interleave(sd[p + "mlp.mlp.gate_proj.weight"], sd[p + "mlp.mlp.up_proj.weight"]))
+                    put(lw["res_down"], sd[p + "mlp.mlp.down_proj.weight"])
+                    put(lw["coef_w"][:2], sd[p + "mlp.coefficient.weight"])
+                    put(lw["coef_b"][:2], sd[p + "mlp.coefficient.bias"])
             else:
                 put(lw["gu"], ops.swiglu_interleave(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
                 put(lw["down"], sd[p + "mlp.down_proj.weight"])
@@ -108,6 +119,11 @@ class LlamaStack:
                     ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
                     sd[ep + "gate_proj.weight"], sd[ep + "up_proj.weight"] = ops.swiglu_deinterleave(lw["gu"][e])
                     sd[ep + "down_proj.weight"] = lw["down"][e]
+                if self.cfg.use_residual:
+                    sd[p + "mlp.mlp.gate_proj.weight"], sd[p + "mlp.mlp.up_proj.weight"] = ops.swiglu_deinterleave(lw["res_gu"])
+                    sd[p + "mlp.mlp.down_proj.weight"] = lw["res_down"]
+                    sd[p + "mlp.coefficient.weight"] = lw["coef_w"][:2]
+                    sd[p + "mlp.coefficient.bias"] = lw["coef_b"][:2].to(torch.bfloat16)
             else:
                 sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = ops.swiglu_deinterleave(lw["gu"])
                 sd[p + "mlp.down_proj.weight"] = lw["down"]
@@ -143,7 +159,7 @@ class LlamaStack:
         cap = self.capacity(T)
         k = cfg.top_k_experts
         logits, gates = ops.moe_gate(h, lw["wg"])
-        if k == 1 and self.ep is None and T <= 8:
+        if k == 1 and self.ep is None and T <= 8 and not cfg.use_residual:
             # decode rows: each row streams its own expert's matrices (GEMV with a device-side expert index); the combine weight,
             # the capacity drop and the residual ride in the down projection's epilogue
             # (no gate draws: random token selection only acts when an expert is over capacity, and capacity >= T for these rows
@@ -153,7 +169,7 @@ class LlamaStack:
             act = ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR, w_index=expert)
             out = ops.gemv(act, lw["down"], residual=x, w_index=expert, row_scale=weight, row_keep=slot)
             return out, l_aux, (expert, slot, counts)
-        if k == 1 and self.ep is None and self.fuse_moe_gather_scatter:
+        if k == 1 and self.ep is None and self.fuse_moe_gather_scatter and not cfg.use_residual:
             # top-1 on one rank: the dispatch is a row gather in the gate|up GEMM's operand fetch and the combine (gate weight and
             # the layer's residual add) a row scatter in the down GEMM's epilogue; every routed token's row is written exactly once,
             # the capacity-dropped ones get the residual stream from a fill kernel
@@ -181,6 +197,12 @@ class LlamaStack:
             ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
             y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
             ops.gemm_batched(act, lw["down"], y, m_dev=kept)
+        if cfg.use_residual:
+            # residual MoE: the routed output and a dense MLP of the same input, mixed by a learned two-way softmax
+            moe = ops.moe_combine(y, expert, slot, weight, None, cap, top_k=k)
+            mlp = ops.gemm(ops.gemm(h, lw["res_gu"], act=ops.ACT_SWIGLU_PAIR), lw["res_down"])
+            coef = ops.gemm(h, lw["coef_w"], bias=lw["coef_b"])
+            return ops.moe_residual_mix(x, moe, mlp, coef), l_aux, (expert, slot, counts)
         out = ops.moe_combine(y, expert, slot, weight, x, cap, top_k=k)
         return out, l_aux, (expert, slot, counts)
 
@@ -263,7 +285,8 @@ class LlamaStack:
             q4 = qkv.view(B, 1, 3, H, D)[:, :, 0]
             attn = ops.attention(q4, kv_cache["k"][i], kv_cache["v"][i], causal=False, sk_dev=counters[1:2])
             x = ops.gemv(attn.view(B, d), lw["o"], residual=x)
-            if i in self.moe_layers and cfg.top_k_experts == 1 and self.ep is None and B <= 8 and self.fuse_decode_routing:
+            if (i in self.moe_layers and cfg.top_k_experts == 1 and self.ep is None and B <= 8 and self.fuse_decode_routing
+                    and not cfg.use_residual):
                 # post-attention norm + gate + routing in one launch, then the two expert GEMVs (same bits as the separate kernels)
                 E, cap = cfg.num_experts, self.capacity(B)
                 draws = None if cap >= B else self._gate_draws(i, B, E, gumbel=False)

@@ -791,6 +791,14 @@ def moe_combine(y, expert, slot, weight, residual, capacity, top_k=1):
     return out
 
 
+def moe_residual_mix(x, moe, mlp, coef):
+    """x + (moe * c0 + mlp * c1), (c0, c1) = softmax(coef[:, :2]) per row (DeepSpeed residual MoE)."""
+    T, d = x.shape
+    out = torch.empty((T, d), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_moe_residual_mix_bf16", _p(x), _p(moe), _p(mlp), _p(coef), coef.stride(0), _p(out), T, d, _stream())
+    return out
+
+
 # ------------------------------------------------------------------ optimizer --------------------------------------------------
 def sumsq_accum(x, out):
     lib().call("mp_sumsq_accum_f32", _p(x), x.numel(), _p(out), _stream())

@@ -335,6 +335,14 @@ def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="",
             aux.append(l_aux)
             if collect is not None:
                 collect.append((idx, slot, counts))
+            if getattr(cfg, "use_residual", False):
+                # DeepSpeed MoE(use_residual=True).forward (deepspeed/moe/layer.py, 0.13.1 — third party, parity unpinned):
+                # output_mlp = self.mlp(x); coef = softmax(self.coefficient(x), -1); out = out * coef[..., 0:1] + output_mlp * coef[..., 1:]
+                hm = h.reshape(T, d)
+                mlp = F.linear(ops.swiglu(F.linear(hm, W[p + "mlp.mlp.gate_proj.weight"]), F.linear(hm, W[p + "mlp.mlp.up_proj.weight"])),
+                               W[p + "mlp.mlp.down_proj.weight"])
+                coef = F.softmax(F.linear(hm, W[p + "mlp.coefficient.weight"], W[p + "mlp.coefficient.bias"]), dim=-1)
+                out = out * coef[:, 0:1] + mlp * coef[:, 1:]
             x = x + out.view(B, S, d)
         else:
             m = F.linear(ops.swiglu(F.linear(h, W[p + "mlp.gate_proj.weight"]), F.linear(h, W[p + "mlp.up_proj.weight"])),

@@ -34,6 +34,12 @@ def init_hf_weights(cfg, seed=0, sam_seed=1234):
                 W[ep + "gate_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
                 W[ep + "up_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
                 W[ep + "down_proj.weight"] = rn(d, ff, s=1.0 / ff ** 0.5)
+            if getattr(cfg, "use_residual", False):
+                W[p + "mlp.mlp.gate_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+                W[p + "mlp.mlp.up_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
+                W[p + "mlp.mlp.down_proj.weight"] = rn(d, ff, s=1.0 / ff ** 0.5)
+                W[p + "mlp.coefficient.weight"] = rn(2, d, s=0.3)
+                W[p + "mlp.coefficient.bias"] = rn(2, s=0.3)
         else:
             W[p + "mlp.gate_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)
             W[p + "mlp.up_proj.weight"] = rn(ff, d, s=1.0 / d ** 0.5)

