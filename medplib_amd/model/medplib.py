@@ -81,7 +81,7 @@ class MedPLIBForCausalLM(nn.Module):
                             ("iou_loss_weight",) * 2, ("focal_loss_weight",) * 2, ("seg_token_idx",) * 2,
                             ("out_dim",) * 2, ("train_mask_decoder",) * 2, ("top_k_experts",) * 2,
                             ("capacity_factor",) * 2, ("eval_capacity_factor",) * 2, ("min_capacity",) * 2,
-                            ("router_aux_loss_coef",) * 2, ("moe_layers_idx",) * 2, ("mm_use_im_start_end", "use_mm_start_end"),
+                            ("router_aux_loss_coef",) * 2, ("moe_layers_idx",) * 2, ("use_residual",) * 2, ("mm_use_im_start_end", "use_mm_start_end"),
                             ("mm_token_compress",) * 2, ("mm_compressed_token_count",) * 2, ("icl_mask_encoder",) * 2,
                             ("mask_encoder_token_count",) * 2):
             if kwargs.get(k_kw) is not None:

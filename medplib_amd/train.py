@@ -61,6 +61,7 @@ def parse_args(argv=None):
     p.add_argument("--capacity_factor", type=float, default=1.5)
     p.add_argument("--eval_capacity_factor", type=float, default=2.0)
     p.add_argument("--min_capacity", type=int, default=0)
+    p.add_argument("--use_residual", type=bool, default=False)        # argparse bool as in train_ds_medplib.py:131
     p.add_argument("--router_aux_loss_coef", type=float, default=0.0)
     p.add_argument("--ep_size", type=int, default=1)
     p.add_argument("--seed", default=42, type=int)
@@ -122,6 +123,7 @@ def dict_to_device(batch, device):
 def build_model(args, device):
     kw = dict(moe_enable=args.moe_enable and not args.lisa, num_experts=args.num_experts, top_k_experts=args.top_k_experts,
               capacity_factor=args.capacity_factor, eval_capacity_factor=args.eval_capacity_factor, min_capacity=args.min_capacity,
+              use_residual=args.use_residual,
               router_aux_loss_coef=args.router_aux_loss_coef, ce_loss_weight=args.ce_loss_weight, dice_loss_weight=args.dice_loss_weight,
               bce_loss_weight=args.bce_loss_weight, iou_loss_weight=args.iou_loss_weight, focal_loss_weight=args.focal_loss_weight,
               train_mask_decoder=args.train_mask_decoder)
