@@ -117,6 +117,7 @@ def main():
     from medplib_amd.model.config import MedPLIBConfig
     from medplib_amd.model.medplib import MedPLIBForCausalLM
 
+    torch.manual_seed(1234)          # the randomly initialised trainable tail is the same on every rank and in every run
     cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers)
     model = MedPLIBForCausalLM(cfg, device=device).train()
     ds_config = {"train_micro_batch_size_per_gpu": args.batch, "gradient_accumulation_steps": 1,

@@ -108,6 +108,10 @@ class Engine:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = None
+        if self.world > 1:
+            # every replica starts from rank 0's trainable parameters (DeepSpeed engine._broadcast_model): one broadcast of the flat
+            # fp32 buffer.  The frozen trunk is loaded / seeded identically on every rank and is not sent.
+            dist.broadcast(self.optimizer.flat_param, src=0)
         # "reduce_single_rank": run the gradient collective even on a one-rank group (SUM over one rank is the identity), so the
         # communication-stream ordering can be exercised on a single GPU (tests/test_gpu_model.py)
         self.reduce_single_rank = bool(config.get("reduce_single_rank", False)) and dist.is_initialized()

@@ -114,9 +114,12 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
 from medplib_amd import engine
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['PORT']}", rank=int(os.environ["RANK"]), world_size=2)
-torch.manual_seed(0)
+torch.manual_seed(int(os.environ["RANK"]))     # the replicas are initialised DIFFERENTLY: initialize() must broadcast rank 0's parameters
 lin = torch.nn.Linear(16, 8)
 eng, opt, _, _ = engine.initialize(model=lin, model_parameters=lin.parameters(), config={"optimizer": {"params": {"lr": 1e-2}}})
+torch.manual_seed(0)
+ref = torch.nn.Linear(16, 8)
+assert torch.equal(lin.weight.data, ref.weight.data) and torch.equal(lin.bias.data, ref.bias.data), "parameters were not broadcast from rank 0"
 # parameters and grads are views of the flat buckets
 assert lin.weight.data_ptr() == opt.flat_param.data_ptr() and lin.weight.grad.data_ptr() == opt.flat_grad.data_ptr()
 rank = dist.get_rank()
