@@ -31,7 +31,7 @@ def parse_args(argv=None):
     for name, typ, dv in (("moe_enable", lambda s: s.lower() in ("1", "true"), True), ("num_experts", int, 2), ("top_k_experts", int, 1),
                           ("capacity_factor", float, 1.5), ("eval_capacity_factor", float, 2.0), ("min_capacity", int, 0),
                           ("router_aux_loss_coef", float, 0.0), ("ce_loss_weight", float, 1.0), ("dice_loss_weight", float, 0.5),
-                          ("bce_loss_weight", float, 2.0), ("iou_loss_weight", float, 2.0), ("focal_loss_weight", float, 2.0), ("ep_size", int, 1)):
+                          ("bce_loss_weight", float, 2.0), ("iou_loss_weight", float, 2.0), ("focal_loss_weight", float, 2.0), ("ep_size", int, 1), ("use_residual", bool, False)):
         p.add_argument("--" + name, type=typ, default=dv)
     p.add_argument("--train_mask_decoder", action="store_true", default=True)
     return p.parse_args(argv)

@@ -123,7 +123,7 @@ def dict_to_device(batch, device):
 def build_model(args, device):
     kw = dict(moe_enable=args.moe_enable and not args.lisa, num_experts=args.num_experts, top_k_experts=args.top_k_experts,
               capacity_factor=args.capacity_factor, eval_capacity_factor=args.eval_capacity_factor, min_capacity=args.min_capacity,
-              use_residual=args.use_residual,
+              use_residual=getattr(args, "use_residual", False),
               router_aux_loss_coef=args.router_aux_loss_coef, ce_loss_weight=args.ce_loss_weight, dice_loss_weight=args.dice_loss_weight,
               bce_loss_weight=args.bce_loss_weight, iou_loss_weight=args.iou_loss_weight, focal_loss_weight=args.focal_loss_weight,
               train_mask_decoder=args.train_mask_decoder)
