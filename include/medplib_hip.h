@@ -267,6 +267,22 @@ int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const in
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,
                         int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
 
+/* ---- attention backward (first piece of the decoder backward for LoRA training) ------------------------ */
+/* mp_attention_fwd_bf16 (transposed-formulation kernel, no rel-pos) that also returns lse2 [B*H, Sq]: the fp32 row log-sum-exp of
+ * the scaled, masked scores in the log2 domain (+inf for a row with no visible key). */
+int mp_attention_fwd_lse_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss, const void* V,
+                              int64_t v_sb, int64_t v_ss, void* O, int64_t o_sb, int64_t o_ss, const uint8_t* key_valid, int B, int H,
+                              int Sq, int Sk, int D, int causal, float scale, float* lse2, hipStream_t stream);
+/* delta[B*H, Sq] = rowsum(dO o O) (fp32). */
+int mp_attention_delta_bf16(const void* O, int64_t o_sb, int64_t o_ss, const void* dO, int64_t do_sb, int64_t do_ss, float* delta, int B,
+                            int H, int Sq, int D, hipStream_t stream);
+/* Autograd of softmax(scale q k^T + causal / key-padding mask, fp32) v (HF-4.31 LlamaAttention eager): dQ, dK, dV (bf16)
+ * from dO, the forward's lse2 and delta; nothing [S, S]-sized is materialised, no atomics (each output element has one owner). */
+int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss, const void* V, int64_t v_sb,
+                          int64_t v_ss, const void* dO, int64_t do_sb, int64_t do_ss, const float* lse2, const float* delta, void* dQ,
+                          int64_t dq_sb, int64_t dq_ss, void* dK, int64_t dk_sb, int64_t dk_ss, void* dV, int64_t dv_sb, int64_t dv_ss,
+                          const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream);
+
 /* ---- image preprocessing in front of the path (datasets/LazySupervisedDataset.py:535-556) -------- */
 /* Window bounds + 22-bit fixed-point coefficients of one axis of PIL's bilinear ImagingResample (Pillow Resample.c
  * precompute_coeffs + normalize_coeffs_8bpc), which is what ResizeLongestSide.apply_image ends in

@@ -35,6 +35,7 @@ struct AttnArgs {
   int causal;
   float scale;
   const int* sk_dev;         // optional: number of valid keys read from device memory (<= Sk); decode steps inside a HIP graph
+  float* lse2;               // optional [B*H, Sq]: row log-sum-exp of the scaled scores in the log2 domain (for the backward; v2 kernel)
 };
 
 template <int D>
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     const int qi = qw0 + j * 16 + fr;
     if (qi >= a.Sq) continue;
     const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (a.lse2 && fq == 0) a.lse2[(int64_t)bh * a.Sq + qi] = l > 0.f ? m_run[j] + __builtin_amdgcn_logf(l) : INFINITY;   // v_log_f32 = log2
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
       bf16x4 v;
@@ -613,4 +615,18 @@ extern "C" int mp_attention_fwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, 
   if (variant == 0) variant = 2;
   if (D == 64) return variant == 1 ? launch_attn<64, true>(a, stream) : launch_attn<64, false>(a, stream);
   return variant == 1 ? launch_attn<128, true>(a, stream) : launch_attn<128, false>(a, stream);
+}
+
+// Forward that also returns the row log-sum-exp (log2 domain) the backward needs; transposed-formulation kernel only (no rel-pos).
+extern "C" int mp_attention_fwd_lse_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss,
+                                         const void* V, int64_t v_sb, int64_t v_ss, void* O, int64_t o_sb, int64_t o_ss,
+                                         const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D, int causal, float scale,
+                                         float* lse2, hipStream_t stream) {
+  MP_REQUIRE(D == 64 || D == 128, MP_ERR_SHAPE, "mp_attention_fwd_lse_bf16: head_dim %d unsupported (64/128)", D);
+  MP_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0 && lse2, MP_ERR_SHAPE, "mp_attention_fwd_lse_bf16: bad shape");
+  MP_REQUIRE((q_ss % 8 == 0) && (k_ss % 8 == 0) && (v_ss % 8 == 0) && (o_ss % 4 == 0), MP_ERR_SHAPE,
+             "mp_attention_fwd_lse_bf16: sequence strides must be multiples of 8 (inputs) / 4 (output) elements");
+  AttnArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss,
+             o_sb, o_ss, key_valid, nullptr, nullptr, 0, 0, B, H, Sq, Sk, causal, scale, nullptr, lse2};
+  return D == 64 ? launch_attn2<64>(a, stream) : launch_attn2<128>(a, stream);
 }

@@ -1,0 +1,301 @@
+// Flash-attention BACKWARD for the Llama causal self-attention (bf16, D = 128 / 64), the first piece of the decoder backward that
+// LoRA training needs (HF-4.31 LlamaAttention eager semantics, SURVEY A.1 — the autograd of
+// softmax(q k^T / sqrt(D) + mask, fp32) v).  Nothing [S, S]-sized is materialised.
+//
+// One templated kernel, two instantiations — the transposed formulation of attn_fwd2_kernel (attention.hip) carries over.  A wave
+// owns 32 RESIDENT columns (128 per workgroup) and the workgroup streams 64-row tiles of two operands X, Y through LDS:
+//     T1 = X R1^T      T2 = Y R2^T            (MFMA accumulators: lane = resident column, registers = streamed rows)
+//     P  = 2^(T1 c - L[query])                 dS = P o (T2 - delta[query])
+//     Out1^T += X^T dS                         Out2^T += Y^T P          (X^T / Y^T by ds_read_b64_tr_b16, dS / P straight from registers)
+//   dQ      : resident = (Q, dO) of a query block, streamed = (K, V) tiles; query index = lane;            Out1 = dQ
+//   dK / dV : resident = (K, V) of a key block,   streamed = (Q, dO) tiles; query index = accumulator row; Out1 = dK, Out2 = dV
+// L = the forward's row log-sum-exp in the log2 domain (mp_attention_fwd_lse_bf16), delta = rowsum(dO o O) (mp_attention_delta_bf16).
+// Every output element has exactly one owner: no atomics, bit-reproducible.  Up to 256 accumulator registers -> one wave per SIMD.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct AttnBwdArgs {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO;
+  bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+  const float* lse2; const float* delta;            // [B*H, Sq]
+  int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, do_sb, do_ss;
+  int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
+  const uint8_t* key_valid;                          // [B, Sk] or null
+  int B, H, Sq, Sk, causal;
+  float scale;
+};
+
+template <int D>
+__device__ __forceinline__ int sw_off(int r, int c) {  // byte offset of 16-B chunk c of row r in a [64][D] bf16 tile, XOR-swizzled
+  return r * (D * 2) + ((c ^ (r & 7)) << 4);
+}
+
+// A fragment of the TRANSPOSE of a swizzled [64][D] tile: M = d rows n*16 .. +15, K = the 32 streamed rows kp*32 .. +31 in the
+// order the accumulator packing below uses (attn_fwd2_kernel's V^T read, with the chunk swizzle applied per lane)
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kp, int n, int fr, int fq) {
+  const int row = kp * 32 + fq * 4 + (fr >> 2);
+  const int cb = n * 32 + (fr & 3) * 8;                               // byte column of this lane's 8-byte piece
+  const char* p0 = tile + row * (D * 2) + ((((cb >> 4) ^ (row & 7)) << 4) | (cb & 15));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * (D * 2)));
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int D, bool DKV>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
+  constexpr int TT = 64, CH = D / 8, NF = D / 16, KS = D / 32;
+  constexpr int TILE_BYTES = TT * D * 2;
+  constexpr int RPI = 1024 / (D * 2);             // rows per 1-KiB DMA instruction
+  constexpr int IPW = (TILE_BYTES / 1024) / 4;    // DMA instructions per wave per operand per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int r0 = blockIdx.x * 128;                // first resident column of the workgroup
+  const int rw0 = r0 + wave * 32;                 // ... of this wave
+  const int Sres = DKV ? a.Sk : a.Sq;             // resident axis length
+  const int Sstr = DKV ? a.Sq : a.Sk;             // streamed axis length
+
+  const bf16_t* Qb = a.Q + b * a.q_sb + (int64_t)h * D;
+  const bf16_t* Kb = a.K + b * a.k_sb + (int64_t)h * D;
+  const bf16_t* Vb = a.V + b * a.v_sb + (int64_t)h * D;
+  const bf16_t* Gb = a.dO + b * a.do_sb + (int64_t)h * D;
+  const uint8_t* kv = a.key_valid ? a.key_valid + (int64_t)b * a.Sk : nullptr;
+  const float* Lb = a.lse2 + (int64_t)bh * a.Sq;
+  const float* Db = a.delta + (int64_t)bh * a.Sq;
+
+  // streamed operands X (scores) and Y (dP); resident operands R1, R2
+  const bf16_t* Xb = DKV ? Qb : Kb;  const int64_t x_ss = DKV ? a.q_ss : a.k_ss;
+  const bf16_t* Yb = DKV ? Gb : Vb;  const int64_t y_ss = DKV ? a.do_ss : a.v_ss;
+  const bf16_t* R1b = DKV ? Kb : Qb; const int64_t r1_ss = DKV ? a.k_ss : a.q_ss;
+  const bf16_t* R2b = DKV ? Vb : Gb; const int64_t r2_ss = DKV ? a.v_ss : a.do_ss;
+
+  // tile range of the streamed axis
+  int t_begin = 0, t_end = (Sstr + TT - 1) / TT;
+  if (a.causal) {
+    if (DKV) t_begin = r0 / TT;                                   // queries before the block's first key see none of its keys
+    else t_end = min(t_end, (min(r0 + 128, a.Sq) + TT - 1) / TT); // keys after the block's last query are in its future
+  }
+
+  const int dma_row = lane / CH, dma_c = lane % CH;
+  auto issue = [&](int t, int stage) {
+    const int s0 = t * TT;
+    char* sX = smem + stage * 2 * TILE_BYTES;
+    char* sY = sX + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int j = wave * IPW + i;
+      const int row = j * RPI + dma_row;
+      const int sr = min(s0 + row, Sstr - 1);
+      const int c = (dma_c ^ (row & 7)) << 3;                     // the swizzle lives on the source address
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + (int64_t)sr * x_ss + c),
+                                       (__attribute__((address_space(3))) void*)(sX + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Yb + (int64_t)sr * y_ss + c),
+                                       (__attribute__((address_space(3))) void*)(sY + j * 1024), 16, 0, 0);
+    }
+  };
+  if (t_begin < t_end) issue(t_begin, 0);
+
+  // resident fragments (B operands): column = rw0 + j*16 + fr, k = kk*32 + fq*8 .. +8
+  bf16x8 r1f[2][KS], r2f[2][KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rr = min(rw0 + j * 16 + fr, Sres - 1);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      r1f[j][kk] = *reinterpret_cast<const bf16x8*>(R1b + (int64_t)rr * r1_ss + kk * 32 + fq * 8);
+      r2f[j][kk] = *reinterpret_cast<const bf16x8*>(R2b + (int64_t)rr * r2_ss + kk * 32 + fq * 8);
+    }
+  }
+  // per-lane query statistics when the query is the resident index
+  float Lq[2] = {0.f, 0.f}, Dq[2] = {0.f, 0.f};
+  if (!DKV) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int qi = min(rw0 + j * 16 + fr, a.Sq - 1);
+      Lq[j] = Lb[qi]; Dq[j] = Db[qi];
+    }
+  }
+
+  f32x4 o1[NF][2], o2[DKV ? NF : 1][2];
+#pragma unroll
+  for (int n = 0; n < NF; ++n)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o1[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < (DKV ? NF : 1); ++n)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o2[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = a.scale * 1.44269504088896340736f;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int s0 = t * TT;
+    const int stage = (t - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile t has landed for every wave; nobody still reads the other stage
+    if (t + 1 < t_end) issue(t + 1, stage ^ 1);
+    if (a.causal) {                        // wave-uniform skips of tiles that cannot interact with this wave's columns
+      if (DKV) { if (s0 + TT - 1 < rw0) continue; }          // every query of the tile precedes every key of the wave
+      else { if (s0 > rw0 + 31) continue; }                  // every key of the tile follows every query of the wave
+    }
+    const char* sX = smem + stage * 2 * TILE_BYTES;
+    const char* sY = sX + TILE_BYTES;
+
+    // ---- T1 = X R1^T, T2 = Y R2^T: 4 streamed fragments x 2 resident fragments ----
+    f32x4 s[4][2], dp[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { s[f][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[f][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sX + sw_off<D>(f * 16 + fr, kk * 4 + fq));
+        const bf16x8 yf = *reinterpret_cast<const bf16x8*>(sY + sw_off<D>(f * 16 + fr, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, r1f[j][kk], s[f][j], 0, 0, 0);
+          dp[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, r2f[j][kk], dp[f][j], 0, 0, 0);
+        }
+      }
+
+    // ---- P and dS; element (f, j, r): streamed index s0 + f*16 + fq*4 + r, resident index rw0 + j*16 + fr ----
+    bf16x8 pb[2][2], dsb[2][2];            // [streamed-fragment pair][resident fragment]: B operands of the output MFMAs
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float Lr[4], Dr[4];
+      if (DKV) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = min(s0 + f * 16 + fq * 4 + r, a.Sq - 1);
+          Lr[r] = Lb[qi]; Dr[r] = Db[qi];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ri = rw0 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int si = s0 + f * 16 + fq * 4 + r;
+          const int qi = DKV ? si : ri, kj = DKV ? ri : si;
+          bool ok = (kj < a.Sk) && (qi < a.Sq);
+          if (a.causal) ok = ok && (kj <= qi);
+          if (kv) ok = ok && (kv[min(kj, a.Sk - 1)] != 0);
+          const float L = DKV ? Lr[r] : Lq[j], dl = DKV ? Dr[r] : Dq[j];
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[f][j][r], c2, -L)) : 0.f;
+          const float ds = p * (dp[f][j][r] - dl);
+          pb[f >> 1][j][(f & 1) * 4 + r] = (bf16_t)p;
+          dsb[f >> 1][j][(f & 1) * 4 + r] = (bf16_t)ds;
+        }
+      }
+    }
+
+    // ---- Out1^T += X^T dS, Out2^T += Y^T P ----
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const bf16x8 xt = tr_frag<D>(sX, kp, n, fr, fq);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o1[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xt, dsb[kp][j], o1[n][j], 0, 0, 0);
+        if (DKV) {
+          const bf16x8 yt = tr_frag<D>(sY, kp, n, fr, fq);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) o2[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yt, pb[kp][j], o2[n][j], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- store: o[n][j][r] = Out[resident rw0 + j*16 + fr][d = n*16 + fq*4 + r]; dQ and dK carry the score scale ----
+  bf16_t* O1 = DKV ? a.dK + b * a.dk_sb + (int64_t)h * D : a.dQ + b * a.dq_sb + (int64_t)h * D;
+  const int64_t o1_ss = DKV ? a.dk_ss : a.dq_ss;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ri = rw0 + j * 16 + fr;
+    if (ri >= Sres) continue;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      bf16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o1[n][j][r] * a.scale);
+      *reinterpret_cast<bf16x4*>(O1 + (int64_t)ri * o1_ss + n * 16 + fq * 4) = v;
+      if (DKV) {
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)o2[n][j][r];
+        *reinterpret_cast<bf16x4*>(a.dV + b * a.dv_sb + (int64_t)h * D + (int64_t)ri * a.dv_ss + n * 16 + fq * 4) = w;
+      }
+    }
+  }
+}
+
+// delta[bh, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]   (fp32): one wave per (bh, q)
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, int64_t o_sb, int64_t o_ss, const bf16_t* __restrict__ dO,
+                                                         int64_t do_sb, int64_t do_ss, float* __restrict__ delta, int B, int H, int Sq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (int64_t)B * H * Sq) return;
+  const int q = (int)(w % Sq), bh = (int)(w / Sq), b = bh / H, h = bh % H;
+  float acc = 0.f;
+  for (int i = lane * 2; i < D; i += 128) {
+    const bf16x2 ov = *reinterpret_cast<const bf16x2*>(O + b * o_sb + (int64_t)q * o_ss + (int64_t)h * D + i);
+    const bf16x2 gv = *reinterpret_cast<const bf16x2*>(dO + b * do_sb + (int64_t)q * do_ss + (int64_t)h * D + i);
+    acc = fmaf((float)ov[0], (float)gv[0], acc);
+    acc = fmaf((float)ov[1], (float)gv[1], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) delta[w] = acc;
+}
+
+template <int D>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
+  constexpr int LDS = 4 * 64 * D * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<D, false>), dim3((a.Sq + 127) / 128, a.B * a.H), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, true>), dim3((a.Sk + 127) / 128, a.B * a.H), dim3(256), LDS, stream, a);
+  return mp_check_launch("mp_attention_bwd_bf16");
+}
+
+}  // namespace
+
+extern "C" int mp_attention_delta_bf16(const void* O, int64_t o_sb, int64_t o_ss, const void* dO, int64_t do_sb, int64_t do_ss, float* delta,
+                                       int B, int H, int Sq, int D, hipStream_t stream) {
+  MP_REQUIRE(D == 64 || D == 128, MP_ERR_SHAPE, "mp_attention_delta_bf16: head_dim %d unsupported (64/128)", D);
+  MP_REQUIRE(B > 0 && H > 0 && Sq > 0 && o_ss % 2 == 0 && do_ss % 2 == 0, MP_ERR_SHAPE, "mp_attention_delta_bf16: bad shape");
+  const int64_t waves = (int64_t)B * H * Sq;
+  if (D == 64) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)mp_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)O, o_sb, o_ss,
+                                  (const bf16_t*)dO, do_sb, do_ss, delta, B, H, Sq);
+  else hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)mp_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)O, o_sb, o_ss,
+                          (const bf16_t*)dO, do_sb, do_ss, delta, B, H, Sq);
+  return mp_check_launch("mp_attention_delta_bf16");
+}
+
+extern "C" int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss, const void* V,
+                                     int64_t v_sb, int64_t v_ss, const void* dO, int64_t do_sb, int64_t do_ss, const float* lse2,
+                                     const float* delta, void* dQ, int64_t dq_sb, int64_t dq_ss, void* dK, int64_t dk_sb, int64_t dk_ss,
+                                     void* dV, int64_t dv_sb, int64_t dv_ss, const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D,
+                                     int causal, float scale, hipStream_t stream) {
+  MP_REQUIRE(D == 64 || D == 128, MP_ERR_SHAPE, "mp_attention_bwd_bf16: head_dim %d unsupported (64/128)", D);
+  MP_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, MP_ERR_SHAPE, "mp_attention_bwd_bf16: bad shape");
+  MP_REQUIRE(q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && do_ss % 8 == 0 && dq_ss % 4 == 0 && dk_ss % 4 == 0 && dv_ss % 4 == 0, MP_ERR_SHAPE,
+             "mp_attention_bwd_bf16: input sequence strides must be multiples of 8 elements, output ones of 4");
+  MP_REQUIRE(lse2 && delta, MP_ERR_ARG, "mp_attention_bwd_bf16: needs the forward's log-sum-exp and delta");
+  AttnBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, lse2, delta,
+                q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, do_sb, do_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, key_valid, B, H, Sq, Sk, causal, scale};
+  return D == 64 ? launch_bwd<64>(a, stream) : launch_bwd<128>(a, stream);
+}

@@ -193,6 +193,44 @@ def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w
     return out
 
 
+def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None):
+    """Attention forward that also returns the row log-sum-exp (log2 domain) for the backward.  q,k,v: [B,S,H,D] bf16 views.
+    -> (out [B,Sq,H*D] bf16, lse2 [B*H, Sq] fp32)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, torch.bfloat16, "attention_fwd_lse." + n)
+        assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    out = torch.empty((B, Sq, H * D), dtype=torch.bfloat16, device=q.device)
+    lse2 = torch.empty((B * H, Sq), dtype=torch.float32, device=q.device)
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "attention_fwd_lse.key_valid"); assert key_valid.is_contiguous()
+    lib().call("mp_attention_fwd_lse_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+               _p(out), out.stride(0), out.stride(1), _p(key_valid), B, H, Sq, Sk, D, int(bool(causal)),
+               float(D ** -0.5 if scale is None else scale), _p(lse2), _stream())
+    return out, lse2
+
+
+def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=None):
+    """Backward of softmax(scale q k^T + mask) v.  q,k,v [B,S,H,D] bf16 views, out / d_out [B,Sq,H*D] bf16, lse2 from attention_fwd_lse.
+    -> (dq, dk, dv) as [B,S,H,D] views of one [B,S,3,H,D] buffer (the layout of the fused qkv projection output)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    assert Sq == Sk, "self-attention backward (the fused dqkv buffer holds one row per position)"
+    _chk(d_out, torch.bfloat16, "attention_bwd.d_out"); _chk(out, torch.bfloat16, "attention_bwd.out")
+    assert d_out.stride(2) == 1 and out.stride(2) == 1
+    delta = torch.empty((B * H, Sq), dtype=torch.float32, device=q.device)
+    lib().call("mp_attention_delta_bf16", _p(out), out.stride(0), out.stride(1), _p(d_out), d_out.stride(0), d_out.stride(1), _p(delta),
+               B, H, Sq, D, _stream())
+    dqkv = torch.empty((B, Sq, 3, H, D), dtype=torch.bfloat16, device=q.device)
+    dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+    lib().call("mp_attention_bwd_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+               _p(d_out), d_out.stride(0), d_out.stride(1), _p(lse2), _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0),
+               dk.stride(1), _p(dv), dv.stride(0), dv.stride(1), _p(key_valid), B, H, Sq, Sk, D, int(bool(causal)),
+               float(D ** -0.5 if scale is None else scale), _stream())
+    return dq, dk, dv
+
+
 def decode_rope_append(qkv, cos_t, sin_t, cache_k, cache_v, pos_dev, heads, head_dim):
     """qkv [B, 3*H*D] (one new token per sequence): q rotated in place, rotated k / v written to the caches [B, max_len, H, D] at
     position pos_dev[0] (int32 on the device)."""

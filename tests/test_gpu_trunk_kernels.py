@@ -324,3 +324,39 @@ def test_decode_norm_gate_route_equals_separate_kernels(dev):
         assert torch.equal(got[0], h_ref), (T, E, d)
         for a, b, name in zip(got[1:], ref, ["expert", "slot", "weight", "kept", "counts", "l_aux"]):
             assert torch.equal(a, b), (name, T, E, d, a, b)
+
+
+@pytest.mark.parametrize("B,H,S,D,ragged", [(2, 3, 150, 128, True), (1, 2, 300, 128, False), (2, 2, 200, 64, True), (1, 1, 64, 128, False)])
+def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
+    """mp_attention_bwd_bf16 (+ the forward's log-sum-exp, delta) vs torch autograd of the eager fp32 attention on the same
+    bf16-rounded q, k, v, dO: causal mask + key padding (HF-4.31 LlamaAttention semantics).  Tolerance: the kernel
+    rounds P and dS to bf16 for the MFMAs like a bf16 autograd would: 2 % of each gradient's largest magnitude."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(100 + S + D)
+    qkv = (torch.randn(B, S, 3, H, D, generator=g) * 0.8).to(torch.bfloat16)
+    d_out = torch.randn(B, S, H * D, generator=g).to(torch.bfloat16)
+    kvalid = torch.ones(B, S, dtype=torch.bool)
+    if ragged:
+        kvalid[0, S - 17:] = False
+    q, k, v = [qkv[:, :, i].float().clone().requires_grad_(True) for i in range(3)]
+    scale = D ** -0.5
+    sc = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    mask = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None] & kvalid[:, None, None, :]
+    sc = sc.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(sc, dim=-1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", p, v).reshape(B, S, H * D)
+    ref.backward(d_out.float())
+    qd = qkv.to(dev)
+    kvd = kvalid.to(torch.uint8).to(dev) if ragged else None
+    out, lse2 = ops.attention_fwd_lse(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], causal=True, key_valid=kvd)
+    _report("attention fwd (lse variant)", out, ref.detach(), rtol=3 * BF16_EPS, atol=2e-2)
+    lse_ref = torch.logsumexp(sc.detach(), dim=-1).reshape(B * H, S) * 1.4426950408889634
+    assert (lse2.cpu() - lse_ref).abs().max().item() < 2e-2
+    dq, dk, dv = ops.attention_bwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], out, d_out.to(dev), lse2, causal=True, key_valid=kvd)
+    torch.cuda.synchronize()
+    for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
+        err = (got.float().cpu() - want).abs().max().item()
+        print(f"attention bwd {name}: max|err| {err:.3e}, ref absmax {want.abs().max().item():.3e}")
+        assert err <= 2e-2 * want.abs().max().item() + 1e-3, name
+    if ragged:                                  # padded keys receive no gradient
+        assert float(dk[0, S - 17:].abs().max()) == 0.0 and float(dv[0, S - 17:].abs().max()) == 0.0
