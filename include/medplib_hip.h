@@ -283,6 +283,27 @@ int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void*
                           int64_t dq_sb, int64_t dq_ss, void* dK, int64_t dk_sb, int64_t dk_ss, void* dV, int64_t dv_sb, int64_t dv_ss,
                           const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream);
 
+/* ---- decoder backward pieces (LoRA training; train_ds_medplib.py:262-303, scripts/train_stage3.sh) -------- */
+/* Autograd of LlamaRMSNorm w.r.t. its input (weight frozen): dx = rs * (dy*w - xhat * mean(dy*w*xhat)) [+ add], xhat = x*rs. */
+int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
+                        int64_t ldo, int64_t rows, int dim, float eps, hipStream_t stream);
+/* silu(gate) * up and its autograd on the gate|up GEMM output [tokens, 2*ff] whose columns are interleaved in blocks of 32 (the
+ * fused weight layout); act / dact [tokens, ff]. */
+int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream);
+int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream);
+/* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R % 8 == 0, R <= 32): the LoRA weight gradients dB = dY^T (x A^T) and
+ * dA^T = x^T (dY B) — reads X once, fixed summation order. */
+int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, int64_t tokens, int N, int R, float scale,
+                     hipStream_t stream);
+/* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
+ * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
+int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,
+                   int64_t rows, int V, hipStream_t stream);
+/* out[rows[i], :] = bf16(g[i, :]): backward of the row gathers in front of lm_head / text_hidden_fcs (out pre-zeroed, rows unique). */
+int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int64_t n, int dim, hipStream_t stream);
+/* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
+int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
+
 /* ---- image preprocessing in front of the path (datasets/LazySupervisedDataset.py:535-556) -------- */
 /* Window bounds + 22-bit fixed-point coefficients of one axis of PIL's bilinear ImagingResample (Pillow Resample.c
  * precompute_coeffs + normalize_coeffs_8bpc), which is what ResizeLongestSide.apply_image ends in

@@ -1,0 +1,252 @@
+// Row / elementwise kernels of the decoder BACKWARD (LoRA training; the autograd of HF-4.31 LlamaRMSNorm,
+// LlamaMLP's silu(gate) * up, the filtered cross-entropy of medplib_moe_llama.py:392-408, and peft's LoRA adapters,
+// train_ds_medplib.py:262-303).  All HBM-bound; the GEMMs of the backward are the forward's NT kernel on transposed weight copies.
+//
+//   mp_rmsnorm_bwd_bf16        dx = rs * (dy*w - xhat * mean(dy*w*xhat)) (+ add), xhat = x*rs              one block per row
+//   mp_swiglu_pair_fwd/bwd     act = silu(g)*u on the gate|up GEMM output with gate / up interleaved in blocks of 32 columns
+//                              (the layout of the fused weights, ops.swiglu_interleave); d_g, d_u in the same layout
+//   mp_tn_skinny_f32           out[n, j] = scale * sum_t X[t, n] * G[t, j], j < R <= 32: the adapters' weight gradients (a column
+//                              block per workgroup, the token axis split over its waves and combined in a fixed order)
+//   mp_ce_rows_bwd             d_logits = g * (softmax(logits) - onehot(label)) for the supervised rows, written as bf16 [n, ldo]
+//   mp_scatter_rows_f32_bf16   out[rows[i], :] = bf16(g[i, :])  (backward of the row gather in front of text_hidden_fcs / lm_head)
+//   mp_dropout_bf16            y = x * keep / (1 - p) with keep from the stateless hash generator (peft lora_dropout on the adapter input)
+#include "common.h"
+
+namespace {
+
+constexpr int RB_THREADS = 256, RB_MAXC = 4;
+
+__global__ __launch_bounds__(RB_THREADS) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                 const bf16_t* __restrict__ dy, const bf16_t* __restrict__ add,
+                                                                 bf16_t* __restrict__ dx, int dim, float eps, int64_t ldx, int64_t ldy,
+                                                                 int64_t lda, int64_t ldo) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const bf16_t* xr = x + row * ldx;
+  const bf16_t* gr = dy + row * ldy;
+  bf16x8 xv[RB_MAXC], gv[RB_MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < RB_MAXC; ++c) {
+    const int i = (c * RB_THREADS + threadIdx.x) * 8;
+    if (i < dim) {
+      xv[c] = *reinterpret_cast<const bf16x8*>(xr + i);
+      gv[c] = *reinterpret_cast<const bf16x8*>(gr + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)xv[c][j]; ss += f * f; }
+    }
+  }
+  ss = block_sum(ss, red);
+  const float rs = rsqrtf(ss / (float)dim + eps);
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < RB_MAXC; ++c) {
+    const int i = (c * RB_THREADS + threadIdx.x) * 8;
+    if (i < dim) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += (float)gv[c][j] * w[i + j] * ((float)xv[c][j] * rs);
+    }
+  }
+  dot = block_sum(dot, red) / (float)dim;
+#pragma unroll
+  for (int c = 0; c < RB_MAXC; ++c) {
+    const int i = (c * RB_THREADS + threadIdx.x) * 8;
+    if (i < dim) {
+      bf16x8 av;
+      if (add) av = *reinterpret_cast<const bf16x8*>(add + row * lda + i);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (float)xv[c][j] * rs;
+        float v = rs * ((float)gv[c][j] * w[i + j] - xh * dot);
+        if (add) v += (float)av[j];
+        o[j] = (bf16_t)v;
+      }
+      *reinterpret_cast<bf16x8*>(dx + row * ldo + i) = o;
+    }
+  }
+}
+
+// gate|up interleaved in blocks of 32: column blk*64 + j = gate channel blk*32 + j, column blk*64 + 32 + j = its up channel
+__global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int64_t T, int ff) {
+  const int per_row = ff / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * per_row) return;
+  const int64_t t = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;                 // act channel (8 consecutive, inside one block of 32)
+  const int64_t col = (int64_t)(c >> 5) * 64 + (c & 31);
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col);
+  const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col + 32);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float gf = (float)g[j]; o[j] = (bf16_t)(gf / (1.f + __expf(-gf)) * (float)u[j]); }
+  *reinterpret_cast<bf16x8*>(act + t * ff + c) = o;
+}
+
+__global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu, int64_t T,
+                                       int ff) {
+  const int per_row = ff / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * per_row) return;
+  const int64_t t = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;
+  const int64_t col = (int64_t)(c >> 5) * 64 + (c & 31);
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col);
+  const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col + 32);
+  const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + t * ff + c);
+  bf16x8 dg, du;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float gf = (float)g[j], uf = (float)u[j], df = (float)d[j];
+    const float sg = 1.f / (1.f + __expf(-gf));
+    du[j] = (bf16_t)(df * gf * sg);
+    dg[j] = (bf16_t)(df * uf * sg * (1.f + gf * (1.f - sg)));
+  }
+  *reinterpret_cast<bf16x8*>(dgu + t * 2 * ff + col) = dg;
+  *reinterpret_cast<bf16x8*>(dgu + t * 2 * ff + col + 32) = du;
+}
+
+// out[n, j] = scale * sum_t X[t, n] * G[t, j]   (j < R <= 32).  Block = 64 columns n x 4 waves; wave w walks rows w, w+4, ...;
+// the four partial sums meet in LDS and are added in wave order.
+constexpr int TN_MAXR = 32;
+__global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
+                                                        float* __restrict__ out, int64_t T, int N, int R, float scale) {
+  __shared__ float part[3][64][TN_MAXR + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const bool live = n < N;
+  float acc[TN_MAXR];
+#pragma unroll
+  for (int j = 0; j < TN_MAXR; ++j) acc[j] = 0.f;
+  for (int64_t t = wave; t < T; t += 4) {
+    const float xv = live ? (float)X[t * ldx + n] : 0.f;
+    const bf16_t* gr = G + t * ldg;
+#pragma unroll
+    for (int j8 = 0; j8 < TN_MAXR; j8 += 8) {
+      if (j8 < R) {                                          // R is a multiple of 8 (checked on the host)
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + j8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j8 + j] = fmaf(xv, (float)gv[j], acc[j8 + j]);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < TN_MAXR; ++j) part[wave - 1][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int j = 0; j < TN_MAXR; ++j)
+      if (j < R) out[(int64_t)n * R + j] = scale * (((acc[j] + part[0][lane][j]) + part[1][lane][j]) + part[2][lane][j]);
+  }
+}
+
+// d_logits[i, v] = g * (exp(logit - lse_i) - [v == label_i]); one block per supervised row; bf16 output, columns >= V zeroed up to ldo
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          const float* __restrict__ gscale, float gconst, bf16_t* __restrict__ out, int V,
+                                                          int64_t ldl, int64_t ldo) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const float* lr = logits + row * ldl;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, lr[v]);
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) s += expf(lr[v] - mx);
+  s = block_sum(s, red);
+  const float g = gconst * (gscale ? gscale[0] : 1.f);
+  const int64_t lab = labels[row];
+  const float inv = 1.f / s;
+  for (int v = threadIdx.x; v < ldo; v += 256) {
+    float d = 0.f;
+    if (v < V) d = g * (expf(lr[v] - mx) * inv - (v == lab ? 1.f : 0.f));
+    out[row * ldo + v] = (bf16_t)d;
+  }
+}
+
+__global__ void scatter_rows_f32_bf16_kernel(const float* __restrict__ g, const int64_t* __restrict__ rows, bf16_t* __restrict__ out, int64_t n,
+                                             int d) {
+  const int per_row = d / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * per_row) return;
+  const int64_t i = idx / per_row;
+  const int c = (int)(idx % per_row) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * d + c);
+  *reinterpret_cast<bf16x4*>(out + rows[i] * d + c) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+__device__ __forceinline__ uint32_t hash32(uint64_t k) {       // splitmix64 finaliser, as the gate-noise generator uses
+  k += 0x9e3779b97f4a7c15ull;
+  k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ull;
+  k = (k ^ (k >> 27)) * 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return (uint32_t)(k >> 32);
+}
+__global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, float p, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)i) >> 8) * (1.f / 16777216.f);
+  y[i] = (bf16_t)(u >= p ? (float)x[i] * (1.f / (1.f - p)) : 0.f);
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
+
+extern "C" int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda,
+                                   void* dx, int64_t ldo, int64_t rows, int dim, float eps, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && dim <= RB_THREADS * 8 * RB_MAXC && ldx % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && (!add || lda % 8 == 0), MP_ERR_SHAPE,
+             "mp_rmsnorm_bwd_bf16: dim=%d unsupported", dim);
+  if (rows == 0) return MP_OK;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)rows), dim3(RB_THREADS), 0, stream, (const bf16_t*)x, w, (const bf16_t*)dy,
+                     (const bf16_t*)add, (bf16_t*)dx, dim, eps, ldx, ldy, lda, ldo);
+  return mp_check_launch("mp_rmsnorm_bwd_bf16");
+}
+
+extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream) {
+  MP_REQUIRE(ff % 32 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_fwd_bf16: ff %% 32 != 0");
+  const int64_t n = tokens * (ff / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(swiglu_pair_fwd_kernel, GRID1D(n), (const bf16_t*)gu, (bf16_t*)act, tokens, ff);
+  return mp_check_launch("mp_swiglu_pair_fwd_bf16");
+}
+
+extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream) {
+  MP_REQUIRE(ff % 32 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_bwd_bf16: ff %% 32 != 0");
+  const int64_t n = tokens * (ff / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(swiglu_pair_bwd_kernel, GRID1D(n), (const bf16_t*)gu, (const bf16_t*)dact, (bf16_t*)dgu, tokens, ff);
+  return mp_check_launch("mp_swiglu_pair_bwd_bf16");
+}
+
+extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, int64_t tokens, int N, int R, float scale,
+                                hipStream_t stream) {
+  MP_REQUIRE(N > 0 && R > 0 && R <= TN_MAXR && R % 8 == 0 && ldg % 8 == 0, MP_ERR_SHAPE, "mp_tn_skinny_f32: R must be a multiple of 8, <= %d", TN_MAXR);
+  hipLaunchKernelGGL(tn_skinny_kernel, dim3((unsigned)mp_cdiv(N, 64)), dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, out,
+                     tokens, N, R, scale);
+  return mp_check_launch("mp_tn_skinny_f32");
+}
+
+extern "C" int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits,
+                              int64_t ldo, int64_t rows, int V, hipStream_t stream) {
+  MP_REQUIRE(V > 0 && ldo >= V, MP_ERR_SHAPE, "mp_ce_rows_bwd: bad shape");
+  if (rows == 0) return MP_OK;
+  hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, logits, labels, gscale, gconst, (bf16_t*)dlogits, V, ldl, ldo);
+  return mp_check_launch("mp_ce_rows_bwd");
+}
+
+extern "C" int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int64_t n, int dim, hipStream_t stream) {
+  MP_REQUIRE(dim % 4 == 0, MP_ERR_SHAPE, "mp_scatter_rows_f32_bf16: dim %% 4 != 0");
+  const int64_t m = n * (dim / 4);
+  if (m == 0) return MP_OK;
+  hipLaunchKernelGGL(scatter_rows_f32_bf16_kernel, GRID1D(m), g, rows, (bf16_t*)out, n, dim);
+  return mp_check_launch("mp_scatter_rows_f32_bf16");
+}
+
+extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream) {
+  MP_REQUIRE(p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_dropout_bf16: p must be in [0, 1)");
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(dropout_bf16_kernel, GRID1D(n), (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+  return mp_check_launch("mp_dropout_bf16");
+}

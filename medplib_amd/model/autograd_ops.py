@@ -197,7 +197,8 @@ class MaskLossFn(torch.autograd.Function):
         pred, gt, stats = ctx.saved_tensors
         gscale = dout[0:1].contiguous()
         dpred, dq = ops.mask_losses_bwd(pred, gt, stats, gscale, ctx.weights, ctx.offsets)
-        return dpred, None, dq, None, None, None
+        d_ce = gscale * ctx.weights[0] if ctx.needs_input_grad[3] else None      # loss = ce * ce_loss_weight + mask terms
+        return dpred, None, dq, d_ce, None, None
 
 
 class BuildTokensFn(torch.autograd.Function):

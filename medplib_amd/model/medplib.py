@@ -139,11 +139,22 @@ class MedPLIBForCausalLM(nn.Module):
         return self.model
 
     def trainable_parameters(self):
-        """Stage-III 'LoRA off' selection (train_ds_medplib.py:316-326 with sft_modules mask_decoder,text_hidden_fcs)."""
+        """Stage-III selection (train_ds_medplib.py:316-326 with sft_modules mask_decoder,text_hidden_fcs) + the LoRA adapters when
+        enable_lora() attached them (get_peft_model marks exactly those trainable, :294-303)."""
         ps = list(self.model.text_hidden_fcs.parameters())
         if self.config.train_mask_decoder:
             ps += list(self.model.visual_model.mask_decoder.parameters())
+        if getattr(self.model, "lora", None) is not None:
+            ps += list(self.model.lora.parameters())
         return ps
+
+    def enable_lora(self, lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules=("gate_proj", "up_proj", "down_proj"), seed=0):
+        """get_peft_model(LoraConfig(r, lora_alpha, target_modules, lora_dropout)) for the decoder's MLP projections
+        (train_ds_medplib.py:262-303; scripts/train_stage3.sh).  Call after the weights are loaded."""
+        from . import llama_lora as LL
+        targets = tuple(t for t in (lora_target_modules.split(",") if isinstance(lora_target_modules, str) else lora_target_modules))
+        self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed)
+        return self.model.lora
 
     def train(self, mode=True):
         super().train(mode)
@@ -330,11 +341,25 @@ class MedPLIBForCausalLM(nn.Module):
             exp = self.expand_index(valid_mask_bool, B) if seg_flag else None
             exp_d = _h2d(np.asarray(exp, dtype=np.int64), dev) if (seg_flag and exp != list(range(B))) else None
             embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(B, plan.seq_len, cfg.hidden_size)
-            last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
-            ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, aux)
+            lora_train = getattr(m.llm, "lora", None) is not None and self.training and not inference
+            if not lora_train:
+                last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
+                ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, aux)
+        if lora_train and torch.is_grad_enabled():
+            # LoRA training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so loss.backward()
+            # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
+            from . import llama_lora as LL
+            last_hidden = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *m.llm.lora.params)
+            ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm) if sup_rows_d.numel() else \
+                torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+        elif lora_train:
+            from . import llama_lora as LL
+            with torch.no_grad():
+                last_hidden, _ = LL.forward_train(m.llm, embeds, key_valid)
+                ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, [])
         if not seg_flag:
             z = torch.zeros(1, dtype=torch.float32, device=dev)
-            ce_w = ops.mean_plus(ce, cfg.ce_loss_weight)          # ce * ce_loss_weight
+            ce_w = ce * cfg.ce_loss_weight if ce.requires_grad else ops.mean_plus(ce, cfg.ce_loss_weight)          # ce * ce_loss_weight
             out = {k: z[0] for k in LOSS_KEYS}
             out["loss"] = out["ce_loss"] = ce_w[0]
             return out
@@ -377,7 +402,10 @@ class MedPLIBForCausalLM(nn.Module):
             assert image_tokens.shape[0] == B
             if exp_d is not None:
                 image_tokens = ops.gather_rows_f32(image_tokens, exp_d)
-            hidden_rows = ops.gather_rows_bf16_to_f32(last_hidden.view(-1, cfg.hidden_size), seg_rows_d)
+            hidden_rows = None if last_hidden.requires_grad else ops.gather_rows_bf16_to_f32(last_hidden.view(-1, cfg.hidden_size), seg_rows_d)
+        if hidden_rows is None:                                   # LoRA training: the <SEG> rows carry gradient back into the decoder
+            from . import llama_lora as LL
+            hidden_rows = LL.GatherRowsFn.apply(last_hidden, seg_rows_d)
         n = hidden_rows.shape[0]
         assert n <= image_tokens.shape[0], "more <SEG> rows than expanded image embeddings"   # pairing by position, :473-487
         if n < image_tokens.shape[0]:

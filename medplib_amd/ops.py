@@ -213,7 +213,7 @@ def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None):
 
 def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=None):
     """Backward of softmax(scale q k^T + mask) v.  q,k,v [B,S,H,D] bf16 views, out / d_out [B,Sq,H*D] bf16, lse2 from attention_fwd_lse.
-    -> (dq, dk, dv) as [B,S,H,D] views of one [B,S,3,H,D] buffer (the layout of the fused qkv projection output)."""
+    -> (dq, dk, dv, dqkv): [B,S,H,D] views of one [B,S,3,H,D] buffer (the layout of the fused qkv projection output) and the buffer."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     assert Sq == Sk, "self-attention backward (the fused dqkv buffer holds one row per position)"
@@ -228,7 +228,64 @@ def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=
                _p(d_out), d_out.stride(0), d_out.stride(1), _p(lse2), _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0),
                dk.stride(1), _p(dv), dv.stride(0), dv.stride(1), _p(key_valid), B, H, Sq, Sk, D, int(bool(causal)),
                float(D ** -0.5 if scale is None else scale), _stream())
-    return dq, dk, dv
+    return dq, dk, dv, dqkv
+
+
+# ------------------------------------------------------------------ decoder backward pieces (LoRA training) --------------------
+def rmsnorm_bwd(x, w, dy, eps, add=None):
+    """dx of LlamaRMSNorm (weight frozen), optionally + add (the residual-stream gradient).  x, dy [T, d] bf16."""
+    _chk(x, torch.bfloat16, "rmsnorm_bwd.x"); _chk(dy, torch.bfloat16, "rmsnorm_bwd.dy")
+    T, d = x.shape
+    out = torch.empty((T, d), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_rmsnorm_bwd_bf16", _p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0,
+               _p(out), out.stride(0), T, d, float(eps), _stream())
+    return out
+
+
+def swiglu_pair_fwd(gu):
+    T, ff2 = gu.shape
+    act = torch.empty((T, ff2 // 2), dtype=torch.bfloat16, device=gu.device)
+    lib().call("mp_swiglu_pair_fwd_bf16", _p(gu), _p(act), T, ff2 // 2, _stream())
+    return act
+
+
+def swiglu_pair_bwd(gu, dact):
+    T, ff2 = gu.shape
+    dgu = torch.empty_like(gu)
+    lib().call("mp_swiglu_pair_bwd_bf16", _p(gu), _p(dact), _p(dgu), T, ff2 // 2, _stream())
+    return dgu
+
+
+def tn_skinny(x, g, R, scale=1.0):
+    """out[n, j] = scale * sum_t x[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= R] bf16."""
+    _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
+    T, N = x.shape
+    out = torch.empty((N, R), dtype=torch.float32, device=x.device)
+    lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), T, N, int(R), float(scale), _stream())
+    return out
+
+
+def ce_rows_bwd(logits, labels, gscale, gconst, ldo):
+    """bf16 [n, ldo] = gconst * gscale[0] * (softmax(logits) - onehot(labels)), zero beyond V."""
+    n, V = logits.shape
+    out = torch.empty((n, ldo), dtype=torch.bfloat16, device=logits.device)
+    lib().call("mp_ce_rows_bwd", _p(logits), logits.stride(0), _p(labels), _p(gscale), float(gconst), _p(out), ldo, n, V, _stream())
+    return out
+
+
+def scatter_rows_f32_bf16(g, rows, T):
+    """zeros [T, d] bf16 with row rows[i] = bf16(g[i])."""
+    _chk(g, torch.float32, "scatter_rows.g")
+    n, d = g.shape
+    out = torch.zeros((T, d), dtype=torch.bfloat16, device=g.device)
+    lib().call("mp_scatter_rows_f32_bf16", _p(g.contiguous()), _p(rows), _p(out), n, d, _stream())
+    return out
+
+
+def dropout_bf16(x, p, seed):
+    y = torch.empty_like(x)
+    lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())
+    return y
 
 
 def decode_rope_append(qkv, cos_t, sin_t, cache_k, cache_v, pos_dev, heads, head_dim):

@@ -345,8 +345,14 @@ def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="",
                 out = out * coef[:, 0:1] + mlp * coef[:, 1:]
             x = x + out.view(B, S, d)
         else:
-            m = F.linear(ops.swiglu(F.linear(h, W[p + "mlp.gate_proj.weight"]), F.linear(h, W[p + "mlp.up_proj.weight"])),
-                         W[p + "mlp.down_proj.weight"])
+            def lin(t, name):
+                # peft 0.10 LoRA Linear (parity unpinned: peft is not installed): W x + (alpha / r) * B (A x); dropout off here
+                y = F.linear(t, W[p + f"mlp.{name}.weight"])
+                ka = p + f"mlp.{name}.lora_A.default.weight"
+                if ka in W:
+                    y = y + W["lora_scaling"] * F.linear(F.linear(t, W[ka]), W[p + f"mlp.{name}.lora_B.default.weight"])
+                return y
+            m = lin(ops.swiglu(lin(h, "gate_proj"), lin(h, "up_proj")), "down_proj")
             x = x + m
     return ops.rmsnorm(x, W[prefix + "model.norm.weight"].float(), cfg.rms_norm_eps), aux
 

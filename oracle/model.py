@@ -4,6 +4,8 @@ End-to-end CPU fp32 restatement of `MedPLIBForCausalLM.model_forward` / `LISAFor
 (model/MedPLIB.py:364-572, model/LISA.py:260-471) from an HF-layout state dict, plus seeded weight / batch generators
 shared by the tests, smoke() and bench.py's cpu_baseline leg."""
 import numpy as np
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -140,7 +142,7 @@ def make_batch_icl(cfg, B, n_ctx=2, H=96, Wd=80, seed=0, sam_size=256, mask_size
     return base
 
 
-def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None):
+def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None, llm_grad=False):
     """model/MedPLIB.py:364-572 end to end on the CPU in fp32.  `override` (tests only) may inject `hidden` [B,S,d],
     `image_emb` [B,256,16,16] and `ce` so the trainable tail can be checked on exactly the trunk outputs another
     implementation produced."""
@@ -171,13 +173,15 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token,
                                                                       region_features=region_features, valid_region_masks_bool=valid)
         kv = None if att2.all() else att2
+    # llm_grad (LoRA training): the decoder and the CE stay on the autograd tape so `loss.backward()` reaches the adapters in W
+    with (contextlib.nullcontext() if llm_grad else torch.no_grad()):
         hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
         ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)
         if override:
             hidden = override.get("hidden", hidden); image_emb = override.get("image_emb", image_emb); ce = override.get("ce", ce)
     seg_mask = llm.build_seg_token_mask(ids, cfg.seg_token_idx, tok, batch.get("image_token_lengths"))
     SW = {k[len("model.visual_model."):]: v for k, v in W.items() if k.startswith("model.visual_model.")}
-    hid = hidden.detach()
+    hid = hidden if llm_grad else hidden.detach()
     fc = lambda x: F.linear(F.relu(F.linear(x, W["model.text_hidden_fcs.0.0.weight"], W["model.text_hidden_fcs.0.0.bias"])),
                             W["model.text_hidden_fcs.0.2.weight"], W["model.text_hidden_fcs.0.2.bias"])
     last = fc(hid)                                            # applied to every row like the reference (MedPLIB.py:456)

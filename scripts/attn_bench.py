@@ -31,3 +31,22 @@ for variant in (2, 0):
         us = s.elapsed_time(e) * 1e3 / n
         fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
         print(f"  {name:26s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+
+# backward (the decoder-backward piece for LoRA training): dQ + dK/dV kernels + delta
+print("backward")
+for name, B, S, H, D in [("llama causal", 8, 639, 32, 128), ("llama S=1316 (config 5)", 4, 1316, 32, 128)]:
+    qkv = torch.randn(B, S, 3, H, D, device=dev).to(torch.bfloat16)
+    d_out = torch.randn(B, S, H * D, device=dev).to(torch.bfloat16)
+    out, lse2 = ops.attention_fwd_lse(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True)
+    for _ in range(3):
+        ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, d_out, lse2, causal=True)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    s.record()
+    for _ in range(n):
+        ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, d_out, lse2, causal=True)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / n
+    fl = 2.0 * B * H * S * S * D * 0.5 * 7           # 3 matmuls in dQ, 4 in dK/dV, causal half
+    print(f"  {name:26s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s (incl. delta)", flush=True)

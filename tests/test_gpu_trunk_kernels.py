@@ -352,7 +352,7 @@ def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
     _report("attention fwd (lse variant)", out, ref.detach(), rtol=3 * BF16_EPS, atol=2e-2)
     lse_ref = torch.logsumexp(sc.detach(), dim=-1).reshape(B * H, S) * 1.4426950408889634
     assert (lse2.cpu() - lse_ref).abs().max().item() < 2e-2
-    dq, dk, dv = ops.attention_bwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], out, d_out.to(dev), lse2, causal=True, key_valid=kvd)
+    dq, dk, dv, _ = ops.attention_bwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], out, d_out.to(dev), lse2, causal=True, key_valid=kvd)
     torch.cuda.synchronize()
     for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
         err = (got.float().cpu() - want).abs().max().item()
