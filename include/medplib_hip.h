@@ -291,10 +291,11 @@ int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* 
  * fused weight layout); act / dact [tokens, ff]. */
 int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream);
 int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream);
-/* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R % 8 == 0, R <= 32): the LoRA weight gradients dB = dY^T (x A^T) and
- * dA^T = x^T (dY B) — reads X once, fixed summation order. */
-int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, int64_t tokens, int N, int R, float scale,
-                     hipStream_t stream);
+/* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R in {8, 16, 32}): the LoRA weight gradients dB = dY^T (x A^T) and
+ * dA^T = x^T (dY B) — reads X once; `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
+ * order (fixed summation order). */
+int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
+                     int64_t tokens, int N, int R, float scale, hipStream_t stream);
 /* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
  * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
 int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,

@@ -106,40 +106,78 @@ __global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16
   *reinterpret_cast<bf16x8*>(dgu + t * 2 * ff + col + 32) = du;
 }
 
-// out[n, j] = scale * sum_t X[t, n] * G[t, j]   (j < R <= 32).  Block = 64 columns n x 4 waves; wave w walks rows w, w+4, ...;
-// the four partial sums meet in LDS and are added in wave order.
-constexpr int TN_MAXR = 32;
-__global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
-                                                        float* __restrict__ out, int64_t T, int N, int R, float scale) {
-  __shared__ float part[3][64][TN_MAXR + 1];
+// out[n, j] = scale * sum_t X[t, n] * G[t, j]   (j < R <= 32).  Pass 1: a workgroup owns 256 columns x a chunk of 256 token rows;
+// the chunk's G rows sit in LDS as fp32 (every lane reads the same row: broadcast), a thread owns 4 columns (8-byte loads of X) and
+// R accumulators per column, the 4 waves take the chunk's rows round-robin and meet in LDS in wave order -> partial[chunk][n][R].
+// Pass 2 adds the chunks in ascending order (fixed summation order: bit-reproducible).
+constexpr int TN_MAXR = 32, TN_CHUNK = 256;
+template <int R>
+__global__ __launch_bounds__(256) void tn_skinny_partial_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G,
+                                                                int64_t ldg, float* __restrict__ partial, int64_t T, int N) {
+  __shared__ float gs[TN_CHUNK][R];
+  __shared__ float red[3][64][4 * R + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + lane;
-  const bool live = n < N;
-  float acc[TN_MAXR];
+  const int n0 = blockIdx.x * 256 + lane * 4;
+  const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
+  const int rows = (int)min((int64_t)TN_CHUNK, T - t0);
+  for (int i = threadIdx.x; i < rows * (R / 8); i += 256) {
+    const int rr = i / (R / 8), c8 = (i % (R / 8)) * 8;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (t0 + rr) * ldg + c8);
 #pragma unroll
-  for (int j = 0; j < TN_MAXR; ++j) acc[j] = 0.f;
-  for (int64_t t = wave; t < T; t += 4) {
-    const float xv = live ? (float)X[t * ldx + n] : 0.f;
-    const bf16_t* gr = G + t * ldg;
+    for (int j = 0; j < 8; ++j) gs[rr][c8 + j] = (float)gv[j];
+  }
+  __syncthreads();
+  float acc[4][R];
 #pragma unroll
-    for (int j8 = 0; j8 < TN_MAXR; j8 += 8) {
-      if (j8 < R) {                                          // R is a multiple of 8 (checked on the host)
-        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + j8);
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j8 + j] = fmaf(xv, (float)gv[j], acc[j8 + j]);
-      }
+    for (int j = 0; j < R; ++j) acc[c][j] = 0.f;
+  const bool full = n0 + 4 <= N;
+  for (int rr = wave; rr < rows; rr += 4) {
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xp = X + (t0 + rr) * ldx + n0;
+    if (full) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[c] = (float)v[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (n0 + c < N) xv[c] = (float)xp[c];
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < R; j4 += 4) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gs[rr][j4]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j4 + j] = fmaf(xv[c], g4[j], acc[c][j4 + j]);
     }
   }
   if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < TN_MAXR; ++j) part[wave - 1][lane][j] = acc[j];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < R; ++j) red[wave - 1][lane][c * R + j] = acc[c][j];
   }
   __syncthreads();
-  if (wave == 0 && live) {
+  if (wave == 0) {
+    float* po = partial + ((int64_t)blockIdx.y * N) * R;
 #pragma unroll
-    for (int j = 0; j < TN_MAXR; ++j)
-      if (j < R) out[(int64_t)n * R + j] = scale * (((acc[j] + part[0][lane][j]) + part[1][lane][j]) + part[2][lane][j]);
+    for (int c = 0; c < 4; ++c) {
+      if (n0 + c >= N) continue;
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        po[(int64_t)(n0 + c) * R + j] = ((acc[c][j] + red[0][lane][c * R + j]) + red[1][lane][c * R + j]) + red[2][lane][c * R + j];
+    }
   }
+}
+
+__global__ void tn_skinny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t NR, int chunks, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NR) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * NR + i];
+  out[i] = scale * s;
 }
 
 // d_logits[i, v] = g * (exp(logit - lse_i) - [v == label_i]); one block per supervised row; bf16 output, columns >= V zeroed up to ldo
@@ -184,10 +222,24 @@ __device__ __forceinline__ uint32_t hash32(uint64_t k) {       // splitmix64 fin
   return (uint32_t)(k >> 32);
 }
 __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, float p, uint64_t seed) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)i) >> 8) * (1.f / 16777216.f);
-  y[i] = (bf16_t)(u >= p ? (float)x[i] * (1.f / (1.f - p)) : 0.f);
+  const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i8 >= n) return;
+  const float keep_scale = 1.f / (1.f - p);
+  if (i8 + 8 <= n) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)(i8 + j)) >> 8) * (1.f / 16777216.f);
+      o[j] = (bf16_t)(u >= p ? (float)v[j] * keep_scale : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(y + i8) = o;
+  } else {
+    for (int64_t i = i8; i < n; ++i) {
+      const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)i) >> 8) * (1.f / 16777216.f);
+      y[i] = (bf16_t)(u >= p ? (float)x[i] * keep_scale : 0.f);
+    }
+  }
 }
 
 }  // namespace
@@ -220,11 +272,19 @@ extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* d
   return mp_check_launch("mp_swiglu_pair_bwd_bf16");
 }
 
-extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, int64_t tokens, int N, int R, float scale,
-                                hipStream_t stream) {
-  MP_REQUIRE(N > 0 && R > 0 && R <= TN_MAXR && R % 8 == 0 && ldg % 8 == 0, MP_ERR_SHAPE, "mp_tn_skinny_f32: R must be a multiple of 8, <= %d", TN_MAXR);
-  hipLaunchKernelGGL(tn_skinny_kernel, dim3((unsigned)mp_cdiv(N, 64)), dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, out,
-                     tokens, N, R, scale);
+extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
+                                int64_t tokens, int N, int R, float scale, hipStream_t stream) {
+  MP_REQUIRE(N > 0 && tokens > 0 && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 4 == 0, MP_ERR_SHAPE,
+             "mp_tn_skinny_f32: R must be 8, 16 or 32; ldx %% 4, ldg %% 8");
+  const int chunks = (int)mp_cdiv(tokens, TN_CHUNK);
+  MP_REQUIRE(partial && partial_floats >= (int64_t)chunks * N * R, MP_ERR_WORKSPACE, "mp_tn_skinny_f32: partial needs %lld floats",
+             (long long)((int64_t)chunks * N * R));
+  const dim3 grid((unsigned)mp_cdiv(N, 256), (unsigned)chunks);
+  if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
+  else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
+  else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
+  const int64_t NR = (int64_t)N * R;
+  hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
   return mp_check_launch("mp_tn_skinny_f32");
 }
 
@@ -247,6 +307,6 @@ extern "C" int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, voi
 extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream) {
   MP_REQUIRE(p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_dropout_bf16: p must be in [0, 1)");
   if (n == 0) return MP_OK;
-  hipLaunchKernelGGL(dropout_bf16_kernel, GRID1D(n), (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+  hipLaunchKernelGGL(dropout_bf16_kernel, GRID1D(mp_cdiv(n, 8)), (const bf16_t*)x, (bf16_t*)y, n, p, seed);
   return mp_check_launch("mp_dropout_bf16");
 }

@@ -261,7 +261,10 @@ def tn_skinny(x, g, R, scale=1.0):
     _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
     T, N = x.shape
     out = torch.empty((N, R), dtype=torch.float32, device=x.device)
-    lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), T, N, int(R), float(scale), _stream())
+    chunks = (T + 255) // 256
+    partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
+    lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), T, N, int(R), float(scale),
+               _stream())
     return out
 
 
