@@ -53,24 +53,32 @@ class LoRAState(torch.nn.Module):
         return self.params[self.index[f"model.layers.{i}.mlp.{t}.lora_{which}.default.weight"]]
 
     def padded(self, i):
-        """bf16 GEMM operands of layer i: (A_gu [64, d], A_gu^T, B_gu [2ff, 64], B_gu^T, R_gu) and the same for down."""
+        """bf16 GEMM operands of layer i: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) for the fused gate|up
+        adapter pair and for down.  All four are written directly from the small fp32 parameters (no big transposes)."""
         r, dev = self.r, self.gate_rows.device
+        bf = torch.bfloat16
         out = {}
         tg = [t for t in ("gate_proj", "up_proj") if t in self.targets]
         if tg:
             d = self.get(i, tg[0], "A").shape[1]
             ff = self.gate_rows.numel()
-            A = torch.zeros(64, d, dtype=torch.bfloat16, device=dev)
-            B = torch.zeros(2 * ff, 64, dtype=torch.bfloat16, device=dev)
+            A = torch.zeros(64, d, dtype=bf, device=dev); AT = torch.zeros(d, 64, dtype=bf, device=dev)
+            B = torch.zeros(2 * ff, 64, dtype=bf, device=dev); BT = torch.zeros(64, 2 * ff, dtype=bf, device=dev)
             for k, t in enumerate(tg):
-                A[k * r:(k + 1) * r] = self.get(i, t, "A").detach().to(torch.bfloat16)
-                B[self.gate_rows if t == "gate_proj" else self.up_rows, k * r:(k + 1) * r] = self.get(i, t, "B").detach().to(torch.bfloat16)
-            out["gu"] = (A, A.t().contiguous(), B, B.t().contiguous(), len(tg) * r, tg)
+                a, b = self.get(i, t, "A").detach().to(bf), self.get(i, t, "B").detach().to(bf)
+                rows = self.gate_rows if t == "gate_proj" else self.up_rows
+                A[k * r:(k + 1) * r] = a
+                AT[:, k * r:(k + 1) * r] = a.t()
+                B[rows, k * r:(k + 1) * r] = b
+                BT[k * r:(k + 1) * r].index_copy_(1, rows, b.t().contiguous())
+            out["gu"] = (A, AT, B, BT, len(tg) * r, tg)
         if "down_proj" in self.targets:
-            a, b = self.get(i, "down_proj", "A"), self.get(i, "down_proj", "B")
-            A = torch.zeros(64, a.shape[1], dtype=torch.bfloat16, device=dev); A[:r] = a.detach().to(torch.bfloat16)
-            B = torch.zeros(b.shape[0], 64, dtype=torch.bfloat16, device=dev); B[:, :r] = b.detach().to(torch.bfloat16)
-            out["down"] = (A, A.t().contiguous(), B, B.t().contiguous(), r, ["down_proj"])
+            a, b = self.get(i, "down_proj", "A").detach().to(bf), self.get(i, "down_proj", "B").detach().to(bf)
+            A = torch.zeros(64, a.shape[1], dtype=bf, device=dev); A[:r] = a
+            AT = torch.zeros(a.shape[1], 64, dtype=bf, device=dev); AT[:, :r] = a.t()
+            B = torch.zeros(b.shape[0], 64, dtype=bf, device=dev); B[:, :r] = b
+            BT = torch.zeros(64, b.shape[0], dtype=bf, device=dev); BT[:r] = b.t()
+            out["down"] = (A, AT, B, BT, r, ["down_proj"])
         return out
 
 

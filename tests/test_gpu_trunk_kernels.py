@@ -360,3 +360,54 @@ def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
         assert err <= 2e-2 * want.abs().max().item() + 1e-3, name
     if ragged:                                  # padded keys receive no gradient
         assert float(dk[0, S - 17:].abs().max()) == 0.0 and float(dv[0, S - 17:].abs().max()) == 0.0
+
+
+def test_decoder_backward_row_kernels(dev):
+    """rmsnorm_bwd / swiglu_pair fwd+bwd / tn_skinny / ce_rows_bwd / dropout vs torch autograd on the CPU (fp32 math on the same
+    bf16-rounded inputs; outputs rounded to bf16 once: 1 bf16 ulp of the output scale + fp32 noise)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(77)
+    T, d, ff = 70, 256, 320
+    # ---- RMSNorm backward (+ residual-stream add)
+    x = torch.randn(T, d, generator=g).to(torch.bfloat16); dy = torch.randn(T, d, generator=g).to(torch.bfloat16)
+    add = torch.randn(T, d, generator=g).to(torch.bfloat16)
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    xf = x.float().requires_grad_(True)
+    y = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    y.backward(dy.float())
+    got = ops.rmsnorm_bwd(x.to(dev), w.to(dev), dy.to(dev), 1e-5, add=add.to(dev))
+    _report("rmsnorm_bwd", got, xf.grad + add.float(), rtol=2 * BF16_EPS, atol=2e-2)
+    # ---- SwiGLU on the interleaved gate|up layout
+    gate = torch.randn(T, ff, generator=g).to(torch.bfloat16); up = torch.randn(T, ff, generator=g).to(torch.bfloat16)
+    gu = torch.empty(T, 2 * ff, dtype=torch.bfloat16)
+    c = torch.arange(ff); rows_g = (c // 32) * 64 + c % 32
+    gu[:, rows_g] = gate; gu[:, rows_g + 32] = up
+    gf, uf = gate.float().requires_grad_(True), up.float().requires_grad_(True)
+    act_ref = torch.nn.functional.silu(gf) * uf
+    dact = torch.randn(T, ff, generator=g).to(torch.bfloat16)
+    act_ref.backward(dact.float())
+    _report("swiglu_pair_fwd", ops.swiglu_pair_fwd(gu.to(dev)), act_ref.detach(), rtol=2 * BF16_EPS, atol=1e-2)
+    dgu = ops.swiglu_pair_bwd(gu.to(dev), dact.to(dev)).cpu().float()
+    _report("swiglu_pair_bwd d_gate", dgu[:, rows_g], gf.grad, rtol=2 * BF16_EPS, atol=1e-2)
+    _report("swiglu_pair_bwd d_up", dgu[:, rows_g + 32], uf.grad, rtol=2 * BF16_EPS, atol=1e-2)
+    # ---- skinny TN product (adapter weight gradients), token count not a multiple of the chunk
+    for Tn, N, R in ((700, 332, 8), (513, 4096, 16), (70, 64, 32)):
+        X = torch.randn(Tn, N, generator=g).to(torch.bfloat16); G = torch.randn(Tn, 64, generator=g).to(torch.bfloat16)
+        ref = 0.5 * X.float().t() @ G.float()[:, :R]
+        _report(f"tn_skinny {Tn}x{N}x{R}", ops.tn_skinny(X.to(dev), G.to(dev), R, 0.5), ref, rtol=1e-5, atol=1e-3)
+    # ---- CE backward on supervised rows
+    n, V = 9, 515
+    logits = (torch.randn(n, V, generator=g) * 3).requires_grad_(True)
+    labels = torch.randint(0, V, (n,), generator=g)
+    ce = torch.nn.functional.cross_entropy(logits, labels)
+    ce.backward()
+    gs = torch.tensor([0.7])
+    got = ops.ce_rows_bwd(logits.detach().to(dev), labels.to(dev), gs.to(dev), 1.0 / n, 576).cpu().float()
+    _report("ce_rows_bwd", got[:, :V], 0.7 * logits.grad, rtol=2 * BF16_EPS, atol=1e-4)
+    assert float(got[:, V:].abs().max()) == 0.0
+    # ---- dropout: keep rate, scale, determinism, and the same mask again for the backward
+    xs = torch.ones(1000, 333, dtype=torch.bfloat16, device=dev)
+    y1 = ops.dropout_bf16(xs, 0.25, 1234); y2 = ops.dropout_bf16(xs, 0.25, 1234); y3 = ops.dropout_bf16(xs, 0.25, 1235)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.75) < 5e-3 and abs(float(y1.max()) - 1 / 0.75) < 1e-2
