@@ -52,6 +52,16 @@ class LoRAState(torch.nn.Module):
     def get(self, i, t, which):
         return self.params[self.index[f"model.layers.{i}.mlp.{t}.lora_{which}.default.weight"]]
 
+    def peft_state_dict(self):
+        """The adapters under peft's key names (`base_model.model.<module>.lora_{A,B}.default.weight`), bf16 like a bf16 peft model saves
+        them; `lora.merge_lora_state_dict` folds such a dict into the base weights (merge_lora_weights_and_save_hf_model_moe.py:270-345)."""
+        return {"base_model.model." + n: p.detach().to(torch.bfloat16) for n, p in zip(self.names, self.params)}
+
+    def load_peft_state_dict(self, sd):
+        for n, p in zip(self.names, self.params):
+            k = n if n in sd else "base_model.model." + n
+            p.data.copy_(sd[k].to(p.dtype))
+
     def padded(self, i):
         """bf16 GEMM operands of layer i: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) for the fused gate|up
         adapter pair and for down.  All four are written directly from the small fp32 parameters (no big transposes)."""

@@ -871,3 +871,32 @@ def test_lora_training_step_vs_oracle_autograd(dev):
     eng.step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p_).all() for p_ in lora.params)
+
+
+def test_lora_adapters_equal_merged_weights_and_entry_point(dev, tmp_path):
+    """(a) The adapter forward of the training path equals the plain forward of a model whose weights had the same adapters merged
+    in by `lora.merge_lora_state_dict` (peft merge_and_unload): ties the training path to the checkpoint path.  (b) train.main with
+    --lora_r 8 on the dense model runs, the loss goes down and stays finite."""
+    from medplib_amd import lora as lora_ckpt, train
+    from medplib_amd.model import llama_lora as LL
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lo = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0)
+    g = torch.Generator().manual_seed(8)
+    for p_ in lo.params:
+        p_.data.copy_((torch.randn(p_.shape, generator=g) * 0.05).to(torch.bfloat16).float().to(dev))
+    emb = (torch.randn(2, 70, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        h_adapter, _ = LL.forward_train(m.model.llm, emb, None)
+    peft_sd = {("base_model.model." + k): v for k, v in W.items() if k.startswith("model.layers.") or k in ("model.norm.weight", "lm_head.weight", "model.embed_tokens.weight")}
+    peft_sd = {k.replace(".weight", ".base_layer.weight") if any(t in k for t in ("gate_proj", "up_proj", "down_proj")) else k: v for k, v in peft_sd.items()}
+    peft_sd.update({k: v.float().cpu() for k, v in lo.peft_state_dict().items()})
+    merged = lora_ckpt.merge_lora_state_dict(peft_sd, lora_alpha=16)
+    W2 = dict(W); W2.update(merged)
+    m2 = _model(cfg, dev, W2).eval()
+    h_merged, _, _ = m2.model.llm.forward(emb, None)
+    _stat("adapter forward vs merged weights", h_adapter, h_merged, atol=0.0, rtol=8 * 2 ** -8)
+    hist = train.main(["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "6", "--lr", "2e-3",
+                       "--lora_r", "8", "--lora_dropout", "0.05", "--log_dir", str(tmp_path)])
+    assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
