@@ -4,8 +4,8 @@ II-IV checkpoints load into this build's inference path (`load_hf_state_dict`). 
 
 peft key layout of a wrapped Linear `…<name>`:  `base_model.model.…<name>.base_layer.weight` (the frozen W; older peft:
 `…<name>.weight`), `…<name>.lora_A.default.weight` [r, in], `…<name>.lora_B.default.weight` [out, r]; merge:
-W += (lora_alpha / r) * B @ A  (peft LoraLayer.get_delta_weight, bias="none").  Training LoRA (backward through the LLM) is
-outside this round's path (BASELINE config 4 is "LoRA off")."""
+W += (lora_alpha / r) * B @ A  (peft LoraLayer.get_delta_weight, bias="none").  Training the adapters (the whole decoder backward) lives in
+`medplib_amd/model/llama_lora.py`; this module is the checkpoint side."""
 import re
 from typing import Dict
 
