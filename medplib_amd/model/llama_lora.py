@@ -11,7 +11,8 @@ N-tile; gate and up share one pair on the fused, interleaved gate|up matrix).  T
 (`W^T`, +13 GB), `mp_attention_bwd_bf16`, `mp_rmsnorm_bwd_bf16`, `mp_swiglu_pair_bwd_bf16`, RoPE backward = the forward kernel
 with −sin, adapter weight gradients by `mp_tn_skinny_f32` (fixed summation order: the step stays bit-reproducible).
 autograd sees three Functions: LlamaLoRAFn (the stack), CrossEntropyFn (lm_head + filtered CE), GatherRowsFn (<SEG> rows for the
-fp32 tail); everything inside them is this library's kernels.  MoE layers + adapters, and adapters on q/k/v/o, are not built yet."""
+fp32 tail); everything inside them is this library's kernels.  Targets: any of q/k/v/o/gate/up/down_proj (the shipped scripts' sets);
+adapters inside MoE layers are not built yet."""
 import math
 
 import torch
@@ -19,6 +20,13 @@ import torch
 from .. import ops
 
 MLP_TARGETS = ("gate_proj", "up_proj", "down_proj")
+ALL_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj") + MLP_TARGETS
+# adapter groups: targets that share an input and whose outputs are row blocks of one fused projection get ONE pair of thin GEMMs
+GROUPS = {"qkv": ("q_proj", "k_proj", "v_proj"), "o": ("o_proj",), "gu": ("gate_proj", "up_proj"), "down": ("down_proj",)}
+
+
+def _module(t):
+    return ("self_attn." if t in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp.") + t
 
 
 class LoRAState(torch.nn.Module):
@@ -28,29 +36,34 @@ class LoRAState(torch.nn.Module):
     def __init__(self, cfg, llm, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0):
         super().__init__()
         assert r % 8 == 0 and 0 < r <= 16, "lora_r must be 8 or 16 (the shipped scripts' values)"
-        assert all(t in MLP_TARGETS for t in targets), f"adapters are built for {MLP_TARGETS} (q/k/v/o: not yet)"
+        assert all(t in ALL_TARGETS for t in targets), f"adapters are built for {ALL_TARGETS}"
         assert not llm.moe_layers, "LoRA training is built for the dense decoder (MoE layers + adapters: not yet)"
-        self.r, self.alpha, self.p, self.targets = r, float(alpha), float(dropout), tuple(targets)
+        self.r, self.alpha, self.p = r, float(alpha), float(dropout)
+        self.targets = tuple(t for t in ALL_TARGETS if t in targets)
         self.scaling = self.alpha / r
         d, ff, dev = cfg.hidden_size, cfg.intermediate_size, llm.device
         g = torch.Generator().manual_seed(seed)
         self.names, plist = [], []
         for i in range(cfg.num_hidden_layers):
             for t in self.targets:
-                fin, fout = (ff, d) if t == "down_proj" else (d, ff)
+                fin, fout = (ff, d) if t == "down_proj" else ((d, ff) if t in ("gate_proj", "up_proj") else (d, d))
                 bound = 1.0 / math.sqrt(fin)                      # kaiming_uniform_(a=sqrt(5)) on [r, in]
                 a = (torch.rand(r, fin, generator=g) * 2 - 1) * bound
-                self.names += [f"model.layers.{i}.mlp.{t}.lora_A.default.weight", f"model.layers.{i}.mlp.{t}.lora_B.default.weight"]
+                self.names += [f"model.layers.{i}.{_module(t)}.lora_A.default.weight", f"model.layers.{i}.{_module(t)}.lora_B.default.weight"]
                 plist += [torch.nn.Parameter(a.to(dev)), torch.nn.Parameter(torch.zeros(fout, r, device=dev))]
         self.params = torch.nn.ParameterList(plist)
         self.index = {n: k for k, n in enumerate(self.names)}
         c = torch.arange(ff, device=dev)
-        self.gate_rows = (c // 32) * 64 + c % 32                  # interleaved row of gate channel c in the fused gate|up matrix
-        self.up_rows = self.gate_rows + 32
+        gate_rows = (c // 32) * 64 + c % 32                       # interleaved row of gate channel c in the fused gate|up matrix
+        ar = torch.arange(d, device=dev)
+        # rows of each target inside its group's fused output, and the fused output width
+        self.rows = {"q_proj": ar, "k_proj": ar + d, "v_proj": ar + 2 * d, "o_proj": ar, "gate_proj": gate_rows, "up_proj": gate_rows + 32,
+                     "down_proj": ar}
+        self.width = {"qkv": 3 * d, "o": d, "gu": 2 * ff, "down": d}
         self.step = 0
 
     def get(self, i, t, which):
-        return self.params[self.index[f"model.layers.{i}.mlp.{t}.lora_{which}.default.weight"]]
+        return self.params[self.index[f"model.layers.{i}.{_module(t)}.lora_{which}.default.weight"]]
 
     def peft_state_dict(self):
         """The adapters under peft's key names (`base_model.model.<module>.lora_{A,B}.default.weight`), bf16 like a bf16 peft model saves
@@ -63,32 +76,27 @@ class LoRAState(torch.nn.Module):
             p.data.copy_(sd[k].to(p.dtype))
 
     def padded(self, i):
-        """bf16 GEMM operands of layer i: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) for the fused gate|up
-        adapter pair and for down.  All four are written directly from the small fp32 parameters (no big transposes)."""
-        r, dev = self.r, self.gate_rows.device
-        bf = torch.bfloat16
+        """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets), written
+        directly from the small fp32 parameters.  R = rank of the fused pair (targets x r), rounded up to what the wgrad kernel takes."""
+        r, dev, bf = self.r, self.rows["q_proj"].device, torch.bfloat16
         out = {}
-        tg = [t for t in ("gate_proj", "up_proj") if t in self.targets]
-        if tg:
-            d = self.get(i, tg[0], "A").shape[1]
-            ff = self.gate_rows.numel()
-            A = torch.zeros(64, d, dtype=bf, device=dev); AT = torch.zeros(d, 64, dtype=bf, device=dev)
-            B = torch.zeros(2 * ff, 64, dtype=bf, device=dev); BT = torch.zeros(64, 2 * ff, dtype=bf, device=dev)
+        for grp, members in GROUPS.items():
+            tg = [t for t in members if t in self.targets]
+            if not tg:
+                continue
+            fin = self.get(i, tg[0], "A").shape[1]
+            W = self.width[grp]
+            A = torch.zeros(64, fin, dtype=bf, device=dev); AT = torch.zeros(fin, 64, dtype=bf, device=dev)
+            B = torch.zeros(W, 64, dtype=bf, device=dev); BT = torch.zeros(64, W, dtype=bf, device=dev)
             for k, t in enumerate(tg):
                 a, b = self.get(i, t, "A").detach().to(bf), self.get(i, t, "B").detach().to(bf)
-                rows = self.gate_rows if t == "gate_proj" else self.up_rows
+                rows = self.rows[t]
                 A[k * r:(k + 1) * r] = a
                 AT[:, k * r:(k + 1) * r] = a.t()
                 B[rows, k * r:(k + 1) * r] = b
                 BT[k * r:(k + 1) * r].index_copy_(1, rows, b.t().contiguous())
-            out["gu"] = (A, AT, B, BT, len(tg) * r, tg)
-        if "down_proj" in self.targets:
-            a, b = self.get(i, "down_proj", "A").detach().to(bf), self.get(i, "down_proj", "B").detach().to(bf)
-            A = torch.zeros(64, a.shape[1], dtype=bf, device=dev); A[:r] = a
-            AT = torch.zeros(a.shape[1], 64, dtype=bf, device=dev); AT[:, :r] = a.t()
-            B = torch.zeros(b.shape[0], 64, dtype=bf, device=dev); B[:, :r] = b
-            BT = torch.zeros(64, b.shape[0], dtype=bf, device=dev); BT[:r] = b.t()
-            out["down"] = (A, AT, B, BT, r, ["down_proj"])
+            R = len(tg) * r
+            out[grp] = (A, AT, B, BT, 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64, tg)
         return out
 
 
@@ -125,16 +133,21 @@ def forward_train(llm, embeds, key_valid):
     saved = []
     for i, lw in enumerate(llm.layers):
         pad = lora.padded(i)
+        s = {"x": x, "pad": pad}
+        seed = (lora.step * 4096 + i) * 4
         h1 = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
         qkv = ops.gemm(h1, lw["qkv"])
+        if "qkv" in pad:
+            qkv, s["h1d"], s["t_qkv"] = _adapter_fwd(lora, pad["qkv"], h1, qkv, seed + 2)
         ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
         q5 = qkv.view(B, S, 3, H, D)
         attn, lse = ops.attention_fwd_lse(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
         x_mid = ops.gemm(attn.view(T, d), lw["o"], residual=x)
+        if "o" in pad:
+            x_mid, s["attnd"], s["t_o"] = _adapter_fwd(lora, pad["o"], attn.view(T, d), x_mid, seed + 3)
         h2 = ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps)
         gu = ops.gemm(h2, lw["gu"])
-        s = {"x": x, "qkv": qkv, "attn": attn, "lse": lse, "x_mid": x_mid, "pad": pad}
-        seed = (lora.step * 4096 + i) * 2
+        s.update(qkv=qkv, attn=attn, lse=lse, x_mid=x_mid)
         if "gu" in pad:
             gu, s["h2d"], s["t_gu"] = _adapter_fwd(lora, pad["gu"], h2, gu, seed)
         act = ops.swiglu_pair_fwd(gu)
@@ -170,6 +183,13 @@ def backward(llm, saved, d_hidden):
     T = B * S
     r = lora.r
     grads = {}
+
+    def take(i, ops_pad, dB, dAT):
+        """Unpack the fused pair's gradients into the per-target parameters."""
+        for k, t in enumerate(ops_pad[5]):
+            grads[f"model.layers.{i}.{_module(t)}.lora_B.default.weight"] = dB[lora.rows[t], k * r:(k + 1) * r]
+            grads[f"model.layers.{i}.{_module(t)}.lora_A.default.weight"] = dAT[:, k * r:(k + 1) * r].t()
+
     dx = ops.rmsnorm_bwd(saved["x_last"], llm.norm_w, d_hidden.reshape(T, d).contiguous(), cfg.rms_norm_eps)
     for i in range(len(llm.layers) - 1, -1, -1):
         lw, s = llm.layers[i], saved["layers"][i]
@@ -178,25 +198,27 @@ def backward(llm, saved, d_hidden):
         d_act = ops.gemm(dx, lw["down_T"])
         if "down" in pad:
             d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1)
-            grads[f"model.layers.{i}.mlp.down_proj.lora_B.default.weight"] = dB[:, :r]
-            grads[f"model.layers.{i}.mlp.down_proj.lora_A.default.weight"] = dAT[:, :r].t()
+            take(i, pad["down"], dB, dAT)
         d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
         d_h2 = ops.gemm(d_gu, lw["gu_T"])
         if "gu" in pad:
             d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
-            for k, t in enumerate(pad["gu"][5]):
-                rows = lora.gate_rows if t == "gate_proj" else lora.up_rows
-                grads[f"model.layers.{i}.mlp.{t}.lora_B.default.weight"] = dB[rows, k * r:(k + 1) * r]
-                grads[f"model.layers.{i}.mlp.{t}.lora_A.default.weight"] = dAT[:, k * r:(k + 1) * r].t()
+            take(i, pad["gu"], dB, dAT)
         d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)
-        # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x)))))
+        # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]
         d_attn = ops.gemm(d_mid, lw["o_T"])
+        if "o" in pad:
+            d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3)
+            take(i, pad["o"], dB, dAT)
         q5 = s["qkv"].view(B, S, 3, H, D)
         _, _, _, dqkv = ops.attention_bwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], s["attn"], d_attn.view(B, S, d), s["lse"], causal=True,
                                           key_valid=saved["key_valid"])
         dqkv = dqkv.view(T, 3 * d)
         ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)           # the transpose of a rotation is the rotation by -theta
         d_h1 = ops.gemm(dqkv, lw["qkv_T"])
+        if "qkv" in pad:
+            d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2)
+            take(i, pad["qkv"], dB, dAT)
         dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
     return grads
 

@@ -260,6 +260,8 @@ def tn_skinny(x, g, R, scale=1.0):
     """out[n, j] = scale * sum_t x[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= R] bf16."""
     _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
     T, N = x.shape
+    if R > 32:                      # wider than the kernel's register budget: two passes over column halves of g
+        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale) for j in range(0, R, 32)], dim=1)
     out = torch.empty((N, R), dtype=torch.float32, device=x.device)
     chunks = (T + 255) // 256
     partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)

@@ -311,11 +311,18 @@ def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="",
     for i in range(cfg.num_hidden_layers):
         p = f"{prefix}model.layers.{i}."
         h = ops.rmsnorm(x, W[p + "input_layernorm.weight"].float(), cfg.rms_norm_eps)
-        q = F.linear(h, W[p + "self_attn.q_proj.weight"]).view(B, S, H, D)
-        k = F.linear(h, W[p + "self_attn.k_proj.weight"]).view(B, S, H, D)
-        v = F.linear(h, W[p + "self_attn.v_proj.weight"]).view(B, S, H, D)
+        def alin(t, name):
+            # peft 0.10 LoRA Linear on an attention projection (parity unpinned): W x + (alpha / r) * B (A x)
+            y = F.linear(t, W[p + f"self_attn.{name}.weight"])
+            ka = p + f"self_attn.{name}.lora_A.default.weight"
+            if ka in W:
+                y = y + W["lora_scaling"] * F.linear(F.linear(t, W[ka]), W[p + f"self_attn.{name}.lora_B.default.weight"])
+            return y
+        q = alin(h, "q_proj").view(B, S, H, D)
+        k = alin(h, "k_proj").view(B, S, H, D)
+        v = alin(h, "v_proj").view(B, S, H, D)
         a = ops.attention(ops.rope(q, cos, sin), ops.rope(k, cos, sin), v, causal=True, key_valid=key_valid)
-        x = x + F.linear(a, W[p + "self_attn.o_proj.weight"])
+        x = x + alin(a, "o_proj")
         h = ops.rmsnorm(x, W[p + "post_attention_layernorm.weight"].float(), cfg.rms_norm_eps)
         if i in moe_layers:
             T = B * S

@@ -827,7 +827,10 @@ def test_inference_entry_point(dev):
     assert set(out["per_modality"]) == {"synthetic"}
 
 
-def test_lora_training_step_vs_oracle_autograd(dev):
+@pytest.mark.parametrize("r,alpha,targets", [(8, 16, "gate_proj,up_proj,down_proj"),                              # train_stage3.sh
+                                             (16, 16, "q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj"),      # train_stage2.sh
+                                             (8, 16, "gate_proj,up_proj,down_proj,q_proj,v_proj")])                    # train_stage4.sh
+def test_lora_training_step_vs_oracle_autograd(dev, r, alpha, targets):
     """LoRA training of the dense decoder (scripts/train_stage3.sh targets gate/up/down_proj, r 8, alpha 16): one
     forward + backward through the whole decoder (attention backward, RMSNorm / SwiGLU / RoPE backward, dgrad GEMMs, adapter weight
     gradients) vs torch autograd of the oracle with the same adapters in fp32.  The adapters get non-zero B so every gradient is
@@ -836,10 +839,11 @@ def test_lora_training_step_vs_oracle_autograd(dev):
     cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
-    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0)
+    lora = m.enable_lora(lora_r=r, lora_alpha=alpha, lora_dropout=0.0, lora_target_modules=targets)
+    assert len(lora.names) == 2 * len(targets.split(",")) * cfg.num_hidden_layers
     g = torch.Generator().manual_seed(31)
     Wl = dict(W)
-    Wl["lora_scaling"] = 16 / 8
+    Wl["lora_scaling"] = alpha / r
     for n, p_ in zip(lora.names, lora.params):
         v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
         p_.data.copy_(v.to(dev))
