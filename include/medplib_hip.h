@@ -302,6 +302,10 @@ int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, cons
                    int64_t rows, int V, hipStream_t stream);
 /* out[rows[i], :] = bf16(g[i, :]): backward of the row gathers in front of lm_head / text_hidden_fcs (out pre-zeroed, rows unique). */
 int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int64_t n, int dim, hipStream_t stream);
+/* One adapter (fp32 A [r, fin], B [fout, r]) written into its group's padded bf16 GEMM operands, both orientations: A [64, fin],
+ * A^T [fin, 64] at rank offset k0; B [W, 64], B^T [64, W] at the output rows `rows[o]` of the fused projection. */
+int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout, int k0,
+                 int W, hipStream_t stream);
 /* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
 int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
 

@@ -242,6 +242,28 @@ __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __rest
   }
 }
 
+// One adapter's fp32 parameters written into the padded bf16 GEMM operands of its group (both orientations): A [64, fin] rows
+// k0..k0+r-1, A^T [fin, 64] columns k0.., B [W, 64] rows rows[o] columns k0.., B^T [64, W] rows k0.. columns rows[o]
+__global__ void lora_pack_kernel(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ rows, bf16_t* __restrict__ A,
+                                 bf16_t* __restrict__ AT, bf16_t* __restrict__ B, bf16_t* __restrict__ BT, int r, int fin, int fout, int k0,
+                                 int W) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t na = (int64_t)r * fin, nb = (int64_t)fout * r;
+  if (idx < na) {
+    const int i = (int)(idx / fin), c = (int)(idx % fin);
+    const bf16_t v = (bf16_t)a[idx];
+    A[(int64_t)(k0 + i) * fin + c] = v;
+    AT[(int64_t)c * 64 + k0 + i] = v;
+  } else if (idx < na + nb) {
+    const int64_t e = idx - na;
+    const int o = (int)(e / r), j = (int)(e % r);
+    const int64_t ro = rows[o];
+    const bf16_t v = (bf16_t)b[e];
+    B[ro * 64 + k0 + j] = v;
+    BT[(int64_t)(k0 + j) * W + ro] = v;
+  }
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -309,4 +331,12 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(dropout_bf16_kernel, GRID1D(mp_cdiv(n, 8)), (const bf16_t*)x, (bf16_t*)y, n, p, seed);
   return mp_check_launch("mp_dropout_bf16");
+}
+
+extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout,
+                            int k0, int W, hipStream_t stream) {
+  MP_REQUIRE(r > 0 && k0 >= 0 && k0 + r <= 64 && fin > 0 && fout > 0 && W >= fout, MP_ERR_SHAPE, "mp_lora_pack: bad shape");
+  const int64_t n = (int64_t)r * fin + (int64_t)fout * r;
+  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W);
+  return mp_check_launch("mp_lora_pack");
 }

@@ -61,6 +61,7 @@ class LoRAState(torch.nn.Module):
                      "down_proj": ar}
         self.width = {"qkv": 3 * d, "o": d, "gu": 2 * ff, "down": d}
         self.step = 0
+        self._bufs = {}
 
     def get(self, i, t, which):
         return self.params[self.index[f"model.layers.{i}.{_module(t)}.lora_{which}.default.weight"]]
@@ -76,25 +77,22 @@ class LoRAState(torch.nn.Module):
             p.data.copy_(sd[k].to(p.dtype))
 
     def padded(self, i):
-        """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets), written
-        directly from the small fp32 parameters.  R = rank of the fused pair (targets x r), rounded up to what the wgrad kernel takes."""
+        """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets).  The
+        buffers persist (zeroed once: the padding never changes); each step one pack kernel per adapter rewrites its slices.
+        R = rank of the fused pair (targets x r), rounded up to what the wgrad kernel takes."""
         r, dev, bf = self.r, self.rows["q_proj"].device, torch.bfloat16
+        if i not in self._bufs:
+            self._bufs[i] = {}
+            for grp, members in GROUPS.items():
+                tg = [t for t in members if t in self.targets]
+                if tg:
+                    fin, W = self.get(i, tg[0], "A").shape[1], self.width[grp]
+                    self._bufs[i][grp] = (torch.zeros(64, fin, dtype=bf, device=dev), torch.zeros(fin, 64, dtype=bf, device=dev),
+                                          torch.zeros(W, 64, dtype=bf, device=dev), torch.zeros(64, W, dtype=bf, device=dev), tg)
         out = {}
-        for grp, members in GROUPS.items():
-            tg = [t for t in members if t in self.targets]
-            if not tg:
-                continue
-            fin = self.get(i, tg[0], "A").shape[1]
-            W = self.width[grp]
-            A = torch.zeros(64, fin, dtype=bf, device=dev); AT = torch.zeros(fin, 64, dtype=bf, device=dev)
-            B = torch.zeros(W, 64, dtype=bf, device=dev); BT = torch.zeros(64, W, dtype=bf, device=dev)
+        for grp, (A, AT, B, BT, tg) in self._bufs[i].items():
             for k, t in enumerate(tg):
-                a, b = self.get(i, t, "A").detach().to(bf), self.get(i, t, "B").detach().to(bf)
-                rows = self.rows[t]
-                A[k * r:(k + 1) * r] = a
-                AT[:, k * r:(k + 1) * r] = a.t()
-                B[rows, k * r:(k + 1) * r] = b
-                BT[k * r:(k + 1) * r].index_copy_(1, rows, b.t().contiguous())
+                ops.lora_pack(self.get(i, t, "A").detach(), self.get(i, t, "B").detach(), self.rows[t], A, AT, B, BT, k * r)
             R = len(tg) * r
             out[grp] = (A, AT, B, BT, 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64, tg)
         return out

@@ -287,6 +287,13 @@ def scatter_rows_f32_bf16(g, rows, T):
     return out
 
 
+def lora_pack(a, b, rows, A, AT, B, BT, k0):
+    """fp32 adapter (a [r, fin], b [fout, r]) -> its slices of the padded bf16 operands (both orientations)."""
+    r, fin = a.shape
+    fout = b.shape[0]
+    lib().call("mp_lora_pack", _p(a), _p(b), _p(rows), _p(A), _p(AT), _p(B), _p(BT), r, fin, fout, int(k0), B.shape[0], _stream())
+
+
 def dropout_bf16(x, p, seed):
     y = torch.empty_like(x)
     lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())
