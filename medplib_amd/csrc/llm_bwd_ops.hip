@@ -246,7 +246,7 @@ __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __rest
 // k0..k0+r-1, A^T [fin, 64] columns k0.., B [W, 64] rows rows[o] columns k0.., B^T [64, W] rows k0.. columns rows[o]
 __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ rows, bf16_t* __restrict__ A,
                                  bf16_t* __restrict__ AT, bf16_t* __restrict__ B, bf16_t* __restrict__ BT, int r, int fin, int fout, int k0,
-                                 int W) {
+                                 int W, float bscale) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t na = (int64_t)r * fin, nb = (int64_t)fout * r;
   if (idx < na) {
@@ -258,10 +258,81 @@ __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __res
     const int64_t e = idx - na;
     const int o = (int)(e / r), j = (int)(e % r);
     const int64_t ro = rows[o];
-    const bf16_t v = (bf16_t)b[e];
+    const bf16_t v = (bf16_t)(b[e] * bscale);
     B[ro * 64 + k0 + j] = v;
     BT[(int64_t)(k0 + j) * W + ro] = v;
   }
+}
+
+// ---- MoE layer backward (top-1; DeepSpeed MOELayer + top1gating autograd) ----
+// combine backward: out[t] = residual[t] + w[t] * y[e_t, slot_t]  =>  d_y[e_t, slot_t] = w[t] * d_out[t],  d_w[t] = <d_out[t], y[e_t, slot_t]>
+// (dropped tokens: nothing).  One wave per token; d_y is pre-zeroed.
+__global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                              const int* __restrict__ expert, const int* __restrict__ slot,
+                                                              const float* __restrict__ weight, bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                              int64_t T, int d, int capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int sl = slot[t];
+  if (sl < 0) { if (lane == 0) dw[t] = 0.f; return; }
+  const int64_t row = ((int64_t)expert[t] * capacity + sl) * d;
+  const float w = weight[t];
+  float acc = 0.f;
+  for (int i = lane * 8; i < d; i += 512) {
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + t * d + i);
+    const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + row + i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc = fmaf((float)g[j], (float)yv[j], acc); o[j] = (bf16_t)(w * (float)g[j]); }
+    *reinterpret_cast<bf16x8*>(dy + row + i) = o;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dw[t] = acc;
+}
+
+// gate backward: the combine weight is the softmax probability of the chosen expert (kept tokens) and
+// l_aux = E * sum_e mean_t(p[t, e]) * (counts_e / T)  =>  g[t, j] = dw[t] [j == e_t, kept] + c_aux * E * counts_j / T^2,
+// d_logits[t, j] = p_j (g_j - sum_k p_k g_k)
+__global__ void moe_gate_bwd_kernel(const float* __restrict__ gates, const int* __restrict__ expert, const int* __restrict__ slot,
+                                    const float* __restrict__ dw, const long long* __restrict__ counts, const float* __restrict__ c_aux,
+                                    float aux_coef, float* __restrict__ dlogits, int64_t T, int E) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float ca = (c_aux ? c_aux[0] : 0.f) * aux_coef * (float)E / ((float)T * (float)T);
+  const int e = expert[t];
+  const bool kept = slot[t] >= 0;
+  float dot = 0.f;
+  for (int j = 0; j < E; ++j) {
+    const float g = ((j == e && kept) ? dw[t] : 0.f) + ca * (float)counts[j];
+    dot += gates[t * E + j] * g;
+  }
+  for (int j = 0; j < E; ++j) {
+    const float g = ((j == e && kept) ? dw[t] : 0.f) + ca * (float)counts[j];
+    dlogits[t * E + j] = gates[t * E + j] * (g - dot);
+  }
+}
+
+// d_x[t, :] += sum_e d_logits[t, e] * wg[e, :]   (the gate's input gradient; wg fp32 [E, d])
+__global__ void moe_gate_dgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ wg, bf16_t* __restrict__ dx, int64_t T, int d,
+                                      int E) {
+  const int per_row = d / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * per_row) return;
+  const int64_t t = idx / per_row;
+  const int c = (int)(idx % per_row) * 8;
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(dx + t * d + c);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (float)v[j];
+  for (int e = 0; e < E; ++e) {
+    const float g = dlogits[t * E + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, wg[(int64_t)e * d + c + j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16_t)acc[j];
+  *reinterpret_cast<bf16x8*>(dx + t * d + c) = v;
 }
 
 }  // namespace
@@ -334,9 +405,34 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
 }
 
 extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout,
-                            int k0, int W, hipStream_t stream) {
+                            int k0, int W, float bscale, hipStream_t stream) {
   MP_REQUIRE(r > 0 && k0 >= 0 && k0 + r <= 64 && fin > 0 && fout > 0 && W >= fout, MP_ERR_SHAPE, "mp_lora_pack: bad shape");
   const int64_t n = (int64_t)r * fin + (int64_t)fout * r;
-  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W);
+  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W, bscale);
   return mp_check_launch("mp_lora_pack");
+}
+
+extern "C" int mp_moe_combine_bwd_bf16(const void* dout, const void* y, const int* expert, const int* slot, const float* weight, void* dy,
+                                       float* dw, int64_t tokens, int dim, int capacity, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && capacity >= 0, MP_ERR_SHAPE, "mp_moe_combine_bwd_bf16: bad shape");
+  if (tokens == 0) return MP_OK;
+  hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((unsigned)mp_cdiv(tokens, 4)), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)y,
+                     expert, slot, weight, (bf16_t*)dy, dw, tokens, dim, capacity);
+  return mp_check_launch("mp_moe_combine_bwd_bf16");
+}
+
+extern "C" int mp_moe_gate_bwd_f32(const float* gates, const int* expert, const int* slot, const float* dw, const long long* exp_counts,
+                                   const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, hipStream_t stream) {
+  MP_REQUIRE(n_experts >= 1 && n_experts <= 8, MP_ERR_SHAPE, "mp_moe_gate_bwd_f32: experts <= 8");
+  if (tokens == 0) return MP_OK;
+  hipLaunchKernelGGL(moe_gate_bwd_kernel, GRID1D(tokens), gates, expert, slot, dw, exp_counts, c_aux, aux_coef, dlogits, tokens, n_experts);
+  return mp_check_launch("mp_moe_gate_bwd_f32");
+}
+
+extern "C" int mp_moe_gate_dgrad_bf16(const float* dlogits, const float* wg, void* dx, int64_t tokens, int dim, int n_experts, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && n_experts >= 1 && n_experts <= 8, MP_ERR_SHAPE, "mp_moe_gate_dgrad_bf16: bad shape");
+  const int64_t n = tokens * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(moe_gate_dgrad_kernel, GRID1D(n), dlogits, wg, (bf16_t*)dx, tokens, dim, n_experts);
+  return mp_check_launch("mp_moe_gate_dgrad_bf16");
 }

@@ -11,8 +11,9 @@ N-tile; gate and up share one pair on the fused, interleaved gate|up matrix).  T
 (`W^T`, +13 GB), `mp_attention_bwd_bf16`, `mp_rmsnorm_bwd_bf16`, `mp_swiglu_pair_bwd_bf16`, RoPE backward = the forward kernel
 with −sin, adapter weight gradients by `mp_tn_skinny_f32` (fixed summation order: the step stays bit-reproducible).
 autograd sees three Functions: LlamaLoRAFn (the stack), CrossEntropyFn (lm_head + filtered CE), GatherRowsFn (<SEG> rows for the
-fp32 tail); everything inside them is this library's kernels.  Targets: any of q/k/v/o/gate/up/down_proj (the shipped scripts' sets);
-adapters inside MoE layers are not built yet."""
+fp32 tail); everything inside them is this library's kernels.  Targets: any of q/k/v/o/gate/up/down_proj (the shipped scripts' sets).
+MoE layers (top-1, one rank): per-expert adapters on the capacity slabs, the routed dgrad, the gate-probability and l_aux gradients
+into the gate and a trainable `wg` (scripts/train_stage4.sh's `--sft_modules wg,...`)."""
 import math
 
 import torch
@@ -33,14 +34,16 @@ class LoRAState(torch.nn.Module):
     """The adapters of every decoder layer as fp32 nn.Parameters (the engine's flat AdamW buffer adopts them) plus the bf16 padded
     GEMM operands rebuilt from them before each forward."""
 
-    def __init__(self, cfg, llm, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0):
+    def __init__(self, cfg, llm, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True):
         super().__init__()
         assert r % 8 == 0 and 0 < r <= 16, "lora_r must be 8 or 16 (the shipped scripts' values)"
         assert all(t in ALL_TARGETS for t in targets), f"adapters are built for {ALL_TARGETS}"
-        assert not llm.moe_layers, "LoRA training is built for the dense decoder (MoE layers + adapters: not yet)"
+        assert cfg.top_k_experts == 1 and llm.ep is None and not cfg.use_residual or not llm.moe_layers, \
+            "adapters in MoE layers: top-1 routing on one rank (top-2 / expert parallel / residual MoE: not yet)"
         self.r, self.alpha, self.p = r, float(alpha), float(dropout)
         self.targets = tuple(t for t in ALL_TARGETS if t in targets)
         self.scaling = self.alpha / r
+        self.moe_layers, self.E, self.train_gate = set(llm.moe_layers), cfg.num_experts, bool(train_gate) and bool(llm.moe_layers)
         d, ff, dev = cfg.hidden_size, cfg.intermediate_size, llm.device
         g = torch.Generator().manual_seed(seed)
         self.names, plist = [], []
@@ -48,9 +51,14 @@ class LoRAState(torch.nn.Module):
             for t in self.targets:
                 fin, fout = (ff, d) if t == "down_proj" else ((d, ff) if t in ("gate_proj", "up_proj") else (d, d))
                 bound = 1.0 / math.sqrt(fin)                      # kaiming_uniform_(a=sqrt(5)) on [r, in]
-                a = (torch.rand(r, fin, generator=g) * 2 - 1) * bound
-                self.names += [f"model.layers.{i}.{_module(t)}.lora_A.default.weight", f"model.layers.{i}.{_module(t)}.lora_B.default.weight"]
-                plist += [torch.nn.Parameter(a.to(dev)), torch.nn.Parameter(torch.zeros(fout, r, device=dev))]
+                # peft wraps every Linear whose name matches: in a MoE layer the MLP targets are the experts' projections
+                for mod in self._modules_of(i, t):
+                    a = (torch.rand(r, fin, generator=g) * 2 - 1) * bound
+                    self.names += [f"model.layers.{i}.{mod}.lora_A.default.weight", f"model.layers.{i}.{mod}.lora_B.default.weight"]
+                    plist += [torch.nn.Parameter(a.to(dev)), torch.nn.Parameter(torch.zeros(fout, r, device=dev))]
+            if self.train_gate and i in self.moe_layers:          # `wg` in --sft_modules (scripts/train_stage4.sh:33)
+                self.names.append(f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight")
+                plist.append(torch.nn.Parameter(llm.layers[i]["wg"].detach().clone()))
         self.params = torch.nn.ParameterList(plist)
         self.index = {n: k for k, n in enumerate(self.names)}
         c = torch.arange(ff, device=dev)
@@ -63,8 +71,21 @@ class LoRAState(torch.nn.Module):
         self.step = 0
         self._bufs = {}
 
-    def get(self, i, t, which):
-        return self.params[self.index[f"model.layers.{i}.{_module(t)}.lora_{which}.default.weight"]]
+    def _modules_of(self, i, t):
+        if i in self.moe_layers and t in MLP_TARGETS:
+            return [f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}.{t}" for e in range(self.E)]
+        return [_module(t)]
+
+    def get(self, i, t, which, e=None):
+        mod = self._modules_of(i, t)[e if e is not None else 0]
+        return self.params[self.index[f"model.layers.{i}.{mod}.lora_{which}.default.weight"]]
+
+    def gate_weight(self, i, llm):
+        """The gate of MoE layer i: the trainable fp32 copy when `wg` trains (the model's tensor is re-pointed to it), else the model's."""
+        k = self.index.get(f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight")
+        if k is not None:
+            llm.layers[i]["wg"] = self.params[k].data
+        return llm.layers[i]["wg"]
 
     def peft_state_dict(self):
         """The adapters under peft's key names (`base_model.model.<module>.lora_{A,B}.default.weight`), bf16 like a bf16 peft model saves
@@ -77,33 +98,42 @@ class LoRAState(torch.nn.Module):
             p.data.copy_(sd[k].to(p.dtype))
 
     def padded(self, i):
-        """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets).  The
+        """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) — with a
+        leading expert axis for the MLP groups of a MoE layer, and B stored * scaling there (the batched GEMM has no alpha).  The
         buffers persist (zeroed once: the padding never changes); each step one pack kernel per adapter rewrites its slices.
         R = rank of the fused pair (targets x r), rounded up to what the wgrad kernel takes."""
         r, dev, bf = self.r, self.rows["q_proj"].device, torch.bfloat16
+        moe = i in self.moe_layers
         if i not in self._bufs:
             self._bufs[i] = {}
             for grp, members in GROUPS.items():
                 tg = [t for t in members if t in self.targets]
                 if tg:
                     fin, W = self.get(i, tg[0], "A").shape[1], self.width[grp]
-                    self._bufs[i][grp] = (torch.zeros(64, fin, dtype=bf, device=dev), torch.zeros(fin, 64, dtype=bf, device=dev),
-                                          torch.zeros(W, 64, dtype=bf, device=dev), torch.zeros(64, W, dtype=bf, device=dev), tg)
+                    lead = (self.E,) if (moe and grp in ("gu", "down")) else ()
+                    self._bufs[i][grp] = (torch.zeros(lead + (64, fin), dtype=bf, device=dev), torch.zeros(lead + (fin, 64), dtype=bf, device=dev),
+                                          torch.zeros(lead + (W, 64), dtype=bf, device=dev), torch.zeros(lead + (64, W), dtype=bf, device=dev), tg)
         out = {}
         for grp, (A, AT, B, BT, tg) in self._bufs[i].items():
+            batched = A.dim() == 3
             for k, t in enumerate(tg):
-                ops.lora_pack(self.get(i, t, "A").detach(), self.get(i, t, "B").detach(), self.rows[t], A, AT, B, BT, k * r)
+                for e in range(self.E if batched else 1):
+                    a, b = self.get(i, t, "A", e).detach(), self.get(i, t, "B", e).detach()
+                    if batched:
+                        ops.lora_pack(a, b, self.rows[t], A[e], AT[e], B[e], BT[e], k * r, bscale=self.scaling)
+                    else:
+                        ops.lora_pack(a, b, self.rows[t], A, AT, B, BT, k * r)
             R = len(tg) * r
             out[grp] = (A, AT, B, BT, 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64, tg)
         return out
 
 
-def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0):
+def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True):
     """Attach adapters to a LlamaStack and make the transposed weight copies the dgrad GEMMs read."""
-    llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed)
+    llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed, train_gate)
     for lw in llm.layers:
         for k in ("qkv", "o", "gu", "down"):
-            lw[k + "_T"] = lw[k].t().contiguous()
+            lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()          # experts: [E, out, in] -> [E, in, out]
     V, d = llm.lm_head.shape
     vp = (V + 63) // 64 * 64
     llm.lm_head_T = torch.zeros(d, vp, dtype=torch.bfloat16, device=llm.device)
@@ -120,6 +150,84 @@ def _adapter_fwd(lora, ops_pad, x, y, seed):
     return ops.gemm(t, B, residual=y, alpha=lora.scaling), xd, t
 
 
+def _zeros(shape, dev):
+    return torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+
+
+def _adapter_fwd_moe(lora, ops_pad, xbuf, ybuf, kept, seed):
+    """Per-expert adapters on the capacity slabs: ybuf + (dropout(xbuf) A_e^T) (scaling B_e)^T -> (y', x_dropped, t)."""
+    A, _, B, _, _, _ = ops_pad
+    E, cap, _ = xbuf.shape
+    xd = ops.dropout_bf16(xbuf, lora.p, seed) if lora.p > 0 else xbuf
+    t = ops.gemm_batched(xd, A, _zeros((E, cap, 64), xbuf.device), m_dev=kept)
+    delta = ops.gemm_batched(t, B, _zeros(ybuf.shape, xbuf.device), m_dev=kept)
+    return ops.add3(ybuf, delta), xd, t
+
+
+def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
+    """DeepSpeed MoE layer (top-1) in training-with-adapters mode on capacity slabs that are zero where no token sits, so every
+    row of every slab is finite and rows without a token contribute nothing to the weight gradients."""
+    cfg = llm.cfg
+    T, d = h2.shape
+    E, ff = cfg.num_experts, cfg.intermediate_size
+    cap = llm.capacity(T)
+    wg = lora.gate_weight(i, llm)
+    _, gates = ops.moe_gate(h2, wg)
+    expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, llm._gate_draws(i, T, E, gumbel=False))
+    buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=_zeros((E, cap, d), h2.device))
+    gu = ops.gemm_batched(buf, lw["gu"], _zeros((E, cap, 2 * ff), h2.device), m_dev=kept)
+    if "gu" in pad:
+        gu, s["bufd"], s["t_gu"] = _adapter_fwd_moe(lora, pad["gu"], buf, gu, kept, seed)
+    act = ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
+    y = ops.gemm_batched(act, lw["down"], _zeros((E, cap, d), h2.device), m_dev=kept)
+    if "down" in pad:
+        y, s["actd"], s["t_d"] = _adapter_fwd_moe(lora, pad["down"], act, y, kept, seed + 1)
+    s.update(moe=True, h2=h2, gates=gates, expert=expert, slot=slot, weight=weight, kept=kept, counts=counts, gu=gu, y=y, cap=cap, wg=wg)
+    return ops.moe_combine(y, expert, slot, weight, x_mid, cap), l_aux
+
+
+def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
+    """Per-expert adapter gradients on the slabs: (dx', [dB_e [out, R]], [dA_e^T [in, R]])."""
+    A, AT, B, BT, R, _ = ops_pad
+    E, cap, _ = dy.shape
+    dt = ops.gemm_batched(dy, BT, _zeros((E, cap, 64), dy.device), m_dev=kept)            # scaling rides in the packed B
+    dB = [ops.tn_skinny(dy[e], t[e], R, lora.scaling) for e in range(E)]
+    dAT = [ops.tn_skinny(xd[e], dt[e], R, 1.0) for e in range(E)]
+    dxa = ops.gemm_batched(dt, AT, _zeros(dx.shape, dy.device), m_dev=kept)
+    if lora.p > 0:
+        dxa = ops.dropout_bf16(dxa, lora.p, seed)
+    return ops.add3(dx, dxa), dB, dAT
+
+
+def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
+    """Backward of _moe_fwd: routed dgrad through the experts (+ their adapters), the combine weights' gradient into the gate
+    (softmax probability of the chosen expert) together with l_aux's, the gate's input gradient, and d wg.  -> d_h2 [T, d]."""
+    cfg = llm.cfg
+    E, ff, cap = cfg.num_experts, cfg.intermediate_size, s["cap"]
+    T, d = dx.shape
+    pad, kept = s["pad"], s["kept"]
+    d_y, d_w = ops.moe_combine_bwd(dx, s["y"], s["expert"], s["slot"], s["weight"], cap)
+    d_act = ops.gemm_batched(d_y, lw["down_T"], _zeros((E, cap, ff), dx.device), m_dev=kept)
+    if "down" in pad:
+        d_act, dB, dAT = _adapter_bwd_moe(lora, pad["down"], d_y, s["actd"], s["t_d"], d_act, kept, s["seed"] + 1)
+        take_e(i, pad["down"], dB, dAT)
+    d_gu = ops.swiglu_pair_bwd(s["gu"].view(E * cap, 2 * ff), d_act.view(E * cap, ff)).view(E, cap, 2 * ff)
+    d_buf = ops.gemm_batched(d_gu, lw["gu_T"], _zeros((E, cap, d), dx.device), m_dev=kept)
+    if "gu" in pad:
+        d_buf, dB, dAT = _adapter_bwd_moe(lora, pad["gu"], d_gu, s["bufd"], s["t_gu"], d_buf, kept, s["seed"])
+        take_e(i, pad["gu"], dB, dAT)
+    ones = torch.ones(T, dtype=torch.float32, device=dx.device)
+    d_h2 = ops.moe_combine(d_buf, s["expert"], s["slot"], ones, None, cap)                 # rows back to their tokens (dropped: 0)
+    dl = ops.moe_gate_bwd(s["gates"], s["expert"], s["slot"], d_w, s["counts"], d_aux, 1.0)
+    ops.moe_gate_dgrad_(dl, s["wg"], d_h2)
+    name = f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight"
+    if name in lora.index:
+        dlb = torch.zeros((T, 8), dtype=torch.bfloat16, device=dx.device)
+        dlb[:, :E] = dl
+        grads[name] = ops.tn_skinny(s["h2"], dlb, 8, 1.0)[:, :E].t()
+    return d_h2
+
+
 def forward_train(llm, embeds, key_valid):
     """The decoder forward in training-with-adapters mode -> (last_hidden [B,S,d], saved)."""
     cfg, lora = llm.cfg, llm.lora
@@ -128,7 +236,8 @@ def forward_train(llm, embeds, key_valid):
     T = B * S
     x = embeds.reshape(T, d)
     lora.step += 1
-    saved = []
+    llm.gate_pass += 1
+    saved, aux = [], []
     for i, lw in enumerate(llm.layers):
         pad = lora.padded(i)
         s = {"x": x, "pad": pad}
@@ -144,19 +253,24 @@ def forward_train(llm, embeds, key_valid):
         if "o" in pad:
             x_mid, s["attnd"], s["t_o"] = _adapter_fwd(lora, pad["o"], attn.view(T, d), x_mid, seed + 3)
         h2 = ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps)
-        gu = ops.gemm(h2, lw["gu"])
-        s.update(qkv=qkv, attn=attn, lse=lse, x_mid=x_mid)
-        if "gu" in pad:
-            gu, s["h2d"], s["t_gu"] = _adapter_fwd(lora, pad["gu"], h2, gu, seed)
-        act = ops.swiglu_pair_fwd(gu)
-        x_out = ops.gemm(act, lw["down"], residual=x_mid)
-        if "down" in pad:
-            x_out, s["actd"], s["t_d"] = _adapter_fwd(lora, pad["down"], act, x_out, seed + 1)
-        s["gu"], s["seed"] = gu, seed
+        s.update(qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, seed=seed)
+        if i in llm.moe_layers:
+            x_out, l_aux = _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed)
+            aux.append(l_aux)
+        else:
+            gu = ops.gemm(h2, lw["gu"])
+            if "gu" in pad:
+                gu, s["h2d"], s["t_gu"] = _adapter_fwd(lora, pad["gu"], h2, gu, seed)
+            act = ops.swiglu_pair_fwd(gu)
+            x_out = ops.gemm(act, lw["down"], residual=x_mid)
+            if "down" in pad:
+                x_out, s["actd"], s["t_d"] = _adapter_fwd(lora, pad["down"], act, x_out, seed + 1)
+            s["gu"] = gu
         saved.append(s)
         x = x_out
     out = ops.rmsnorm(x, llm.norm_w, cfg.rms_norm_eps)
-    return out.view(B, S, d), {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
+    aux_sum = torch.stack([a.reshape(()) for a in aux]).sum().reshape(1) if aux else torch.zeros(1, dtype=torch.float32, device=x.device)
+    return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
 def _adapter_bwd(lora, ops_pad, dy, xd, t, dx, seed):
@@ -173,8 +287,8 @@ def _adapter_bwd(lora, ops_pad, dy, xd, t, dx, seed):
     return dx, dB, dAT
 
 
-def backward(llm, saved, d_hidden):
-    """d_hidden [B,S,d] bf16 (gradient of the stack's output) -> {parameter name: fp32 gradient}."""
+def backward(llm, saved, d_hidden, d_aux=None):
+    """d_hidden [B,S,d] bf16 (gradient of the stack's output), d_aux [1] fp32 (gradient of the summed l_aux) -> {parameter name: fp32 gradient}."""
     cfg, lora = llm.cfg, llm.lora
     B, S = saved["B"], saved["S"]
     H, D, d = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size
@@ -188,20 +302,30 @@ def backward(llm, saved, d_hidden):
             grads[f"model.layers.{i}.{_module(t)}.lora_B.default.weight"] = dB[lora.rows[t], k * r:(k + 1) * r]
             grads[f"model.layers.{i}.{_module(t)}.lora_A.default.weight"] = dAT[:, k * r:(k + 1) * r].t()
 
+    def take_e(i, ops_pad, dB, dAT):
+        """The same for the per-expert adapters of a MoE layer."""
+        for k, t in enumerate(ops_pad[5]):
+            for e, mod in enumerate(lora._modules_of(i, t)):
+                grads[f"model.layers.{i}.{mod}.lora_B.default.weight"] = dB[e][lora.rows[t], k * r:(k + 1) * r]
+                grads[f"model.layers.{i}.{mod}.lora_A.default.weight"] = dAT[e][:, k * r:(k + 1) * r].t()
+
     dx = ops.rmsnorm_bwd(saved["x_last"], llm.norm_w, d_hidden.reshape(T, d).contiguous(), cfg.rms_norm_eps)
     for i in range(len(llm.layers) - 1, -1, -1):
         lw, s = llm.layers[i], saved["layers"][i]
         pad = s["pad"]
-        # ---- MLP: x_out = x_mid + down(act) [+ adapter]
-        d_act = ops.gemm(dx, lw["down_T"])
-        if "down" in pad:
-            d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1)
-            take(i, pad["down"], dB, dAT)
-        d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
-        d_h2 = ops.gemm(d_gu, lw["gu_T"])
-        if "gu" in pad:
-            d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
-            take(i, pad["gu"], dB, dAT)
+        # ---- MLP: x_out = x_mid + down(act) [+ adapter], or the MoE layer
+        if s.get("moe"):
+            d_h2 = _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e)
+        else:
+            d_act = ops.gemm(dx, lw["down_T"])
+            if "down" in pad:
+                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1)
+                take(i, pad["down"], dB, dAT)
+            d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
+            d_h2 = ops.gemm(d_gu, lw["gu_T"])
+            if "gu" in pad:
+                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
+                take(i, pad["gu"], dB, dAT)
         d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)
         # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]
         d_attn = ops.gemm(d_mid, lw["o_T"])
@@ -224,14 +348,14 @@ def backward(llm, saved, d_hidden):
 class LlamaLoRAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, llm, embeds, key_valid, *params):
-        out, saved = forward_train(llm, embeds, key_valid)
+        out, aux_sum, saved = forward_train(llm, embeds, key_valid)
         ctx.llm, ctx.saved = llm, saved
-        return out
+        return out, aux_sum
 
     @staticmethod
-    def backward(ctx, d_hidden):
+    def backward(ctx, d_hidden, d_aux):
         llm = ctx.llm
-        grads = backward(llm, ctx.saved, d_hidden.contiguous())
+        grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous())
         ctx.saved = None
         return (None, None, None) + tuple(grads[n].contiguous() for n in llm.lora.names)
 

@@ -148,12 +148,13 @@ class MedPLIBForCausalLM(nn.Module):
             ps += list(self.model.lora.parameters())
         return ps
 
-    def enable_lora(self, lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules=("gate_proj", "up_proj", "down_proj"), seed=0):
+    def enable_lora(self, lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules=("gate_proj", "up_proj", "down_proj"), seed=0,
+                    train_gate=True):
         """get_peft_model(LoraConfig(r, lora_alpha, target_modules, lora_dropout)) for the decoder's MLP projections
         (train_ds_medplib.py:262-303; scripts/train_stage3.sh).  Call after the weights are loaded."""
         from . import llama_lora as LL
         targets = tuple(t for t in (lora_target_modules.split(",") if isinstance(lora_target_modules, str) else lora_target_modules))
-        self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed)
+        self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed, train_gate)
         return self.model.lora
 
     def train(self, mode=True):
@@ -349,14 +350,16 @@ class MedPLIBForCausalLM(nn.Module):
             # LoRA training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so loss.backward()
             # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
             from . import llama_lora as LL
-            last_hidden = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *m.llm.lora.params)
+            last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *m.llm.lora.params)
             ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm) if sup_rows_d.numel() else \
                 torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+            if m.llm.moe_layers and cfg.router_aux_loss_coef != 0.0:
+                ce = ce + cfg.router_aux_loss_coef * aux_sum       # medplib_moe_llama.py:410-421
         elif lora_train:
             from . import llama_lora as LL
             with torch.no_grad():
-                last_hidden, _ = LL.forward_train(m.llm, embeds, key_valid)
-                ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, [])
+                last_hidden, aux_sum, _ = LL.forward_train(m.llm, embeds, key_valid)
+                ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, [aux_sum] if m.llm.moe_layers else [])
         if not seg_flag:
             z = torch.zeros(1, dtype=torch.float32, device=dev)
             ce_w = ce * cfg.ce_loss_weight if ce.requires_grad else ops.mean_plus(ce, cfg.ce_loss_weight)          # ce * ce_loss_weight

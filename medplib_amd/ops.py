@@ -287,11 +287,35 @@ def scatter_rows_f32_bf16(g, rows, T):
     return out
 
 
-def lora_pack(a, b, rows, A, AT, B, BT, k0):
-    """fp32 adapter (a [r, fin], b [fout, r]) -> its slices of the padded bf16 operands (both orientations)."""
+def lora_pack(a, b, rows, A, AT, B, BT, k0, bscale=1.0):
+    """fp32 adapter (a [r, fin], b [fout, r]) -> its slices of the padded bf16 operands (both orientations); B is stored * bscale."""
     r, fin = a.shape
     fout = b.shape[0]
-    lib().call("mp_lora_pack", _p(a), _p(b), _p(rows), _p(A), _p(AT), _p(B), _p(BT), r, fin, fout, int(k0), B.shape[0], _stream())
+    lib().call("mp_lora_pack", _p(a), _p(b), _p(rows), _p(A), _p(AT), _p(B), _p(BT), r, fin, fout, int(k0), B.shape[0], float(bscale),
+               _stream())
+
+
+def moe_combine_bwd(dout, y, expert, slot, weight, capacity):
+    """-> (d_y [E, cap, d] bf16 (zeros where no token sits), d_w [T] fp32)."""
+    T, d = dout.shape
+    dy = torch.zeros_like(y)
+    dw = torch.empty(T, dtype=torch.float32, device=dout.device)
+    lib().call("mp_moe_combine_bwd_bf16", _p(dout), _p(y), _p(expert), _p(slot), _p(weight), _p(dy), _p(dw), T, d, int(capacity), _stream())
+    return dy, dw
+
+
+def moe_gate_bwd(gates, expert, slot, dw, counts, c_aux, aux_coef):
+    T, E = gates.shape
+    dl = torch.empty((T, E), dtype=torch.float32, device=gates.device)
+    lib().call("mp_moe_gate_bwd_f32", _p(gates), _p(expert), _p(slot), _p(dw), _p(counts), _p(c_aux), float(aux_coef), _p(dl), T, E, _stream())
+    return dl
+
+
+def moe_gate_dgrad_(dlogits, wg, dx):
+    """dx += dlogits @ wg, in place on the bf16 [T, d] gradient."""
+    T, d = dx.shape
+    lib().call("mp_moe_gate_dgrad_bf16", _p(dlogits), _p(wg), _p(dx), T, d, wg.shape[0], _stream())
+    return dx
 
 
 def dropout_bf16(x, p, seed):

@@ -329,10 +329,16 @@ def llama_forward(embeds, key_valid, W, cfg, training=True, rts=None, prefix="",
             cf = cfg.capacity_factor if training else cfg.eval_capacity_factor
             cap = max(int(math.ceil(T / cfg.num_experts * cf * cfg.top_k_experts)), cfg.min_capacity)   # top2gating: 2 * cf
             experts = []
+            def elin(t, ep, name):
+                # an expert's projection, with its peft LoRA adapter when the state dict carries one (stage IV; parity unpinned)
+                y = F.linear(t, W[ep + name + ".weight"])
+                ka = ep + name + ".lora_A.default.weight"
+                if ka in W:
+                    y = y + W["lora_scaling"] * F.linear(F.linear(t, W[ka]), W[ep + name + ".lora_B.default.weight"])
+                return y
             for e in range(cfg.num_experts):
                 ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
-                experts.append(lambda t, ep=ep: F.linear(ops.swiglu(F.linear(t, W[ep + "gate_proj.weight"]),
-                                                                    F.linear(t, W[ep + "up_proj.weight"])), W[ep + "down_proj.weight"]))
+                experts.append(lambda t, ep=ep: elin(ops.swiglu(elin(t, ep, "gate_proj"), elin(t, ep, "up_proj")), ep, "down_proj"))
             if cfg.top_k_experts == 2:
                 out, l_aux, counts, idx, slot, _ = moe_top2(h.reshape(T, d), W[p + "mlp.deepspeed_moe.gate.wg.weight"], experts, cap,
                                                             None if rts is None else rts.get(i))

@@ -892,7 +892,7 @@ def test_lora_adapters_equal_merged_weights_and_entry_point(dev, tmp_path):
         p_.data.copy_((torch.randn(p_.shape, generator=g) * 0.05).to(torch.bfloat16).float().to(dev))
     emb = (torch.randn(2, 70, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     with torch.no_grad():
-        h_adapter, _ = LL.forward_train(m.model.llm, emb, None)
+        h_adapter, _, _ = LL.forward_train(m.model.llm, emb, None)
     peft_sd = {("base_model.model." + k): v for k, v in W.items() if k.startswith("model.layers.") or k in ("model.norm.weight", "lm_head.weight", "model.embed_tokens.weight")}
     peft_sd = {k.replace(".weight", ".base_layer.weight") if any(t in k for t in ("gate_proj", "up_proj", "down_proj")) else k: v for k, v in peft_sd.items()}
     peft_sd.update({k: v.float().cpu() for k, v in lo.peft_state_dict().items()})
@@ -904,3 +904,56 @@ def test_lora_adapters_equal_merged_weights_and_entry_point(dev, tmp_path):
     hist = train.main(["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "6", "--lr", "2e-3",
                        "--lora_r", "8", "--lora_dropout", "0.05", "--log_dir", str(tmp_path)])
     assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+
+
+def test_lora_training_moe_layers_vs_oracle_autograd(dev):
+    """Stage-IV shape of the problem (scripts/train_stage4.sh): MoE decoder, adapters on the experts' gate/up/down_proj and on
+    q_proj / v_proj, `wg` trainable, router aux loss on.  The MoE layer backward (routed dgrad through the experts and their adapters,
+    the combine weight's gradient into the gate, l_aux's gradient, d wg) vs torch autograd of the oracle.  Capacity drops tokens
+    (cf 1.0, RTS draws injected on both sides); tokens whose routing differs between bf16 and fp32 would make gradients incomparable,
+    so the case is seeded to have none and the test asserts it."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_hidden_layers=2, num_experts=2, capacity_factor=1.0, router_aux_loss_coef=0.05)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj,q_proj,v_proj")
+    assert any("deepspeed_experts.1.down_proj.lora_B" in n for n in lora.names) and any(n.endswith("gate.wg.weight") for n in lora.names)
+    g = torch.Generator().manual_seed(41)
+    Wl = dict(W)
+    Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if n.endswith("wg.weight"):
+            Wl[n] = W[n].clone().requires_grad_(True)
+            continue
+        v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+        p_.data.copy_(v.to(dev))
+        Wl[n] = v.clone().requires_grad_(True)
+    batch = OM.make_batch(cfg, 2, seed=6)
+    bq = dict(batch)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    T = 2 * (batch["input_ids"].shape[1] - 1 + cfg.clip_num_patches)
+    draws = {i: torch.rand(T, cfg.num_experts, generator=g) for i in range(cfg.num_hidden_layers)}
+    m.model.llm.rts_uniform_provider = lambda i, T_, E_: draws[i].to(dev)
+    ref, inter = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True, rts=draws, return_intermediates=True)
+    ref["loss"].backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                     config={"optimizer": {"params": {"lr": 1e-4, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    out = eng(**gb)
+    for k in O.LOSS_KEYS:
+        _stat(f"moe-lora loss[{k}]", out[k], ref[k], atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p_ in zip(lora.names, lora.params):
+        want = Wl[n].grad
+        err = (p_.grad.float().cpu() - want).abs().max().item()
+        rel = err / (want.abs().max().item() + 1e-12)
+        worst = max(worst, rel)
+        print(f"{n}: max|err| {err:.3e} / grad absmax {want.abs().max().item():.3e} = {rel:.3f}")
+        assert want.abs().max().item() > 0 and rel < 0.1, n
+    print("worst relative gradient error (MoE + LoRA)", worst)
+    eng.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p_).all() for p_ in lora.params)
