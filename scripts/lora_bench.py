@@ -12,7 +12,7 @@ import torch
 import bench
 from medplib_amd import engine
 from medplib_amd.model.config import MedPLIBConfig
-from medplib_amd.model.medplib import LISAForCausalLM
+from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=5)
@@ -21,11 +21,12 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--lora_r", type=int, default=8)
 ap.add_argument("--lora_dropout", type=float, default=0.05)
 ap.add_argument("--targets", type=str, default="gate_proj,up_proj,down_proj")
+ap.add_argument("--moe", action="store_true", help="MoE decoder (E = 2, top-1): per-expert adapters + trainable gate (stage IV / ICL scripts)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
-cfg = MedPLIBConfig.medplib_7b(moe_enable=False)
-model = LISAForCausalLM(cfg, device=dev).train()
+cfg = MedPLIBConfig.medplib_7b(moe_enable=args.moe)
+model = (MedPLIBForCausalLM if args.moe else LISAForCausalLM)(cfg, device=dev).train()
 lora = model.enable_lora(lora_r=args.lora_r, lora_alpha=16, lora_dropout=args.lora_dropout, lora_target_modules=args.targets)
 for n, p in zip(lora.names, lora.params):                  # B = 0 at initialisation would make half the gradients trivially zero
     if "lora_B" in n:
@@ -57,7 +58,7 @@ S, d, ff, nl = 639, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layer
 T = args.batch * S
 gemm_flop = 2 * T * nl * (4 * d * d + 3 * d * ff) * 2                   # forward + dgrad of the frozen projections
 attn_flop = args.batch * nl * cfg.num_attention_heads * S * S * cfg.head_dim * (4 + 14) / 2      # causal: fwd 2 + bwd 7 matmuls
-print(json.dumps({"what": "dense 7B + LoRA (%s, r=%d, dropout %.2f) training step, batch %d" % (args.targets, args.lora_r, args.lora_dropout, args.batch),
+print(json.dumps({"what": "%s 7B + LoRA (%s, r=%d, dropout %.2f) training step, batch %d" % ("MoE (E=2, top-1, wg trainable)" if args.moe else "dense", args.targets, args.lora_r, args.lora_dropout, args.batch),
                   "ms_per_step": round(dt * 1e3, 1), "samples_per_s": round(args.batch / dt, 2),
                   "decoder_tflop_per_step": round((gemm_flop + attn_flop) / 1e12, 1), "decoder_tflops": round((gemm_flop + attn_flop) / dt / 1e12, 1),
                   "trainable_params": eng.optimizer.numel, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
