@@ -314,6 +314,10 @@ int mp_moe_combine_bwd_bf16(const void* dout, const void* y, const int* expert, 
 int mp_moe_gate_bwd_f32(const float* gates, const int* expert, const int* slot, const float* dw, const long long* exp_counts,
                         const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, hipStream_t stream);
 int mp_moe_gate_dgrad_bf16(const float* dlogits, const float* wg, void* dx, int64_t tokens, int dim, int n_experts, hipStream_t stream);
+/* Gradient of the token-embedding table (`embed_tokens` in --sft_modules): out[ids[u], :] = sum of g[row, :] over the rows of segment
+ * u of rows_sorted (seg [n_unique + 1]), in list order; out fp32 [vocab, dim] pre-zeroed. */
+int mp_embed_grad_f32(const void* g, const int64_t* rows_sorted, const int64_t* seg, const int64_t* ids, float* out, int64_t n_unique, int dim,
+                      hipStream_t stream);
 /* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
 int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
 

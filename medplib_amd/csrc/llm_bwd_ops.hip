@@ -335,6 +335,23 @@ __global__ void moe_gate_dgrad_kernel(const float* __restrict__ dlogits, const f
   *reinterpret_cast<bf16x8*>(dx + t * d + c) = v;
 }
 
+// embedding-table gradient: out[ids[u], :] = sum over the rows of segment u (rows_sorted[seg[u] .. seg[u+1])) of g[row, :], added in
+// list order (the host sorts the token rows by id): no atomics, duplicates of a token id across the batch included
+__global__ void embed_grad_kernel(const bf16_t* __restrict__ g, const int64_t* __restrict__ rows_sorted, const int64_t* __restrict__ seg,
+                                  const int64_t* __restrict__ ids, float* __restrict__ out, int d) {
+  const int64_t u = blockIdx.x;
+  const int64_t b = seg[u], e = seg[u + 1];
+  float* o = out + ids[u] * d;
+  for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = b; k < e; ++k) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(g + rows_sorted[k] * d + c);
+      acc += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    *reinterpret_cast<f32x4*>(o + c) = acc;
+  }
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -435,4 +452,12 @@ extern "C" int mp_moe_gate_dgrad_bf16(const float* dlogits, const float* wg, voi
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(moe_gate_dgrad_kernel, GRID1D(n), dlogits, wg, (bf16_t*)dx, tokens, dim, n_experts);
   return mp_check_launch("mp_moe_gate_dgrad_bf16");
+}
+
+extern "C" int mp_embed_grad_f32(const void* g, const int64_t* rows_sorted, const int64_t* seg, const int64_t* ids, float* out, int64_t n_unique,
+                                 int dim, hipStream_t stream) {
+  MP_REQUIRE(dim % 4 == 0, MP_ERR_SHAPE, "mp_embed_grad_f32: dim %% 4 != 0");
+  if (n_unique == 0) return MP_OK;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3((unsigned)n_unique), dim3(256), 0, stream, (const bf16_t*)g, rows_sorted, seg, ids, out, dim);
+  return mp_check_launch("mp_embed_grad_f32");
 }

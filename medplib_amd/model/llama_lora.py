@@ -34,7 +34,7 @@ class LoRAState(torch.nn.Module):
     """The adapters of every decoder layer as fp32 nn.Parameters (the engine's flat AdamW buffer adopts them) plus the bf16 padded
     GEMM operands rebuilt from them before each forward."""
 
-    def __init__(self, cfg, llm, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True):
+    def __init__(self, cfg, llm, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True, sft_modules=()):
         super().__init__()
         assert r % 8 == 0 and 0 < r <= 16, "lora_r must be 8 or 16 (the shipped scripts' values)"
         assert all(t in ALL_TARGETS for t in targets), f"adapters are built for {ALL_TARGETS}"
@@ -59,6 +59,10 @@ class LoRAState(torch.nn.Module):
             if self.train_gate and i in self.moe_layers:          # `wg` in --sft_modules (scripts/train_stage4.sh:33)
                 self.names.append(f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight")
                 plist.append(torch.nn.Parameter(llm.layers[i]["wg"].detach().clone()))
+        for full in ("lm_head", "embed_tokens"):                  # whole-matrix fine-tuning of --sft_modules (train_stage4.sh:33)
+            if full in sft_modules:
+                self.names.append("lm_head.weight" if full == "lm_head" else "model.embed_tokens.weight")
+                plist.append(torch.nn.Parameter(getattr(llm, full).detach().float().clone()))
         self.params = torch.nn.ParameterList(plist)
         self.index = {n: k for k, n in enumerate(self.names)}
         c = torch.arange(ff, device=dev)
@@ -79,6 +83,20 @@ class LoRAState(torch.nn.Module):
     def get(self, i, t, which, e=None):
         mod = self._modules_of(i, t)[e if e is not None else 0]
         return self.params[self.index[f"model.layers.{i}.{mod}.lora_{which}.default.weight"]]
+
+    def full_param(self, name):
+        k = self.index.get(name)
+        return None if k is None else self.params[k]
+
+    def sync_model(self, llm):
+        """bf16 working copies of the fully fine-tuned matrices (and lm_head^T for its dgrad) from their fp32 masters; once per step."""
+        p = self.full_param("lm_head.weight")
+        if p is not None:
+            llm.lm_head.copy_(p.detach())
+            llm.lm_head_T[:, :p.shape[0]] = llm.lm_head.t()
+        p = self.full_param("model.embed_tokens.weight")
+        if p is not None:
+            llm.embed_tokens.copy_(p.detach())
 
     def gate_weight(self, i, llm):
         """The gate of MoE layer i: the trainable fp32 copy when `wg` trains (the model's tensor is re-pointed to it), else the model's."""
@@ -128,9 +146,9 @@ class LoRAState(torch.nn.Module):
         return out
 
 
-def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True):
+def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True, sft_modules=()):
     """Attach adapters to a LlamaStack and make the transposed weight copies the dgrad GEMMs read."""
-    llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed, train_gate)
+    llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed, train_gate, tuple(sft_modules))
     for lw in llm.layers:
         for k in ("qkv", "o", "gu", "down"):
             lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()          # experts: [E, out, in] -> [E, in, out]
@@ -342,6 +360,7 @@ def backward(llm, saved, d_hidden, d_aux=None):
             d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2)
             take(i, pad["qkv"], dB, dAT)
         dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
+    grads["__d_embeds__"] = dx                                     # gradient of the decoder's input rows (for embed_tokens)
     return grads
 
 
@@ -356,32 +375,42 @@ class LlamaLoRAFn(torch.autograd.Function):
     def backward(ctx, d_hidden, d_aux):
         llm = ctx.llm
         grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous())
+        d_emb = grads.pop("__d_embeds__").view(ctx.saved["B"], ctx.saved["S"], -1) if ctx.needs_input_grad[1] else None
         ctx.saved = None
-        return (None, None, None) + tuple(grads[n].contiguous() for n in llm.lora.names)
+        own = [n for n in llm.lora.names if n not in ("lm_head.weight", "model.embed_tokens.weight")]
+        return (None, d_emb, None) + tuple(grads[n].contiguous() for n in own)
 
 
 class CrossEntropyFn(torch.autograd.Function):
     """lm_head on the supervised rows + filtered mean CE (medplib_moe_llama.py:388-408) with its backward into the hidden states."""
 
     @staticmethod
-    def forward(ctx, last_hidden, sup_rows, sup_labels, llm):
+    def forward(ctx, last_hidden, sup_rows, sup_labels, llm, lm_head_param=None):
         d = last_hidden.shape[-1]
         rows = ops.cast_to_bf16(ops.gather_rows_bf16_to_f32(last_hidden.reshape(-1, d), sup_rows))
         logits = ops.gemm(rows, llm.lm_head, out_dtype=torch.float32)
         ce = ops.mean_plus(ops.cross_entropy_rows(logits, sup_labels), 1.0)
-        ctx.save_for_backward(logits, sup_rows, sup_labels)
+        ctx.save_for_backward(logits, sup_rows, sup_labels, rows)
         ctx.llm, ctx.shape = llm, last_hidden.shape
         return ce
 
     @staticmethod
     def backward(ctx, g):
-        logits, sup_rows, sup_labels = ctx.saved_tensors
+        logits, sup_rows, sup_labels, rows = ctx.saved_tensors
         llm = ctx.llm
-        n = logits.shape[0]
-        dl = ops.ce_rows_bwd(logits, sup_labels, g.contiguous(), 1.0 / n, llm.lm_head_T.shape[1])
+        n, V = logits.shape
+        vp = llm.lm_head_T.shape[1]
+        dl = ops.ce_rows_bwd(logits, sup_labels, g.contiguous(), 1.0 / n, vp)
         d_rows = ops.gemm(dl, llm.lm_head_T, out_dtype=torch.float32)
         T = ctx.shape[0] * ctx.shape[1]
-        return ops.scatter_rows_f32_bf16(d_rows, sup_rows, T).view(ctx.shape), None, None, None
+        d_w = None
+        if ctx.needs_input_grad[4]:
+            # d lm_head [V, d] = d_logits^T rows: the NT GEMM on the two small transposes (the supervised-row count padded to a K-tile)
+            n64 = (n + 63) // 64 * 64
+            dlT = torch.zeros((vp, n64), dtype=torch.bfloat16, device=dl.device); dlT[:, :n] = dl.t()
+            rT = torch.zeros((rows.shape[1], n64), dtype=torch.bfloat16, device=dl.device); rT[:, :n] = rows.t()
+            d_w = ops.gemm(dlT, rT, out_dtype=torch.float32)[:V].contiguous()
+        return ops.scatter_rows_f32_bf16(d_rows, sup_rows, T).view(ctx.shape), None, None, None, d_w
 
 
 class GatherRowsFn(torch.autograd.Function):
@@ -397,3 +426,28 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         (rows,) = ctx.saved_tensors
         return ops.scatter_rows_f32_bf16(g.contiguous(), rows, ctx.shape[0] * ctx.shape[1]).view(ctx.shape), None
+
+
+class EmbedSpliceFn(torch.autograd.Function):
+    """The multimodal splice (token-embedding gather + image-feature rows) with the embedding table's gradient: the rows that came
+    from the table are grouped by token id on the host (the ids are host data) and summed per id in list order."""
+
+    @staticmethod
+    def forward(ctx, embed_param, llm, feats, src_dev, src_host, shape):
+        import numpy as np
+        ctx.llm, ctx.shape = llm, shape
+        flat = src_host.reshape(-1)
+        tok_rows = np.flatnonzero(flat >= 0)
+        order = tok_rows[np.argsort(flat[tok_rows], kind="stable")]
+        ids_sorted = flat[order]
+        uniq, first = np.unique(ids_sorted, return_index=True)
+        seg = np.concatenate([first, [ids_sorted.size]]).astype(np.int64)
+        dev = src_dev.device
+        ctx.idx = tuple(torch.from_numpy(a.astype(np.int64)).to(dev) for a in (order, seg, uniq))
+        return ops.splice_rows(llm.embed_tokens, feats, src_dev, shape[2]).view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        order, seg, uniq = ctx.idx
+        V, d = ctx.llm.embed_tokens.shape
+        return ops.embed_grad(g.reshape(-1, d).contiguous(), order, seg, uniq, V), None, None, None, None, None

@@ -149,12 +149,14 @@ class MedPLIBForCausalLM(nn.Module):
         return ps
 
     def enable_lora(self, lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules=("gate_proj", "up_proj", "down_proj"), seed=0,
-                    train_gate=True):
+                    train_gate=True, sft_modules=()):
         """get_peft_model(LoraConfig(r, lora_alpha, target_modules, lora_dropout)) for the decoder's MLP projections
         (train_ds_medplib.py:262-303; scripts/train_stage3.sh).  Call after the weights are loaded."""
         from . import llama_lora as LL
         targets = tuple(t for t in (lora_target_modules.split(",") if isinstance(lora_target_modules, str) else lora_target_modules))
-        self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed, train_gate)
+        sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens"))
+        self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
+                                         train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
         return self.model.lora
 
     def train(self, mode=True):
@@ -341,6 +343,8 @@ class MedPLIBForCausalLM(nn.Module):
             seg_rows_d = _h2d(seg_rows, dev) if seg_flag else None
             exp = self.expand_index(valid_mask_bool, B) if seg_flag else None
             exp_d = _h2d(np.asarray(exp, dtype=np.int64), dev) if (seg_flag and exp != list(range(B))) else None
+            if getattr(m.llm, "lora", None) is not None and self.training and not inference:
+                m.llm.lora.sync_model(m.llm)                        # bf16 working copies of lm_head / embed_tokens when they train
             embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(B, plan.seq_len, cfg.hidden_size)
             lora_train = getattr(m.llm, "lora", None) is not None and self.training and not inference
             if not lora_train:
@@ -350,8 +354,13 @@ class MedPLIBForCausalLM(nn.Module):
             # LoRA training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so loss.backward()
             # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
             from . import llama_lora as LL
-            last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *m.llm.lora.params)
-            ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm) if sup_rows_d.numel() else \
+            lo = m.llm.lora
+            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight")]
+            emb_p = lo.full_param("model.embed_tokens.weight")
+            if emb_p is not None:                                   # embed_tokens trains: the splice joins the autograd tape
+                embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
+            last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *own)
+            ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight")) if sup_rows_d.numel() else \
                 torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
             if m.llm.moe_layers and cfg.router_aux_loss_coef != 0.0:
                 ce = ce + cfg.router_aux_loss_coef * aux_sum       # medplib_moe_llama.py:410-421

@@ -318,6 +318,14 @@ def moe_gate_dgrad_(dlogits, wg, dx):
     return dx
 
 
+def embed_grad(g, rows_sorted, seg, ids, vocab):
+    """fp32 [vocab, d] gradient of the embedding table from the bf16 row gradients g [T, d] (segments of rows per token id)."""
+    T, d = g.shape
+    out = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
+    lib().call("mp_embed_grad_f32", _p(g), _p(rows_sorted), _p(seg), _p(ids), _p(out), ids.numel(), d, _stream())
+    return out
+
+
 def dropout_bf16(x, p, seed):
     y = torch.empty_like(x)
     lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())

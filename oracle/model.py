@@ -170,8 +170,9 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
             valid = torch.tensor([any(v) for v in batch["valid_region_masks_bool"]])
             rmap = F.linear(raw_feats, W["model.region_fea_adapter.weight"], W["model.region_fea_adapter.bias"])[valid]
             region_features = llm.extract_region_feature(rmap, batch["region_masks"], cfg.max_sample_point)
-        att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token,
-                                                                      region_features=region_features, valid_region_masks_bool=valid)
+        with (torch.enable_grad() if llm_grad else contextlib.nullcontext()):      # embed_tokens may be trainable (--sft_modules)
+            att2, embeds, lab2 = llm.prepare_inputs_labels_for_multimodal(ids, att, labels, feat_list, W["model.embed_tokens.weight"], per_token,
+                                                                          region_features=region_features, valid_region_masks_bool=valid)
         kv = None if att2.all() else att2
     # llm_grad (LoRA training): the decoder and the CE stay on the autograd tape so `loss.backward()` reaches the adapters in W
     with (contextlib.nullcontext() if llm_grad else torch.no_grad()):

@@ -957,3 +957,50 @@ def test_lora_training_moe_layers_vs_oracle_autograd(dev):
     eng.step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p_).all() for p_ in lora.params)
+
+
+def test_lora_training_with_lm_head_and_embed_tokens(dev):
+    """`--sft_modules lm_head,embed_tokens` next to the adapters (train_ds_medplib.py:316-326; the script default and stage IV): the two
+    matrices train whole.  Their gradients (lm_head: d_logits^T rows on the supervised rows; embed_tokens: the decoder's input-row
+    gradients summed per token id, duplicates across the batch included) vs the oracle's autograd."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, sft_modules="lm_head,embed_tokens,mask_decoder,text_hidden_fcs")
+    assert lora.names[-2:] == ["lm_head.weight", "model.embed_tokens.weight"]
+    g = torch.Generator().manual_seed(51)
+    Wl = dict(W)
+    Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev))
+            Wl[n] = v.clone().requires_grad_(True)
+        else:
+            Wl[n] = W[n].clone().requires_grad_(True)
+    batch = OM.make_batch(cfg, 3, seed=7)
+    bq = dict(batch)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    ref = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True)
+    ref["loss"].backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                     config={"optimizer": {"params": {"lr": 1e-4, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    out = eng(**gb)
+    _stat("loss", out["loss"], ref["loss"], atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    for n in ("lm_head.weight", "model.embed_tokens.weight", "model.layers.0.mlp.up_proj.lora_A.default.weight"):
+        want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
+        err = (got - want).abs().max().item()
+        rel = err / (want.abs().max().item() + 1e-12)
+        print(f"{n}: max|err| {err:.3e} / grad absmax {want.abs().max().item():.3e} = {rel:.3f}; nonzero rows {int((want.abs().sum(1) > 0).sum())}")
+        assert want.abs().max().item() > 0 and rel < 0.05, n
+        assert torch.equal(got.abs().sum(1) > 0, want.abs().sum(1) > 0) or "lora" in n, "rows that received gradient"
+    before = lora.params[lora.index["lm_head.weight"]].detach().clone()
+    eng.step()
+    out2 = eng(**gb)                                              # the next forward reads the updated matrices (bf16 working copies re-synced)
+    torch.cuda.synchronize()
+    assert not torch.equal(before, lora.params[lora.index["lm_head.weight"]]) and torch.isfinite(out2["loss"]).all()
