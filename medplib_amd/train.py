@@ -65,6 +65,7 @@ def parse_args(argv=None):
     p.add_argument("--lora_alpha", default=16, type=int)
     p.add_argument("--lora_dropout", default=0.05, type=float)
     p.add_argument("--lora_target_modules", default="gate_proj,up_proj,down_proj", type=str)
+    p.add_argument("--sft_modules", default="mask_decoder,text_hidden_fcs", type=str)      # train_ds_medplib.py:54 (+ wg, lm_head, embed_tokens)
     p.add_argument("--use_residual", type=bool, default=False)        # argparse bool as in train_ds_medplib.py:131
     p.add_argument("--router_aux_loss_coef", type=float, default=0.0)
     p.add_argument("--ep_size", type=int, default=1)
@@ -139,7 +140,8 @@ def build_model(args, device):
         model.load_sam_state_dict(torch.load(args.vision_pretrained, map_location="cpu")["model"])
     if getattr(args, "lora_r", 0) > 0:
         # get_peft_model(LoraConfig(...)) (train_ds_medplib.py:262-303): adapters on the decoder's MLP projections, dense decoder only
-        model.enable_lora(args.lora_r, args.lora_alpha, args.lora_dropout, args.lora_target_modules)
+        model.enable_lora(args.lora_r, args.lora_alpha, args.lora_dropout, args.lora_target_modules,
+                          sft_modules=getattr(args, "sft_modules", "mask_decoder,text_hidden_fcs"))
     if args.ep_size > 1:
         from .expert_parallel import ExpertParallel, build_groups
         ep_group, _ = build_groups(args.ep_size)
