@@ -284,9 +284,15 @@ int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void*
                           const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream);
 
 /* ---- decoder backward pieces (LoRA training; train_ds_medplib.py:262-303, scripts/train_stage3.sh) -------- */
-/* Autograd of LlamaRMSNorm w.r.t. its input (weight frozen): dx = rs * (dy*w - xhat * mean(dy*w*xhat)) [+ add], xhat = x*rs. */
+/* Autograd of LlamaRMSNorm w.r.t. its input: dx = rs * (dy*w - xhat * mean(dy*w*xhat)) [+ add], xhat = x*rs; rs_out (optional, [rows])
+ * receives the row scales for the weight gradient. */
 int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
-                        int64_t ldo, int64_t rows, int dim, float eps, hipStream_t stream);
+                        int64_t ldo, int64_t rows, int dim, float eps, float* rs_out, hipStream_t stream);
+/* ... and w.r.t. its weight (`input_layernorm,post_attention_layernorm` in --sft_modules, scripts/train_stage2.sh): dw[c] =
+ * sum_t dy[t, c] * bf16(x[t, c] * rs[t]), rs [rows] from mp_rmsnorm_bwd_bf16 (rs_out); partial >= ceil(rows / 256) * dim floats,
+ * chunks added in ascending order. */
+int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* rs, float* dw, float* partial,
+                         int64_t partial_floats, int64_t rows, int dim, hipStream_t stream);
 /* silu(gate) * up and its autograd on the gate|up GEMM output [tokens, 2*ff] whose columns are interleaved in blocks of 32 (the
  * fused weight layout); act / dact [tokens, ff]. */
 int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream);

@@ -19,7 +19,7 @@ constexpr int RB_THREADS = 256, RB_MAXC = 4;
 __global__ __launch_bounds__(RB_THREADS) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                  const bf16_t* __restrict__ dy, const bf16_t* __restrict__ add,
                                                                  bf16_t* __restrict__ dx, int dim, float eps, int64_t ldx, int64_t ldy,
-                                                                 int64_t lda, int64_t ldo) {
+                                                                 int64_t lda, int64_t ldo, float* __restrict__ rs_out) {
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
   const bf16_t* xr = x + row * ldx;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(RB_THREADS) void rmsnorm_bwd_kernel(const bf16_t* _
   }
   ss = block_sum(ss, red);
   const float rs = rsqrtf(ss / (float)dim + eps);
+  if (rs_out && threadIdx.x == 0) rs_out[row] = rs;
   float dot = 0.f;
 #pragma unroll
   for (int c = 0; c < RB_MAXC; ++c) {
@@ -352,17 +353,30 @@ __global__ void embed_grad_kernel(const bf16_t* __restrict__ g, const int64_t* _
   }
 }
 
+// RMSNorm weight gradient: dw[c] = sum_t dy[t, c] * bf16(x[t, c] * rs[t]) (the normalised value as the forward rounded it).
+// A block owns 256 columns x a chunk of 256 rows -> partial[chunk][c]; the chunks are added in ascending order by tn_skinny_reduce.
+__global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                                                    int64_t ldy, const float* __restrict__ rs, float* __restrict__ partial,
+                                                                    int64_t T, int dim) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.y * 256, t1 = min(T, t0 + 256);
+  if (c >= dim) return;
+  float acc = 0.f;
+  for (int64_t t = t0; t < t1; ++t) acc = fmaf((float)dy[t * ldy + c], (float)(bf16_t)((float)x[t * ldx + c] * rs[t]), acc);
+  partial[(int64_t)blockIdx.y * dim + c] = acc;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
 
 extern "C" int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda,
-                                   void* dx, int64_t ldo, int64_t rows, int dim, float eps, hipStream_t stream) {
+                                   void* dx, int64_t ldo, int64_t rows, int dim, float eps, float* rs_out, hipStream_t stream) {
   MP_REQUIRE(dim % 8 == 0 && dim <= RB_THREADS * 8 * RB_MAXC && ldx % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && (!add || lda % 8 == 0), MP_ERR_SHAPE,
              "mp_rmsnorm_bwd_bf16: dim=%d unsupported", dim);
   if (rows == 0) return MP_OK;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)rows), dim3(RB_THREADS), 0, stream, (const bf16_t*)x, w, (const bf16_t*)dy,
-                     (const bf16_t*)add, (bf16_t*)dx, dim, eps, ldx, ldy, lda, ldo);
+                     (const bf16_t*)add, (bf16_t*)dx, dim, eps, ldx, ldy, lda, ldo, rs_out);
   return mp_check_launch("mp_rmsnorm_bwd_bf16");
 }
 
@@ -460,4 +474,15 @@ extern "C" int mp_embed_grad_f32(const void* g, const int64_t* rows_sorted, cons
   if (n_unique == 0) return MP_OK;
   hipLaunchKernelGGL(embed_grad_kernel, dim3((unsigned)n_unique), dim3(256), 0, stream, (const bf16_t*)g, rows_sorted, seg, ids, out, dim);
   return mp_check_launch("mp_embed_grad_f32");
+}
+
+extern "C" int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* rs, float* dw, float* partial,
+                                    int64_t partial_floats, int64_t rows, int dim, hipStream_t stream) {
+  const int chunks = (int)mp_cdiv(rows, 256);
+  MP_REQUIRE(rows > 0 && dim > 0 && partial && partial_floats >= (int64_t)chunks * dim, MP_ERR_WORKSPACE,
+             "mp_rmsnorm_wgrad_f32: partial needs %lld floats", (long long)((int64_t)chunks * dim));
+  hipLaunchKernelGGL(rmsnorm_wgrad_partial_kernel, dim3((unsigned)mp_cdiv(dim, 256), (unsigned)chunks), dim3(256), 0, stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dy, ldy, rs, partial, rows, dim);
+  hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(dim, 256)), dim3(256), 0, stream, partial, dw, (int64_t)dim, chunks, 1.f);
+  return mp_check_launch("mp_rmsnorm_wgrad_f32");
 }

@@ -59,6 +59,13 @@ class LoRAState(torch.nn.Module):
             if self.train_gate and i in self.moe_layers:          # `wg` in --sft_modules (scripts/train_stage4.sh:33)
                 self.names.append(f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight")
                 plist.append(torch.nn.Parameter(llm.layers[i]["wg"].detach().clone()))
+        self.norm_names = {}
+        for key, short in (("input_layernorm", "ln1"), ("post_attention_layernorm", "ln2")):   # train_stage2.sh's --sft_modules
+            if key in sft_modules:
+                for i in range(cfg.num_hidden_layers):
+                    self.norm_names[(i, short)] = f"model.layers.{i}.{key}.weight"
+                    self.names.append(self.norm_names[(i, short)])
+                    plist.append(torch.nn.Parameter(llm.layers[i][short].detach().clone()))
         for full in ("lm_head", "embed_tokens"):                  # whole-matrix fine-tuning of --sft_modules (train_stage4.sh:33)
             if full in sft_modules:
                 self.names.append("lm_head.weight" if full == "lm_head" else "model.embed_tokens.weight")
@@ -89,7 +96,10 @@ class LoRAState(torch.nn.Module):
         return None if k is None else self.params[k]
 
     def sync_model(self, llm):
-        """bf16 working copies of the fully fine-tuned matrices (and lm_head^T for its dgrad) from their fp32 masters; once per step."""
+        """bf16 working copies of the fully fine-tuned matrices (and lm_head^T for its dgrad) from their fp32 masters; once per step.
+        Trainable norm weights are fp32 in the model already: its tensors are re-pointed to the parameters."""
+        for (i, short), n in self.norm_names.items():
+            llm.layers[i][short] = self.params[self.index[n]].data
         p = self.full_param("lm_head.weight")
         if p is not None:
             llm.lm_head.copy_(p.detach())
@@ -344,7 +354,10 @@ def backward(llm, saved, d_hidden, d_aux=None):
             if "gu" in pad:
                 d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
                 take(i, pad["gu"], dB, dAT)
-        d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)
+        if (i, "ln2") in lora.norm_names:
+            d_mid, grads[lora.norm_names[(i, "ln2")]] = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx, want_wgrad=True)
+        else:
+            d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)
         # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]
         d_attn = ops.gemm(d_mid, lw["o_T"])
         if "o" in pad:
@@ -359,7 +372,10 @@ def backward(llm, saved, d_hidden, d_aux=None):
         if "qkv" in pad:
             d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2)
             take(i, pad["qkv"], dB, dAT)
-        dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
+        if (i, "ln1") in lora.norm_names:
+            dx, grads[lora.norm_names[(i, "ln1")]] = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid, want_wgrad=True)
+        else:
+            dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
     grads["__d_embeds__"] = dx                                     # gradient of the decoder's input rows (for embed_tokens)
     return grads
 

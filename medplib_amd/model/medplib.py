@@ -154,7 +154,7 @@ class MedPLIBForCausalLM(nn.Module):
         (train_ds_medplib.py:262-303; scripts/train_stage3.sh).  Call after the weights are loaded."""
         from . import llama_lora as LL
         targets = tuple(t for t in (lora_target_modules.split(",") if isinstance(lora_target_modules, str) else lora_target_modules))
-        sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens"))
+        sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm"))
         self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
                                          train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
         return self.model.lora

@@ -232,14 +232,20 @@ def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=
 
 
 # ------------------------------------------------------------------ decoder backward pieces (LoRA training) --------------------
-def rmsnorm_bwd(x, w, dy, eps, add=None):
-    """dx of LlamaRMSNorm (weight frozen), optionally + add (the residual-stream gradient).  x, dy [T, d] bf16."""
+def rmsnorm_bwd(x, w, dy, eps, add=None, want_wgrad=False):
+    """dx of LlamaRMSNorm, optionally + add (the residual-stream gradient).  x, dy [T, d] bf16.  want_wgrad: -> (dx, dw [d] fp32)."""
     _chk(x, torch.bfloat16, "rmsnorm_bwd.x"); _chk(dy, torch.bfloat16, "rmsnorm_bwd.dy")
     T, d = x.shape
     out = torch.empty((T, d), dtype=torch.bfloat16, device=x.device)
+    rs = torch.empty(T, dtype=torch.float32, device=x.device) if want_wgrad else None
     lib().call("mp_rmsnorm_bwd_bf16", _p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0,
-               _p(out), out.stride(0), T, d, float(eps), _stream())
-    return out
+               _p(out), out.stride(0), T, d, float(eps), _p(rs), _stream())
+    if not want_wgrad:
+        return out
+    dw = torch.empty(d, dtype=torch.float32, device=x.device)
+    partial = torch.empty(((T + 255) // 256) * d, dtype=torch.float32, device=x.device)
+    lib().call("mp_rmsnorm_wgrad_f32", _p(x), x.stride(0), _p(dy), dy.stride(0), _p(rs), _p(dw), _p(partial), partial.numel(), T, d, _stream())
+    return out, dw
 
 
 def swiglu_pair_fwd(gu):

@@ -967,8 +967,9 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
-    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, sft_modules="lm_head,embed_tokens,mask_decoder,text_hidden_fcs")
-    assert lora.names[-2:] == ["lm_head.weight", "model.embed_tokens.weight"]
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0,
+                         sft_modules="lm_head,embed_tokens,input_layernorm,post_attention_layernorm,mask_decoder,text_hidden_fcs")
+    assert lora.names[-2:] == ["lm_head.weight", "model.embed_tokens.weight"] and "model.layers.1.input_layernorm.weight" in lora.names
     g = torch.Generator().manual_seed(51)
     Wl = dict(W)
     Wl["lora_scaling"] = 2.0
@@ -992,6 +993,11 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     _stat("loss", out["loss"], ref["loss"], atol=3e-2)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
+    for n in ("model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight"):
+        want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
+        rel = (got - want).abs().max().item() / want.abs().max().item()
+        print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
+        assert rel < 0.05, n
     for n in ("lm_head.weight", "model.embed_tokens.weight", "model.layers.0.mlp.up_proj.lora_A.default.weight"):
         want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
         err = (got - want).abs().max().item()
