@@ -1010,3 +1010,48 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     out2 = eng(**gb)                                              # the next forward reads the updated matrices (bf16 working copies re-synced)
     torch.cuda.synchronize()
     assert not torch.equal(before, lora.params[lora.index["lm_head.weight"]]) and torch.isfinite(out2["loss"]).all()
+
+
+def test_lora_training_ragged_batch_and_ce_only(dev):
+    """Right-padded prompts (key padding in the attention forward AND backward, padded rows outside every loss) and a CE-only batch
+    (seg_flag False: the gradient reaches the adapters through the CE alone) vs the oracle's autograd."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
+    W = OM.init_hf_weights(cfg)
+    for ragged, seg in ((True, True), (True, False)):
+        m = _model(cfg, dev, W).train()
+        lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="q_proj,v_proj,down_proj")
+        g = torch.Generator().manual_seed(61)
+        Wl = dict(W); Wl["lora_scaling"] = 2.0
+        for n, p_ in zip(lora.names, lora.params):
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev)); Wl[n] = v.clone().requires_grad_(True)
+        batch = OM.make_batch(cfg, 3, seed=9, ragged=ragged)
+        assert not batch["attention_mask"].all()
+        if not seg:
+            batch.update(seg_flag=False, masks_list=[], label_list=[], valid_mask_bool=[[]] * 3)
+        bq = dict(batch)
+        bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+        if seg:
+            ref = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True)
+            ref_loss = ref["loss"]
+        else:                                                     # the oracle's CE-only path: loss = ce * ce_loss_weight
+            _, inter = OM.model_forward(dict(bq, seg_flag=True, masks_list=OM.make_batch(cfg, 3, seed=9)["masks_list"],
+                                             label_list=OM.make_batch(cfg, 3, seed=9)["label_list"], valid_mask_bool=[[True]] * 3),
+                                        Wl, cfg, training=True, llm_grad=True, return_intermediates=True)
+            ref_loss = inter["ce"] * cfg.ce_loss_weight
+        ref_loss.backward()
+        eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                         config={"optimizer": {"params": {"lr": 1e-4}}, "gradient_clipping": 1.0})
+        gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+        out = eng(**gb)
+        _stat(f"loss (ragged={ragged}, seg={seg})", out["loss"], ref_loss, atol=3e-2)
+        eng.backward(out["loss"])
+        torch.cuda.synchronize()
+        worst = 0.0
+        for n, p_ in zip(lora.names, lora.params):
+            want = Wl[n].grad
+            worst = max(worst, (p_.grad.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-12))
+        print(f"ragged={ragged} seg={seg}: worst relative adapter gradient error {worst:.4f}")
+        assert worst < 0.08
