@@ -324,6 +324,10 @@ int mp_moe_gate_dgrad_bf16(const float* dlogits, const float* wg, void* dx, int6
  * u of rows_sorted (seg [n_unique + 1]), in list order; out fp32 [vocab, dim] pre-zeroed. */
 int mp_embed_grad_f32(const void* g, const int64_t* rows_sorted, const int64_t* seg, const int64_t* ids, float* out, int64_t n_unique, int dim,
                       hipStream_t stream);
+/* GELU on a bf16 tensor (the GEMM epilogue's function) and its derivative: the mm_projector's activation when the projector
+ * trains (`mm_projector` in --sft_modules, scripts/train_stage2.sh; multimodal_projector/builder.py:39-46). */
+int mp_gelu_fwd_bf16(const void* x, void* y, int64_t n, hipStream_t stream);
+int mp_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream);
 /* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
 int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
 

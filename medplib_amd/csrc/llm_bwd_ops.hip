@@ -11,6 +11,7 @@
 //   mp_scatter_rows_f32_bf16   out[rows[i], :] = bf16(g[i, :])  (backward of the row gather in front of text_hidden_fcs / lm_head)
 //   mp_dropout_bf16            y = x * keep / (1 - p) with keep from the stateless hash generator (peft lora_dropout on the adapter input)
 #include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -366,6 +367,33 @@ __global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t
   partial[(int64_t)blockIdx.y * dim + c] = acc;
 }
 
+// GELU on a bf16 tensor with the GEMM epilogue's own function, and its derivative (mm_projector training, train_stage2.sh):
+// d/dx gelu(x) = Phi(x) + x phi(x)
+__global__ void gelu_fwd_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)gelu_erf_fast((float)v[j]);
+  *reinterpret_cast<bf16x8*>(y + i) = o;
+}
+__global__ void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i);
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + i);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float xf = (float)v[j];
+    const float cdf = 0.5f * (1.f + erff(xf * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * xf * xf);
+    o[j] = (bf16_t)((float)g[j] * (cdf + xf * pdf));
+  }
+  *reinterpret_cast<bf16x8*>(dx + i) = o;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -485,4 +513,18 @@ extern "C" int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, 
                      (const bf16_t*)dy, ldy, rs, partial, rows, dim);
   hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(dim, 256)), dim3(256), 0, stream, partial, dw, (int64_t)dim, chunks, 1.f);
   return mp_check_launch("mp_rmsnorm_wgrad_f32");
+}
+
+extern "C" int mp_gelu_fwd_bf16(const void* x, void* y, int64_t n, hipStream_t stream) {
+  MP_REQUIRE(n % 8 == 0, MP_ERR_SHAPE, "mp_gelu_fwd_bf16: n %% 8 != 0");
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(gelu_fwd_bf16_kernel, GRID1D(n / 8), (const bf16_t*)x, (bf16_t*)y, n);
+  return mp_check_launch("mp_gelu_fwd_bf16");
+}
+
+extern "C" int mp_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream) {
+  MP_REQUIRE(n % 8 == 0, MP_ERR_SHAPE, "mp_gelu_bwd_bf16: n %% 8 != 0");
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(gelu_bwd_bf16_kernel, GRID1D(n / 8), (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+  return mp_check_launch("mp_gelu_bwd_bf16");
 }

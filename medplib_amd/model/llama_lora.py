@@ -91,6 +91,18 @@ class LoRAState(torch.nn.Module):
         mod = self._modules_of(i, t)[e if e is not None else 0]
         return self.params[self.index[f"model.layers.{i}.{mod}.lora_{which}.default.weight"]]
 
+    def add_projector(self, tower):
+        """`mm_projector` in --sft_modules (train_stage2.sh): the two Linears train whole; fp32 masters here, bf16 working copies
+        (and W2^T for the dgrad) in the tower."""
+        self.tower = tower
+        pr = tower.proj
+        for n, t in (("model.mm_projector.0.weight", pr["w0"]), ("model.mm_projector.0.bias", pr["b0"]),
+                     ("model.mm_projector.2.weight", pr["w2"]), ("model.mm_projector.2.bias", pr["b2"])):
+            self.index[n] = len(self.names)
+            self.names.append(n)
+            self.params.append(torch.nn.Parameter(t.detach().float().clone()))
+        pr["w2_T"] = pr["w2"].t().contiguous()
+
     def full_param(self, name):
         k = self.index.get(name)
         return None if k is None else self.params[k]
@@ -107,6 +119,13 @@ class LoRAState(torch.nn.Module):
         p = self.full_param("model.embed_tokens.weight")
         if p is not None:
             llm.embed_tokens.copy_(p.detach())
+        if self.full_param("model.mm_projector.0.weight") is not None:
+            pr = self.tower.proj
+            pr["w0"].copy_(self.full_param("model.mm_projector.0.weight").detach())
+            pr["w2"].copy_(self.full_param("model.mm_projector.2.weight").detach())
+            pr["b0"] = self.full_param("model.mm_projector.0.bias").data
+            pr["b2"] = self.full_param("model.mm_projector.2.bias").data
+            pr["w2_T"].copy_(pr["w2"].t())
 
     def gate_weight(self, i, llm):
         """The gate of MoE layer i: the trainable fp32 copy when `wg` trains (the model's tensor is re-pointed to it), else the model's."""
@@ -393,7 +412,7 @@ class LlamaLoRAFn(torch.autograd.Function):
         grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous())
         d_emb = grads.pop("__d_embeds__").view(ctx.saved["B"], ctx.saved["S"], -1) if ctx.needs_input_grad[1] else None
         ctx.saved = None
-        own = [n for n in llm.lora.names if n not in ("lm_head.weight", "model.embed_tokens.weight")]
+        own = [n for n in llm.lora.names if n in grads]
         return (None, d_emb, None) + tuple(grads[n].contiguous() for n in own)
 
 
@@ -453,6 +472,9 @@ class EmbedSpliceFn(torch.autograd.Function):
         import numpy as np
         ctx.llm, ctx.shape = llm, shape
         flat = src_host.reshape(-1)
+        frows = np.flatnonzero((flat < 0) & (flat != np.iinfo(np.int64).min))         # rows that came from the feature block
+        ctx.fidx = (torch.from_numpy(frows.astype(np.int64)).to(src_dev.device), torch.from_numpy((-1 - flat[frows]).astype(np.int64)).to(src_dev.device),
+                    feats.shape[0])
         tok_rows = np.flatnonzero(flat >= 0)
         order = tok_rows[np.argsort(flat[tok_rows], kind="stable")]
         ids_sorted = flat[order]
@@ -466,4 +488,46 @@ class EmbedSpliceFn(torch.autograd.Function):
     def backward(ctx, g):
         order, seg, uniq = ctx.idx
         V, d = ctx.llm.embed_tokens.shape
-        return ops.embed_grad(g.reshape(-1, d).contiguous(), order, seg, uniq, V), None, None, None, None, None
+        g2 = g.reshape(-1, d).contiguous()
+        d_emb = ops.embed_grad(g2, order, seg, uniq, V) if ctx.needs_input_grad[0] else None
+        d_feats = None
+        if ctx.needs_input_grad[2]:                                 # every feature row is spliced at most once: a row copy
+            rows, fi, nf = ctx.fidx
+            d_feats = torch.zeros((nf, d), dtype=torch.bfloat16, device=g2.device)
+            d_feats[fi] = g2[rows]
+        return d_emb, None, d_feats, None, None, None
+
+
+class ProjectorFn(torch.autograd.Function):
+    """mm_projector (Linear - GELU - Linear, multimodal_projector/builder.py:39-46) with trainable weights: the tower features are
+    frozen inputs; the weight gradients are NT GEMMs on transposed copies of the (small) token-major operands."""
+
+    @staticmethod
+    def forward(ctx, raw, tower, w0, b0, w2, b2):
+        pr = tower.proj
+        h_pre = ops.gemm(raw, pr["w0"], bias=pr["b0"])
+        h = ops.gelu_fwd_bf16(h_pre)
+        ctx.save_for_backward(raw, h_pre, h)
+        ctx.tower = tower
+        return ops.gemm(h, pr["w2"], bias=pr["b2"])
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, h_pre, h = ctx.saved_tensors
+        pr = ctx.tower.proj
+        g = g.contiguous()
+        n = g.shape[0]
+        n64 = (n + 63) // 64 * 64
+
+        def tpad(x):                                                # [n, c] -> [c, n64] (zero columns beyond n)
+            out = torch.zeros((x.shape[1], n64), dtype=torch.bfloat16, device=x.device)
+            out[:, :n] = x.t()
+            return out
+        gT = tpad(g)
+        d_w2 = ops.gemm(gT, tpad(h), out_dtype=torch.float32)                       # [out, in] = g^T h
+        d_b2 = ops.colsum_f32(ops.cast_to_f32(g))
+        d_hpre = ops.gelu_bwd_bf16(h_pre, ops.gemm(g, pr["w2_T"]))
+        d_w0 = ops.gemm(tpad(d_hpre), tpad(raw), out_dtype=torch.float32)
+        d_b0 = ops.colsum_f32(ops.cast_to_f32(d_hpre))
+        return None, None, d_w0, d_b0, d_w2, d_b2
+

@@ -157,6 +157,9 @@ class MedPLIBForCausalLM(nn.Module):
         sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm"))
         self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
                                          train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
+        if "mm_projector" in sft_modules:
+            self.model.lora.add_projector(self.model.vision_tower)
+            self._want_raw_feats = True
         return self.model.lora
 
     def train(self, mode=True):
@@ -272,9 +275,12 @@ class MedPLIBForCausalLM(nn.Module):
         multi = isinstance(images_clip, (list, tuple)) or images_clip.dim() == 5
         clip_in = torch.cat([im for im in images_clip], 0) if multi else images_clip
         region_flag = region_masks is not None and len(region_masks) > 0                        # medplib_arch.py:221-227
+        self._last_raw = None
         if region_flag:
             assert not multi, "region prompts come with one image per sample"                     # medplib_arch.py:248, 269
             feats, raw = m.vision_tower.encode_images(clip_in, return_raw=True)
+        elif getattr(self, "_want_raw_feats", False):                # a trainable mm_projector re-runs the projector from these
+            feats, self._last_raw = m.vision_tower.encode_images(clip_in, return_raw=True)
         else:
             feats = m.vision_tower.encode_images(clip_in)
         if m.mm_token_compressor is not None:
@@ -355,9 +361,14 @@ class MedPLIBForCausalLM(nn.Module):
             # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
             from . import llama_lora as LL
             lo = m.llm.lora
-            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight")]
+            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_]
             emb_p = lo.full_param("model.embed_tokens.weight")
-            if emb_p is not None:                                   # embed_tokens trains: the splice joins the autograd tape
+            proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
+            if proj_p[0] is not None:                               # mm_projector trains (stage II): recompute it on the autograd tape
+                assert self._last_raw is not None and feats.shape[0] == self._last_raw.shape[0], \
+                    "a trainable mm_projector is built for the plain image layout (no compressor / ICL / region rows)"
+                feats = LL.ProjectorFn.apply(self._last_raw, m.vision_tower, *proj_p)
+            if emb_p is not None or proj_p[0] is not None:          # embed_tokens / projector train: the splice joins the autograd tape
                 embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
             last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *own)
             ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight")) if sup_rows_d.numel() else \

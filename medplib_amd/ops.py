@@ -332,6 +332,18 @@ def embed_grad(g, rows_sorted, seg, ids, vocab):
     return out
 
 
+def gelu_fwd_bf16(x):
+    y = torch.empty_like(x)
+    lib().call("mp_gelu_fwd_bf16", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd_bf16(x, dy):
+    dx = torch.empty_like(x)
+    lib().call("mp_gelu_bwd_bf16", _p(x), _p(dy), _p(dx), x.numel(), _stream())
+    return dx
+
+
 def dropout_bf16(x, p, seed):
     y = torch.empty_like(x)
     lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())

@@ -154,7 +154,8 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         clip_in = batch["images_clip"]
         multi = isinstance(clip_in, (list, tuple)) or clip_in.dim() == 5
         raw_feats = llm.clip_features(torch.cat(list(clip_in), 0) if multi else clip_in, W, cfg)
-        feats = llm.mm_projector(raw_feats, W)
+        with (torch.enable_grad() if llm_grad else contextlib.nullcontext()):      # mm_projector may be trainable (--sft_modules)
+            feats = llm.mm_projector(raw_feats, W)
         tok = cfg.clip_num_patches
         if getattr(cfg, "mm_token_compress", False):                    # encode_images, medplib_arch.py:198-202
             tok = cfg.mm_compressed_token_count

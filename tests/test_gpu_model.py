@@ -968,8 +968,8 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
     lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0,
-                         sft_modules="lm_head,embed_tokens,input_layernorm,post_attention_layernorm,mask_decoder,text_hidden_fcs")
-    assert lora.names[-2:] == ["lm_head.weight", "model.embed_tokens.weight"] and "model.layers.1.input_layernorm.weight" in lora.names
+                         sft_modules="lm_head,embed_tokens,input_layernorm,post_attention_layernorm,mm_projector,mask_decoder,text_hidden_fcs")
+    assert "lm_head.weight" in lora.names and "model.layers.1.input_layernorm.weight" in lora.names and "model.mm_projector.2.bias" in lora.names
     g = torch.Generator().manual_seed(51)
     Wl = dict(W)
     Wl["lora_scaling"] = 2.0
@@ -993,7 +993,8 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     _stat("loss", out["loss"], ref["loss"], atol=3e-2)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
-    for n in ("model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight"):
+    for n in ("model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight", "model.mm_projector.0.weight",
+              "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias"):
         want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
         rel = (got - want).abs().max().item() / want.abs().max().item()
         print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
