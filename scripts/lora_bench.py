@@ -21,13 +21,14 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--lora_r", type=int, default=8)
 ap.add_argument("--lora_dropout", type=float, default=0.05)
 ap.add_argument("--targets", type=str, default="gate_proj,up_proj,down_proj")
+ap.add_argument("--sft", type=str, default="mask_decoder,text_hidden_fcs", help="--sft_modules (lm_head, embed_tokens, input_layernorm, post_attention_layernorm, mm_projector, wg)")
 ap.add_argument("--moe", action="store_true", help="MoE decoder (E = 2, top-1): per-expert adapters + trainable gate (stage IV / ICL scripts)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
 cfg = MedPLIBConfig.medplib_7b(moe_enable=args.moe)
 model = (MedPLIBForCausalLM if args.moe else LISAForCausalLM)(cfg, device=dev).train()
-lora = model.enable_lora(lora_r=args.lora_r, lora_alpha=16, lora_dropout=args.lora_dropout, lora_target_modules=args.targets)
+lora = model.enable_lora(lora_r=args.lora_r, lora_alpha=16, lora_dropout=args.lora_dropout, lora_target_modules=args.targets, sft_modules=args.sft)
 for n, p in zip(lora.names, lora.params):                  # B = 0 at initialisation would make half the gradients trivially zero
     if "lora_B" in n:
         p.data.normal_(0, 0.01)
@@ -61,5 +62,5 @@ attn_flop = args.batch * nl * cfg.num_attention_heads * S * S * cfg.head_dim * (
 print(json.dumps({"what": "%s 7B + LoRA (%s, r=%d, dropout %.2f) training step, batch %d" % ("MoE (E=2, top-1, wg trainable)" if args.moe else "dense", args.targets, args.lora_r, args.lora_dropout, args.batch),
                   "ms_per_step": round(dt * 1e3, 1), "samples_per_s": round(args.batch / dt, 2),
                   "decoder_tflop_per_step": round((gemm_flop + attn_flop) / 1e12, 1), "decoder_tflops": round((gemm_flop + attn_flop) / dt / 1e12, 1),
-                  "trainable_params": eng.optimizer.numel, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                  "sft_modules": args.sft, "trainable_params": eng.optimizer.numel, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                   "loss_after_warmup": l0, "loss_last": repr(float(out["loss"].detach()))}))
