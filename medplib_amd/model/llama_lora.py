@@ -103,6 +103,16 @@ class LoRAState(torch.nn.Module):
             self.params.append(torch.nn.Parameter(t.detach().float().clone()))
         pr["w2_T"] = pr["w2"].t().contiguous()
 
+    def add_token_compressor(self, comp):
+        """`mm_token_compressor` in --sft_modules (scripts/train_medplib_icl.sh:8): LayerNorm + Linear train; fp32 masters here."""
+        self.comp = comp
+        for n, t in (("model.mm_token_compressor.norm.weight", comp.norm[0]), ("model.mm_token_compressor.norm.bias", comp.norm[1]),
+                     ("model.mm_token_compressor.proj.weight", comp.proj_w), ("model.mm_token_compressor.proj.bias", comp.proj_b)):
+            self.index[n] = len(self.names)
+            self.names.append(n)
+            self.params.append(torch.nn.Parameter(t.detach().float().clone()))
+        comp.proj_w_T = comp.proj_w.t().contiguous()
+
     def full_param(self, name):
         k = self.index.get(name)
         return None if k is None else self.params[k]
@@ -119,6 +129,12 @@ class LoRAState(torch.nn.Module):
         p = self.full_param("model.embed_tokens.weight")
         if p is not None:
             llm.embed_tokens.copy_(p.detach())
+        if self.full_param("model.mm_token_compressor.proj.weight") is not None:
+            c = self.comp
+            c.proj_w.copy_(self.full_param("model.mm_token_compressor.proj.weight").detach())
+            c.proj_w_T.copy_(c.proj_w.t())
+            c.proj_b = self.full_param("model.mm_token_compressor.proj.bias").data
+            c.norm = (self.full_param("model.mm_token_compressor.norm.weight").data, self.full_param("model.mm_token_compressor.norm.bias").data)
         if self.full_param("model.mm_projector.0.weight") is not None:
             pr = self.tower.proj
             pr["w0"].copy_(self.full_param("model.mm_projector.0.weight").detach())
@@ -531,3 +547,38 @@ class ProjectorFn(torch.autograd.Function):
         d_b0 = ops.colsum_f32(ops.cast_to_f32(d_hpre))
         return None, None, d_w0, d_b0, d_w2, d_b2
 
+
+
+def _tpad(x):
+    """[n, c] bf16 -> [c, n64] with zero columns beyond n: the operand shape of the NT GEMM for x^T-products."""
+    n = x.shape[0]
+    out = torch.zeros((x.shape[1], (n + 63) // 64 * 64), dtype=torch.bfloat16, device=x.device)
+    out[:, :n] = x.t()
+    return out
+
+
+class TokenCompressorFn(torch.autograd.Function):
+    """TokenCompressor (AdaptiveAvgPool1d over tokens -> LayerNorm -> Linear, medplib_arch.py:67-77) with trainable LayerNorm and
+    Linear; its input (the projector's output) is frozen."""
+
+    @staticmethod
+    def forward(ctx, feats, comp, n_images, tokens_in, nw, nb, pw, pb):
+        pooled = ops.adaptive_avgpool_tokens(feats.view(n_images, tokens_in, comp.hidden), comp.num_tokens).view(-1, comp.hidden)
+        h = ops.layernorm(pooled, comp.norm[0], comp.norm[1], 1e-5)
+        ctx.save_for_backward(pooled, h)
+        ctx.comp = comp
+        return ops.gemm(h, comp.proj_w, bias=comp.proj_b)
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled, h = ctx.saved_tensors
+        comp = ctx.comp
+        g = g.contiguous()
+        d_pw = ops.gemm(_tpad(g), _tpad(h), out_dtype=torch.float32)
+        d_pb = ops.colsum_f32(ops.cast_to_f32(g))
+        d_h = ops.cast_to_f32(ops.gemm(g, comp.proj_w_T))
+        xf = ops.cast_to_f32(pooled)
+        _, mean, rstd = ops.layernorm_fwd_f32(xf, comp.norm[0], comp.norm[1], 1e-5)
+        dw, db = torch.zeros_like(comp.norm[0]), torch.zeros_like(comp.norm[0])
+        ops.layernorm_bwd_f32(d_h, xf, comp.norm[0], mean, rstd, dw, db)
+        return None, None, None, None, dw, db, d_pw, d_pb

@@ -157,6 +157,8 @@ class MedPLIBForCausalLM(nn.Module):
         sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm"))
         self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
                                          train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
+        if "mm_token_compressor" in sft_modules and self.model.mm_token_compressor is not None:
+            self.model.lora.add_token_compressor(self.model.mm_token_compressor)
         if "mm_projector" in sft_modules:
             self.model.lora.add_projector(self.model.vision_tower)
             self._want_raw_feats = True
@@ -284,6 +286,7 @@ class MedPLIBForCausalLM(nn.Module):
         else:
             feats = m.vision_tower.encode_images(clip_in)
         if m.mm_token_compressor is not None:
+            self._comp_in = (feats, clip_in.shape[0])               # kept for a trainable compressor (re-run on the autograd tape)
             feats = m.mm_token_compressor.forward(feats, clip_in.shape[0], cfg.clip_num_patches)
         if region_flag:
             rfeats, rbases = self._region_features(raw, clip_in.shape[0], region_masks, valid_region_masks_bool)
@@ -361,14 +364,20 @@ class MedPLIBForCausalLM(nn.Module):
             # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
             from . import llama_lora as LL
             lo = m.llm.lora
-            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_]
+            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_
+                   and "mm_token_compressor" not in n_]
             emb_p = lo.full_param("model.embed_tokens.weight")
             proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
             if proj_p[0] is not None:                               # mm_projector trains (stage II): recompute it on the autograd tape
                 assert self._last_raw is not None and feats.shape[0] == self._last_raw.shape[0], \
                     "a trainable mm_projector is built for the plain image layout (no compressor / ICL / region rows)"
                 feats = LL.ProjectorFn.apply(self._last_raw, m.vision_tower, *proj_p)
-            if emb_p is not None or proj_p[0] is not None:          # embed_tokens / projector train: the splice joins the autograd tape
+            comp_p = [lo.full_param(f"model.mm_token_compressor.{k}") for k in ("norm.weight", "norm.bias", "proj.weight", "proj.bias")]
+            if comp_p[0] is not None:                               # mm_token_compressor trains (train_medplib_icl.sh)
+                cin, n_img = self._comp_in
+                new = LL.TokenCompressorFn.apply(cin, m.mm_token_compressor, n_img, cfg.clip_num_patches, *comp_p)
+                feats = new if feats.shape[0] == new.shape[0] else torch.cat([new, feats[new.shape[0]:]], 0)   # + mask / region rows
+            if emb_p is not None or proj_p[0] is not None or comp_p[0] is not None:   # the splice joins the autograd tape
                 embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
             last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *own)
             ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight")) if sup_rows_d.numel() else \

@@ -148,7 +148,8 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
     implementation produced."""
     ids, labels, att = batch["input_ids"], batch["labels"], batch["attention_mask"]
     B = ids.shape[0]
-    with torch.no_grad():
+    # llm_grad (training tests): the front end stays on the autograd tape too (trainable projector / compressor / embed_tokens)
+    with (torch.enable_grad() if llm_grad else torch.no_grad()):
         image_emb = sam.image_encoder(batch["images"], {k[len("model.visual_model."):]: v for k, v in W.items()
                                                         if k.startswith("model.visual_model.")}, depth=cfg.sam_depth)
         clip_in = batch["images_clip"]
@@ -159,7 +160,8 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         tok = cfg.clip_num_patches
         if getattr(cfg, "mm_token_compress", False):                    # encode_images, medplib_arch.py:198-202
             tok = cfg.mm_compressed_token_count
-            feats = llm.token_compressor(feats, W, tok)
+            with (torch.enable_grad() if llm_grad else contextlib.nullcontext()):  # mm_token_compressor may be trainable
+                feats = llm.token_compressor(feats, W, tok)
         feat_list, per_token = feats, False
         if batch.get("image_token_types") is not None and batch.get("mask_images") is not None and len(batch["mask_images"]) > 0:
             mf = llm.mask_token_encoder(torch.cat(list(batch["mask_images"]), 0), W, cfg.mask_encoder_token_count)

@@ -1056,3 +1056,44 @@ def test_lora_training_ragged_batch_and_ce_only(dev):
             worst = max(worst, (p_.grad.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-12))
         print(f"ragged={ragged} seg={seg}: worst relative adapter gradient error {worst:.4f}")
         assert worst < 0.08
+
+
+def test_lora_training_icl_moe_with_trainable_token_compressor(dev):
+    """scripts/train_medplib_icl.sh (first variant): ICL separate mode, MoE decoder with adapters on the experts' gate/up/down_proj,
+    `--sft_modules mask_decoder,text_hidden_fcs,mm_token_compressor`: the compressor's LayerNorm and Linear gradients come back
+    through the splice's feature rows; vs the oracle's autograd."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_hidden_layers=2, num_experts=2, mm_token_compress=True,
+                             mm_compressed_token_count=8, icl_mask_encoder=True, mask_encoder_token_count=4, router_aux_loss_coef=0.01)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, sft_modules="mask_decoder,text_hidden_fcs,mm_token_compressor")
+    assert "model.mm_token_compressor.proj.weight" in lora.names
+    g = torch.Generator().manual_seed(71)
+    Wl = dict(W); Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev)); Wl[n] = v.clone().requires_grad_(True)
+        else:
+            Wl[n] = W[n].clone().requires_grad_(True)
+    batch = OM.make_batch_icl(cfg, 2, n_ctx=2, seed=3)
+    bq = dict(batch)
+    bq["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]; bq["images"] = batch["images"].to(torch.bfloat16).float()
+    ref = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True)
+    ref["loss"].backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                     config={"optimizer": {"params": {"lr": 1e-4}}, "gradient_clipping": 1.0})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
+    out = eng(**gb)
+    _stat("icl moe lora loss", out["loss"], ref["loss"], atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    assert not any(k.endswith("wg.weight") for k in lora.names)          # `wg` is not in this script's --sft_modules: the gate stays frozen
+    for n in [k for k in lora.names if "mm_token_compressor" in k] + ["model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.1.up_proj.lora_B.default.weight"]:
+        want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
+        rel = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
+        assert want.abs().max().item() > 0 and rel < 0.1, n
