@@ -328,6 +328,10 @@ int mp_embed_grad_f32(const void* g, const int64_t* rows_sorted, const int64_t* 
  * trains (`mm_projector` in --sft_modules, scripts/train_stage2.sh; multimodal_projector/builder.py:39-46). */
 int mp_gelu_fwd_bf16(const void* x, void* y, int64_t n, hipStream_t stream);
 int mp_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream);
+/* Backward of mp_region_point_mean_bf16 w.r.t. the feature maps (`region_fea_adapter` in --sft_modules, scripts/train_stage4.sh:33):
+ * dfmap [n_maps, h*w, C] bf16 from dout [n_masks, C]; wt = scratch of n_masks * h * w floats; no atomics. */
+int mp_region_point_mean_bwd_bf16(const float* xy, const int64_t* offsets, const int* map_index, const void* dout, void* dfmap, float* wt,
+                                  int n_maps, int n_masks, int h, int w, int C, hipStream_t stream);
 /* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
 int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
 

@@ -394,6 +394,54 @@ __global__ void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t*
   *reinterpret_cast<bf16x8*>(dx + i) = o;
 }
 
+// extract_region_feature backward (medplib_arch.py:580-613; region_fea_adapter in --sft_modules): the forward is, per mask m, the
+// mean over its sampled points of the bilinear (align_corners=True, zero padding) read-out of feature map map_index[m].
+// Pass 1: wt[m, pixel] = (1 / n_m) * sum over m's points of the bilinear weight that point puts on the pixel (a thread per (m, pixel)
+// walks m's points: no atomics).  Pass 2: d_fmap[j, pixel, :] = sum over the masks of map j of wt[m, pixel] * d_out[m, :].
+__global__ void region_weights_kernel(const float* __restrict__ xy, const int64_t* __restrict__ offsets, float* __restrict__ wt, int n_masks,
+                                      int h, int w) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_masks * h * w) return;
+  const int pix = (int)(idx % (h * w)), m = (int)(idx / (h * w));
+  const int py = pix / w, px = pix % w;
+  const int64_t p0 = offsets[m], p1 = offsets[m + 1];
+  float acc = 0.f;
+  for (int64_t p = p0; p < p1; ++p) {
+    const float gx = 2.f * xy[2 * p] - 1.f, gy = 2.f * xy[2 * p + 1] - 1.f;
+    const float ix = ((gx + 1.f) * 0.5f) * (float)(w - 1), iy = ((gy + 1.f) * 0.5f) * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy;
+    const float wxs = px == x0 ? 1.f - wx1 : (px == x0 + 1 ? wx1 : 0.f);
+    const float wys = py == y0 ? 1.f - wy1 : (py == y0 + 1 ? wy1 : 0.f);
+    acc += wxs * wys;
+  }
+  wt[idx] = p1 > p0 ? acc / (float)(p1 - p0) : 0.f;
+}
+__global__ void region_fmap_grad_kernel(const float* __restrict__ wt, const bf16_t* __restrict__ dout, const int* __restrict__ map_index,
+                                        bf16_t* __restrict__ dfmap, int n_maps, int n_masks, int hw, int C) {
+  const int per_row = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_maps * hw * per_row) return;
+  const int c = (int)(idx % per_row) * 8;
+  const int pix = (int)((idx / per_row) % hw), j = (int)(idx / ((int64_t)per_row * hw));
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int m = 0; m < n_masks; ++m) {
+    if (map_index[m] != j) continue;
+    const float wv = wt[(int64_t)m * hw + pix];
+    if (wv == 0.f) continue;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + (int64_t)m * C + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(wv, (float)g[k], acc[k]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (bf16_t)acc[k];
+  *reinterpret_cast<bf16x8*>(dfmap + ((int64_t)j * hw + pix) * C + c) = o;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -527,4 +575,15 @@ extern "C" int mp_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(gelu_bwd_bf16_kernel, GRID1D(n / 8), (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
   return mp_check_launch("mp_gelu_bwd_bf16");
+}
+
+extern "C" int mp_region_point_mean_bwd_bf16(const float* xy, const int64_t* offsets, const int* map_index, const void* dout, void* dfmap,
+                                             float* wt, int n_maps, int n_masks, int h, int w, int C, hipStream_t stream) {
+  MP_REQUIRE(n_maps > 0 && n_masks >= 0 && h > 0 && w > 0 && C % 8 == 0 && wt, MP_ERR_SHAPE, "mp_region_point_mean_bwd_bf16: bad shape");
+  if (n_masks > 0) {
+    hipLaunchKernelGGL(region_weights_kernel, GRID1D((int64_t)n_masks * h * w), xy, offsets, wt, n_masks, h, w);
+  }
+  hipLaunchKernelGGL(region_fmap_grad_kernel, GRID1D((int64_t)n_maps * h * w * (C / 8)), wt, (const bf16_t*)dout, map_index, (bf16_t*)dfmap, n_maps,
+                     n_masks, h * w, C);
+  return mp_check_launch("mp_region_point_mean_bwd_bf16");
 }

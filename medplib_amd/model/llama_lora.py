@@ -103,6 +103,14 @@ class LoRAState(torch.nn.Module):
             self.params.append(torch.nn.Parameter(t.detach().float().clone()))
         pr["w2_T"] = pr["w2"].t().contiguous()
 
+    def add_region_adapter(self, tower):
+        """`region_fea_adapter` in --sft_modules (scripts/train_stage4.sh:33): the Linear on the raw tower features trains whole."""
+        self.region_tower = tower
+        for n, t in (("model.region_fea_adapter.weight", tower.region_adapter["w"]), ("model.region_fea_adapter.bias", tower.region_adapter["b"])):
+            self.index[n] = len(self.names)
+            self.names.append(n)
+            self.params.append(torch.nn.Parameter(t.detach().float().clone()))
+
     def add_token_compressor(self, comp):
         """`mm_token_compressor` in --sft_modules (scripts/train_medplib_icl.sh:8): LayerNorm + Linear train; fp32 masters here."""
         self.comp = comp
@@ -129,6 +137,10 @@ class LoRAState(torch.nn.Module):
         p = self.full_param("model.embed_tokens.weight")
         if p is not None:
             llm.embed_tokens.copy_(p.detach())
+        if self.full_param("model.region_fea_adapter.weight") is not None:
+            ra = self.region_tower.region_adapter
+            ra["w"].copy_(self.full_param("model.region_fea_adapter.weight").detach())
+            ra["b"] = self.full_param("model.region_fea_adapter.bias").data
         if self.full_param("model.mm_token_compressor.proj.weight") is not None:
             c = self.comp
             c.proj_w.copy_(self.full_param("model.mm_token_compressor.proj.weight").detach())
@@ -582,3 +594,27 @@ class TokenCompressorFn(torch.autograd.Function):
         dw, db = torch.zeros_like(comp.norm[0]), torch.zeros_like(comp.norm[0])
         ops.layernorm_bwd_f32(d_h, xf, comp.norm[0], mean, rstd, dw, db)
         return None, None, None, None, dw, db, d_pw, d_pb
+
+
+class RegionAdapterFn(torch.autograd.Function):
+    """region_fea_adapter (Linear on the raw tower features) + extract_region_feature (medplib_arch.py:207, 580-613) with a trainable
+    adapter: the point-sampling mean's backward spreads each mask's gradient over the pixels its points touch (gather form), the
+    Linear's weight gradient is an NT GEMM on transposed copies."""
+
+    @staticmethod
+    def forward(ctx, raw_sel, tower, xy, offsets, map_index, hw, w, b):
+        ra = tower.region_adapter
+        n_maps = raw_sel.shape[0] // (hw * hw)
+        fmap = ops.gemm(raw_sel, ra["w"], bias=ra["b"]).view(n_maps, hw * hw, -1)
+        ctx.save_for_backward(raw_sel, xy, offsets, map_index)
+        ctx.hw, ctx.n_maps = hw, n_maps
+        return ops.region_point_mean(fmap.contiguous(), xy, offsets, map_index, hw, hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        raw_sel, xy, offsets, map_index = ctx.saved_tensors
+        dfmap = ops.region_point_mean_bwd(xy, offsets, map_index, g.contiguous(), ctx.n_maps, ctx.hw, ctx.hw)
+        dfm2 = dfmap.view(-1, dfmap.shape[-1])
+        d_w = ops.gemm(_tpad(dfm2), _tpad(raw_sel), out_dtype=torch.float32)
+        d_b = ops.colsum_f32(ops.cast_to_f32(dfm2))
+        return None, None, None, None, None, None, d_w, d_b

@@ -157,6 +157,8 @@ class MedPLIBForCausalLM(nn.Module):
         sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm"))
         self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
                                          train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
+        if "region_fea_adapter" in sft_modules:
+            self.model.lora.add_region_adapter(self.model.vision_tower)
         if "mm_token_compressor" in sft_modules and self.model.mm_token_compressor is not None:
             self.model.lora.add_token_compressor(self.model.mm_token_compressor)
         if "mm_projector" in sft_modules:
@@ -260,8 +262,10 @@ class MedPLIBForCausalLM(nn.Module):
                 map_index.append(j)
                 n_rows += 1
         dev = self.device_
-        feats = ops.region_point_mean(fmap.contiguous(), _h2d(np.concatenate(xy).astype(np.float32).reshape(-1, 2), dev),
-                                      _h2d(np.asarray(offsets, dtype=np.int64), dev), _h2d(np.asarray(map_index, dtype=np.int32), dev), hw, hw)
+        xy_d, off_d = _h2d(np.concatenate(xy).astype(np.float32).reshape(-1, 2), dev), _h2d(np.asarray(offsets, dtype=np.int64), dev)
+        mi_d = _h2d(np.asarray(map_index, dtype=np.int32), dev)
+        self._region_ctx = (sel.reshape(-1, C), xy_d, off_d, mi_d, hw)      # kept for a trainable region_fea_adapter
+        feats = ops.region_point_mean(fmap.contiguous(), xy_d, off_d, mi_d, hw, hw)
         return feats, bases
 
     def _encode_and_plan(self, ids_np, lab_np, att_np, images_clip, mask_images=None, image_token_types=None,
@@ -365,19 +369,26 @@ class MedPLIBForCausalLM(nn.Module):
             from . import llama_lora as LL
             lo = m.llm.lora
             own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_
-                   and "mm_token_compressor" not in n_]
+                   and "mm_token_compressor" not in n_ and "region_fea_adapter" not in n_]
             emb_p = lo.full_param("model.embed_tokens.weight")
             proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
             if proj_p[0] is not None:                               # mm_projector trains (stage II): recompute it on the autograd tape
                 assert self._last_raw is not None and feats.shape[0] == self._last_raw.shape[0], \
                     "a trainable mm_projector is built for the plain image layout (no compressor / ICL / region rows)"
                 feats = LL.ProjectorFn.apply(self._last_raw, m.vision_tower, *proj_p)
+            reg_p = [lo.full_param(f"model.region_fea_adapter.{k}") for k in ("weight", "bias")]
+            if reg_p[0] is not None and region_masks is not None and len(region_masks) > 0:      # region_fea_adapter trains (stage IV)
+                rsel, xy_d, off_d, mi_d, hw_ = self._region_ctx
+                rnew = LL.RegionAdapterFn.apply(rsel, m.vision_tower, xy_d, off_d, mi_d, hw_, *reg_p)
+                feats = torch.cat([feats[:feats.shape[0] - rnew.shape[0]], rnew], 0)              # the region rows sit behind the image rows
+            else:
+                reg_p = [None, None]
             comp_p = [lo.full_param(f"model.mm_token_compressor.{k}") for k in ("norm.weight", "norm.bias", "proj.weight", "proj.bias")]
             if comp_p[0] is not None:                               # mm_token_compressor trains (train_medplib_icl.sh)
                 cin, n_img = self._comp_in
                 new = LL.TokenCompressorFn.apply(cin, m.mm_token_compressor, n_img, cfg.clip_num_patches, *comp_p)
                 feats = new if feats.shape[0] == new.shape[0] else torch.cat([new, feats[new.shape[0]:]], 0)   # + mask / region rows
-            if emb_p is not None or proj_p[0] is not None or comp_p[0] is not None:   # the splice joins the autograd tape
+            if emb_p is not None or proj_p[0] is not None or comp_p[0] is not None or reg_p[0] is not None:   # the splice joins the autograd tape
                 embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
             last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *own)
             ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight")) if sup_rows_d.numel() else \

@@ -344,6 +344,16 @@ def gelu_bwd_bf16(x, dy):
     return dx
 
 
+def region_point_mean_bwd(xy, offsets, map_index, dout, n_maps, h, w):
+    """d(feature maps) [n_maps, h*w, C] bf16 of region_point_mean from dout [n_masks, C] bf16."""
+    n_masks, C = dout.shape
+    dfmap = torch.empty((n_maps, h * w, C), dtype=torch.bfloat16, device=dout.device)
+    wt = torch.empty(max(n_masks, 1) * h * w, dtype=torch.float32, device=dout.device)
+    lib().call("mp_region_point_mean_bwd_bf16", _p(xy), _p(offsets), _p(map_index), _p(dout.contiguous()), _p(dfmap), _p(wt), n_maps, n_masks,
+               h, w, C, _stream())
+    return dfmap
+
+
 def dropout_bf16(x, p, seed):
     y = torch.empty_like(x)
     lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())

@@ -1097,3 +1097,47 @@ def test_lora_training_icl_moe_with_trainable_token_compressor(dev):
         rel = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
         print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
         assert want.abs().max().item() > 0 and rel < 0.1, n
+
+
+def test_lora_training_with_trainable_region_adapter(dev):
+    """`region_fea_adapter` in --sft_modules (scripts/train_stage4.sh:33) on a Region-VQA batch (CE only): the adapter's weight and bias
+    gradients come back through the splice's region rows and the point-sampling mean (one mask is subsampled by torch.randperm, drawn
+    in the same order on both sides); vs the oracle's autograd."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2, max_sample_point=40)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="q_proj,v_proj", sft_modules="region_fea_adapter")
+    g = torch.Generator().manual_seed(81)
+    Wl = dict(W); Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev)); Wl[n] = v.clone().requires_grad_(True)
+        else:
+            Wl[n] = W[n].clone().requires_grad_(True)
+    masks = [[(torch.rand(30, 22, generator=g) > 0.97).float(), (torch.rand(30, 22, generator=g) > 0.5).float()], [(torch.rand(30, 22, generator=g) > 0.9).float()]]
+    batch = OM.make_batch(cfg, 3, seed=4)
+    ids = batch["input_ids"]
+    ids[0, 40] = -300; ids[0, 44] = -300; ids[2, 42] = -300
+    batch["region_masks"] = [[masks[0][0], masks[0][1]], [masks[1][0]]]
+    batch["valid_region_masks_bool"] = [[True, True], [False], [True]]
+    batch.update(seg_flag=False, masks_list=[], label_list=[], valid_mask_bool=[[]] * 3)
+    bq = dict(batch, seg_flag=True, masks_list=OM.make_batch(cfg, 3, seed=4)["masks_list"], label_list=OM.make_batch(cfg, 3, seed=4)["label_list"],
+              valid_mask_bool=[[True]] * 3)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    torch.manual_seed(5)
+    _, inter = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True, return_intermediates=True)
+    (inter["ce"] * cfg.ce_loss_weight).backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(), config={"optimizer": {"params": {"lr": 1e-4}}})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(5)
+    out = eng(**gb)
+    _stat("region-adapter training loss", out["loss"], inter["ce"] * cfg.ce_loss_weight, atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    for n in ("model.region_fea_adapter.weight", "model.region_fea_adapter.bias", "model.layers.0.self_attn.q_proj.lora_B.default.weight"):
+        want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
+        rel = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
+        assert want.abs().max().item() > 0 and rel < 0.08, n
