@@ -59,6 +59,11 @@ int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const v
                             void* C, int64_t ldc, int64_t strideC, const float* bias, int64_t strideBias, int batch,
                             int M, int N, int K, int act, int out_dtype, const int* m_dev, hipStream_t stream);
 
+/* ... with a batched bf16 residual added after the product is rounded to bf16 (per-expert LoRA delta onto the expert output). */
+int mp_gemm_bf16_nt_batched_res(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW, void* C,
+                                int64_t ldc, int64_t strideC, const void* residual, int64_t ldr, int64_t strideR, int batch, int M, int N,
+                                int K, const int* m_dev, hipStream_t stream);
+
 /* The same expert GEMMs with the MOELayer's dispatch / combine einsums folded in (top-1 routing): A rows are GATHERED from the shared
  * [tokens, K] activations by a_rows[b * rows_stride + r] (= mp_moe_route_top1's slot_token), and with c_rows the C rows are SCATTERED
  * to the shared [tokens, N] output as residual[row] + c_scale[row] * bf16(acc) — the combine weights and the decoder layer's residual

@@ -408,6 +408,26 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   return mp_check_launch("mp_gemm_bf16_nt_batched");
 }
 
+// batched variant with a batched residual: C[b] = bf16(A[b] W[b]^T) + R[b] (the per-expert LoRA delta added onto the expert projection's
+// output in training, llama_lora.py)
+extern "C" int mp_gemm_bf16_nt_batched_res(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW, void* C,
+                                           int64_t ldc, int64_t strideC, const void* residual, int64_t ldr, int64_t strideR, int batch, int M,
+                                           int N, int K, const int* m_dev, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0 && K % BK == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched_res: bad shape");
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0 && residual, MP_ERR_SHAPE,
+             "mp_gemm_bf16_nt_batched_res: strides must be multiples of 8, residual required");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.bias = nullptr; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
+  g.act = ACT_NONE; g.out_f32 = 0; g.alpha = 1.f;
+  g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = strideR; g.sBias = 0; g.m_dev_stride = 1; g.group_m = gemm_group_m();
+  if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
+  const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
+  launch_gemm(g, dim3(tiles, batch), stream);
+  return mp_check_launch("mp_gemm_bf16_nt_batched_res");
+}
+
 // Expert GEMMs with the MoE dispatch / combine folded in (top-1 routing): per expert b, A row r comes from row a_rows[b*rows_stride+r]
 // of the shared [tokens, K] activation matrix (a_rows null = A is [batch, M, K] as in the plain batched call), and — when c_rows is
 // given — C row r goes to row c_rows[b*rows_stride+r] of the shared [tokens, N] output as residual[row] + c_scale[row] * bf16(acc).

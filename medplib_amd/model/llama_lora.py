@@ -235,8 +235,7 @@ def _adapter_fwd_moe(lora, ops_pad, xbuf, ybuf, kept, seed):
     E, cap, _ = xbuf.shape
     xd = ops.dropout_bf16(xbuf, lora.p, seed) if lora.p > 0 else xbuf
     t = ops.gemm_batched(xd, A, _zeros((E, cap, 64), xbuf.device), m_dev=kept)
-    delta = ops.gemm_batched(t, B, _zeros(ybuf.shape, xbuf.device), m_dev=kept)
-    return ops.add3(ybuf, delta), xd, t
+    return ops.gemm_batched_res(t, B, ybuf, _zeros(ybuf.shape, xbuf.device), m_dev=kept), xd, t
 
 
 def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
@@ -268,10 +267,10 @@ def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
     dt = ops.gemm_batched(dy, BT, _zeros((E, cap, 64), dy.device), m_dev=kept)            # scaling rides in the packed B
     dB = [ops.tn_skinny(dy[e], t[e], R, lora.scaling) for e in range(E)]
     dAT = [ops.tn_skinny(xd[e], dt[e], R, 1.0) for e in range(E)]
-    dxa = ops.gemm_batched(dt, AT, _zeros(dx.shape, dy.device), m_dev=kept)
     if lora.p > 0:
-        dxa = ops.dropout_bf16(dxa, lora.p, seed)
-    return ops.add3(dx, dxa), dB, dAT
+        dxa = ops.dropout_bf16(ops.gemm_batched(dt, AT, _zeros(dx.shape, dy.device), m_dev=kept), lora.p, seed)
+        return ops.add3(dx, dxa), dB, dAT
+    return ops.gemm_batched_res(dt, AT, dx, _zeros(dx.shape, dy.device), m_dev=kept), dB, dAT
 
 
 def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):

@@ -166,6 +166,17 @@ def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
     return out
 
 
+def gemm_batched_res(a, w, residual, out, m_dev=None):
+    """out[e] = bf16(a[e] @ w[e]^T) + residual[e]; a [E,M,K], w [E,N,K], residual / out [E,M,N] bf16."""
+    E, M, K = a.shape
+    N = w.shape[1]
+    assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1 and residual.stride(2) == 1
+    _ensure_gemm_workspace(a.device)
+    lib().call("mp_gemm_bf16_nt_batched_res", _p(a), a.stride(1), a.stride(0), _p(w), w.stride(1), w.stride(0), _p(out), out.stride(1),
+               out.stride(0), _p(residual), residual.stride(1), residual.stride(0), E, M, N, K, _p(m_dev), _stream())
+    return out
+
+
 def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w=None, scale=None, variant=0, sk_dev=None):
     """q,k,v: [B,S,H,D] bf16 views (stride(3)==1, stride(2)==D); returns [B,Sq,H*D] bf16."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
