@@ -172,6 +172,23 @@ class LoRAState(torch.nn.Module):
             k = n if n in sd else "base_model.model." + n
             p.data.copy_(sd[k].to(p.dtype))
 
+    @torch.no_grad()
+    def merge_into(self, llm):
+        """peft merge_and_unload (merge_lora_weights_and_save_hf_model_moe.py:339): W += scaling * B A for every adapter, into the
+        model's bf16 weights in place (the fused / interleaved / per-expert row layouts included); fully fine-tuned matrices are synced."""
+        self.sync_model(llm)
+        for i, lw in enumerate(llm.layers):
+            for t in self.targets:
+                grp = next(g for g, mem in GROUPS.items() if t in mem)
+                for e, _ in enumerate(self._modules_of(i, t)):
+                    delta = self.scaling * (self.get(i, t, "B", e).float() @ self.get(i, t, "A", e).float())
+                    W = lw[grp] if lw[grp].dim() == 2 else lw[grp][e]
+                    rows = self.rows[t]
+                    W[rows] = (W[rows].float() + delta).to(W.dtype)
+            for k in ("qkv", "o", "gu", "down"):
+                if k + "_T" in lw:
+                    lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()
+
     def padded(self, i):
         """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) — with a
         leading expert axis for the MLP groups of a MoE layer, and B stored * scaling there (the batched GEMM has no alpha).  The

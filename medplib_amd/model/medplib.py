@@ -148,6 +148,15 @@ class MedPLIBForCausalLM(nn.Module):
             ps += list(self.model.lora.parameters())
         return ps
 
+    def merge_and_unload(self):
+        """peft `merge_and_unload()`: fold the trained adapters into the weights and drop them; inference / evaluate() / export then see
+        the fine-tuned model (the adapters only act in the training forward)."""
+        if getattr(self.model, "lora", None) is not None:
+            self.model.lora.merge_into(self.model.llm)
+            self.model.lora = None
+            self.model.llm.lora = None
+        return self
+
     def enable_lora(self, lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules=("gate_proj", "up_proj", "down_proj"), seed=0,
                     train_gate=True, sft_modules=()):
         """get_peft_model(LoraConfig(r, lora_alpha, target_modules, lora_dropout)) for the decoder's MLP projections

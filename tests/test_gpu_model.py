@@ -901,6 +901,10 @@ def test_lora_adapters_equal_merged_weights_and_entry_point(dev, tmp_path):
     m2 = _model(cfg, dev, W2).eval()
     h_merged, _, _ = m2.model.llm.forward(emb, None)
     _stat("adapter forward vs merged weights", h_adapter, h_merged, atol=0.0, rtol=8 * 2 ** -8)
+    m.merge_and_unload()                                          # the in-place merge of the live model gives the same weights
+    assert m.model.lora is None
+    h_live, _, _ = m.eval().model.llm.forward(emb, None)
+    _stat("merge_and_unload vs checkpoint-side merge", h_live, h_merged, atol=0.0, rtol=2 ** -8)
     hist = train.main(["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "6", "--lr", "2e-3",
                        "--lora_r", "8", "--lora_dropout", "0.05", "--log_dir", str(tmp_path)])
     assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
