@@ -81,6 +81,7 @@ class LoRAState(torch.nn.Module):
         self.width = {"qkv": 3 * d, "o": d, "gu": 2 * ff, "down": d}
         self.step = 0
         self._bufs = {}
+        self.p_active = self.p                                  # dropout in effect: p while training, 0 in eval (set per forward)
 
     def _modules_of(self, i, t):
         if i in self.moe_layers and t in MLP_TARGETS:
@@ -237,7 +238,7 @@ def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=
 def _adapter_fwd(lora, ops_pad, x, y, seed):
     """y + scaling * (dropout(x) A^T) B^T  -> (y', x_dropped, t)."""
     A, _, B, _, _, _ = ops_pad
-    xd = ops.dropout_bf16(x, lora.p, seed) if lora.p > 0 else x
+    xd = ops.dropout_bf16(x, lora.p_active, seed) if lora.p_active > 0 else x
     t = ops.gemm(xd, A)                                           # [T, 64] (columns >= R are zero)
     return ops.gemm(t, B, residual=y, alpha=lora.scaling), xd, t
 
@@ -250,7 +251,7 @@ def _adapter_fwd_moe(lora, ops_pad, xbuf, ybuf, kept, seed):
     """Per-expert adapters on the capacity slabs: ybuf + (dropout(xbuf) A_e^T) (scaling B_e)^T -> (y', x_dropped, t)."""
     A, _, B, _, _, _ = ops_pad
     E, cap, _ = xbuf.shape
-    xd = ops.dropout_bf16(xbuf, lora.p, seed) if lora.p > 0 else xbuf
+    xd = ops.dropout_bf16(xbuf, lora.p_active, seed) if lora.p_active > 0 else xbuf
     t = ops.gemm_batched(xd, A, _zeros((E, cap, 64), xbuf.device), m_dev=kept)
     return ops.gemm_batched_res(t, B, ybuf, _zeros(ybuf.shape, xbuf.device), m_dev=kept), xd, t
 
@@ -284,8 +285,8 @@ def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
     dt = ops.gemm_batched(dy, BT, _zeros((E, cap, 64), dy.device), m_dev=kept)            # scaling rides in the packed B
     dB = [ops.tn_skinny(dy[e], t[e], R, lora.scaling) for e in range(E)]
     dAT = [ops.tn_skinny(xd[e], dt[e], R, 1.0) for e in range(E)]
-    if lora.p > 0:
-        dxa = ops.dropout_bf16(ops.gemm_batched(dt, AT, _zeros(dx.shape, dy.device), m_dev=kept), lora.p, seed)
+    if lora.p_active > 0:
+        dxa = ops.dropout_bf16(ops.gemm_batched(dt, AT, _zeros(dx.shape, dy.device), m_dev=kept), lora.p_active, seed)
         return ops.add3(dx, dxa), dB, dAT
     return ops.gemm_batched_res(dt, AT, dx, _zeros(dx.shape, dy.device), m_dev=kept), dB, dAT
 
@@ -327,6 +328,7 @@ def forward_train(llm, embeds, key_valid):
     T = B * S
     x = embeds.reshape(T, d)
     lora.step += 1
+    lora.p_active = lora.p if llm.training else 0.0
     llm.gate_pass += 1
     saved, aux = [], []
     for i, lw in enumerate(llm.layers):
@@ -370,8 +372,8 @@ def _adapter_bwd(lora, ops_pad, dy, xd, t, dx, seed):
     dt = ops.gemm(dy, BT, alpha=lora.scaling)                      # [T, 64] = scaling * dy B
     dB = ops.tn_skinny(dy, t, R, lora.scaling)                     # [out, R] = scaling * dy^T t
     dAT = ops.tn_skinny(xd, dt, R, 1.0)                            # [in, R]  = x_d^T (scaling * dy B)
-    if lora.p > 0:
-        dxa = ops.dropout_bf16(ops.gemm(dt, AT), lora.p, seed)    # the same mask and 1/(1-p) as the forward
+    if lora.p_active > 0:
+        dxa = ops.dropout_bf16(ops.gemm(dt, AT), lora.p_active, seed)    # the same mask and 1/(1-p) as the forward
         dx = ops.add3(dx, dxa)
     else:
         dx = ops.gemm(dt, AT, residual=dx)

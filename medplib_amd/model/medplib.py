@@ -148,6 +148,11 @@ class MedPLIBForCausalLM(nn.Module):
             ps += list(self.model.lora.parameters())
         return ps
 
+    def _require_merged(self, what):
+        if getattr(self.model, "lora", None) is not None:
+            raise RuntimeError(f"{what}() decodes with the KV cache on the plain weights: call merge_and_unload() first (the reference "
+                               "merges its adapters before inference too, merge_lora_weights_and_save_hf_model_moe.py)")
+
     def merge_and_unload(self):
         """peft `merge_and_unload()`: fold the trained adapters into the weights and drop them; inference / evaluate() / export then see
         the fine-tuned model (the adapters only act in the training forward)."""
@@ -365,14 +370,16 @@ class MedPLIBForCausalLM(nn.Module):
             seg_rows_d = _h2d(seg_rows, dev) if seg_flag else None
             exp = self.expand_index(valid_mask_bool, B) if seg_flag else None
             exp_d = _h2d(np.asarray(exp, dtype=np.int64), dev) if (seg_flag and exp != list(range(B))) else None
-            if getattr(m.llm, "lora", None) is not None and self.training and not inference:
+            if getattr(m.llm, "lora", None) is not None:
                 m.llm.lora.sync_model(m.llm)                        # bf16 working copies of lm_head / embed_tokens when they train
             embeds = ops.splice_rows(m.llm.embed_tokens, feats, src, cfg.hidden_size).view(B, plan.seq_len, cfg.hidden_size)
-            lora_train = getattr(m.llm, "lora", None) is not None and self.training and not inference
+            # adapters attached: they act in every forward of this method (training, validation, inference masks) like a peft
+            # model; the KV-cache decode paths want them merged (merge_and_unload())
+            lora_train = getattr(m.llm, "lora", None) is not None
             if not lora_train:
                 last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
                 ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, aux)
-        if lora_train and torch.is_grad_enabled():
+        if lora_train and torch.is_grad_enabled() and self.training and not inference:
             # LoRA training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so loss.backward()
             # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
             from . import llama_lora as LL
@@ -573,6 +580,7 @@ class MedPLIBForCausalLM(nn.Module):
         do_sample=False)`, vqa_infer.py:430-442): greedy decoding, one sample per call like the reference's loop (batch rows are
         decoded one after the other).  Returns output ids [B, L + n_max] (right-padded with eos), prompt included, as HF does."""
         self.sync_side_streams()
+        self._require_merged("generate")
         ids = _np_ids(input_ids).astype(np.int64)
         was_training = self.training
         self.train(False)
@@ -605,6 +613,7 @@ class MedPLIBForCausalLM(nn.Module):
         yields; the mask's final position is always False (shifted mask), so it is truncated to the hidden length."""
         cfg, dev, m = self.config, self.device_, self.model
         self.sync_side_streams()
+        self._require_merged("evaluate")
         ids = _np_ids(input_ids).astype(np.int64)
         assert ids.shape[0] == 1, "evaluate() decodes one sample at a time, like the reference's validate_seg (vqa_infer.py:528)"
         was_training = self.training
