@@ -337,6 +337,15 @@ int mp_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t n, hipStre
  * dfmap [n_maps, h*w, C] bf16 from dout [n_masks, C]; wt = scratch of n_masks * h * w floats; no atomics. */
 int mp_region_point_mean_bwd_bf16(const float* xy, const int64_t* offsets, const int* map_index, const void* dout, void* dfmap, float* wt,
                                   int n_maps, int n_masks, int h, int w, int C, hipStream_t stream);
+/* MaskTokenEncoder training (`mask_encoder` in --sft_modules, scripts/train_medplib_icl.sh:12; medplib_arch.py:80-108): layer 1 without
+ * its GELU (the pre-activation is kept) and its weight [CO, 9] / bias gradients; AdaptiveAvgPool1d-over-tokens backward; col2im of
+ * a k3 / s2 / p1 convolution in gather form (dcols [n*OH*OW, 9*C] tap-major -> dx [n, H, W, C]). */
+int mp_conv3x3s2_c1_pre_bf16(const void* img, int img_dtype, const float* w, const float* bias, void* out, int n, int H, int W, int CO,
+                             hipStream_t stream);
+int mp_conv3x3s2_c1_wgrad_f32(const void* img, int img_dtype, const void* dpre, float* dw, float* db, int n, int H, int W, int CO,
+                              hipStream_t stream);
+int mp_adaptive_avgpool_tokens_bwd_bf16(const void* dout, void* dx, int n, int len_in, int len_out, int C, hipStream_t stream);
+int mp_col2im_k3s2p1_bf16(const void* dcols, void* dx, int n, int H, int W, int C, hipStream_t stream);
 /* peft lora_dropout on the adapter input: y = x * keep / (1 - p), keep from a stateless hash of (seed, index). */
 int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t stream);
 

@@ -442,6 +442,109 @@ __global__ void region_fmap_grad_kernel(const float* __restrict__ wt, const bf16
   *reinterpret_cast<bf16x8*>(dfmap + ((int64_t)j * hw + pix) * C + c) = o;
 }
 
+// ---- MaskTokenEncoder backward pieces (`mask_encoder` in --sft_modules, scripts/train_medplib_icl.sh:12; medplib_arch.py:80-108) ----
+// layer 1 without its GELU (the training forward keeps the pre-activation): Conv2d(1, CO, k3, s2, p1) on a single-channel image
+template <typename TIN>
+__global__ void conv3x3s2_c1_pre_kernel(const TIN* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                        bf16_t* __restrict__ out, int n, int H, int W, int OH, int OW, int CO) {
+  const int per_pix = CO / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * OH * OW * per_pix) return;
+  const int co = (int)(idx % per_pix) * 8;
+  const int64_t pix = idx / per_pix;
+  const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias[co + j];
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const float v = (float)(bf16_t)(float)img[((int64_t)b * H + iy) * W + ix];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[(co + j) * 9 + ky * 3 + kx], acc[j]);
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+  *reinterpret_cast<bf16x8*>(out + pix * CO + co) = o;
+}
+// its weight / bias gradient: block (q, co), q = tap 0..8 or 9 = bias; fixed-order block reduction over all output pixels
+template <typename TIN>
+__global__ __launch_bounds__(256) void conv3x3s2_c1_wgrad_kernel(const TIN* __restrict__ img, const bf16_t* __restrict__ dpre,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int n, int H, int W, int OH,
+                                                                 int OW, int CO) {
+  __shared__ float red[16];
+  const int q = blockIdx.x, co = blockIdx.y;
+  const int ky = q / 3, kx = q % 3;
+  float acc = 0.f;
+  const int64_t total = (int64_t)n * OH * OW;
+  for (int64_t pix = threadIdx.x; pix < total; pix += 256) {
+    const float g = (float)dpre[pix * CO + co];
+    if (q == 9) { acc += g; continue; }
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    acc = fmaf(g, (float)(bf16_t)(float)img[((int64_t)b * H + iy) * W + ix], acc);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) { if (q == 9) db[co] = acc; else dw[co * 9 + q] = acc; }
+}
+// AdaptiveAvgPool1d over tokens, backward: d_x[b, t, :] = sum over the outputs i whose window [t0_i, t1_i) holds t of d_out[b, i, :] / size_i
+__global__ void adaptive_avgpool_tokens_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dx, int n, int Lin, int Lout, int C) {
+  const int per_row = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * Lin * per_row) return;
+  const int c = (int)(idx % per_row) * 8;
+  const int t = (int)((idx / per_row) % Lin);
+  const int b = (int)(idx / ((int64_t)per_row * Lin));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int i_lo = max(0, (int)(((int64_t)t * Lout) / Lin) - 1), i_hi = min(Lout - 1, (int)((((int64_t)t + 1) * Lout + Lin - 1) / Lin));
+  for (int i = i_lo; i <= i_hi; ++i) {
+    const int t0 = (int)(((int64_t)i * Lin) / Lout), t1 = (int)((((int64_t)(i + 1)) * Lin + Lout - 1) / Lout);
+    if (t < t0 || t >= t1) continue;
+    const float inv = 1.f / (float)(t1 - t0);
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + ((int64_t)b * Lout + i) * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)g[j], inv, acc[j]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+  *reinterpret_cast<bf16x8*>(dx + ((int64_t)b * Lin + t) * C + c) = o;
+}
+// col2im of a k3 / s2 / p1 convolution in gather form: d_x[b, y, x, :] = sum over the taps (ky, kx) that read this pixel of
+// d_cols[(b, oy, ox), ky*3+kx, :],  oy = (y + 1 - ky) / 2 (when even and in range), ox likewise
+__global__ void col2im_k3s2p1_kernel(const bf16_t* __restrict__ dcols, bf16_t* __restrict__ dx, int n, int H, int W, int C, int OH, int OW) {
+  const int per_pix = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * H * W * per_pix) return;
+  const int c = (int)(idx % per_pix) * 8;
+  const int64_t pix = idx / per_pix;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = y + 1 - ky;
+    if (ty < 0 || (ty & 1) || ty / 2 >= OH) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = x + 1 - kx;
+      if (tx < 0 || (tx & 1) || tx / 2 >= OW) continue;
+      const int64_t orow = ((int64_t)b * OH + ty / 2) * OW + tx / 2;
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dcols + orow * (9 * (int64_t)C) + (int64_t)(ky * 3 + kx) * C + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)g[j];
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+  *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+}
+
 }  // namespace
 
 #define GRID1D(n) dim3((unsigned)mp_cdiv((n), 256)), dim3(256), 0, stream
@@ -586,4 +689,41 @@ extern "C" int mp_region_point_mean_bwd_bf16(const float* xy, const int64_t* off
   hipLaunchKernelGGL(region_fmap_grad_kernel, GRID1D((int64_t)n_maps * h * w * (C / 8)), wt, (const bf16_t*)dout, map_index, (bf16_t*)dfmap, n_maps,
                      n_masks, h * w, C);
   return mp_check_launch("mp_region_point_mean_bwd_bf16");
+}
+
+extern "C" int mp_conv3x3s2_c1_pre_bf16(const void* img, int img_dtype, const float* w, const float* bias, void* out, int n, int H, int W, int CO,
+                                        hipStream_t stream) {
+  MP_REQUIRE(CO % 8 == 0 && (img_dtype == MP_BF16 || img_dtype == MP_F32), MP_ERR_SHAPE, "mp_conv3x3s2_c1_pre_bf16: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)n * OH * OW * (CO / 8);
+  if (total == 0) return MP_OK;
+  if (img_dtype == MP_F32) hipLaunchKernelGGL(conv3x3s2_c1_pre_kernel<float>, GRID1D(total), (const float*)img, w, bias, (bf16_t*)out, n, H, W, OH, OW, CO);
+  else hipLaunchKernelGGL(conv3x3s2_c1_pre_kernel<bf16_t>, GRID1D(total), (const bf16_t*)img, w, bias, (bf16_t*)out, n, H, W, OH, OW, CO);
+  return mp_check_launch("mp_conv3x3s2_c1_pre_bf16");
+}
+
+extern "C" int mp_conv3x3s2_c1_wgrad_f32(const void* img, int img_dtype, const void* dpre, float* dw, float* db, int n, int H, int W, int CO,
+                                         hipStream_t stream) {
+  MP_REQUIRE(CO > 0 && (img_dtype == MP_BF16 || img_dtype == MP_F32), MP_ERR_SHAPE, "mp_conv3x3s2_c1_wgrad_f32: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  if (img_dtype == MP_F32) hipLaunchKernelGGL(conv3x3s2_c1_wgrad_kernel<float>, dim3(10, CO), dim3(256), 0, stream, (const float*)img, (const bf16_t*)dpre, dw, db, n, H, W, OH, OW, CO);
+  else hipLaunchKernelGGL(conv3x3s2_c1_wgrad_kernel<bf16_t>, dim3(10, CO), dim3(256), 0, stream, (const bf16_t*)img, (const bf16_t*)dpre, dw, db, n, H, W, OH, OW, CO);
+  return mp_check_launch("mp_conv3x3s2_c1_wgrad_f32");
+}
+
+extern "C" int mp_adaptive_avgpool_tokens_bwd_bf16(const void* dout, void* dx, int n, int len_in, int len_out, int C, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0 && len_in > 0 && len_out > 0, MP_ERR_SHAPE, "mp_adaptive_avgpool_tokens_bwd_bf16: bad shape");
+  const int64_t total = (int64_t)n * len_in * (C / 8);
+  if (total == 0) return MP_OK;
+  hipLaunchKernelGGL(adaptive_avgpool_tokens_bwd_kernel, GRID1D(total), (const bf16_t*)dout, (bf16_t*)dx, n, len_in, len_out, C);
+  return mp_check_launch("mp_adaptive_avgpool_tokens_bwd_bf16");
+}
+
+extern "C" int mp_col2im_k3s2p1_bf16(const void* dcols, void* dx, int n, int H, int W, int C, hipStream_t stream) {
+  MP_REQUIRE(C % 8 == 0, MP_ERR_SHAPE, "mp_col2im_k3s2p1_bf16: bad shape");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)n * H * W * (C / 8);
+  if (total == 0) return MP_OK;
+  hipLaunchKernelGGL(col2im_k3s2p1_kernel, GRID1D(total), (const bf16_t*)dcols, (bf16_t*)dx, n, H, W, C, OH, OW);
+  return mp_check_launch("mp_col2im_k3s2p1_bf16");
 }

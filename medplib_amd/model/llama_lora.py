@@ -112,6 +112,20 @@ class LoRAState(torch.nn.Module):
             self.names.append(n)
             self.params.append(torch.nn.Parameter(t.detach().float().clone()))
 
+    def add_mask_encoder(self, enc):
+        """`mask_encoder` in --sft_modules (scripts/train_medplib_icl.sh:12): the four convolutions, the projection and the LayerNorm of
+        MaskTokenEncoder train.  fp32 masters in this build's own weight layouts (conv weights [cout, 9*cin], tap-major)."""
+        self.menc = enc
+        items = [("model.mask_encoder.encoder.0.weight", enc.w0), ("model.mask_encoder.encoder.0.bias", enc.b0)]
+        for j, i in enumerate((2, 4, 6)):
+            items += [(f"model.mask_encoder.encoder.{i}.weight", enc.convs[j][0]), (f"model.mask_encoder.encoder.{i}.bias", enc.convs[j][1])]
+        items += [("model.mask_encoder.proj.weight", enc.proj_w), ("model.mask_encoder.proj.bias", enc.proj_b),
+                  ("model.mask_encoder.norm.weight", enc.norm[0]), ("model.mask_encoder.norm.bias", enc.norm[1])]
+        for n, t in items:
+            self.index[n] = len(self.names)
+            self.names.append(n)
+            self.params.append(torch.nn.Parameter(t.detach().float().clone()))
+
     def add_token_compressor(self, comp):
         """`mm_token_compressor` in --sft_modules (scripts/train_medplib_icl.sh:8): LayerNorm + Linear train; fp32 masters here."""
         self.comp = comp
@@ -138,6 +152,15 @@ class LoRAState(torch.nn.Module):
         p = self.full_param("model.embed_tokens.weight")
         if p is not None:
             llm.embed_tokens.copy_(p.detach())
+        if self.full_param("model.mask_encoder.proj.weight") is not None:
+            e, fp = self.menc, self.full_param
+            e.w0, e.b0 = fp("model.mask_encoder.encoder.0.weight").data, fp("model.mask_encoder.encoder.0.bias").data
+            for j, i in enumerate((2, 4, 6)):
+                e.convs[j][0].copy_(fp(f"model.mask_encoder.encoder.{i}.weight").detach())
+                e.convs[j] = (e.convs[j][0], fp(f"model.mask_encoder.encoder.{i}.bias").data)
+            e.proj_w.copy_(fp("model.mask_encoder.proj.weight").detach())
+            e.proj_b = fp("model.mask_encoder.proj.bias").data
+            e.norm = (fp("model.mask_encoder.norm.weight").data, fp("model.mask_encoder.norm.bias").data)
         if self.full_param("model.region_fea_adapter.weight") is not None:
             ra = self.region_tower.region_adapter
             ra["w"].copy_(self.full_param("model.region_fea_adapter.weight").detach())
@@ -636,3 +659,60 @@ class RegionAdapterFn(torch.autograd.Function):
         d_w = ops.gemm(_tpad(dfm2), _tpad(raw_sel), out_dtype=torch.float32)
         d_b = ops.colsum_f32(ops.cast_to_f32(dfm2))
         return None, None, None, None, None, None, d_w, d_b
+
+
+class MaskEncoderFn(torch.autograd.Function):
+    """MaskTokenEncoder (4 x [Conv3x3 s2 p1 + GELU] -> AdaptiveAvgPool1d over tokens -> Linear -> LayerNorm, medplib_arch.py:80-108)
+    with every parameter trainable.  The training forward keeps the pre-activations (unfused GELU) and the im2col matrices; the
+    backward is dgrad GEMM + gather-form col2im per convolution, NT GEMMs on transposed copies for the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, masks, enc, *params):
+        from .icl import _conv_taps
+        if masks.dim() == 4:
+            masks = masks[:, 0]
+        if masks.dtype not in (torch.float32, torch.bfloat16):
+            masks = masks.float()
+        masks = masks.contiguous()
+        pre = [ops.conv3x3s2_c1_pre(masks, enc.w0, enc.b0)]
+        x = ops.gelu_fwd_bf16(pre[0])
+        n = x.shape[0]
+        cols, shapes = [], []
+        for w, b in enc.convs:
+            H, W, C = x.shape[1:]
+            OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            shapes.append((H, W, C, OH, OW))
+            cols.append(ops.im2col_nhwc(x, OH, OW, 2, _conv_taps(3, 1)))
+            pre.append(ops.gemm(cols[-1], w, bias=b).view(n, OH, OW, w.shape[0]))
+            x = ops.gelu_fwd_bf16(pre[-1])
+        L = x.shape[1] * x.shape[2]
+        toks = ops.adaptive_avgpool_tokens(x.view(n, L, x.shape[3]), enc.num_tokens).view(-1, 256)
+        h = ops.gemm(toks, enc.proj_w, bias=enc.proj_b)
+        ctx.enc, ctx.masks, ctx.pre, ctx.cols, ctx.shapes, ctx.toks, ctx.h, ctx.L, ctx.n = enc, masks, pre, cols, shapes, toks, h, L, n
+        return ops.layernorm(h, enc.norm[0], enc.norm[1], 1e-5)
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, n = ctx.enc, ctx.n
+        hf = ops.cast_to_f32(ctx.h)
+        _, mean, rstd = ops.layernorm_fwd_f32(hf, enc.norm[0], enc.norm[1], 1e-5)
+        d_nw, d_nb = torch.zeros_like(enc.norm[0]), torch.zeros_like(enc.norm[0])
+        d_h = ops.cast_to_bf16(ops.layernorm_bwd_f32(ops.cast_to_f32(g.contiguous()), hf, enc.norm[0], mean, rstd, d_nw, d_nb))
+        d_pw = ops.gemm(_tpad(d_h), _tpad(ctx.toks), out_dtype=torch.float32)
+        d_pb = ops.colsum_f32(ops.cast_to_f32(d_h))
+        d_toks = ops.gemm(d_h, enc.proj_w.t().contiguous())
+        d_x = ops.adaptive_avgpool_tokens_bwd(d_toks.view(n, enc.num_tokens, 256), ctx.L)
+        conv_grads = []
+        for j in (2, 1, 0):
+            w, _ = enc.convs[j]
+            H, W, C, OH, OW = ctx.shapes[j]
+            d_pre = ops.gelu_bwd_bf16(ctx.pre[j + 1].view(-1, w.shape[0]), d_x.reshape(-1, w.shape[0]).contiguous())
+            conv_grads.append((ops.gemm(_tpad(d_pre), _tpad(ctx.cols[j]), out_dtype=torch.float32), ops.colsum_f32(ops.cast_to_f32(d_pre))))
+            d_cols = ops.gemm(d_pre, w.t().contiguous())
+            d_x = ops.col2im_k3s2p1(d_cols, n, H, W, C)
+        d_pre1 = ops.gelu_bwd_bf16(ctx.pre[0].view(-1, 64), d_x.reshape(-1, 64).contiguous()).view(ctx.pre[0].shape)
+        d_w0, d_b0 = ops.conv3x3s2_c1_wgrad(ctx.masks, d_pre1)
+        out = [d_w0, d_b0]
+        for dw, db in reversed(conv_grads):
+            out += [dw, db]
+        return (None, None) + tuple(out) + (d_pw, d_pb, d_nw, d_nb)

@@ -171,6 +171,8 @@ class MedPLIBForCausalLM(nn.Module):
         sft = tuple(x for x in (sft_modules.split(",") if isinstance(sft_modules, str) else sft_modules) if x in ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm"))
         self.model.lora = LL.enable_lora(self.model.llm, self.config, lora_r, lora_alpha, lora_dropout, targets, seed,
                                          train_gate and ("wg" in sft_modules or sft_modules == ()), sft)
+        if "mask_encoder" in sft_modules and self.model.mask_encoder is not None:
+            self.model.lora.add_mask_encoder(self.model.mask_encoder)
         if "region_fea_adapter" in sft_modules:
             self.model.lora.add_region_adapter(self.model.vision_tower)
         if "mm_token_compressor" in sft_modules and self.model.mm_token_compressor is not None:
@@ -316,7 +318,8 @@ class MedPLIBForCausalLM(nn.Module):
             assert multi, "ICL separate mode expects a list (or 5-D tensor) of images"     # medplib_arch.py:247
             if m.mask_encoder is None:
                 raise ValueError("mask_images given but the model was built without icl_mask_encoder")
-            mfeats = m.mask_encoder.forward(torch.cat([mk for mk in mask_images], 0).to(self.device_))
+            self._mask_in = torch.cat([mk for mk in mask_images], 0).to(self.device_)      # kept for a trainable mask encoder
+            mfeats = m.mask_encoder.forward(self._mask_in)
             lengths, bases = icl_feature_layout(image_token_types, tok, cfg.mask_encoder_token_count)
             plan = plan_splice(ids_np, lab_np, att_np, lengths, seg_token_idx=seg_idx, seg_feature_lengths=seg_lens, feature_bases=bases)
             feats = torch.cat([feats, mfeats], 0)
@@ -385,7 +388,7 @@ class MedPLIBForCausalLM(nn.Module):
             from . import llama_lora as LL
             lo = m.llm.lora
             own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_
-                   and "mm_token_compressor" not in n_ and "region_fea_adapter" not in n_]
+                   and "mm_token_compressor" not in n_ and "region_fea_adapter" not in n_ and "mask_encoder" not in n_]
             emb_p = lo.full_param("model.embed_tokens.weight")
             proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
             if proj_p[0] is not None:                               # mm_projector trains (stage II): recompute it on the autograd tape
@@ -399,6 +402,11 @@ class MedPLIBForCausalLM(nn.Module):
                 feats = torch.cat([feats[:feats.shape[0] - rnew.shape[0]], rnew], 0)              # the region rows sit behind the image rows
             else:
                 reg_p = [None, None]
+            menc_names = [n_ for n_ in lo.names if n_.startswith("model.mask_encoder.")]
+            if menc_names and kwargs.get("mask_images") is not None and len(kwargs["mask_images"]) > 0:   # mask_encoder trains (ICL)
+                mnew = LL.MaskEncoderFn.apply(self._mask_in, m.mask_encoder, *[lo.full_param(n_) for n_ in menc_names])
+                feats = torch.cat([feats[:feats.shape[0] - mnew.shape[0]], mnew], 0)                     # the mask rows sit behind the image rows
+                reg_p = [mnew, None]                                 # (marks the splice as differentiable below)
             comp_p = [lo.full_param(f"model.mm_token_compressor.{k}") for k in ("norm.weight", "norm.bias", "proj.weight", "proj.bias")]
             if comp_p[0] is not None:                               # mm_token_compressor trains (train_medplib_icl.sh)
                 cin, n_img = self._comp_in

@@ -365,6 +365,37 @@ def region_point_mean_bwd(xy, offsets, map_index, dout, n_maps, h, w):
     return dfmap
 
 
+def conv3x3s2_c1_pre(img, w, b):
+    """Conv2d(1, CO, k3, s2, p1) without the GELU: img [n, H, W] (bf16 / f32) -> pre-activation [n, OH, OW, CO] bf16."""
+    n, H, W = img.shape
+    CO = w.shape[0]
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty((n, OH, OW, CO), dtype=torch.bfloat16, device=img.device)
+    lib().call("mp_conv3x3s2_c1_pre_bf16", _p(img), _dt(img.dtype), _p(w), _p(b), _p(out), n, H, W, CO, _stream())
+    return out
+
+
+def conv3x3s2_c1_wgrad(img, dpre):
+    n, H, W = img.shape
+    CO = dpre.shape[-1]
+    dw = torch.empty((CO, 9), dtype=torch.float32, device=img.device); db = torch.empty(CO, dtype=torch.float32, device=img.device)
+    lib().call("mp_conv3x3s2_c1_wgrad_f32", _p(img), _dt(img.dtype), _p(dpre.contiguous()), _p(dw), _p(db), n, H, W, CO, _stream())
+    return dw, db
+
+
+def adaptive_avgpool_tokens_bwd(dout, len_in):
+    n, len_out, C = dout.shape
+    dx = torch.empty((n, len_in, C), dtype=torch.bfloat16, device=dout.device)
+    lib().call("mp_adaptive_avgpool_tokens_bwd_bf16", _p(dout.contiguous()), _p(dx), n, len_in, len_out, C, _stream())
+    return dx
+
+
+def col2im_k3s2p1(dcols, n, H, W, C):
+    dx = torch.empty((n, H, W, C), dtype=torch.bfloat16, device=dcols.device)
+    lib().call("mp_col2im_k3s2p1_bf16", _p(dcols.contiguous()), _p(dx), n, H, W, C, _stream())
+    return dx
+
+
 def dropout_bf16(x, p, seed):
     y = torch.empty_like(x)
     lib().call("mp_dropout_bf16", _p(x), _p(y), x.numel(), float(p), int(seed), _stream())

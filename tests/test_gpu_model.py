@@ -1145,3 +1145,45 @@ def test_lora_training_with_trainable_region_adapter(dev):
         rel = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
         print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
         assert want.abs().max().item() > 0 and rel < 0.08, n
+
+
+def test_lora_training_icl_with_trainable_mask_encoder(dev):
+    """scripts/train_medplib_icl.sh, second variant: `--sft_modules mask_decoder,text_hidden_fcs,mask_encoder,mm_token_compressor` on the ICL
+    separate-mode batch.  MaskTokenEncoder's backward (LayerNorm, projection, AdaptiveAvgPool1d, four strided convolutions with
+    their GELUs: dgrad GEMM + gather-form col2im, weight gradients as NT GEMMs) vs the oracle's autograd; the conv weights live in
+    this build's im2col layout [cout, (ky, kx, cin)], so the oracle's [cout, cin, ky, kx] gradients are permuted for the comparison."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2, mm_token_compress=True, mm_compressed_token_count=8,
+                             icl_mask_encoder=True, mask_encoder_token_count=4)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W, cls=None).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, sft_modules="mask_decoder,text_hidden_fcs,mask_encoder,mm_token_compressor")
+    assert "model.mask_encoder.encoder.4.weight" in lora.names
+    g = torch.Generator().manual_seed(91)
+    Wl = dict(W); Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev)); Wl[n] = v.clone().requires_grad_(True)
+        else:
+            Wl[n] = W[n].clone().requires_grad_(True)
+    batch = OM.make_batch_icl(cfg, 2, n_ctx=2, seed=3)
+    bq = dict(batch)
+    bq["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]; bq["images"] = batch["images"].to(torch.bfloat16).float()
+    ref = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True)
+    ref["loss"].backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(), config={"optimizer": {"params": {"lr": 1e-4}}})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
+    out = eng(**gb)
+    _stat("icl mask-encoder training loss", out["loss"], ref["loss"], atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    for n in [k for k in lora.names if k.startswith("model.mask_encoder.")] + ["model.mm_token_compressor.proj.weight"]:
+        want, got = Wl[n].grad, lora.params[lora.index[n]].grad.float().cpu()
+        if want.dim() == 4:
+            want = want.permute(0, 2, 3, 1).reshape(want.shape[0], -1)
+        rel = (got.reshape(want.shape) - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
+        assert want.abs().max().item() > 0 and rel < 0.08, n
