@@ -317,13 +317,14 @@ int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int
  * A^T [fin, 64] at rank offset k0; B * bscale in B [W, 64], B^T [64, W] at the output rows `rows[o]` of the fused projection. */
 int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout, int k0,
                  int W, float bscale, hipStream_t stream);
-/* MoE layer backward, top-1 (autograd of DeepSpeed MOELayer + top1gating): the combine's d_y[e, slot] = w d_out and
+/* MoE layer backward, top-1 / top-2 (autograd of DeepSpeed MOELayer + top1gating / top2gating; entries = choice * tokens +
+ * token; top-2 weights are the kept pair renormalised; l_aux uses the first choices' counts): the combine's d_y[e, slot] = w d_out and
  * d_w = <d_out, y[e, slot]> (d_y pre-zeroed); the gate's d_logits from d_w (chosen expert of kept tokens) and from l_aux
  * (c_aux[0] * aux_coef = d loss / d l_aux); the gate's input gradient d_x += d_logits wg. */
 int mp_moe_combine_bwd_bf16(const void* dout, const void* y, const int* expert, const int* slot, const float* weight, void* dy, float* dw,
-                            int64_t tokens, int dim, int capacity, hipStream_t stream);
-int mp_moe_gate_bwd_f32(const float* gates, const int* expert, const int* slot, const float* dw, const long long* exp_counts,
-                        const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, hipStream_t stream);
+                            int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
+int mp_moe_gate_bwd_f32(const float* gates, const int* expert, const int* slot, const float* dw, const long long* first_choice_counts,
+                        const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, int top_k, hipStream_t stream);
 int mp_moe_gate_dgrad_bf16(const float* dlogits, const float* wg, void* dx, int64_t tokens, int dim, int n_experts, hipStream_t stream);
 /* Gradient of the token-embedding table (`embed_tokens` in --sft_modules): out[ids[u], :] = sum of g[row, :] over the rows of segment
  * u of rows_sorted (seg [n_unique + 1]), in list order; out fp32 [vocab, dim] pre-zeroed. */

@@ -272,14 +272,15 @@ __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __res
 __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                               const int* __restrict__ expert, const int* __restrict__ slot,
                                                               const float* __restrict__ weight, bf16_t* __restrict__ dy, float* __restrict__ dw,
-                                                              int64_t T, int d, int capacity) {
+                                                              int64_t T, int d, int capacity, int top_k) {
   const int lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  const int sl = slot[t];
-  if (sl < 0) { if (lane == 0) dw[t] = 0.f; return; }
-  const int64_t row = ((int64_t)expert[t] * capacity + sl) * d;
-  const float w = weight[t];
+  const int64_t en = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // entry = choice * T + token (top_k choices per token)
+  if (en >= T * top_k) return;
+  const int64_t t = en % T;
+  const int sl = slot[en];
+  if (sl < 0) { if (lane == 0) dw[en] = 0.f; return; }
+  const int64_t row = ((int64_t)expert[en] * capacity + sl) * d;
+  const float w = weight[en];
   float acc = 0.f;
   for (int i = lane * 8; i < d; i += 512) {
     const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + t * d + i);
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const bf16_t* __re
     *reinterpret_cast<bf16x8*>(dy + row + i) = o;
   }
   acc = wave_sum(acc);
-  if (lane == 0) dw[t] = acc;
+  if (lane == 0) dw[en] = acc;
 }
 
 // gate backward: the combine weight is the softmax probability of the chosen expert (kept tokens) and
@@ -298,19 +299,34 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const bf16_t* __re
 // d_logits[t, j] = p_j (g_j - sum_k p_k g_k)
 __global__ void moe_gate_bwd_kernel(const float* __restrict__ gates, const int* __restrict__ expert, const int* __restrict__ slot,
                                     const float* __restrict__ dw, const long long* __restrict__ counts, const float* __restrict__ c_aux,
-                                    float aux_coef, float* __restrict__ dlogits, int64_t T, int E) {
+                                    float aux_coef, float* __restrict__ dlogits, int64_t T, int E, int top_k) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   const float ca = (c_aux ? c_aux[0] : 0.f) * aux_coef * (float)E / ((float)T * (float)T);
-  const int e = expert[t];
-  const bool kept = slot[t] >= 0;
+  const int e1 = expert[t];
+  const bool kept1 = slot[t] >= 0;
+  int e2 = -1;
+  float dg1 = kept1 ? dw[t] : 0.f, dg2 = 0.f;
+  if (top_k == 2) {
+    // top2gating: w1 = g1 / D, w2 = g2 / D with g = the (kept) choices' probabilities and D = max(g1 + g2, eps):
+    // d g1 = g2 (dw1 - dw2) / D^2, d g2 = g1 (dw2 - dw1) / D^2 (both zero when one choice was dropped: the other weight is 1)
+    e2 = expert[T + t];
+    const bool kept2 = slot[T + t] >= 0;
+    const float g1 = kept1 ? gates[t * E + e1] : 0.f, g2 = kept2 ? gates[t * E + e2] : 0.f;
+    const float D = g1 + g2;
+    const float dw1 = kept1 ? dw[t] : 0.f, dw2 = kept2 ? dw[T + t] : 0.f;
+    if (D > 1.1920929e-07f) { dg1 = g2 * (dw1 - dw2) / (D * D); dg2 = g1 * (dw2 - dw1) / (D * D); }
+    else { dg1 = 0.f; dg2 = 0.f; }
+    if (!kept1) dg1 = 0.f;
+    if (!kept2) dg2 = 0.f;
+  }
   float dot = 0.f;
   for (int j = 0; j < E; ++j) {
-    const float g = ((j == e && kept) ? dw[t] : 0.f) + ca * (float)counts[j];
+    const float g = (j == e1 ? dg1 : 0.f) + (j == e2 ? dg2 : 0.f) + ca * (float)counts[j];
     dot += gates[t * E + j] * g;
   }
   for (int j = 0; j < E; ++j) {
-    const float g = ((j == e && kept) ? dw[t] : 0.f) + ca * (float)counts[j];
+    const float g = (j == e1 ? dg1 : 0.f) + (j == e2 ? dg2 : 0.f) + ca * (float)counts[j];
     dlogits[t * E + j] = gates[t * E + j] * (g - dot);
   }
 }
@@ -623,19 +639,20 @@ extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows,
 }
 
 extern "C" int mp_moe_combine_bwd_bf16(const void* dout, const void* y, const int* expert, const int* slot, const float* weight, void* dy,
-                                       float* dw, int64_t tokens, int dim, int capacity, hipStream_t stream) {
-  MP_REQUIRE(dim % 8 == 0 && capacity >= 0, MP_ERR_SHAPE, "mp_moe_combine_bwd_bf16: bad shape");
+                                       float* dw, int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && capacity >= 0 && (top_k == 1 || top_k == 2), MP_ERR_SHAPE, "mp_moe_combine_bwd_bf16: bad shape");
   if (tokens == 0) return MP_OK;
-  hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((unsigned)mp_cdiv(tokens, 4)), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)y,
-                     expert, slot, weight, (bf16_t*)dy, dw, tokens, dim, capacity);
+  hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((unsigned)mp_cdiv(tokens * top_k, 4)), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)y,
+                     expert, slot, weight, (bf16_t*)dy, dw, tokens, dim, capacity, top_k);
   return mp_check_launch("mp_moe_combine_bwd_bf16");
 }
 
 extern "C" int mp_moe_gate_bwd_f32(const float* gates, const int* expert, const int* slot, const float* dw, const long long* exp_counts,
-                                   const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, hipStream_t stream) {
-  MP_REQUIRE(n_experts >= 1 && n_experts <= 8, MP_ERR_SHAPE, "mp_moe_gate_bwd_f32: experts <= 8");
+                                   const float* c_aux, float aux_coef, float* dlogits, int64_t tokens, int n_experts, int top_k,
+                                   hipStream_t stream) {
+  MP_REQUIRE(n_experts >= 1 && n_experts <= 8 && (top_k == 1 || top_k == 2), MP_ERR_SHAPE, "mp_moe_gate_bwd_f32: experts <= 8, top_k 1 or 2");
   if (tokens == 0) return MP_OK;
-  hipLaunchKernelGGL(moe_gate_bwd_kernel, GRID1D(tokens), gates, expert, slot, dw, exp_counts, c_aux, aux_coef, dlogits, tokens, n_experts);
+  hipLaunchKernelGGL(moe_gate_bwd_kernel, GRID1D(tokens), gates, expert, slot, dw, exp_counts, c_aux, aux_coef, dlogits, tokens, n_experts, top_k);
   return mp_check_launch("mp_moe_gate_bwd_f32");
 }
 

@@ -38,8 +38,8 @@ class LoRAState(torch.nn.Module):
         super().__init__()
         assert r % 8 == 0 and 0 < r <= 16, "lora_r must be 8 or 16 (the shipped scripts' values)"
         assert all(t in ALL_TARGETS for t in targets), f"adapters are built for {ALL_TARGETS}"
-        assert cfg.top_k_experts == 1 and llm.ep is None and not cfg.use_residual or not llm.moe_layers, \
-            "adapters in MoE layers: top-1 routing on one rank (top-2 / expert parallel / residual MoE: not yet)"
+        assert llm.ep is None and not cfg.use_residual or not llm.moe_layers, \
+            "training MoE layers: one expert-parallel rank, no residual MoE (not yet)"
         self.r, self.alpha, self.p = r, float(alpha), float(dropout)
         self.targets = tuple(t for t in ALL_TARGETS if t in targets)
         self.scaling = self.alpha / r
@@ -287,9 +287,14 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     E, ff = cfg.num_experts, cfg.intermediate_size
     cap = llm.capacity(T)
     wg = lora.gate_weight(i, llm)
-    _, gates = ops.moe_gate(h2, wg)
-    expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, llm._gate_draws(i, T, E, gumbel=False))
-    buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=_zeros((E, cap, d), h2.device))
+    k = cfg.top_k_experts
+    logits, gates = ops.moe_gate(h2, wg)
+    if k == 1:
+        expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, llm._gate_draws(i, T, E, gumbel=False))
+    else:
+        expert, slot, weight, kept, _, l_aux = ops.moe_route_top2(gates, logits, cap, llm._gate_draws(i, T, E, gumbel=True))
+        counts = torch.bincount(expert[:T].long(), minlength=E)    # l_aux is built on the FIRST choices (top2gating's mask1)
+    buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=_zeros((E, cap, d), h2.device), top_k=k)
     gu = ops.gemm_batched(buf, lw["gu"], _zeros((E, cap, 2 * ff), h2.device), m_dev=kept)
     if "gu" in pad:
         gu, s["bufd"], s["t_gu"] = _adapter_fwd_moe(lora, pad["gu"], buf, gu, kept, seed)
@@ -298,7 +303,7 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     if "down" in pad:
         y, s["actd"], s["t_d"] = _adapter_fwd_moe(lora, pad["down"], act, y, kept, seed + 1)
     s.update(moe=True, h2=h2, gates=gates, expert=expert, slot=slot, weight=weight, kept=kept, counts=counts, gu=gu, y=y, cap=cap, wg=wg)
-    return ops.moe_combine(y, expert, slot, weight, x_mid, cap), l_aux
+    return ops.moe_combine(y, expert, slot, weight, x_mid, cap, top_k=k), l_aux
 
 
 def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
@@ -321,7 +326,8 @@ def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
     E, ff, cap = cfg.num_experts, cfg.intermediate_size, s["cap"]
     T, d = dx.shape
     pad, kept = s["pad"], s["kept"]
-    d_y, d_w = ops.moe_combine_bwd(dx, s["y"], s["expert"], s["slot"], s["weight"], cap)
+    k = cfg.top_k_experts
+    d_y, d_w = ops.moe_combine_bwd(dx, s["y"], s["expert"], s["slot"], s["weight"], cap, top_k=k)
     d_act = ops.gemm_batched(d_y, lw["down_T"], _zeros((E, cap, ff), dx.device), m_dev=kept)
     if "down" in pad:
         d_act, dB, dAT = _adapter_bwd_moe(lora, pad["down"], d_y, s["actd"], s["t_d"], d_act, kept, s["seed"] + 1)
@@ -331,9 +337,9 @@ def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
     if "gu" in pad:
         d_buf, dB, dAT = _adapter_bwd_moe(lora, pad["gu"], d_gu, s["bufd"], s["t_gu"], d_buf, kept, s["seed"])
         take_e(i, pad["gu"], dB, dAT)
-    ones = torch.ones(T, dtype=torch.float32, device=dx.device)
-    d_h2 = ops.moe_combine(d_buf, s["expert"], s["slot"], ones, None, cap)                 # rows back to their tokens (dropped: 0)
-    dl = ops.moe_gate_bwd(s["gates"], s["expert"], s["slot"], d_w, s["counts"], d_aux, 1.0)
+    ones = torch.ones(T * k, dtype=torch.float32, device=dx.device)
+    d_h2 = ops.moe_combine(d_buf, s["expert"], s["slot"], ones, None, cap, top_k=k)        # rows back to their tokens (dropped: 0)
+    dl = ops.moe_gate_bwd(s["gates"], s["expert"], s["slot"], d_w, s["counts"], d_aux, 1.0, top_k=k)
     ops.moe_gate_dgrad_(dl, s["wg"], d_h2)
     name = f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight"
     if name in lora.index:

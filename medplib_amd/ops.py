@@ -312,19 +312,21 @@ def lora_pack(a, b, rows, A, AT, B, BT, k0, bscale=1.0):
                _stream())
 
 
-def moe_combine_bwd(dout, y, expert, slot, weight, capacity):
-    """-> (d_y [E, cap, d] bf16 (zeros where no token sits), d_w [T] fp32)."""
+def moe_combine_bwd(dout, y, expert, slot, weight, capacity, top_k=1):
+    """-> (d_y [E, cap, d] bf16 (zeros where no token sits), d_w [top_k * T] fp32)."""
     T, d = dout.shape
     dy = torch.zeros_like(y)
-    dw = torch.empty(T, dtype=torch.float32, device=dout.device)
-    lib().call("mp_moe_combine_bwd_bf16", _p(dout), _p(y), _p(expert), _p(slot), _p(weight), _p(dy), _p(dw), T, d, int(capacity), _stream())
+    dw = torch.empty(T * top_k, dtype=torch.float32, device=dout.device)
+    lib().call("mp_moe_combine_bwd_bf16", _p(dout), _p(y), _p(expert), _p(slot), _p(weight), _p(dy), _p(dw), T, d, int(capacity), int(top_k),
+               _stream())
     return dy, dw
 
 
-def moe_gate_bwd(gates, expert, slot, dw, counts, c_aux, aux_coef):
+def moe_gate_bwd(gates, expert, slot, dw, first_counts, c_aux, aux_coef, top_k=1):
     T, E = gates.shape
     dl = torch.empty((T, E), dtype=torch.float32, device=gates.device)
-    lib().call("mp_moe_gate_bwd_f32", _p(gates), _p(expert), _p(slot), _p(dw), _p(counts), _p(c_aux), float(aux_coef), _p(dl), T, E, _stream())
+    lib().call("mp_moe_gate_bwd_f32", _p(gates), _p(expert), _p(slot), _p(dw), _p(first_counts), _p(c_aux), float(aux_coef), _p(dl), T, E,
+               int(top_k), _stream())
     return dl
 
 

@@ -1187,3 +1187,48 @@ def test_lora_training_icl_with_trainable_mask_encoder(dev):
         rel = (got.reshape(want.shape) - want).abs().max().item() / (want.abs().max().item() + 1e-12)
         print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
         assert want.abs().max().item() > 0 and rel < 0.08, n
+
+
+def test_lora_training_top2_moe_layers(dev):
+    """The ICL script's MoE defaults (train_ds_medplib.py:128-129: 3 experts, top-2): top2gating under training — both choices'
+    combine weights (the kept pair renormalised) feed the gate gradient, second choices picked with injected Gumbel noise, capacity
+    factor 1.0 so second choices get dropped; per-expert adapters, wg, aux loss.  vs the oracle's autograd."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_hidden_layers=2, num_experts=3, top_k_experts=2, capacity_factor=1.0,
+                             router_aux_loss_coef=0.05)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj")
+    g = torch.Generator().manual_seed(101)
+    Wl = dict(W); Wl["lora_scaling"] = 2.0
+    for n, p_ in zip(lora.names, lora.params):
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(dev)); Wl[n] = v.clone().requires_grad_(True)
+        else:
+            Wl[n] = W[n].clone().requires_grad_(True)
+    batch = OM.make_batch(cfg, 2, seed=8)
+    bq = dict(batch)
+    bq["images_clip"] = batch["images_clip"].to(torch.bfloat16).float(); bq["images"] = batch["images"].to(torch.bfloat16).float()
+    T = 2 * (batch["input_ids"].shape[1] - 1 + cfg.clip_num_patches)
+    u = {i: torch.rand(T, cfg.num_experts, generator=g).clamp_(1e-6, 1 - 1e-6) for i in range(cfg.num_hidden_layers)}
+    noise = {i: -torch.log(-torch.log(u[i])) for i in u}                      # Gumbel(0, 1)
+    m.model.llm.rts_uniform_provider = lambda i, T_, E_: noise[i].to(dev)
+    ref = OM.model_forward(bq, Wl, cfg, training=True, llm_grad=True, rts=noise)
+    ref["loss"].backward()
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(), config={"optimizer": {"params": {"lr": 1e-4}}})
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    out = eng(**gb)
+    _stat("top-2 moe lora loss", out["loss"], ref["loss"], atol=3e-2)
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p_ in zip(lora.names, lora.params):
+        want = Wl[n].grad
+        rel = (p_.grad.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        worst = max(worst, rel)
+        if n.endswith("wg.weight"):
+            print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
+        assert want.abs().max().item() > 0 and rel < 0.12, (n, rel)
+    print("worst relative gradient error (top-2 MoE + LoRA)", worst)
