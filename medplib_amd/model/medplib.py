@@ -333,6 +333,51 @@ class MedPLIBForCausalLM(nn.Module):
     def forward(self, **kwargs):
         return self.model_forward(**kwargs)
 
+    def _lora_training_forward(self, plan, feats, src, embeds, key_valid, sup_rows_d, sup_labels_d, region_masks, mask_images, B):
+        """LoRA / --sft_modules training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so
+        loss.backward() runs the whole decoder backward and leaves every trainable tensor's gradient in the engine's flat buffer.
+        Front-end modules that train (projector, token compressor, mask encoder, region adapter) are re-run on the autograd tape
+        from the frozen tensors the no-grad pass kept, and their rows replace the frozen ones in the feature block.
+        -> (last_hidden [B, S, d] with grad, ce [1] with grad)."""
+        from . import llama_lora as LL
+        cfg, m, dev = self.config, self.model, self.device_
+        lo = m.llm.lora
+        front = ("lm_head.weight", "model.embed_tokens.weight", "model.mm_projector.", "model.mm_token_compressor.", "model.region_fea_adapter.",
+                 "model.mask_encoder.")
+        decoder_params = [p_ for n_, p_ in zip(lo.names, lo.params) if not n_.startswith(front)]
+        feats_on_tape = False
+        proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
+        if proj_p[0] is not None:                                   # mm_projector trains (stage II)
+            assert self._last_raw is not None and feats.shape[0] == self._last_raw.shape[0], \
+                "a trainable mm_projector is built for the plain image layout (no compressor / ICL / region rows)"
+            feats, feats_on_tape = LL.ProjectorFn.apply(self._last_raw, m.vision_tower, *proj_p), True
+        reg_p = [lo.full_param(f"model.region_fea_adapter.{k}") for k in ("weight", "bias")]
+        if reg_p[0] is not None and region_masks is not None and len(region_masks) > 0:          # region_fea_adapter trains (stage IV)
+            rsel, xy_d, off_d, mi_d, hw_ = self._region_ctx
+            rnew = LL.RegionAdapterFn.apply(rsel, m.vision_tower, xy_d, off_d, mi_d, hw_, *reg_p)
+            feats, feats_on_tape = torch.cat([feats[:feats.shape[0] - rnew.shape[0]], rnew], 0), True   # region rows sit behind the image rows
+        menc_names = [n_ for n_ in lo.names if n_.startswith("model.mask_encoder.")]
+        if menc_names and mask_images is not None and len(mask_images) > 0:                      # mask_encoder trains (ICL)
+            mnew = LL.MaskEncoderFn.apply(self._mask_in, m.mask_encoder, *[lo.full_param(n_) for n_ in menc_names])
+            feats, feats_on_tape = torch.cat([feats[:feats.shape[0] - mnew.shape[0]], mnew], 0), True   # mask rows sit behind the image rows
+        comp_p = [lo.full_param(f"model.mm_token_compressor.{k}") for k in ("norm.weight", "norm.bias", "proj.weight", "proj.bias")]
+        if comp_p[0] is not None:                                   # mm_token_compressor trains (train_medplib_icl.sh)
+            cin, n_img = self._comp_in
+            new = LL.TokenCompressorFn.apply(cin, m.mm_token_compressor, n_img, cfg.clip_num_patches, *comp_p)
+            feats = new if feats.shape[0] == new.shape[0] else torch.cat([new, feats[new.shape[0]:]], 0)   # + mask / region rows
+            feats_on_tape = True
+        emb_p = lo.full_param("model.embed_tokens.weight")
+        if emb_p is not None or feats_on_tape:                      # the splice joins the autograd tape
+            embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
+        last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *decoder_params)
+        if sup_rows_d.numel():
+            ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight"))
+        else:
+            ce = torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+        if m.llm.moe_layers and cfg.router_aux_loss_coef != 0.0:
+            ce = ce + cfg.router_aux_loss_coef * aux_sum           # medplib_moe_llama.py:410-421
+        return last_hidden, ce
+
     def model_forward(self, images, images_clip, input_ids, labels, attention_mask=None, masks_list=None, label_list=None,
                       resize_list=None, region_masks=None, offset=None, inference=False, seg_flag=True, valid_mask_bool=None,
                       rp_flag=False, valid_region_masks_bool=None, attention_masks=None, **kwargs):
@@ -383,42 +428,8 @@ class MedPLIBForCausalLM(nn.Module):
                 last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
                 ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, aux)
         if lora_train and torch.is_grad_enabled() and self.training and not inference:
-            # LoRA training (llama_lora.py): the decoder, the CE and the <SEG>-row gather are autograd Functions, so loss.backward()
-            # runs the whole decoder backward and leaves the adapters' gradients in the engine's flat buffer
-            from . import llama_lora as LL
-            lo = m.llm.lora
-            own = [p_ for n_, p_ in zip(lo.names, lo.params) if n_ not in ("lm_head.weight", "model.embed_tokens.weight") and "mm_projector" not in n_
-                   and "mm_token_compressor" not in n_ and "region_fea_adapter" not in n_ and "mask_encoder" not in n_]
-            emb_p = lo.full_param("model.embed_tokens.weight")
-            proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
-            if proj_p[0] is not None:                               # mm_projector trains (stage II): recompute it on the autograd tape
-                assert self._last_raw is not None and feats.shape[0] == self._last_raw.shape[0], \
-                    "a trainable mm_projector is built for the plain image layout (no compressor / ICL / region rows)"
-                feats = LL.ProjectorFn.apply(self._last_raw, m.vision_tower, *proj_p)
-            reg_p = [lo.full_param(f"model.region_fea_adapter.{k}") for k in ("weight", "bias")]
-            if reg_p[0] is not None and region_masks is not None and len(region_masks) > 0:      # region_fea_adapter trains (stage IV)
-                rsel, xy_d, off_d, mi_d, hw_ = self._region_ctx
-                rnew = LL.RegionAdapterFn.apply(rsel, m.vision_tower, xy_d, off_d, mi_d, hw_, *reg_p)
-                feats = torch.cat([feats[:feats.shape[0] - rnew.shape[0]], rnew], 0)              # the region rows sit behind the image rows
-            else:
-                reg_p = [None, None]
-            menc_names = [n_ for n_ in lo.names if n_.startswith("model.mask_encoder.")]
-            if menc_names and kwargs.get("mask_images") is not None and len(kwargs["mask_images"]) > 0:   # mask_encoder trains (ICL)
-                mnew = LL.MaskEncoderFn.apply(self._mask_in, m.mask_encoder, *[lo.full_param(n_) for n_ in menc_names])
-                feats = torch.cat([feats[:feats.shape[0] - mnew.shape[0]], mnew], 0)                     # the mask rows sit behind the image rows
-                reg_p = [mnew, None]                                 # (marks the splice as differentiable below)
-            comp_p = [lo.full_param(f"model.mm_token_compressor.{k}") for k in ("norm.weight", "norm.bias", "proj.weight", "proj.bias")]
-            if comp_p[0] is not None:                               # mm_token_compressor trains (train_medplib_icl.sh)
-                cin, n_img = self._comp_in
-                new = LL.TokenCompressorFn.apply(cin, m.mm_token_compressor, n_img, cfg.clip_num_patches, *comp_p)
-                feats = new if feats.shape[0] == new.shape[0] else torch.cat([new, feats[new.shape[0]:]], 0)   # + mask / region rows
-            if emb_p is not None or proj_p[0] is not None or comp_p[0] is not None or reg_p[0] is not None:   # the splice joins the autograd tape
-                embeds = LL.EmbedSpliceFn.apply(emb_p, m.llm, feats, src, plan.src_code, (B, plan.seq_len, cfg.hidden_size))
-            last_hidden, aux_sum = LL.LlamaLoRAFn.apply(m.llm, embeds, key_valid, *own)
-            ce = LL.CrossEntropyFn.apply(last_hidden, sup_rows_d, sup_labels_d, m.llm, lo.full_param("lm_head.weight")) if sup_rows_d.numel() else \
-                torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
-            if m.llm.moe_layers and cfg.router_aux_loss_coef != 0.0:
-                ce = ce + cfg.router_aux_loss_coef * aux_sum       # medplib_moe_llama.py:410-421
+            last_hidden, ce = self._lora_training_forward(plan, feats, src, embeds, key_valid, sup_rows_d, sup_labels_d, region_masks,
+                                                          kwargs.get("mask_images"), B)
         elif lora_train:
             from . import llama_lora as LL
             with torch.no_grad():
