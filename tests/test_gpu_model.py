@@ -905,9 +905,13 @@ def test_lora_adapters_equal_merged_weights_and_entry_point(dev, tmp_path):
     assert m.model.lora is None
     h_live, _, _ = m.eval().model.llm.forward(emb, None)
     _stat("merge_and_unload vs checkpoint-side merge", h_live, h_merged, atol=0.0, rtol=2 ** -8)
-    hist = train.main(["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "6", "--lr", "2e-3",
-                       "--lora_r", "8", "--lora_dropout", "0.05", "--log_dir", str(tmp_path)])
+    argv = ["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "6", "--lr", "2e-3",
+            "--lora_r", "8", "--lora_dropout", "0.05", "--sft_modules", "mask_decoder,text_hidden_fcs,lm_head", "--log_dir", str(tmp_path)]
+    hist = train.main(argv)
     assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+    hist2 = train.main(argv[:6] + ["2"] + argv[7:])               # --epochs 2: resumes from the checkpoint (adapters + lm_head + AdamW state)
+    assert len(hist2) == 6 and all(np.isfinite(hist2))
+    assert open(os.path.join(str(tmp_path), "ckpt_model", "latest")).read().strip() == "global_step12"
 
 
 def test_lora_training_moe_layers_vs_oracle_autograd(dev):
