@@ -3,9 +3,10 @@
 `<log_dir>/ckpt_model/latest` (:453-470), loop `steps_per_epoch x grad_accumulation_steps` micro-batches per epoch with
 `engine(**batch) / backward / step`, all-reduce the meters every `print_freq` steps, save every `save_steps`, validate per epoch.
 
-Out of scope here: the datasets, image I/O, tokenizer and conversation templates.  `--dataset` therefore names either
-`synthetic` (the seeded generator of SURVEY §8d, used by the tests and the benchmark) or `package.module:factory`, a callable
-returning a torch Dataset whose items follow the collator's per-sample contract (medplib_amd/collate.py).
+`--dataset` names either `synthetic` (the seeded generator of SURVEY §8d, used by the tests and the benchmark) or
+`package.module:factory`, a callable `(args, cfg) -> (train, val)` of batch-indexed datasets (`data[i]` = one collated
+micro-batch); `medplib_amd.dataset:from_args` is the one for the reference's JSON data files (`--data_path --image_folder
+--tokenizer_path`, SURVEY §8f rank 3: v1 prompts, target masking, device-side image preprocessing, ICL assembly).
 
 One deliberate difference: the reference calls `.item()` on ten loss tensors after every micro-batch, i.e. synchronises the host
 with the GPU each step; here the meters keep device tensors and are read once per `print_freq` steps, so the host keeps running
@@ -34,6 +35,14 @@ def parse_args(argv=None):
     p.add_argument("--precision", default="bf16", choices=["bf16"])
     p.add_argument("--model_size", default="7b", choices=["7b", "tiny"])
     p.add_argument("--dataset", default="synthetic")
+    p.add_argument("--data_path", default="", help="training JSON (with --dataset medplib_amd.dataset:from_args)")
+    p.add_argument("--val_data_path", default="")
+    p.add_argument("--image_folder", default="")
+    p.add_argument("--tokenizer_path", default="", help="directory with the Llama tokenizer files")
+    p.add_argument("--model_max_length", default=512, type=int)
+    p.add_argument("--icl_enable", action="store_true", default=False)
+    p.add_argument("--icl_mask_mode", default="overlay", choices=["overlay", "separate"])
+    p.add_argument("--icl_mask_encoder", action="store_true", default=False)
     p.add_argument("--log_dir", default="./runs/medplib")
     p.add_argument("--epochs", default=1, type=int)
     p.add_argument("--steps_per_epoch", default=10, type=int)

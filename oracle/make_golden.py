@@ -492,6 +492,125 @@ def golden_preprocess():
     print("preprocess goldens ok")
 
 
+def dataset_text_cases():
+    """Records for the sample-assembly goldens (conversation JSON as the shipped data files hold it)."""
+    return [
+        {"name": "vqa_single", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "<image>\nWhat modality is this image?"}, {"from": "gpt", "value": "It is a CT scan."}]},
+        {"name": "image_tag_last_two_rounds", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "Describe the finding. <image>"}, {"from": "gpt", "value": "A round opacity."},
+            {"from": "human", "value": "Segment it."}, {"from": "gpt", "value": "Sure, it is <SEG>."}]},
+        {"name": "im_start_end", "has_image": True, "im_start_end": True, "conversations": [
+            {"from": "human", "value": "<image>\nIs there a mass?"}, {"from": "gpt", "value": "Yes <SEG>"}]},
+        {"name": "region_prompt", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "<image>\nWhat is in <region></region> of the scan?"}, {"from": "gpt", "value": "The liver."}]},
+        {"name": "leading_gpt_turn_is_skipped", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "gpt", "value": "ignored"}, {"from": "human", "value": "<image>\nOrgan?"}, {"from": "gpt", "value": "Kidney."}]},
+        {"name": "text_only_two_rounds", "has_image": False, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "Define pneumothorax."}, {"from": "gpt", "value": "Air in the pleural space."},
+            {"from": "human", "value": "Treatment?"}, {"from": "gpt", "value": "Chest drain\nif large."}]},
+        {"name": "several_image_tags_collapse", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "Example 1: <image>\nQuery: <image>\nSegment."}, {"from": "gpt", "value": "<SEG>"}]},
+        {"name": "answer_with_separator_text_breaks_round", "has_image": True, "im_start_end": False, "conversations": [
+            {"from": "human", "value": "<image>\nSay the word."}, {"from": "gpt", "value": "The word is ASSISTANT: ok"}]},
+    ]
+
+
+def golden_dataset():
+    """Sample assembly: the reference's own preprocess_multimodal / preprocess_v1 / tokenizer_image_token /
+    extract_masks_fun / generate_mask_with_sub_component (datasets/LazySupervisedDataset.py) and the ICL record helpers
+    (datasets/ICLLazySupervisedDataset.py, called unbound on a holder) executed on the records above with tests/toy_tokenizer.py.
+    cv2 is absent: the ONE cv2 call on these paths, `cv2.connectedComponents` (default 8-connectivity), is served by
+    scipy.ndimage.label with a 3x3 structure -- the sub-region goldens are therefore "reference control flow + scipy labels"."""
+    import importlib
+    import json
+    import random
+    import tempfile
+    import types
+    from PIL import Image
+    from scipy import ndimage
+    _import_reference_medplib()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from toy_tokenizer import ToyTokenizer
+    pkg = types.ModuleType("refds")
+    pkg.__path__ = [os.path.join(REF, "datasets")]
+    sys.modules["refds"] = pkg
+    L = importlib.import_module("refds.LazySupervisedDataset")
+    I = importlib.import_module("refds.ICLLazySupervisedDataset")
+    L.cv2.connectedComponents = lambda m: ndimage.label(m, structure=np.ones((3, 3), dtype=np.uint8))[::-1]
+    L.conversation_lib.default_conversation = L.conversation_lib.conv_templates["v1"]
+    tok = ToyTokenizer()
+    out = {"text": [], "tags": [], "subregion": [], "icl": [], "overlay": None}
+    for case in dataset_text_cases():
+        args = types.SimpleNamespace(is_multimodal=True, mm_use_im_start_end=case["im_start_end"])
+        convs = [json.loads(json.dumps(case["conversations"]))]
+        if case["has_image"]:
+            convs = L.preprocess_multimodal(convs, args)
+        ex = L.preprocess_v1(convs, tok, has_image=case["has_image"])
+        out["text"].append({"name": case["name"], "placed": convs, "input_ids": ex["input_ids"].tolist(), "labels": ex["labels"].tolist(),
+                            "conversations": ex["conversations"], "question": ex["question"], "gt": ex["gt"]})
+    # <mask> / <region> tags (files are opened: tiny PNGs in a temp folder)
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "m"))
+        Image.fromarray(np.array([[0, 7, 0], [255, 0, 1]], dtype=np.uint8)).save(os.path.join(root, "m", "a_mask.png"))
+        Image.fromarray(np.array([[0, 0], [3, 0]], dtype=np.uint8)).save(os.path.join(root, "r.png"))
+        src = {"conversations": [{"from": "human", "value": "<image>\nWhat is <region>r.png</region>? Segment it."},
+                                 {"from": "gpt", "value": "A cyst <SEG><mask>m/a_mask.png</mask>."}]}
+        rec = json.loads(json.dumps(src))
+        masks, _ = L.extract_masks_fun(rec, root, pattern=r"<mask>(.*?)</mask>")
+        regions, _ = L.extract_masks_fun(rec, root, pattern=r"<region>(.*?)</region>")
+        out["tags"].append({"source": src, "after": rec, "masks": [m.tolist() for m in masks], "regions": [m.tolist() for m in regions]})
+    # random sub-region of the largest component (24 x 24 patch-grid masks, the stage-IV parameters)
+    rng = np.random.default_rng(3)
+    grids = []
+    g = np.zeros((24, 24), dtype=np.float32); g[3:12, 4:15] = 1; g[18:21, 18:23] = 1; grids.append(g)          # two components
+    g = np.zeros((24, 24), dtype=np.float32); g[10:13, 10:12] = 1; grids.append(g)                              # below min_thresh
+    grids.append((rng.random((24, 24)) > 0.55).astype(np.float32))                                               # ragged
+    grids.append(np.zeros((24, 24), dtype=np.float32))                                                           # empty -> invalid
+    for seed, sel in ((0, [0]), (1, [1]), (2, [2]), (3, [0, 2]), (4, [3]), (5, [2, 3]), (6, [3, 0])):
+        random.seed(seed)
+        subs, ok = L.generate_mask_with_sub_component([grids[k] for k in sel], min_area=0.2, max_area=1, min_thresh=10)
+        out["subregion"].append({"seed": seed, "masks": [grids[k].astype(int).tolist() for k in sel],
+                                 "subs": [np.asarray(x).astype(int).tolist() for x in subs], "valid": bool(ok),
+                                 "next_draw": random.random()})
+    # ICL record helpers
+    ICL = I.ICLLazySupervisedDataset
+    records = [
+        {"image1": "e1.png", "mask1": "e1_m.png", "image2": "e2.png", "mask2": "e2_m.png", "image3": "q.png", "mask3": "q_m.png"},
+        {"image": "q.png", "target_mask": "q_m.png", "icl_examples": [{"image": "e1.png", "mask": "e1_m.png"}]},
+        {"image": "q.png", "mask": "q_m.png", "examples": [{"image": f"e{k}.png", "mask": f"e{k}_m.png"} for k in range(5)],
+         "conversations": [{"from": "human", "value": "A: <image>\nB: <image>\nC: <image>\nQ: <image>\nSegment."}, {"from": "gpt", "value": "<SEG>"}]},
+        {"image": "q.png", "examples": [{"image": "e0.png", "mask": "e0_m.png"}],
+         "conversations": [{"from": "human", "value": "<image>\nSegment."}, {"from": "gpt", "value": "<SEG>"}]},
+    ]
+    for rec in records:
+        for mode in ("overlay", "separate"):
+            holder = types.SimpleNamespace(data_args=types.SimpleNamespace(icl_mask_mode=mode))
+            for name in ("_mask_mode", "_expected_image_tokens", "_count_image_tokens", "_has_target_mask_tag", "_build_default_conversation"):
+                setattr(holder, name, types.MethodType(getattr(ICL, name), holder))
+            raw = json.loads(json.dumps(rec))
+            ex = ICL._get_flat_icl_examples(holder, raw)
+            prepared = ICL._prepare_source(holder, raw, len(ex))
+            out["icl"].append({"record": rec, "mode": mode, "examples": ex, "raw_after": raw, "prepared": prepared})
+    img = rng.integers(0, 256, (5, 6, 3), dtype=np.uint8)
+    m = (rng.random((5, 6)) > 0.5).astype(np.uint8)
+    out["overlay"] = {"image": img.tolist(), "mask": m.tolist(), "out": ICL._overlay_mask(None, img, m).tolist()}
+
+    # the restatement (medplib_amd/dataset.py is host logic of the product; checked here against what was just executed)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from medplib_amd import dataset as D
+    for case, exp in zip(dataset_text_cases(), out["text"]):
+        convs = [json.loads(json.dumps(case["conversations"]))]
+        if case["has_image"]:
+            D.place_image_token(convs, case["im_start_end"])
+        assert convs == exp["placed"], case["name"]
+        ex = D.build_v1_example(convs, tok, has_image=case["has_image"])
+        assert ex["input_ids"].tolist() == exp["input_ids"] and ex["labels"].tolist() == exp["labels"], case["name"]
+        assert ex["conversations"] == exp["conversations"] and ex["question"] == exp["question"] and ex["gt"] == exp["gt"]
+    json.dump(out, open(os.path.join(OUT, "dataset_reference.json"), "w"), indent=0, separators=(",", ":"))
+    print("dataset goldens ok:", {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["sam", "mask_head", "glue"]
@@ -505,3 +624,5 @@ if __name__ == "__main__":
         check_collate_contract()
     if "preprocess" in which:
         golden_preprocess()
+    if "dataset" in which:
+        golden_dataset()
