@@ -494,9 +494,10 @@ def load_tokenizer(path: str, model_max_length: int = 512, use_mm_start_end: boo
     return tok
 
 
-def from_args(args, cfg):
+def from_args(args, cfg, only_val: bool = False):
     """`train.py --dataset medplib_amd.dataset:from_args --data_path x.json --val_data_path y.json --image_folder DIR
     --tokenizer_path DIR [--icl_enable --icl_mask_mode separate --icl_mask_encoder]` -> (train batches, validation batches)."""
+    from .collate import collate
     tok = load_tokenizer(args.tokenizer_path, args.model_max_length, extra_tokens=("<SEG>", "<region>", "</region>"))
     dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -510,6 +511,16 @@ def from_args(args, cfg):
                                         mask_token_len=getattr(cfg, "mask_encoder_token_count", 64), clip_img_size=cfg.clip_image_size)
         return SupervisedDataset(path, tok, args.image_folder, device=dev, clip_img_size=cfg.clip_image_size)
 
+    if only_val:
+        val = CollatedBatches(make(args.val_data_path), 1, shuffle=False, collate_fn=lambda s: collate(s, inference=True))
+        val.tokenizer = tok
+        return val
     train = CollatedBatches(make(args.data_path), args.batch_size, seed=args.seed)
     val = CollatedBatches(make(args.val_data_path or args.data_path), 1, shuffle=False)
     return train, val
+
+
+def val_from_args(args, cfg):
+    """`infer.py --dataset medplib_amd.dataset:val_from_args --val_data_path y.json --image_folder DIR --tokenizer_path DIR`:
+    single-sample batches through the inference collator (vqa_infer.py:287-314)."""
+    return from_args(args, cfg, only_val=True)

@@ -611,8 +611,12 @@ class MedPLIBForCausalLM(nn.Module):
             img = images[b] if isinstance(images, (list, tuple)) else images[b:b + 1]
             if isinstance(images, (list, tuple)):
                 img = [img]
+            rm, rv = kwargs.get("region_masks") or (), kwargs.get("valid_region_masks_bool") or ()
+            if len(rm) > 0:            # the collator's flat list holds one entry per sample WITH regions: pick this row's
+                before = sum(1 for v in rv[:b] if any(v))
+                rm, rv = (rm[before:before + 1] if any(rv[b]) else ()), rv[b:b + 1]
             out, _ = self._greedy(row, img, max_new_tokens, eos_token_id, kwargs.get("mask_images"), kwargs.get("image_token_types"),
-                                  kwargs.get("image_token_lengths"))
+                                  kwargs.get("image_token_lengths"), rm, rv)
             rows.append(out[0])
         self.train(was_training)
         n = max(r.shape[0] for r in rows)

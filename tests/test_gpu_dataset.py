@@ -176,3 +176,34 @@ def test_icl_records_to_forward(dev, tmp_path):
     model = MedPLIBForCausalLM(cfg, device=dev).train()
     out = model(**dict_to_device(b, dev))
     assert np.isfinite(float(out["loss"].detach())) and float(out["mask_loss"].detach()) > 0 and float(out["ce_loss"].detach()) > 0
+
+
+def test_records_to_inference_loops(dev, tmp_path):
+    """vqa_infer.py control flow from JSON records: inference collator, prompt cut after the last "ASSISTANT:", evaluate / generate,
+    answers file."""
+    from medplib_amd import infer
+    from medplib_amd.model.config import MedPLIBConfig
+    from medplib_amd.model.medplib import MedPLIBForCausalLM
+    rng = np.random.default_rng(15)
+    _write_files(str(tmp_path), rng)
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2)
+    tok = ToyTokenizer(model_max_length=512, vocab_size=cfg.vocab_size, seg_token_idx=cfg.seg_token_idx)
+    ds = D.SupervisedDataset(_records()[:2], tok, str(tmp_path), device=dev, clip_img_size=cfg.clip_image_size)
+    val = D.CollatedBatches(ds, 1, shuffle=False, collate_fn=lambda s: collate(s, inference=True))
+    stub = tok(" ASSISTANT:", add_special_tokens=False).input_ids[-1]
+    b0 = val[0]
+    cut = infer.prompt_cut(b0["input_ids"], stub)
+    assert b0["inference"] and 0 < cut < b0["input_ids"].shape[1] and int(b0["input_ids"][0, cut - 1]) == stub
+    torch.manual_seed(0)
+    model = MedPLIBForCausalLM(cfg, device=dev).eval()
+    random.seed(1)
+    seg_only = D.CollatedBatches(D.SupervisedDataset(_records()[:1], tok, str(tmp_path), device=dev, clip_img_size=cfg.clip_image_size),
+                                 1, shuffle=False, collate_fn=lambda s: collate(s, inference=True))
+    miou, mdice, per = infer.validate_seg(seg_only, model, dev, max_new_tokens=6, colon_id=stub)     # segmentation records only
+    assert 0.0 <= miou <= 1.0 and 0.0 <= mdice <= 1.0 and list(per) == ["img0.png"]
+    random.seed(1)
+    outs = infer.run_vqa(val, model, dev, max_new_tokens=5, colon_id=stub, answers_file=str(tmp_path / "out" / "answers.jsonl"))
+    assert len(outs) == 2 and torch.as_tensor(outs[0]).shape[1] >= cut
+    lines = [json.loads(x) for x in open(tmp_path / "out" / "answers.jsonl")]
+    assert [r["question_id"] for r in lines] == [0, 1] and lines[0]["image_path"].endswith("img0.png")
+    assert lines[0]["prompt"] == ["<image>\nSegment the lesion."] and lines[1]["gt"] == ["The liver."] and len(lines[0]["output_ids"]) <= 5
