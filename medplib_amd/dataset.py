@@ -453,30 +453,40 @@ class ICLSupervisedDataset(SupervisedDataset):
 
 # ------------------------------------------------------------------------------------------------------- batches for train.py
 class CollatedBatches(torch.utils.data.Dataset):
-    """Batch-indexed view for `train.py` (`data[it]` = one collated micro-batch): item i = collate of samples
-    i*B .. i*B + B - 1 of a per-epoch permutation (seeded, the same on every call), wrapping around the end of the data."""
+    """Batch-indexed view for `train.py` (`data[it]` = one collated micro-batch).  The samples are walked in a per-epoch
+    permutation (seeded: the same on every rank and in every run) in strides of world * B; rank r takes the r-th B of each
+    stride, so the ranks' shards are disjoint like a DistributedSampler's (train_ds_medplib.py:430-450); the walk wraps around
+    the end of the data into the next epoch's permutation."""
 
-    def __init__(self, samples, batch_size: int, seed: int = 0, shuffle: bool = True, collate_fn=None):
+    def __init__(self, samples, batch_size: int, seed: int = 0, shuffle: bool = True, collate_fn=None, rank: int = 0, world: int = 1):
         from .collate import collate
         self.samples, self.B, self.seed, self.shuffle = samples, int(batch_size), int(seed), shuffle
+        self.rank, self.world = int(rank), int(world)
         self.collate = collate_fn or collate
+        self._perm = (None, None)
 
     def __len__(self):
-        return (len(self.samples) + self.B - 1) // self.B
+        return (len(self.samples) + self.B * self.world - 1) // (self.B * self.world)
 
     def _order(self, epoch):
-        n = len(self.samples)
-        if not self.shuffle:
-            return list(range(n))
-        return torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + epoch)).tolist()
+        if self._perm[0] != epoch:
+            n = len(self.samples)
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + epoch)).tolist() if self.shuffle else list(range(n))
+            self._perm = (epoch, order)
+        return self._perm[1]
 
-    def __getitem__(self, i):
+    def indices(self, i):
+        """Sample indices of this rank's i-th micro-batch."""
         n = len(self.samples)
+        first = (i * self.world + self.rank) * self.B
         picks = []
-        for j in range(i * self.B, i * self.B + self.B):
+        for j in range(first, first + self.B):
             epoch, k = divmod(j, n)
             picks.append(self._order(epoch)[k])
-        return self.collate([self.samples[k] for k in picks])
+        return picks
+
+    def __getitem__(self, i):
+        return self.collate([self.samples[k] for k in self.indices(i)])
 
 
 def load_tokenizer(path: str, model_max_length: int = 512, use_mm_start_end: bool = False, extra_tokens: Sequence[str] = ()):
@@ -515,7 +525,8 @@ def from_args(args, cfg, only_val: bool = False):
         val = CollatedBatches(make(args.val_data_path), 1, shuffle=False, collate_fn=lambda s: collate(s, inference=True))
         val.tokenizer = tok
         return val
-    train = CollatedBatches(make(args.data_path), args.batch_size, seed=args.seed)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    train = CollatedBatches(make(args.data_path), args.batch_size, seed=args.seed, rank=rank, world=world)
     val = CollatedBatches(make(args.val_data_path or args.data_path), 1, shuffle=False)
     return train, val
 

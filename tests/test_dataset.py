@@ -81,3 +81,20 @@ def test_icl_record_helpers(gold):
     o = gold["overlay"]
     out = D.overlay_mask(np.array(o["image"], dtype=np.uint8), np.array(o["mask"], dtype=np.uint8))
     assert out.dtype == np.uint8 and out.tolist() == o["out"]
+
+
+def test_collated_batches_shard_disjointly_across_ranks():
+    samples = list(range(23))
+    views = [D.CollatedBatches(samples, 3, seed=5, rank=r, world=2, collate_fn=lambda s: s) for r in range(2)]
+    assert len(views[0]) == 4
+    seen = []
+    for i in range(3):                       # 3 strides of 2 x 3 = 18 of the 23 samples, no repeats across ranks / steps
+        a, b = views[0][i], views[1][i]
+        assert len(a) == len(b) == 3 and not set(a) & set(b)
+        seen += a + b
+    assert len(set(seen)) == 18
+    assert views[0][3] != views[0][0] and len(views[0][3]) == 3          # wraps into the next epoch's permutation
+    again = D.CollatedBatches(samples, 3, seed=5, rank=0, world=2, collate_fn=lambda s: s)
+    assert [again[i] for i in range(4)] == [views[0][i] for i in range(4)]          # same order in every run
+    flat = D.CollatedBatches(samples, 4, shuffle=False, collate_fn=lambda s: s)
+    assert flat[0] == [0, 1, 2, 3] and flat[5] == [20, 21, 22, 0]
