@@ -540,15 +540,32 @@ def golden_dataset():
     L.cv2.connectedComponents = lambda m: ndimage.label(m, structure=np.ones((3, 3), dtype=np.uint8))[::-1]
     L.conversation_lib.default_conversation = L.conversation_lib.conv_templates["v1"]
     tok = ToyTokenizer()
-    out = {"text": [], "tags": [], "subregion": [], "icl": [], "overlay": None}
-    for case in dataset_text_cases():
-        args = types.SimpleNamespace(is_multimodal=True, mm_use_im_start_end=case["im_start_end"])
-        convs = [json.loads(json.dumps(case["conversations"]))]
-        if case["has_image"]:
-            convs = L.preprocess_multimodal(convs, args)
-        ex = L.preprocess_v1(convs, tok, has_image=case["has_image"])
-        out["text"].append({"name": case["name"], "placed": convs, "input_ids": ex["input_ids"].tolist(), "labels": ex["labels"].tolist(),
-                            "conversations": ex["conversations"], "question": ex["question"], "gt": ex["gt"]})
+    # a real sentencepiece model with the Llama settings, trained here on the case texts (deterministic; committed as a data fixture)
+    from toy_tokenizer import SentencePieceLlamaLike
+    sp_path = os.path.join(OUT, "tiny_llama_like_sp.model")
+    if not os.path.exists(sp_path):
+        import sentencepiece as spm
+        with tempfile.TemporaryDirectory() as td:
+            lines = [L.conversation_lib.conv_templates["v1"].system, "USER: ASSISTANT:"]
+            for case in dataset_text_cases():
+                lines += [t["value"].replace("<image>", " ").replace("<SEG>", " ") for t in case["conversations"]]
+            open(os.path.join(td, "c.txt"), "w").write("\n".join(lines * 8))
+            spm.SentencePieceTrainer.train(input=os.path.join(td, "c.txt"), model_prefix=os.path.join(td, "m"), vocab_size=420, model_type="bpe",
+                                           byte_fallback=True, character_coverage=1.0, unk_id=0, bos_id=1, eos_id=2, pad_id=-1,
+                                           add_dummy_prefix=True, normalization_rule_name="identity", remove_extra_whitespaces=False,
+                                           split_digits=True, minloglevel=2)
+            os.replace(os.path.join(td, "m.model"), sp_path)
+    sp_tok = SentencePieceLlamaLike(sp_path)
+    out = {"text": [], "text_sp": [], "tags": [], "subregion": [], "icl": [], "overlay": None}
+    for key, tk in (("text", tok), ("text_sp", sp_tok)):
+        for case in dataset_text_cases():
+            args = types.SimpleNamespace(is_multimodal=True, mm_use_im_start_end=case["im_start_end"])
+            convs = [json.loads(json.dumps(case["conversations"]))]
+            if case["has_image"]:
+                convs = L.preprocess_multimodal(convs, args)
+            ex = L.preprocess_v1(convs, tk, has_image=case["has_image"])
+            out[key].append({"name": case["name"], "placed": convs, "input_ids": ex["input_ids"].tolist(), "labels": ex["labels"].tolist(),
+                             "conversations": ex["conversations"], "question": ex["question"], "gt": ex["gt"]})
     # <mask> / <region> tags (files are opened: tiny PNGs in a temp folder)
     with tempfile.TemporaryDirectory() as root:
         os.makedirs(os.path.join(root, "m"))
@@ -599,14 +616,15 @@ def golden_dataset():
     # the restatement (medplib_amd/dataset.py is host logic of the product; checked here against what was just executed)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from medplib_amd import dataset as D
-    for case, exp in zip(dataset_text_cases(), out["text"]):
-        convs = [json.loads(json.dumps(case["conversations"]))]
-        if case["has_image"]:
-            D.place_image_token(convs, case["im_start_end"])
-        assert convs == exp["placed"], case["name"]
-        ex = D.build_v1_example(convs, tok, has_image=case["has_image"])
-        assert ex["input_ids"].tolist() == exp["input_ids"] and ex["labels"].tolist() == exp["labels"], case["name"]
-        assert ex["conversations"] == exp["conversations"] and ex["question"] == exp["question"] and ex["gt"] == exp["gt"]
+    for key, tk in (("text", tok), ("text_sp", sp_tok)):
+        for case, exp in zip(dataset_text_cases(), out[key]):
+            convs = [json.loads(json.dumps(case["conversations"]))]
+            if case["has_image"]:
+                D.place_image_token(convs, case["im_start_end"])
+            assert convs == exp["placed"], case["name"]
+            ex = D.build_v1_example(convs, tk, has_image=case["has_image"])
+            assert ex["input_ids"].tolist() == exp["input_ids"] and ex["labels"].tolist() == exp["labels"], case["name"]
+            assert ex["conversations"] == exp["conversations"] and ex["question"] == exp["question"] and ex["gt"] == exp["gt"]
     json.dump(out, open(os.path.join(OUT, "dataset_reference.json"), "w"), indent=0, separators=(",", ":"))
     print("dataset goldens ok:", {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()})
 

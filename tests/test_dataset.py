@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from toy_tokenizer import ToyTokenizer  # noqa: E402
+from toy_tokenizer import SentencePieceLlamaLike, ToyTokenizer  # noqa: E402
 
 from medplib_amd import dataset as D  # noqa: E402
 from oracle.make_golden import dataset_text_cases  # noqa: E402  (the input records; imports nothing from the reference)
@@ -39,6 +39,24 @@ def test_v1_prompt_and_target_masking_match_the_reference(gold):
     assert by_name["several_image_tags_collapse"]["input_ids"][0].count(D.IMAGE_TOKEN_INDEX) == 1
     assert by_name["region_prompt"]["input_ids"][0].count(D.REGION_TOKEN_INDEX) == 1
     assert all(v == D.IGNORE_INDEX for v in by_name["answer_with_separator_text_breaks_round"]["labels"][0])
+
+
+def test_target_masking_on_a_real_sentencepiece_model(gold, golden_dir):
+    """Same cases through a genuine sentencepiece BPE model with the Llama settings: the `- 2` bookkeeping holds (rows are
+    supervised, not blanked by the mismatch guard) and ids / labels equal the reference's."""
+    tok = SentencePieceLlamaLike(os.path.join(golden_dir, "tiny_llama_like_sp.model"))
+    assert tok("USER: hi ASSISTANT: ").input_ids[-1] == tok.sp.piece_to_id("\u2581")          # the lone trailing-space piece
+    for case, exp in zip(dataset_text_cases(), gold["text_sp"]):
+        convs = [copy.deepcopy(case["conversations"])]
+        if case["has_image"]:
+            D.place_image_token(convs, case["im_start_end"])
+        ex = D.build_v1_example(convs, tok, has_image=case["has_image"])
+        assert ex["input_ids"].tolist() == exp["input_ids"] and ex["labels"].tolist() == exp["labels"], case["name"]
+        n_sup = sum(v != D.IGNORE_INDEX for v in exp["labels"][0])
+        assert (n_sup == 0) == (case["name"] == "answer_with_separator_text_breaks_round"), case["name"]
+        if n_sup:       # the supervised ids decode to exactly the assistant turns, each closed by </s>
+            sup = [i for i, l in zip(exp["input_ids"][0], exp["labels"][0]) if l != D.IGNORE_INDEX]
+            assert sup.count(2) == len(exp["gt"])
 
 
 def test_generation_stub_prompt():

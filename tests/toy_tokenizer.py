@@ -58,3 +58,25 @@ class ToyTokenizer:
                 out[i, :len(r)] = torch.tensor(r, dtype=torch.long)
             return SimpleNamespace(input_ids=out)
         return SimpleNamespace(input_ids=rows)
+
+
+class SentencePieceLlamaLike(ToyTokenizer):
+    """The same interface over a REAL sentencepiece BPE model (tests/golden/tiny_llama_like_sp.model: byte fallback, identity
+    normalisation, dummy prefix, no whitespace stripping -- the Llama settings), with the legacy slow-tokenizer rule that every
+    text segment between special tokens is encoded on its own.  Pins the length bookkeeping of the target masking on genuine
+    sentencepiece behaviour (merges across word boundaries, the lone trailing-space piece)."""
+
+    def __init__(self, model_file, model_max_length=2048):
+        import sentencepiece as spm
+        self.sp = spm.SentencePieceProcessor(model_file=model_file)
+        self.model_max_length = model_max_length
+        n = self.sp.get_piece_size()
+        self.special_ids = {"</s>": 2, "<SEG>": n, "<region>": n + 1, "</region>": n + 2, "<im_start>": n + 3, "<im_end>": n + 4}
+
+    def _pieces(self, text):
+        ids = []
+        for seg in _SPLIT.split(text):
+            if seg == "":
+                continue
+            ids.extend([self.special_ids[seg]] if seg in self.special_ids else self.sp.encode(seg))
+        return ids
