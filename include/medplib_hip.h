@@ -367,6 +367,10 @@ int mp_resample_axis_u8(const void* src, void* dst, int64_t outer, int in_len, i
  * SAM `(x - pixel_mean) / pixel_std` then zero pad; CLIP integer-mean pad then CLIPImageProcessor rescale + normalise. */
 int mp_image_table_pad_chw(const void* src, int h, int w, int C, const float* table, const float* pad, void* dst, int size_h,
                            int size_w, int top, int left, int out_dtype, hipStream_t stream);
+/* uint8 HWC [n_pixels, 3] image + uint8 [n_pixels] mask -> out: where mask > 0, trunc(clip(pixel * 0.45 + tint * 0.55)) in float32
+ * (three separately rounded operations, as numpy does it), else the pixel.  ICLLazySupervisedDataset._overlay_mask (:46-50). */
+int mp_overlay_mask_u8(const void* img, const void* mask, void* out, int64_t n_pixels, float tint_r, float tint_g, float tint_b,
+                       hipStream_t stream);
 
 /* ---- optimizer (train_ds_medplib.py:383-420: AdamW betas (0.9,0.95), wd 0, clip 1.0) ------------------------------ */
 /* out_accum[0] += sum(x^2); out_accum must hold 1 + 256 floats (out_accum[1..256] = per-block partials, summed in index order: the

@@ -87,6 +87,23 @@ __global__ void image_table_pad_chw_kernel(const uint8_t* __restrict__ src, int 
 
 }  // namespace
 
+// ICL overlay mode (ICLLazySupervisedDataset._overlay_mask, :46-50): where the example's mask is set, pixel = trunc(clip(pixel * 0.45f +
+// tint * 0.55f, 0, 255)) in float32 with the two products rounded before the add (numpy evaluates `a * 0.45 + c * 0.55` as three
+// separate float32 operations: no fused multiply-add here either).  One thread per pixel, 3 channels.
+__global__ void overlay_mask_u8_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask, uint8_t* __restrict__ out,
+                                       int64_t n_pixels, float t0, float t1, float t2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  const bool on = mask[i] > 0;
+  const float tint[3] = {t0, t1, t2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const uint8_t p = img[i * 3 + c];
+    const float v = __fadd_rn(__fmul_rn((float)p, 0.45f), __fmul_rn(tint[c], 0.55f));
+    out[i * 3 + c] = on ? (uint8_t)fminf(fmaxf(v, 0.f), 255.f) : p;
+  }
+}
+
 extern "C" int mp_pil_bilinear_ksize(int in_size, int out_size) {
   if (in_size <= 0 || out_size <= 0) return 0;
   double filterscale = (double)((float)in_size - 0.0f) / out_size;
@@ -163,4 +180,13 @@ extern "C" int mp_image_table_pad_chw(const void* src, int h, int w, int C, cons
     hipLaunchKernelGGL(image_table_pad_chw_kernel<bf16_t>, grid, blk, 0, stream, (const uint8_t*)src, h, w, C, table, pad,
                        (bf16_t*)dst, size_h, size_w, top, left);
   return mp_check_launch("mp_image_table_pad_chw");
+}
+
+extern "C" int mp_overlay_mask_u8(const void* img, const void* mask, void* out, int64_t n_pixels, float tint_r, float tint_g,
+                                  float tint_b, hipStream_t stream) {
+  MP_REQUIRE(n_pixels >= 0, MP_ERR_SHAPE, "mp_overlay_mask_u8: bad size");
+  if (n_pixels == 0) return MP_OK;
+  hipLaunchKernelGGL(overlay_mask_u8_kernel, dim3((unsigned)mp_cdiv(n_pixels, 256)), dim3(256), 0, stream, (const uint8_t*)img,
+                     (const uint8_t*)mask, (uint8_t*)out, n_pixels, tint_r, tint_g, tint_b);
+  return mp_check_launch("mp_overlay_mask_u8");
 }

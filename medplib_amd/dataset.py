@@ -268,7 +268,8 @@ def icl_prepare_source(source: Dict, n_examples: int, mask_mode: str) -> Dict:
 
 
 def overlay_mask(image_rgb: np.ndarray, mask: np.ndarray) -> np.ndarray:
-    """Blue 55 % overlay of the reference mask on an example image, float32 arithmetic, truncation to uint8 (:46-50)."""
+    """Blue 55 % overlay of the reference mask on an example image, float32 arithmetic, truncation to uint8 (:46-50).  Host
+    statement of `preprocess.overlay_mask` (the device kernel the dataset uses); kept for the goldens and as documentation."""
     tint = np.array([118, 158, 224], dtype=np.float32)
     img = image_rgb.astype(np.float32)
     on = mask > 0
@@ -431,7 +432,8 @@ class ICLSupervisedDataset(SupervisedDataset):
                     clips.append(clip(np.stack([grey, grey, grey], -1))); kinds.append("image"); lens.append(self.image_token_len)
                 paths += [ex_path, self.resolve(ex["mask"])]
             else:
-                clips.append(clip(overlay_mask(ex_rgb, ex_mask))); kinds.append("image"); lens.append(self.image_token_len)
+                tinted = P.overlay_mask(self._dev(ex_rgb), self._dev(ex_mask))              # device twin of overlay_mask()
+                clips.append(P.preprocess_clip(tinted, self.clip_img_size)); kinds.append("image"); lens.append(self.image_token_len)
                 paths.append(ex_path)
         clips.append(clip(target_rgb)); kinds.append("image"); lens.append(self.image_token_len)
 

@@ -133,3 +133,16 @@ def preprocess_region_mask(mask, size=336):
     top, left = (size - h) // 2, (size - w) // 2
     out[top:top + h, left:left + w] = r
     return out
+
+
+ICL_TINT = (118.0, 158.0, 224.0)                    # ICLLazySupervisedDataset._overlay_mask (:47)
+
+
+def overlay_mask(img_rgb, mask):
+    """CUDA uint8 [H, W, 3] image, uint8 [H, W] mask -> the example image with the mask tinted in (ICL overlay mode, :46-50)."""
+    assert img_rgb.dtype == torch.uint8 and mask.dtype == torch.uint8 and img_rgb.is_cuda and mask.is_cuda
+    img_rgb, mask = img_rgb.contiguous(), mask.contiguous()
+    assert img_rgb.shape[:2] == mask.shape and img_rgb.shape[2] == 3
+    out = torch.empty_like(img_rgb)
+    lib().call("mp_overlay_mask_u8", ops._p(img_rgb), ops._p(mask), ops._p(out), mask.numel(), *ICL_TINT, ops._stream())
+    return out

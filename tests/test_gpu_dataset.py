@@ -207,3 +207,16 @@ def test_records_to_inference_loops(dev, tmp_path):
     lines = [json.loads(x) for x in open(tmp_path / "out" / "answers.jsonl")]
     assert [r["question_id"] for r in lines] == [0, 1] and lines[0]["image_path"].endswith("img0.png")
     assert lines[0]["prompt"] == ["<image>\nSegment the lesion."] and lines[1]["gt"] == ["The liver."] and len(lines[0]["output_ids"]) <= 5
+
+
+def test_overlay_kernel_equals_the_reference_arithmetic(dev, golden_dir):
+    from medplib_amd import preprocess as P
+    o = json.load(open(os.path.join(golden_dir, "dataset_reference.json")))["overlay"]        # the reference's _overlay_mask, executed
+    img, m = np.array(o["image"], dtype=np.uint8), np.array(o["mask"], dtype=np.uint8)
+    got = P.overlay_mask(torch.from_numpy(img).to(dev), torch.from_numpy(m).to(dev))
+    assert got.cpu().numpy().tolist() == o["out"]
+    rng = np.random.default_rng(2)                                                              # every byte value, ragged size
+    img = rng.integers(0, 256, (131, 77, 3), dtype=np.uint8); img.reshape(-1)[:256] = np.arange(256)
+    m = (rng.random((131, 77)) > 0.4).astype(np.uint8) * rng.integers(1, 256, (131, 77)).astype(np.uint8)
+    got = P.overlay_mask(torch.from_numpy(img).to(dev), torch.from_numpy(m).to(dev))
+    assert np.array_equal(got.cpu().numpy(), D.overlay_mask(img, m))
