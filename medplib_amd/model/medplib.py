@@ -10,6 +10,7 @@ Dead work the reference performs but never consumes is not executed (results are
 full-vocabulary fp32 logits for unsupervised rows, text_hidden_fcs on non-<SEG> rows, the 32 intermediate hidden
 states, CLIP's last layer, mask tokens 1-3."""
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -150,8 +151,8 @@ class MedPLIBForCausalLM(nn.Module):
 
     def _require_merged(self, what):
         if getattr(self.model, "lora", None) is not None:
-            raise RuntimeError(f"{what}() decodes with the KV cache on the plain weights: call merge_and_unload() first (the reference "
-                               "merges its adapters before inference too, merge_lora_weights_and_save_hf_model_moe.py)")
+            raise RuntimeError(f"{what}() works on the plain weights (KV-cache decode, export): call merge_and_unload() first (the "
+                               "reference merges its adapters before inference too, merge_lora_weights_and_save_hf_model_moe.py)")
 
     def merge_and_unload(self):
         """peft `merge_and_unload()`: fold the trained adapters into the weights and drop them; inference / evaluate() / export then see
@@ -201,6 +202,39 @@ class MedPLIBForCausalLM(nn.Module):
             m.mm_token_compressor.load_hf(sd)
         if m.mask_encoder is not None:
             m.mask_encoder.load_hf(sd)
+
+    def hf_state_dict(self):
+        """Every weight in the reference's checkpoint key layout (what `model.state_dict()` of the reference class holds after
+        `merge_and_unload()`, merge_lora_weights_and_save_hf_model_moe.py:338-343): `model.layers.*` / `lm_head` /
+        `model.vision_tower.*` / `model.mm_projector.*` / `model.visual_model.*` / `model.text_hidden_fcs.*` (+ the ICL modules and
+        the region adapter).  Adapters must be merged first.  `load_hf_state_dict(hf_state_dict())` is the identity."""
+        self.sync_side_streams()
+        self._require_merged("hf_state_dict")
+        m = self.model
+        sd = dict(m.llm.export_hf())
+        sd.update(m.vision_tower.export_hf())
+        vm = m.visual_model
+        sd.update(vm.image_encoder.export_ref("model.visual_model.image_encoder."))
+        for name, mod in (("mask_decoder", vm.mask_decoder), ("prompt_encoder", vm.prompt_encoder)):
+            sd.update({f"model.visual_model.{name}.{k}": v for k, v in mod.state_dict().items()})
+        sd.update({"model.text_hidden_fcs." + k: v for k, v in m.text_hidden_fcs.state_dict().items()})
+        if m.mm_token_compressor is not None:
+            sd.update(m.mm_token_compressor.export_hf())
+        if m.mask_encoder is not None:
+            sd.update(m.mask_encoder.export_hf())
+        return {k: v.detach() for k, v in sd.items()}
+
+    def save_pretrained(self, save_path, state_dict=None):
+        """`<save_path>/pytorch_model.bin` (one torch.save file, tensors on the host) + `config.json` with this build's config
+        fields -- the hand-over to the reference's inference scripts after training / merging here."""
+        import dataclasses
+        import json
+        os.makedirs(save_path, exist_ok=True)
+        sd = state_dict if state_dict is not None else self.hf_state_dict()
+        torch.save({k: v.detach().cpu() for k, v in sd.items()}, os.path.join(save_path, "pytorch_model.bin"))
+        cfg = dataclasses.asdict(self.config) if dataclasses.is_dataclass(self.config) else dict(vars(self.config))
+        json.dump({k: (list(v) if isinstance(v, (tuple, set)) else v) for k, v in cfg.items()}, open(os.path.join(save_path, "config.json"), "w"),
+                  indent=1, default=str)
 
     def load_sam_state_dict(self, sd):
         """`torch.load(path)['model']` key layout of SAM-Med2D checkpoints (build_sam.py:123-128), loaded non-strict."""

@@ -87,6 +87,35 @@ class SamImageEncoder:
         put(self.neck2, sd[prefix + "neck.2.weight"].permute(0, 2, 3, 1).reshape(O, 9 * O))
         put(self.neck3[0], sd[prefix + "neck.3.weight"]); put(self.neck3[1], sd[prefix + "neck.3.bias"])
 
+    def export_ref(self, prefix="image_encoder."):
+        """Inverse of load_ref: the kernel-layout weights back in the SAM-Med2D checkpoint layout (conv kernels un-flattened, the
+        four parity classes of the adapter's transposed convolution scattered back into its [ci, co, 4, 4] kernel)."""
+        C, O = self.cfg.sam_embed_dim, self.cfg.sam_out_chans
+        sd = {prefix + "patch_embed.proj.weight": self.patch_w.reshape(C, 3, 16, 16), prefix + "patch_embed.proj.bias": self.patch_b,
+              prefix + "pos_embed": self.pos.reshape(1, self.cfg.sam_grid, self.cfg.sam_grid, C)}
+        for i, b in enumerate(self.blocks):
+            p = f"{prefix}blocks.{i}."
+            for n, k in (("norm1", "norm1"), ("norm2", "norm2"), ("Adapter.norm", "ad_norm")):
+                sd[p + n + ".weight"], sd[p + n + ".bias"] = b[k][0], b[k][1]
+            sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"] = b["qkv_w"], b["qkv_b"]
+            sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = b["proj_w"], b["proj_b"]
+            sd[p + "attn.rel_pos_h"], sd[p + "attn.rel_pos_w"] = b["rph"], b["rpw"]
+            sd[p + "mlp.lin1.weight"], sd[p + "mlp.lin1.bias"] = b["lin1_w"], b["lin1_b"]
+            sd[p + "mlp.lin2.weight"], sd[p + "mlp.lin2.bias"] = b["lin2_w"], b["lin2_b"]
+            sd[p + "Adapter.channel.0.weight"], sd[p + "Adapter.channel.2.weight"] = b["ch0"], b["ch2"]
+            sd[p + "Adapter.spatial.0.weight"] = b["sp0"].reshape(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+            wt = torch.zeros((C, C, 4, 4), dtype=b["sp2"][0].dtype, device=b["sp2"][0].device)
+            for cls in range(4):
+                packed = b["sp2"][cls].reshape(C, 4, C)                           # [co, tap, ci]
+                for t, ((ky, kx), _) in enumerate(_convt_parity_taps(cls >> 1, cls & 1)):
+                    wt[:, :, ky, kx] = packed[:, t, :].t()
+            sd[p + "Adapter.spatial.2.weight"] = wt
+        sd[prefix + "neck.0.weight"] = self.neck0.reshape(O, C, 1, 1)
+        sd[prefix + "neck.1.weight"], sd[prefix + "neck.1.bias"] = self.neck1
+        sd[prefix + "neck.2.weight"] = self.neck2.reshape(O, 3, 3, O).permute(0, 3, 1, 2).contiguous()
+        sd[prefix + "neck.3.weight"], sd[prefix + "neck.3.bias"] = self.neck3
+        return sd
+
     # ------------------------------------------------------------------ forward
     def _adapter(self, xn, blk, B):
         """Adapter_Layer.forward on the norm2 output (image_encoder.py:43-56): LN(x + spatial(channel_gate(x) * x))."""

@@ -1236,3 +1236,99 @@ def test_lora_training_top2_moe_layers(dev):
             print(f"{n}: relative error {rel:.3f} (grad absmax {want.abs().max().item():.3e})")
         assert want.abs().max().item() > 0 and rel < 0.12, (n, rel)
     print("worst relative gradient error (top-2 MoE + LoRA)", worst)
+
+
+def test_export_in_the_reference_checkpoint_layout_round_trips(dev, tmp_path):
+    """hf_state_dict() / save_pretrained(): every key of the reference-layout weights the model was loaded from comes back with the
+    same (bf16-rounded) values -- incl. the SAM adapter's conv / transposed-conv kernels, which live in a packed kernel layout --
+    and a second model loaded from the saved file computes the same losses bit for bit.  After LoRA training the export needs
+    merge_and_unload() first."""
+    from medplib_amd.model.medplib import MedPLIBForCausalLM
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, mm_token_compress=True, mm_compressed_token_count=8, icl_mask_encoder=True,
+                             mask_encoder_token_count=4)
+    W = {k: (v.to(torch.bfloat16).float() if torch.is_tensor(v) and v.is_floating_point() else v)
+         for k, v in OM.init_hf_weights(cfg).items()}          # a bf16 checkpoint, as the reference's are
+    m = _model(cfg, dev, W).train()
+    sd = m.hf_state_dict()
+    missing = [k for k in W if k not in sd]
+    assert not missing, missing[:8]
+    worst = 0.0
+    for k, v in W.items():
+        got = sd[k].detach().float().cpu().reshape(-1)
+        ref = torch.as_tensor(v).float().reshape(-1)
+        assert got.numel() == ref.numel(), k
+        err = float((got - ref).abs().max())
+        worst = max(worst, err)
+        assert err == 0.0, (k, err, sd[k].dtype)
+    print(f"  export: {len(sd)} keys, worst difference to the loaded weights {worst:.2e}")
+    m.save_pretrained(str(tmp_path / "hf"))
+    saved = torch.load(tmp_path / "hf" / "pytorch_model.bin")
+    assert set(saved) == set(sd) and os.path.exists(tmp_path / "hf" / "config.json")
+    torch.manual_seed(3)
+    m2 = MedPLIBForCausalLM(cfg, device=dev).train()          # its own random init, then everything overwritten from the file
+    m2.load_hf_state_dict(saved)
+    sd2 = m2.hf_state_dict()
+    for k in sd:
+        assert torch.equal(sd[k].cpu(), sd2[k].cpu()), k
+    batch = OM.make_batch_icl(cfg, 2, n_ctx=1)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
+    torch.manual_seed(0); o1 = m(**gb)
+    torch.manual_seed(0); o2 = m2(**gb)
+    for k in O.LOSS_KEYS:
+        assert float(o1[k].detach()) == float(o2[k].detach()), k
+    m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="q_proj,v_proj")
+    with pytest.raises(RuntimeError):
+        m.hf_state_dict()
+    m.merge_and_unload()
+    assert set(m.hf_state_dict()) == set(sd)
+
+
+def test_merge_entry_point_both_checkpoint_kinds(dev, tmp_path):
+    """medplib_amd.merge (the reference's merge_lora_weights_and_save_hf_model_moe.py): (a) a peft-layout state dict folded on the
+    host, (b) this build's own training checkpoint folded through merge_and_unload(); both against W + alpha/r * B @ A."""
+    from medplib_amd import merge, train
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2)
+    flags = ["--model_size", "tiny", "--lora_r", "8", "--lora_alpha", "16", "--lora_dropout", "0.0", "--lora_target_modules", "q_proj,down_proj"]
+    # a base checkpoint in the reference layout
+    torch.manual_seed(1)
+    base = _model(cfg, dev, {k: (v.to(torch.bfloat16).float() if torch.is_tensor(v) and v.is_floating_point() else v)
+                             for k, v in OM.init_hf_weights(cfg).items()})
+    base.save_pretrained(str(tmp_path / "base"))
+    base_sd = torch.load(tmp_path / "base" / "pytorch_model.bin")
+    # (b) train a few steps from it with this build's entry point, then merge the checkpoint directory
+    train.main(flags + ["--version", str(tmp_path / "base" / "pytorch_model.bin"), "--log_dir", str(tmp_path / "run"), "--steps_per_epoch", "3",
+                        "--batch_size", "2", "--no_eval", "--lr", "3e-3"])
+    m = merge.main(["--weight", str(tmp_path / "run" / "ckpt_model"), "--save_path", str(tmp_path / "merged_b"),
+                    "--version", str(tmp_path / "base" / "pytorch_model.bin")] + flags)
+    out_b = torch.load(tmp_path / "merged_b" / "pytorch_model.bin")
+    assert set(out_b) == set(base_sd)
+    ck = torch.load(tmp_path / "run" / "ckpt_model" / open(tmp_path / "run" / "ckpt_model" / "latest").read().strip() / "mp_rank_00_model_states.pt")
+    changed = [k for k in base_sd if not torch.equal(base_sd[k], out_b[k])]
+    assert any("q_proj" in k for k in changed) and any("down_proj" in k for k in changed) and any("mask_decoder" in k for k in changed)
+    assert not any((k.startswith("model.layers.") and ("k_proj" in k or "gate_proj" in k)) or "vision_tower" in k for k in changed)
+    # (a) the same fine-tune as a peft-layout file: base weights under base_layer + the trained adapters + the trained tail
+    torch.manual_seed(1)
+    tuned = _model(cfg, dev, base_sd)
+    tuned.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="q_proj,down_proj",
+                      sft_modules="mask_decoder,text_hidden_fcs")                  # what train.py's defaults built
+    named = dict(tuned.named_parameters())
+    for n, v in ck["module"].items():
+        named[n].data.copy_(v)
+    peft = dict(tuned.model.lora.peft_state_dict())
+    targets = {k[len("base_model.model."):].split(".lora_")[0] for k in peft}
+    for k, v in out_b.items():                      # non-LLM tensors as trained; LLM weights as in the base (peft keeps them frozen)
+        src = base_sd[k] if (k.startswith("model.layers.") or k in ("lm_head.weight", "model.embed_tokens.weight", "model.norm.weight")) else v
+        name = k[:-len(".weight")] if k.endswith(".weight") else k
+        peft["base_model.model." + (name + ".base_layer.weight" if name in targets else k)] = src
+    torch.save(peft, tmp_path / "peft.bin")
+    merge.main(["--weight", str(tmp_path / "peft.bin"), "--save_path", str(tmp_path / "merged_a"),
+                "--version", str(tmp_path / "base" / "pytorch_model.bin")] + flags)
+    out_a = torch.load(tmp_path / "merged_a" / "pytorch_model.bin")
+    worst = 0.0
+    for k in out_b:
+        d = float((out_a[k].float() - out_b[k].float()).abs().max())
+        worst = max(worst, d / max(float(out_b[k].float().abs().max()), 1e-6))
+    print(f"  merge: host fold vs merge_and_unload, worst difference {worst:.2e} of the tensor's largest entry")
+    assert worst < 1e-2          # one bf16 rounding of W + delta on either path
