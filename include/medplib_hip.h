@@ -53,6 +53,9 @@ const char* mp_last_error_string(void);
 int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
                     const void* residual, int64_t ldr, int M, int N, int K, int act, int out_dtype, float alpha,
                     const int* m_dev, hipStream_t stream);
+/* 256 or 128: the tile size of the kernel the calling thread's last mp_gemm_bf16_nt* call dispatched to (0 before the first call).
+ * Measurement aid: bench.py attributes its HIP-event samples to gemm256v3_bf16_nt_kernel / gemm_bf16_nt_kernel with it. */
+int mp_gemm_last_kernel(void);
 /* `batch` independent GEMMs at fixed strides — the per-expert SwiGLU GEMMs of DeepSpeed `Experts`
  * (call site medplib_moe_llama.py:604-614). m_dev[b] = rows routed to expert b. */
 int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,

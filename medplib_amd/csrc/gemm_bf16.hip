@@ -307,7 +307,7 @@ static int gemm_group_m() {
   return v;
 }
 
-static bool use_256(const GemmArgs& g, int batch) {
+static bool use_256_rule(const GemmArgs& g, int batch) {
   if (g.act == ACT_SWIGLU_PAIR) return true;          // the paired epilogue exists in the 256x256 kernel only
   if (batch > 8) return false;                        // its flat work decode walks at most 8 batches
   if (gemm_variant() != 2) return false;
@@ -326,6 +326,15 @@ static bool use_256(const GemmArgs& g, int batch) {
   if (shortk && g.K <= 1024 && tiles > 256 && (tiles % 256) > 0 && (tiles % 256) < 128) return false;
   return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
 }
+
+// which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)
+static thread_local int g_last_gemm_kernel = 0;
+static bool use_256(const GemmArgs& g, int batch) {
+  const bool big = use_256_rule(g, batch);
+  g_last_gemm_kernel = big ? 256 : 128;
+  return big;
+}
+extern "C" int mp_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
 // implemented in gemm256_bf16.hip: the registered split-K scratch (mp_gemm_set_workspace)
 void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);

@@ -37,10 +37,11 @@ class KernelTimer:
     stride is coprime to the 4-GEMM period of a decoder layer, so the sample walks through every GEMM shape of the step."""
 
     def __init__(self, sample_every=11):
-        self.records = []          # (work, start_event, end_event) of the sampled launches
+        self.records = []          # (work, start_event, end_event, kernel) of the sampled launches
         self.sample_every = max(1, int(sample_every))
         self.launches = 0
         self.total_work = 0.0
+        self.per_kernel = {}       # kernel tile (256 / 128) -> [launches, work] over ALL launches
 
     def begin(self):
         self.launches += 1
@@ -52,16 +53,24 @@ class KernelTimer:
 
     def end(self, work, start):
         self.total_work += work
+        kern = int(lib().raw("mp_gemm_last_kernel")())
+        acc = self.per_kernel.setdefault(kern, [0, 0.0])
+        acc[0] += 1; acc[1] += work
         if start is None:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((work, start, ev))
+        self.records.append((work, start, ev, kern))
 
-    def summary(self):
-        """-> (sampled work, sampled ms, sampled launches, all launches, all work) after a synchronize."""
-        total_ms = sum(s.elapsed_time(e) for _, s, e in self.records)
-        return sum(w for w, _, _ in self.records), total_ms, len(self.records), self.launches, self.total_work
+    def summary(self, kernel=None):
+        """-> (sampled work, sampled ms, sampled launches, all launches, all work) after a synchronize; `kernel` = 256 / 128
+        restricts everything to the launches that went to that kernel."""
+        recs = [r for r in self.records if kernel is None or r[3] == kernel]
+        total_ms = sum(s.elapsed_time(e) for _, s, e, _ in recs)
+        if kernel is None:
+            return sum(r[0] for r in recs), total_ms, len(recs), self.launches, self.total_work
+        n, w = self.per_kernel.get(kernel, [0, 0.0])
+        return sum(r[0] for r in recs), total_ms, len(recs), n, w
 
 
 GEMM_TIMER = None     # set to a KernelTimer by bench.py
