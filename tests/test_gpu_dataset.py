@@ -220,3 +220,31 @@ def test_overlay_kernel_equals_the_reference_arithmetic(dev, golden_dir):
     m = (rng.random((131, 77)) > 0.4).astype(np.uint8) * rng.integers(1, 256, (131, 77)).astype(np.uint8)
     got = P.overlay_mask(torch.from_numpy(img).to(dev), torch.from_numpy(m).to(dev))
     assert np.array_equal(got.cpu().numpy(), D.overlay_mask(img, m))
+
+
+def test_entry_points_on_json_records(dev, tmp_path, monkeypatch):
+    """train.py / infer.py with `--dataset medplib_amd.dataset:{from_args,val_from_args}` on JSON files (the tokenizer files are
+    not in the image: `load_tokenizer` is replaced by the toy tokenizer, everything else is the shipped code path)."""
+    from medplib_amd import infer, train
+    from medplib_amd.model.config import MedPLIBConfig
+    rng = np.random.default_rng(16)
+    _write_files(str(tmp_path), rng)
+    cfg = MedPLIBConfig.tiny()
+    tok = ToyTokenizer(model_max_length=512, vocab_size=cfg.vocab_size, seg_token_idx=cfg.seg_token_idx)
+    monkeypatch.setattr(D, "load_tokenizer", lambda *a, **k: tok)
+    recs = [r for r in _records()[:2]] + [{"image": f"img{k}.png", "conversations": [
+        {"from": "human", "value": "<image>\nFind it."}, {"from": "gpt", "value": f"<SEG><mask>img{k}_mask.png</mask>"}]} for k in (2, 3)]
+    json.dump(recs, open(tmp_path / "train.json", "w"))
+    json.dump(recs[2:], open(tmp_path / "val.json", "w"))
+    common = ["--model_size", "tiny", "--image_folder", str(tmp_path), "--tokenizer_path", "unused"]
+    random.seed(0)
+    hist = train.main(common + ["--dataset", "medplib_amd.dataset:from_args", "--data_path", str(tmp_path / "train.json"),
+                                "--val_data_path", str(tmp_path / "val.json"), "--log_dir", str(tmp_path / "run"), "--steps_per_epoch", "4",
+                                "--batch_size", "2", "--lr", "1e-3"])
+    assert len(hist) == 4 and all(np.isfinite(hist))
+    assert os.path.exists(tmp_path / "run" / "ckpt_model" / "latest")
+    stub = tok(" ASSISTANT:", add_special_tokens=False).input_ids[-1]
+    out = infer.main(common + ["--dataset", "medplib_amd.dataset:val_from_args", "--val_data_path", str(tmp_path / "val.json"),
+                               "--max_new_tokens", "4", "--colon_token_id", str(stub), "--eval_vqa", "--answers_file", str(tmp_path / "ans.jsonl")])
+    assert 0.0 <= out["miou"] <= 1.0 and len(out["vqa_output_ids"]) == 2
+    assert len(open(tmp_path / "ans.jsonl").read().splitlines()) == 2
