@@ -116,3 +116,38 @@ def test_collated_batches_shard_disjointly_across_ranks():
     assert [again[i] for i in range(4)] == [views[0][i] for i in range(4)]          # same order in every run
     flat = D.CollatedBatches(samples, 4, shuffle=False, collate_fn=lambda s: s)
     assert flat[0] == [0, 1, 2, 3] and flat[5] == [20, 21, 22, 0]
+
+
+def test_target_masking_invariants_on_random_conversations():
+    """Property test (hypothesis): for any alternating conversation the supervised positions carry exactly the assistant turns,
+    each closed by </s>, in order; everything else (system prompt, user turns, image sentinel, padding) is IGNORE; ids and labels
+    agree wherever a label is kept."""
+    from hypothesis import given, settings, strategies as st
+    tok = ToyTokenizer()
+    word = st.text(alphabet="abcdefghijklmnopqrstuvwxyz.,?", min_size=1, max_size=7)
+    sentence = st.lists(word, min_size=1, max_size=6).map(" ".join)
+    rounds = st.lists(st.tuples(sentence, sentence), min_size=1, max_size=4)
+
+    @settings(max_examples=60, deadline=None)
+    @given(rounds=rounds, with_image=st.booleans(), seg=st.booleans())
+    def check(rounds, with_image, seg):
+        conv = []
+        for k, (q, a) in enumerate(rounds):
+            conv.append({"from": "human", "value": (q + " <image>" if (with_image and k == 0) else q)})
+            conv.append({"from": "gpt", "value": a + (" <SEG>" if seg and k == len(rounds) - 1 else "")})
+        convs = [copy.deepcopy(conv)]
+        if with_image:
+            D.place_image_token(convs)
+            assert convs[0][0]["value"].startswith("<image>\n")
+        ex = D.build_v1_example(convs, tok, has_image=with_image)
+        ids, lab = ex["input_ids"][0].tolist(), ex["labels"][0].tolist()
+        assert len(ids) == len(lab) and ids.count(D.IMAGE_TOKEN_INDEX) == (1 if with_image else 0)
+        assert all(l == i for i, l in zip(ids, lab) if l != D.IGNORE_INDEX)
+        kept = [l for l in lab if l != D.IGNORE_INDEX]
+        want = []
+        for t in convs[0][1::2]:                      # " answer</s>" of every assistant turn: the space merges into the first word
+            want += tok(" " + t["value"], add_special_tokens=False).input_ids[1:] + [2]
+        assert kept == want
+        assert lab[0] == D.IGNORE_INDEX and ex["gt"] == [t["value"] for t in convs[0][1::2]]
+
+    check()
