@@ -182,9 +182,11 @@ def main():
             # every 11th GEMM launch of the timed steps is bracketed by HIP events on the launch stream (ops.KernelTimer)
             # the dominant kernel alone (mp_gemm_last_kernel tells which kernel a launch went to), then all bf16 GEMM launches
             flops, ms, sampled, launches, all_flops = timer.summary(256)
-            achieved = flops / (ms * 1e-3) / 1e12
             a_flops, a_ms, a_sampled, a_launches, a_all = timer.summary()
-            a_ach = a_flops / (a_ms * 1e-3) / 1e12
+            if sampled == 0:          # very short debug runs: no sampled launch went to the dominant kernel
+                flops, ms, sampled, launches, all_flops = a_flops, a_ms, a_sampled, a_launches, a_all
+            achieved = flops / (max(ms, 1e-9) * 1e-3) / 1e12
+            a_ach = a_flops / (max(a_ms, 1e-9) * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm256v3_bf16_nt_kernel",
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
