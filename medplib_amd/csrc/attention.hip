@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int q0 = blockIdx.x * 128;
+  // grid = (batch*heads, query blocks): the dispatcher walks x fastest, so with the query-block index REVERSED every (batch, head)'s
+  // heaviest causal block (most key tiles) starts first and the 2-tile blocks fill the tail (longest-processing-time order)
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int q0 = (a.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * 128;
   const int qw0 = q0 + wave * 32;
 
   const bf16_t* Qb = a.Q + b * a.q_sb + (int64_t)h * D;
@@ -435,7 +437,7 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-  dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+  dim3 grid(a.B * a.H, (a.Sq + 127) / 128);
   hipLaunchKernelGGL((attn_fwd2_kernel<D>), grid, dim3(256), LDS, stream, a);
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }

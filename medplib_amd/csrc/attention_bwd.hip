@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int r0 = blockIdx.x * 128;                // first resident column of the workgroup
+  // grid = (batch*heads, resident blocks), x walked first by the dispatcher: under a causal mask the blocks with the most streamed
+  // tiles start first (dQ: the LAST query block, so its index is reversed; dK/dV: the first key block, natural order)
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int blk = (!DKV && a.causal) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  const int r0 = blk * 128;                       // first resident column of the workgroup
   const int rw0 = r0 + wave * 32;                 // ... of this wave
   const int Sres = DKV ? a.Sk : a.Sq;             // resident axis length
   const int Sstr = DKV ? a.Sq : a.Sk;             // streamed axis length
@@ -266,8 +269,8 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<D, false>), dim3((a.Sq + 127) / 128, a.B * a.H), dim3(256), LDS, stream, a);
-  hipLaunchKernelGGL((attn_bwd_kernel<D, true>), dim3((a.Sk + 127) / 128, a.B * a.H), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, false>), dim3(a.B * a.H, (a.Sq + 127) / 128), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, true>), dim3(a.B * a.H, (a.Sk + 127) / 128), dim3(256), LDS, stream, a);
   return mp_check_launch("mp_attention_bwd_bf16");
 }
 
