@@ -629,6 +629,197 @@ def golden_dataset():
     print("dataset goldens ok:", {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# LISAForCausalLM.model_forward end to end: the reference's own class, constructed at tiny dims from a
+# seeded HF-layout state dict, run in train mode on seeded batches; the 10-loss dict, the last hidden state, the trainable-tail
+# gradients and a few decoder / front-end gradients of `loss.backward()` become tests/golden/lisa_forward_reference.npz.
+
+LISA_CLIP_DIR = "/tmp/medplib_golden/clip-tiny-336"
+LISA_LOSS_WEIGHTS = dict(ce_loss_weight=1.0, dice_loss_weight=5.0, bce_loss_weight=1.0, iou_loss_weight=0.5, focal_loss_weight=1.0)
+# parameters whose FULL gradient is stored (everything else trainable in the tail is stored as (sum, L2 norm) per tensor)
+LISA_FULL_GRADS = ["model.text_hidden_fcs.0.0.weight", "model.text_hidden_fcs.0.0.bias", "model.text_hidden_fcs.0.2.weight",
+                   "model.text_hidden_fcs.0.2.bias", "model.visual_model.mask_decoder.mask_tokens.weight",
+                   "model.visual_model.mask_decoder.iou_token.weight",
+                   "model.visual_model.mask_decoder.output_upscaling.0.weight",
+                   "model.visual_model.mask_decoder.output_upscaling.3.weight",
+                   "model.visual_model.mask_decoder.output_hypernetworks_mlps.0.layers.2.weight",
+                   "model.visual_model.mask_decoder.iou_prediction_head.layers.2.weight",
+                   "model.visual_model.mask_decoder.transformer.layers.0.self_attn.q_proj.weight",
+                   "model.visual_model.mask_decoder.transformer.layers.1.cross_attn_image_to_token.out_proj.weight",
+                   "model.visual_model.mask_decoder.transformer.final_attn_token_to_image.v_proj.weight",
+                   # the differentiable LLM side (pins the oracle's autograd path used by the LoRA-training tests)
+                   "lm_head.weight", "model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight",
+                   "model.layers.1.mlp.down_proj.weight", "model.layers.0.input_layernorm.weight", "model.mm_projector.2.weight"]
+
+
+def lisa_tiny_cfg():
+    """Tiny decoder / CLIP widths but the true token geometry: LISA.model_forward hard-codes 575 = 576 - 1 image rows in its
+    <SEG> mask (model/LISA.py:321-325), so CLIP stays 336 px / patch 14; SAM-Med2D is whatever build_sam_vit_b builds (12 blocks)."""
+    from medplib_amd.model.config import MedPLIBConfig
+    return MedPLIBConfig.tiny(clip_image_size=336, moe_enable=False, iou_loss_weight=LISA_LOSS_WEIGHTS["iou_loss_weight"])
+
+
+def lisa_cases(cfg):
+    """name -> batch: (i) the standard batch, (ii) ragged right padding, (iii) valid_mask_bool = [[True],[True,True],[]].
+    Pixel inputs are rounded to bf16-representable values so a bf16 trunk sees exactly what the fp32 reference saw."""
+    from . import model as OM
+    cases = {"std": OM.make_batch(cfg, 2, seed=5), "ragged": OM.make_batch(cfg, 3, seed=6, ragged=True),
+             "multimask": OM.make_batch_multimask(cfg, seed=7)}
+    for b in cases.values():
+        b["images"] = b["images"].to(torch.bfloat16).float()
+        b["images_clip"] = b["images_clip"].to(torch.bfloat16).float()
+    return cases
+
+
+def _build_reference_lisa(cfg, W):
+    """Appendix C steps 2-4: a random-init CLIP directory written by a stub-free child process, the stand-in modules, then the
+    reference's LISAForCausalLM(config, **kwargs) with the seeded weights loaded by name."""
+    import subprocess
+    if not os.path.exists(os.path.join(LISA_CLIP_DIR, "config.json")):
+        os.makedirs(LISA_CLIP_DIR, exist_ok=True)
+        code = (
+            "import json\nfrom transformers import CLIPVisionConfig, CLIPVisionModel\n"
+            f"c = CLIPVisionConfig(image_size={cfg.clip_image_size}, patch_size={cfg.clip_patch_size}, hidden_size={cfg.clip_hidden_size}, "
+            f"intermediate_size={cfg.clip_intermediate_size}, num_hidden_layers={cfg.clip_num_layers}, "
+            f"num_attention_heads={cfg.clip_num_heads}, layer_norm_eps={cfg.clip_ln_eps}, hidden_act='quick_gelu')\n"
+            f"CLIPVisionModel(c).save_pretrained('{LISA_CLIP_DIR}')\n"
+            f"json.dump(dict(crop_size={cfg.clip_image_size}, do_center_crop=True, do_normalize=True, do_resize=True, "
+            "image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711], resample=3, "
+            f"size={cfg.clip_image_size}, image_processor_type='CLIPImageProcessor'), open('{LISA_CLIP_DIR}/preprocessor_config.json', 'w'))\n")
+        subprocess.run([sys.executable, "-c", code], check=True)
+    _import_reference_medplib()
+    import model.LISA as RL
+    from model.medplib.model.language_model.medplib_llama import LlavaConfig
+    torch.Tensor.cuda = lambda self, *a, **k: self            # `.cuda()` is hard-coded in LISA.py:234,316,323 (Appendix B.7)
+    hc = LlavaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_attention_heads, rms_norm_eps=cfg.rms_norm_eps,
+                     max_position_embeddings=cfg.max_position_embeddings)
+    hc.mm_vision_tower = hc.vision_tower = LISA_CLIP_DIR
+    hc.mm_vision_select_layer = cfg.mm_vision_select_layer
+    hc.mm_hidden_size = cfg.clip_hidden_size
+    hc.mm_projector_type = "mlp2x_gelu"
+    hc.max_sample_point = cfg.max_sample_point
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):           # the constructors print their whole config
+        m = RL.LISAForCausalLM(hc, seg_token_idx=cfg.seg_token_idx, train_mask_decoder=True, out_dim=cfg.out_dim,
+                               vision_pretrained=None, use_mm_start_end=True, max_sample_point=cfg.max_sample_point,
+                               **LISA_LOSS_WEIGHTS)
+    own = m.state_dict()
+    sd = {}
+    for k, v in W.items():
+        # transformers 5.x dropped the `vision_model.` level of CLIPVisionModel's parameter names (4.31 checkpoints have it)
+        k2 = k if k in own else k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower.")
+        assert k2 in own and own[k2].shape == v.shape, (k, tuple(v.shape))
+        sd[k2] = v
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    # what the seeded dict does not carry: prompt-encoder parts the text-only path never touches (point / box / mask embeddings)
+    # ... and CLIP's post_layernorm, which hidden_states[-2] never passes through
+    assert all(k.startswith("model.visual_model.prompt_encoder.") or ".post_layernorm." in k for k in missing), missing
+    return m
+
+
+def _ref_key(k, own):
+    return k if k in own else k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower.")
+
+
+def golden_lisa():
+    from . import model as OM
+    cfg = lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=3)
+    out = {"weight_seed": np.int64(3), "loss_weights": np.array([LISA_LOSS_WEIGHTS[k] for k in sorted(LISA_LOSS_WEIGHTS)]),
+           "weight_checksum": np.float64(sum(float(v.double().sum()) for v in W.values()))}
+    tail = [k for k in W if k.startswith("model.text_hidden_fcs.") or k.startswith("model.visual_model.mask_decoder.")]
+    # (sum, L2 norm) of the gradient of EVERY tensor loss.backward() reaches: the trainable tail, the whole decoder, lm_head,
+    # embed_tokens and the projector (the frozen towers run under no_grad in the reference too)
+    stat_keys = tail + [k for k in W if k.startswith(("model.layers.", "model.norm.", "lm_head.", "model.embed_tokens.", "model.mm_projector."))]
+    out["tail_keys"] = np.array(tail)
+    out["grad_stat_keys"] = np.array(stat_keys)
+    for name, b in lisa_cases(cfg).items():
+        # A FRESH module per case, called exactly once.  transformers 5.15 collects `output_hidden_states` with forward hooks that the
+        # first LlamaModel.forward installs on every child layer — and the CLIP tower is a child of LisaModel, so from the second
+        # call on CLIP reports 2 entries per layer and `hidden_states[-2]` (clip_encoder.py:32) silently becomes the LAST layer.
+        # transformers 4.31 (the reference's pin) builds the tuple inline; the first call is the one with its semantics.
+        m = _build_reference_lisa(cfg, W)
+        m.train()                                              # dropout is 0; eval mode breaks the dense class (SURVEY §8c caveat)
+        params = dict(m.named_parameters())
+        n_hs = len(m.get_model().get_vision_tower().vision_tower(b["images_clip"][:1], output_hidden_states=True).hidden_states)
+        assert n_hs == cfg.clip_num_layers + 1, n_hs
+        hs = {}
+        h = m.model.norm.register_forward_hook(lambda mod, i, o: hs.__setitem__("last", o.detach()))
+        ref_masks, orig_pp = [], m.postprocess_masks             # the masks the reference's forward produces (LISA.py:415-421)
+        m.postprocess_masks = lambda *a, **k: (lambda r: (ref_masks.append(r.detach()[:, 0]), r)[1])(orig_pp(*a, **k))
+        res = m.model_forward(images=b["images"], images_clip=b["images_clip"], input_ids=b["input_ids"], region_masks=[],
+                              labels=b["labels"], attention_masks=b["attention_mask"], offset=None, masks_list=b["masks_list"],
+                              label_list=b["label_list"], resize_list=b["resize_list"], inference=False, seg_flag=True,
+                              valid_mask_bool=b["valid_mask_bool"], valid_region_masks_bool=[])
+        h.remove()
+        res["loss"].backward()
+        out[f"{name}_losses"] = np.array([float(res[k].detach()) for k in ops.LOSS_KEYS], np.float64)
+        out[f"{name}_hidden_tail"] = hs["last"][:, -72:].numpy()          # the text tail of the last hidden state (post final norm)
+        out[f"{name}_input_checksum"] = np.float64(float(b["images"].double().sum()) + float(b["images_clip"].double().sum())
+                                                   + float(b["input_ids"].sum()))
+        for k in (LISA_FULL_GRADS if name == "multimask" else LISA_FULL_GRADS[:4]):
+            out[f"{name}_grad_{k}"] = params[_ref_key(k, params)].grad.numpy()
+        out[f"{name}_grad_stats"] = np.array([[float(params[k].grad.double().sum()), float(params[k].grad.double().norm())]
+                                              for k in stat_keys])
+        # ---- the restatement next to it
+        Wr = {k: (v.clone().requires_grad_() if k in stat_keys else v) for k, v in W.items()}
+        ora, inter = OM.model_forward(b, Wr, cfg, training=True, llm_grad=True, return_intermediates=True)
+        ora["loss"].backward()
+        dl = max(abs(float(ora[k]) - float(res[k])) for k in ops.LOSS_KEYS)
+        dh = (inter["hidden"][:, -72:].detach() - hs["last"][:, -72:]).abs().max().item()
+        rel = {k: ((Wr[k].grad - params[_ref_key(k, params)].grad).abs().max() / (params[_ref_key(k, params)].grad.abs().max() + 1e-5)).item()   # floor: k_proj.bias gradients are 0 (softmax shift invariance)
+               for k in stat_keys}
+        dg = max(rel.values())
+        if dg >= 2e-2:
+            print({k: f"{v:.1e}" for k, v in rel.items() if v >= 1e-3})
+        print(f"lisa case {name}: losses", {k: round(float(res[k]), 5) for k in ("loss", "ce_loss", "mask_loss")},
+              f"| oracle: max|dloss| {dl:.2e}  max|dhidden| {dh:.2e}  worst relative gradient error {dg:.2e}")
+        assert dl < 2e-4 and dh < 2e-3 and dg < 2e-2, name
+        assert len(ref_masks) == len(inter["pred_masks"])
+        dm = max((r - p.detach()).abs().max().item() for r, p in zip(ref_masks, inter["pred_masks"]))
+        print(f"   masks: {len(ref_masks)} of shapes {[tuple(r.shape) for r in ref_masks]}, max|reference - oracle| {dm:.2e}")
+        assert dm < 1e-3
+        out[f"{name}_pred_masks"] = np.concatenate([r.reshape(-1).numpy() for r in ref_masks]).astype(np.float16)
+    np.savez_compressed(os.path.join(OUT, "lisa_forward_reference.npz"), **out)
+    print("lisa goldens ok:", os.path.getsize(os.path.join(OUT, "lisa_forward_reference.npz")) // 1024, "KiB")
+
+
+def golden_llama_layer():
+    """One dense decoder layer + final norm at the 7B dims (d 4096, ff 11008, 32 heads x 128, S 639, one right-padded sample) run by
+    the installed HuggingFace `LlamaModel` — the class the reference's dense path instantiates (medplib_llama.py:32-37,98-107) — on
+    seeded weights; 64 output rows are stored.  transformers 5.15 here vs the reference's 4.31 pin: same arithmetic."""
+    from transformers import LlamaConfig, LlamaModel
+    from medplib_amd.model.config import MedPLIBConfig
+    from . import llm, model as OM
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=1, vocab_size=1024, moe_enable=False, moe_gate_sampling=False)
+    W, g = OM.init_decoder_layer_weights(cfg, seed=3)
+    emb, kv = OM.decoder_layer_inputs(cfg, g)
+    hc = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=1, num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_attention_heads,
+                     rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, max_position_embeddings=cfg.max_position_embeddings,
+                     attention_bias=False, hidden_act="silu")
+    hc._attn_implementation = "eager"
+    hf = LlamaModel(hc).eval()
+    sd = {k[len("model."):]: v for k, v in W.items() if k.startswith("model.")}
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m_ or "inv_freq" in m_ for m_ in missing), (missing, unexpected)
+    B, S = emb.shape[:2]
+    with torch.no_grad():
+        ref = hf(inputs_embeds=emb.float(), attention_mask=kv.long(), position_ids=torch.arange(S)[None].expand(B, -1)).last_hidden_state
+        ora, _ = llm.llama_forward(emb.float(), kv, W, cfg, training=True)
+    rows = torch.nonzero(kv.view(-1)).flatten()
+    rows = rows[torch.linspace(0, len(rows) - 1, 64).long()]
+    d = (ora.view(B * S, -1)[rows] - ref.view(B * S, -1)[rows]).abs().max().item()
+    print("true-dims dense layer: max|oracle - HF| on the stored rows", d, "absmax", ref.abs().max().item())
+    assert d < 5e-4
+    np.savez_compressed(os.path.join(OUT, "llama_layer_truedims.npz"), rows=rows.numpy(), hidden_rows=ref.view(B * S, -1)[rows].numpy(),
+                        weight_seed=np.int64(3), transformers_version=np.array(__import__("transformers").__version__))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["sam", "mask_head", "glue"]
@@ -644,3 +835,7 @@ if __name__ == "__main__":
         golden_preprocess()
     if "dataset" in which:
         golden_dataset()
+    if "lisa" in which:
+        golden_lisa()
+    if "llama_layer" in which:
+        golden_llama_layer()

@@ -79,6 +79,39 @@ def init_hf_weights(cfg, seed=0, sam_seed=1234):
     return W
 
 
+def init_decoder_layer_weights(cfg, seed=3):
+    """Seeded weights of a ONE-layer decoder at cfg's dims in the HF key layout (embed_tokens, layer 0 dense or MoE, final norm,
+    lm_head), bf16-representable.  Shared by the true-dims layer tests and oracle/make_golden.py: golden_llama_layer."""
+    g = torch.Generator().manual_seed(seed)
+    d, ff, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
+
+    def rn(*shape, s):
+        return (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).float()
+    W = {"model.embed_tokens.weight": rn(cfg.vocab_size, d, s=0.5), "lm_head.weight": rn(cfg.vocab_size, d, s=0.05),
+         "model.norm.weight": 1 + rn(d, s=0.1)}
+    p = "model.layers.0."
+    for n in ("q", "k", "v", "o"):
+        W[p + f"self_attn.{n}_proj.weight"] = rn(d, d, s=d ** -0.5)
+    W[p + "input_layernorm.weight"] = 1 + rn(d, s=0.1); W[p + "post_attention_layernorm.weight"] = 1 + rn(d, s=0.1)
+    if cfg.moe_enable:
+        W[p + "mlp.deepspeed_moe.gate.wg.weight"] = torch.randn(E, d, generator=g) * 0.05
+        for e in range(E):
+            ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
+            W[ep + "gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[ep + "up_proj.weight"] = rn(ff, d, s=d ** -0.5)
+            W[ep + "down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
+    else:
+        W[p + "mlp.gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[p + "mlp.up_proj.weight"] = rn(ff, d, s=d ** -0.5)
+        W[p + "mlp.down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
+    return W, g
+
+
+def decoder_layer_inputs(cfg, g, B=2, S=639):
+    """Inputs of the true-dims layer check, drawn from the generator init_decoder_layer_weights returns (same stream)."""
+    emb = (torch.randn(B, S, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16)
+    kv = torch.ones(B, S, dtype=torch.bool); kv[1, 600:] = False
+    return emb, kv
+
+
 def make_batch(cfg, B, L=64, H=96, Wd=80, seed=0, ragged=False, sam_size=256):
     """Synthetic batch in the collator's contract (datasets/DataCollatorForSupervisedDataset.py:11-138):
     one IMAGE placeholder bracketed by im_start/im_end, <SEG> near the end, labels supervised on the tail."""
@@ -142,6 +175,39 @@ def make_batch_icl(cfg, B, n_ctx=2, H=96, Wd=80, seed=0, sam_size=256, mask_size
     return base
 
 
+def expand_embedding(image_embeddings, valid_mask_bool):
+    """`expand_embedding` (model/MedPLIB.py:292-308, model/LISA.py:228-239): image embedding i repeated once per GT mask of sample
+    i, samples without a mask DROPPED; unchanged when `valid_mask_bool` is empty."""
+    if valid_mask_bool is None or len(valid_mask_bool) == 0:
+        return image_embeddings
+    parts = [image_embeddings[i:i + 1].expand(len(m), -1, -1, -1) for i, m in enumerate(valid_mask_bool) if m]
+    return torch.cat(parts, 0)
+
+
+def make_batch_multimask(cfg, L=64, seed=0, sam_size=256, sizes=((96, 80), (64, 72), (96, 80))):
+    """Three samples with valid_mask_bool = [[True], [True, True], []] (the collator's flat per-mask lists,
+    datasets/DataCollatorForSupervisedDataset.py:31-50): sample 0 one <SEG> + one mask, sample 1 two <SEG> + two masks (of different
+    sizes), sample 2 a VQA sample without <SEG> / masks whose image embedding expand_embedding drops."""
+    b = make_batch(cfg, 3, L=L, seed=seed, ragged=True, sam_size=sam_size)
+    ids, labels = b["input_ids"], b["labels"]
+    n1 = int(b["attention_mask"][1].sum())
+    ids[1, n1 - 6] = cfg.seg_token_idx                     # second <SEG> of sample 1 (the first sits at n1 - 3)
+    labels[1, n1 - 8:n1] = ids[1, n1 - 8:n1]
+    n2 = int(b["attention_mask"][2].sum())
+    g = torch.Generator().manual_seed(seed + 991)
+    ids[2, n2 - 3] = int(torch.randint(3, cfg.seg_token_idx - 1, (1,), generator=g))     # sample 2: no <SEG>
+    labels[2, n2 - 8:n2] = ids[2, n2 - 8:n2]
+    masks = []
+    for (H, Wd) in sizes:
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(Wd), indexing="ij")
+        cy, cx = torch.rand(2, generator=g) * torch.tensor([H, Wd])
+        r = 8 + torch.rand(1, generator=g) * min(H, Wd) / 3
+        masks.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r ** 2).float())
+    b.update(masks_list=masks, label_list=[torch.full(s_, 255.0) for s_ in sizes], resize_list=[(sam_size, sam_size)] * 3,
+             valid_mask_bool=[[True], [True, True], []])
+    return b
+
+
 def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None, llm_grad=False):
     """model/MedPLIB.py:364-572 end to end on the CPU in fp32.  `override` (tests only) may inject `hidden` [B,S,d],
     `image_emb` [B,256,16,16] and `ce` so the trainable tail can be checked on exactly the trunk outputs another
@@ -193,8 +259,9 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
     if batch.get("icl_image_counts") is not None and len(batch["masks_list"]) > 0:
         pred_emb = pred_emb[-len(batch["masks_list"]):]          # MedPLIB.py:462-463
     pe = sam.dense_pe(SW)
+    image_emb = expand_embedding(image_emb, batch.get("valid_mask_bool"))
     pred_masks, pred_ious, low = [], [], []
-    for i in range(len(pred_emb)):
+    for i in range(len(pred_emb)):                 # pred_emb[i] is paired with image_emb[i] BY POSITION (MedPLIB.py:473-487)
         sp, de = sam.prompt_encoder_text(pred_emb[i].view(1, 1, -1), SW)
         lm, io = sam.mask_decoder(image_emb[i:i + 1], pe, sp, de, SW)
         low.append(lm)

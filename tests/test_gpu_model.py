@@ -721,32 +721,12 @@ def test_llama_layer_at_true_dims(dev, moe):
     the SwiGLU-pair epilogue, batched expert GEMMs with device-side counts, D = 128 causal attention over 10 key tiles) at the
     sizes bench.py runs.  Error bound: bf16 storage of ~10 intermediate tensors on O(1) activations."""
     cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=1, vocab_size=1024, moe_enable=moe, moe_gate_sampling=False)
-    g = torch.Generator().manual_seed(3)
-    d, ff, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
-
-    def rn(*shape, s):
-        return (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).float()
-    W = {"model.embed_tokens.weight": rn(cfg.vocab_size, d, s=0.5), "lm_head.weight": rn(cfg.vocab_size, d, s=0.05),
-         "model.norm.weight": 1 + rn(d, s=0.1)}
-    p = "model.layers.0."
-    for n in ("q", "k", "v", "o"):
-        W[p + f"self_attn.{n}_proj.weight"] = rn(d, d, s=d ** -0.5)
-    W[p + "input_layernorm.weight"] = 1 + rn(d, s=0.1); W[p + "post_attention_layernorm.weight"] = 1 + rn(d, s=0.1)
-    if moe:
-        W[p + "mlp.deepspeed_moe.gate.wg.weight"] = torch.randn(E, d, generator=g) * 0.05
-        for e in range(E):
-            ep = p + f"mlp.deepspeed_moe.experts.deepspeed_experts.{e}."
-            W[ep + "gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[ep + "up_proj.weight"] = rn(ff, d, s=d ** -0.5)
-            W[ep + "down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
-    else:
-        W[p + "mlp.gate_proj.weight"] = rn(ff, d, s=d ** -0.5); W[p + "mlp.up_proj.weight"] = rn(ff, d, s=d ** -0.5)
-        W[p + "mlp.down_proj.weight"] = rn(d, ff, s=ff ** -0.5)
+    W, g = OM.init_decoder_layer_weights(cfg, seed=3)
     from medplib_amd.model.llama import LlamaStack
     llm = LlamaStack(cfg, dev)
     llm.load_hf(W)
     B, S = 2, 639
-    emb = (torch.randn(B, S, d, generator=g) * 0.5).to(torch.bfloat16)
-    kv = torch.ones(B, S, dtype=torch.bool); kv[1, 600:] = False
+    emb, kv = OM.decoder_layer_inputs(cfg, g, B, S)
     torch.set_num_threads(min(32, os.cpu_count()))
     coll = []
     with torch.no_grad():
@@ -760,6 +740,13 @@ def test_llama_layer_at_true_dims(dev, moe):
         print(f"true-dims routing agreement {keep.float().mean().item():.4f}; counts ref {coll[0][2].tolist()} got {routing[0][2].cpu().tolist()}")
         assert keep.float().mean().item() > 0.98
     _stat(f"7B-dims layer (moe={moe}) final-norm hidden", out.view(B * S, -1).cpu()[keep], ref.view(B * S, -1)[keep], atol=0.0, rtol=8 * 2 ** -8)
+    if not moe:
+        # ... and against the installed HuggingFace LlamaModel at the same dims (tests/golden/llama_layer_truedims.npz, generated by
+        # oracle/make_golden.py: golden_llama_layer; transformers 5.15 — 4.31 is absent, same arithmetic)
+        gg = np.load(os.path.join(os.path.dirname(__file__), "golden", "llama_layer_truedims.npz"))
+        rows = torch.from_numpy(gg["rows"])
+        _stat("7B-dims dense layer vs HF LlamaModel golden rows", out.view(B * S, -1).cpu()[rows], torch.from_numpy(gg["hidden_rows"]),
+              atol=0.0, rtol=8 * 2 ** -8)
 
 
 @pytest.mark.parametrize("cf", [1.5, 0.6])
@@ -1332,3 +1319,76 @@ def test_merge_entry_point_both_checkpoint_kinds(dev, tmp_path):
         worst = max(worst, d / max(float(out_b[k].float().abs().max()), 1e-6))
     print(f"  merge: host fold vs merge_and_unload, worst difference {worst:.2e} of the tensor's largest entry")
     assert worst < 1e-2          # one bf16 rounding of W + delta on either path
+
+
+@pytest.mark.parametrize("case", ["std", "ragged", "multimask"])
+def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
+    """HIP path vs the EXECUTED REFERENCE (tests/golden/lisa_forward_reference.npz = the reference's own
+    `LISAForCausalLM(config).train().model_forward(...)` + `loss.backward()`, oracle/make_golden.py: golden_lisa).
+    `multimask` is valid_mask_bool = [[True], [True, True], []]: expand_embedding (MedPLIB.py:292-308) repeats sample 1's image
+    embedding for its two <SEG> rows and drops sample 2's; three masks of two sizes go through one ragged loss launch.
+    Bounds: the decoder runs in bf16 against an fp32 reference — last hidden state 6 * 2^-8 of its scale, losses 1e-2 absolute
+    (values 0.1 .. 11), thresholded-mask Dice 1e-3 (BASELINE target).  Trainable-tail gradients are compared with the golden
+    directly at 5 % (a ReLU unit of text_hidden_fcs within bf16 noise of zero toggles rows of dW) and at 2e-3 against the oracle
+    fed this path's own trunk outputs — the oracle itself equals the golden to 1e-5 (tests/test_oracle_golden.py)."""
+    from oracle import make_golden as MG
+    g = np.load(os.path.join(golden_dir, "lisa_forward_reference.npz"))
+    cfg = MG.lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
+    b = MG.lisa_cases(cfg)[case]
+    m = _model(cfg, dev, W).train()
+    m.capture_intermediates = True
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    gb["masks_list"] = [x.to(dev) for x in b["masks_list"]]
+    out = m(**gb)
+    ref_losses = dict(zip(O.LOSS_KEYS, g[f"{case}_losses"]))
+    for k in O.LOSS_KEYS:
+        _stat(f"{case} loss[{k}] vs executed reference", out[k], torch.tensor(ref_losses[k]), atol=1e-2)
+    hid = m.captured["last_hidden"].float().cpu()[:, -72:]
+    ref_hid = torch.from_numpy(g[f"{case}_hidden_tail"])
+    valid = b["attention_mask"][:, -72:]                    # right-padding rows carry unspecified values on both sides
+    _stat(f"{case} last hidden (text tail)", hid[valid], ref_hid[valid], atol=0.0, rtol=6 * 2 ** -8)
+    out["loss"].backward()
+    named = dict(m.named_parameters())
+    train_keys = [str(k) for k in g["tail_keys"]]
+    stat_keys = [str(k) for k in g["grad_stat_keys"]]
+    ref_stats = dict(zip(stat_keys, g[f"{case}_grad_stats"]))
+    worst = 0.0
+    for k in train_keys:
+        gr = named[k].grad
+        if gr is None or ref_stats[k][1] < 1e-3:            # unused hypernets / IoU outputs 1-3, k_proj.bias (zero gradient)
+            continue
+        rel = abs(float(gr.double().norm()) - ref_stats[k][1]) / ref_stats[k][1]
+        worst = max(worst, rel)
+        assert rel < 5e-2, (k, float(gr.double().norm()), ref_stats[k][1])
+    print(f"{case}: worst tail gradient-norm deviation from the executed reference {worst:.3e}")
+    for k in g.files:
+        if k.startswith(f"{case}_grad_model.text_hidden_fcs") or k.startswith(f"{case}_grad_model.visual_model"):
+            pk = k[len(case) + 6:]
+            _stat(f"{case} d {pk} vs executed reference", named[pk].grad, torch.from_numpy(g[k]), atol=0.0, rtol=5e-2)
+    # the same tail on this path's own trunk outputs -> fp32-level agreement with the (golden-pinned) oracle
+    Wr2 = {k: (v.detach().clone().requires_grad_() if k in train_keys else v) for k, v in W.items()}
+    cap = m.captured
+    ov = {"hidden": cap["last_hidden"].float().cpu(), "ce": cap["ce"].cpu()[0],
+          "image_emb": cap["image_tokens"].cpu().view(-1, 16, 16, 256).permute(0, 3, 1, 2).contiguous()}
+    ref2 = OM.model_forward(b, Wr2, cfg, training=True, override=ov)
+    ref2["loss"].backward()
+    for k in O.LOSS_KEYS:
+        _stat(f"{case} tail-injected loss[{k}]", out[k], ref2[k], atol=2e-4)
+    _check_grads({k: named[k] for k in train_keys}, {k: Wr2[k].grad for k in train_keys}, rtol=2e-3, tag=f"{case} (same trunk outputs)")
+    # masks: inference branch vs the masks the reference's forward produced (stored fp16)
+    gb["inference"] = True
+    with torch.no_grad():
+        res = m(**gb)
+    ref_pm = g[f"{case}_pred_masks"].astype(np.float32)
+    off = 0
+    assert len(res["pred_masks"]) == len(b["masks_list"])
+    for i, pmask in enumerate(res["pred_masks"]):
+        n = pmask.numel()
+        rp = torch.from_numpy(ref_pm[off:off + n]).view(pmask.shape[-2:]); off += n
+        assert tuple(pmask.shape[-2:]) == tuple(b["masks_list"][i].shape)
+        _, _, _, dice_ref = O.threshold_iou(rp, b["masks_list"][i])
+        _, _, _, dice_hip = O.threshold_iou(pmask[0].float().cpu(), b["masks_list"][i])
+        print(f"{case} dice[{i}] executed reference {dice_ref:.5f} hip {dice_hip:.5f}")
+        assert abs(dice_ref - dice_hip) <= 1e-3
+    assert off == ref_pm.size

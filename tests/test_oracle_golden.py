@@ -108,3 +108,61 @@ def test_glue_oracle_matches_executed_reference(golden_dir):
         ym = llm.mask_token_encoder(mk, W, 64)
     assert np.abs(y.numpy() - g["tc_y"]).max() < 1e-6
     assert np.abs(ym.numpy() - g["me_y"]).max() < 1e-5
+
+
+def _lisa_golden(golden_dir):
+    from oracle import make_golden as MG, model as OM
+    g = np.load(os.path.join(golden_dir, "lisa_forward_reference.npz"))
+    cfg = MG.lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in W.values()) - float(g["weight_checksum"])) < 1e-6, "seeded weights drifted"
+    return g, cfg, W, MG.lisa_cases(cfg)
+
+
+def test_model_forward_oracle_matches_executed_reference_lisa(golden_dir):
+    """The END-TO-END pin: the oracle's `model_forward` against what the reference's own
+    `LISAForCausalLM(config).train().model_forward(...)` (model/LISA.py:260-471 over medplib_llama.py:55-148, medplib_arch.py:217-527,
+    the SAM-Med2D modules and HF Llama / CLIP) returned on the same seeded weights and batches — oracle/make_golden.py: golden_lisa.
+    Three batches: standard, ragged right padding, and valid_mask_bool = [[True], [True, True], []] (expand_embedding,
+    MedPLIB.py:292-308 = LISA.py:228-239).  Losses 1e-5, last hidden state 2e-5, gradient (sum, norm) of EVERY tensor
+    loss.backward() reaches 2e-3 relative, stored full gradients 2e-3 of the tensor's largest entry."""
+    from oracle import model as OM
+    g, cfg, W, cases = _lisa_golden(golden_dir)
+    stat_keys = [str(k) for k in g["grad_stat_keys"]]
+    for name, b in cases.items():
+        chk = float(b["images"].double().sum()) + float(b["images_clip"].double().sum()) + float(b["input_ids"].sum())
+        assert abs(chk - float(g[f"{name}_input_checksum"])) < 1e-6, "seeded batch drifted"
+        Wr = {k: (v.clone().requires_grad_() if k in stat_keys else v) for k, v in W.items()}
+        out, inter = OM.model_forward(b, Wr, cfg, training=True, llm_grad=True, return_intermediates=True)
+        out["loss"].backward()
+        got = np.array([float(out[k].detach()) for k in ops.LOSS_KEYS])
+        assert np.abs(got - g[f"{name}_losses"]).max() < 1e-5, (name, got, g[f"{name}_losses"])
+        assert np.abs(inter["hidden"][:, -72:].detach().numpy() - g[f"{name}_hidden_tail"]).max() < 2e-5, name
+        stats = np.array([[float(Wr[k].grad.double().sum()), float(Wr[k].grad.double().norm())] for k in stat_keys])
+        ref = g[f"{name}_grad_stats"]
+        scale = ref[:, 1:2] + 1e-4      # the gradient norm scales both statistics (floor: k_proj.bias gradients are 0 + noise)
+        assert (np.abs(stats - ref) / scale).max() < 2e-3, (name, stat_keys[int((np.abs(stats - ref) / scale).max(1).argmax())])
+        for k in g.files:
+            if k.startswith(f"{name}_grad_") and k != f"{name}_grad_stats":
+                pk = k[len(name) + 6:]
+                r = g[k]
+                assert np.abs(Wr[pk].grad.numpy() - r).max() <= 2e-3 * np.abs(r).max() + 1e-9, (name, pk)
+        pm = np.concatenate([p.detach().reshape(-1).numpy() for p in inter["pred_masks"]])
+        assert np.abs(pm - g[f"{name}_pred_masks"].astype(np.float32)).max() < 2e-3 * np.abs(pm).max() + 1e-3, name
+        if name == "multimask":
+            assert len(inter["pred_masks"]) == 3 and [tuple(p.shape[-2:]) for p in inter["pred_masks"]] == [(96, 80), (64, 72), (96, 80)]
+
+
+def test_oracle_decoder_layer_at_true_dims_matches_hf_golden(golden_dir):
+    """One dense decoder layer + final norm at the 7B dims vs 64 rows the installed HuggingFace LlamaModel produced on the same
+    seeded weights (oracle/make_golden.py: golden_llama_layer; transformers 5.15 — the reference pins 4.31)."""
+    from medplib_amd.model.config import MedPLIBConfig
+    from oracle import llm, model as OM
+    g = np.load(os.path.join(golden_dir, "llama_layer_truedims.npz"))
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=1, vocab_size=1024, moe_enable=False, moe_gate_sampling=False)
+    W, gen = OM.init_decoder_layer_weights(cfg, seed=int(g["weight_seed"]))
+    emb, kv = OM.decoder_layer_inputs(cfg, gen)
+    with torch.no_grad():
+        out, _ = llm.llama_forward(emb.float(), kv, W, cfg, training=True)
+    got = out.view(-1, cfg.hidden_size)[torch.from_numpy(g["rows"])].numpy()
+    assert np.abs(got - g["hidden_rows"]).max() < 5e-4
