@@ -1327,8 +1327,8 @@ def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
     `LISAForCausalLM(config).train().model_forward(...)` + `loss.backward()`, oracle/make_golden.py: golden_lisa).
     `multimask` is valid_mask_bool = [[True], [True, True], []]: expand_embedding (MedPLIB.py:292-308) repeats sample 1's image
     embedding for its two <SEG> rows and drops sample 2's; three masks of two sizes go through one ragged loss launch.
-    Bounds: the decoder runs in bf16 against an fp32 reference — last hidden state 6 * 2^-8 of its scale, losses 1e-2 absolute
-    (values 0.1 .. 11), thresholded-mask Dice 1e-3 (BASELINE target).  Trainable-tail gradients are compared with the golden
+    Bounds: the decoder runs in bf16 against an fp32 reference — last hidden state 6 * 2^-8 of its scale, losses 2e-3 absolute
+    (values 0.1 .. 11; measured 3e-4), thresholded-mask Dice 1e-3 (BASELINE target).  Trainable-tail gradients are compared with the golden
     directly at 5 % (a ReLU unit of text_hidden_fcs within bf16 noise of zero toggles rows of dW) and at 2e-3 against the oracle
     fed this path's own trunk outputs — the oracle itself equals the golden to 1e-5 (tests/test_oracle_golden.py)."""
     from oracle import make_golden as MG
@@ -1343,10 +1343,11 @@ def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
     out = m(**gb)
     ref_losses = dict(zip(O.LOSS_KEYS, g[f"{case}_losses"]))
     for k in O.LOSS_KEYS:
-        _stat(f"{case} loss[{k}] vs executed reference", out[k], torch.tensor(ref_losses[k]), atol=1e-2)
+        _stat(f"{case} loss[{k}] vs executed reference", out[k], torch.tensor(ref_losses[k]), atol=2e-3)
     hid = m.captured["last_hidden"].float().cpu()[:, -72:]
     ref_hid = torch.from_numpy(g[f"{case}_hidden_tail"])
-    valid = b["attention_mask"][:, -72:]                    # right-padding rows carry unspecified values on both sides
+    att = b["attention_mask"]                                # the splice left-extends it with True (medplib_arch.py:480-526)
+    valid = torch.cat([torch.ones(att.shape[0], 8, dtype=torch.bool), att], 1)[:, -72:]   # right-padding rows are unspecified
     _stat(f"{case} last hidden (text tail)", hid[valid], ref_hid[valid], atol=0.0, rtol=6 * 2 ** -8)
     out["loss"].backward()
     named = dict(m.named_parameters())
