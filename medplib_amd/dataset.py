@@ -454,6 +454,34 @@ class ICLSupervisedDataset(SupervisedDataset):
 
 
 # ------------------------------------------------------------------------------------------------------- batches for train.py
+class LazySupervisedDataset(SupervisedDataset):
+    """The reference's constructor signature (datasets/LazySupervisedDataset.py:400-420, called at train_ds_medplib.py:368):
+    `LazySupervisedDataset(data_path, tokenizer, data_args, sam_img_size)` with `data_args` the driver's SimpleNamespace (:354-366)."""
+
+    def __init__(self, data_path, tokenizer, data_args, sam_img_size=256, device="cuda"):
+        proc = getattr(data_args, "image_processor", None)
+        crop = getattr(proc, "crop_size", None)
+        clip = int(crop["height"] if isinstance(crop, dict) else (crop or 336))
+        super().__init__(data_path, tokenizer, data_args.image_folder, device=device, is_multimodal=getattr(data_args, "is_multimodal", True),
+                         mm_use_im_start_end=getattr(data_args, "mm_use_im_start_end", False), sam_img_size=sam_img_size, clip_img_size=clip)
+        self.data_args = data_args
+
+
+class ICLLazySupervisedDataset(ICLSupervisedDataset):
+    """`ICLLazySupervisedDataset(data_path, tokenizer, data_args, sam_img_size)` (datasets/ICLLazySupervisedDataset.py:19-60)."""
+
+    def __init__(self, data_path, tokenizer, data_args, sam_img_size=256, device="cuda"):
+        proc = getattr(data_args, "image_processor", None)
+        crop = getattr(proc, "crop_size", None)
+        clip = int(crop["height"] if isinstance(crop, dict) else (crop or 336))
+        n_img = data_args.mm_compressed_token_count if getattr(data_args, "mm_token_compress", False) else (clip // 14) ** 2
+        super().__init__(data_path, tokenizer, data_args.image_folder, device=device, mask_mode=getattr(data_args, "icl_mask_mode", "overlay"),
+                         mask_encoder=getattr(data_args, "icl_mask_encoder", False), image_token_len=n_img,
+                         mask_token_len=getattr(data_args, "mask_encoder_token_count", 64), is_multimodal=False,
+                         mm_use_im_start_end=getattr(data_args, "mm_use_im_start_end", False), sam_img_size=sam_img_size, clip_img_size=clip)
+        self.data_args = data_args
+
+
 class CollatedBatches(torch.utils.data.Dataset):
     """Batch-indexed view for `train.py` (`data[it]` = one collated micro-batch).  The samples are walked in a per-epoch
     permutation (seeded: the same on every rank and in every run) in strides of world * B; rank r takes the r-th B of each

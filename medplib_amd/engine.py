@@ -28,7 +28,7 @@ class WarmupDecayLR:
         self.total, self.min_lr, self.max_lr = max(1, int(total_num_steps)), warmup_min_lr, warmup_max_lr
         self.warmup = max(2, int(warmup_num_steps))            # DeepSpeed clamps warmup_num_steps to >= 2
         self.last_batch_iteration = -1
-        self._lr = self._compute(0)
+        self._lr = self.min_lr                                  # WarmupLR.get_lr() before the first step() returns min_lrs
 
     def _compute(self, it):
         if it < self.warmup:
@@ -48,7 +48,7 @@ class WarmupDecayLR:
 
     def load_state_dict(self, sd):
         self.last_batch_iteration = sd["last_batch_iteration"]
-        self._lr = self._compute(max(0, self.last_batch_iteration))
+        self._lr = self._compute(self.last_batch_iteration) if self.last_batch_iteration >= 0 else self.min_lr
 
 
 class FlatAdamW:
@@ -94,6 +94,9 @@ class FlatAdamW:
 class Engine:
     def __init__(self, model, params, config, training_data=None, collate_fn=None):
         self.module = model
+        # a peft-style wrapper (peft_compat.PeftModel) forwards calls; stream state lives on the model underneath
+        model = model.get_base_model() if hasattr(model, "get_base_model") else model
+        self.core = model
         self.config = config
         opt = config.get("optimizer", {}).get("params", {})
         self.optimizer = FlatAdamW(params, lr=opt.get("lr", 1e-3), betas=tuple(opt.get("betas", (0.9, 0.95))),
@@ -157,12 +160,12 @@ class Engine:
 
     def _tail_ctx(self):
         """The stream the model put the trainable tail on for this step (or the caller's stream)."""
-        st = getattr(self.module, "active_tail_stream", None)
+        st = getattr(self.core, "active_tail_stream", None)
         return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
 
     def sync_side_streams(self):
-        if hasattr(self.module, "sync_side_streams") and torch.cuda.is_available():
-            self.module.sync_side_streams()
+        if hasattr(self.core, "sync_side_streams") and torch.cuda.is_available():
+            self.core.sync_side_streams()
 
     def launch_grad_reduce(self):
         """SUM all-reduce of the flat gradient bucket (averaged by grad_scale = 1/world inside the AdamW kernel)."""
@@ -187,15 +190,15 @@ class Engine:
         self.micro_steps += 1
         if not boundary:
             return
-        if self.scheduler is not None:
-            self.scheduler.step()
-            lr = self.scheduler.get_last_lr()[0]
-        else:
-            lr = self.optimizer.lr
+        # DeepSpeed order (engine._take_model_step): optimizer.step() with the lr currently set, THEN lr_scheduler.step(); the
+        # scheduler starts at warmup_min_lr (last_batch_iteration = -1), so optimizer step k runs at lr(k - 2)
+        lr = self.scheduler.get_last_lr()[0] if self.scheduler is not None else self.optimizer.lr
         with self._tail_ctx():
             self.wait_grad_reduce()
             self.optimizer.step(lr=lr, grad_scale=1.0 / self.world)         # SUM all-reduce -> mean
             self.optimizer.zero_grad()
+        if self.scheduler is not None:
+            self.scheduler.step()
         self.global_steps += 1
 
     def get_lr(self):
@@ -238,9 +241,25 @@ class Engine:
 
 def initialize(model=None, model_parameters=None, training_data=None, collate_fn=None, config=None, **_):
     """deepspeed.initialize look-alike: -> (engine, optimizer, training_dataloader, lr_scheduler)."""
-    params = list(model_parameters) if model_parameters is not None else [p for p in model.parameters() if p.requires_grad]
+    base = model.get_base_model() if hasattr(model, "get_base_model") else model
+    if hasattr(base, "resolve_training_plan"):
+        # the reference's module surface (medplib_amd/surface.py): the driver hands over `model.parameters()` (or MoE param groups,
+        # train_ds_medplib.py:422-436) with requires_grad flags set; they become this build's training state here
+        params = base.resolve_training_plan(model_parameters)
+    else:
+        params = list(model_parameters) if model_parameters is not None else [p for p in model.parameters() if p.requires_grad]
     eng = Engine(model, params, config or {}, training_data, collate_fn)
     return eng, eng.optimizer, eng.training_dataloader, eng.scheduler
+
+
+def split_params_into_different_moe_groups_for_optimizer(param_groups, max_group_size=None):
+    """`deepspeed.moe.utils.split_params_into_different_moe_groups_for_optimizer` (train_ds_medplib.py:422-431): DeepSpeed moves expert
+    parameters (tagged allreduce=False) into their own optimizer groups so they reduce over the expert-data-parallel group.  Here the
+    grouping is a property of the engine's buckets (expert tensors are told apart by name when ep_size > 1), so the call only
+    normalises its argument to a list of group dicts; `initialize()` reads the requires_grad flags off the model."""
+    if isinstance(param_groups, dict):
+        return [param_groups]
+    return list(param_groups)
 
 
 def init_distributed(dist_backend="nccl"):

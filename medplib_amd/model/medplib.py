@@ -127,6 +127,8 @@ class MedPLIBForCausalLM(nn.Module):
 
     def sync_side_streams(self):
         """Order the calling stream behind everything the side streams have been given (tail backward / optimizer, SAM encoder)."""
+        if self._tail_stream_obj is None and self._sam_stream is None:
+            return                                            # nothing was ever put on a side stream (also: host-only surface tests)
         cur = torch.cuda.current_stream()
         for st in (self._tail_stream_obj, self._sam_stream):
             if st is not None:

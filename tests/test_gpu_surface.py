@@ -1,0 +1,94 @@
+"""GPU: the reference's training driver replayed call for call (repo-root train_ds_medplib.py = /root/reference/train_ds_medplib.py
+:181-700 with three imports swapped) against the module surface, at tiny dims, from an HF-layout checkpoint directory written to
+disk: `from_pretrained(**vars(args))` -> initialize_vision_modules / initialize_bird_modules -> get_vision_tower().to() -> flag loops
+-> find_linear_layers + get_peft_model -> initialize_moe_modules -> resize_token_embeddings -> --sft_modules substring loop ->
+deepspeed.initialize(model_parameters=model.parameters()) -> engine(**batch) / backward / step -> save_checkpoint -> auto-resume."""
+import os
+import sys
+
+import pytest
+import torch
+
+from medplib_amd.model.config import MedPLIBConfig
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_base(tmp_path, dev):
+    """A dense 'LLaVA-like' base checkpoint directory in the HF key layout (what --version points at)."""
+    from medplib_amd.model.medplib import LISAForCausalLM
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2)
+    W = OM.init_hf_weights(cfg, seed=11)
+    m = LISAForCausalLM(cfg, device=dev)
+    m.load_hf_state_dict(W)
+    d = str(tmp_path / "base")
+    m.save_pretrained(d)
+    return cfg, W, d
+
+
+def _main(argv):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import train_ds_medplib as T
+    return T.main(argv)
+
+
+COMMON = ["--precision", "bf16", "--dataset", "synthetic", "--batch_size", "2", "--grad_accumulation_steps", "1", "--epochs", "1",
+          "--steps_per_epoch", "3", "--lr", "1e-3", "--train_mask_decoder", "--dice_loss_weight", "5.0", "--bce_loss_weight", "1.0",
+          "--iou_loss_weight", "0.5", "--focal_loss_weight", "1.0"]
+
+
+def test_reference_driver_dense_lora_off(dev, tmp_path):
+    """BASELINE configs[3]'s trainable set through the reference's flow: LISA class, --lora_r 0, --sft_modules mask_decoder,
+    text_hidden_fcs.  The first micro-batch's loss must equal what the core class gives on the same weights and batch (the surface adds
+    no arithmetic), training must move it, a checkpoint must appear and a second invocation must resume from it."""
+    cfg, W, base = _write_base(tmp_path, dev)
+    argv = COMMON + ["--version", base, "--lora_r", "0", "--sft_modules", "mask_decoder,text_hidden_fcs", "--log_base_dir", str(tmp_path),
+                     "--exp_name", "dense"]
+    hist = _main(argv)
+    assert len(hist) == 3 and all(h == h for h in hist)
+    from medplib_amd.model.medplib import LISAForCausalLM
+    from medplib_amd.train import synth_batch
+    import train_ds_medplib as T
+    ref = LISAForCausalLM(MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, dice_loss_weight=5.0, bce_loss_weight=1.0, iou_loss_weight=0.5,
+                                             focal_loss_weight=1.0, ce_loss_weight=1.0), device=dev).train()
+    ref.load_hf_state_dict(W)
+    b = T.dict_to_cuda(synth_batch(ref.config, 2, 42, tiny=True), dev)
+    b["images"], b["images_clip"] = b["images"].bfloat16(), b["images_clip"].bfloat16()
+    first = float(ref(**b)["loss"])
+    assert abs(first - hist[0]) < 1e-6, (first, hist[0])
+    ck = tmp_path / "dense" / "ckpt_model"
+    assert (ck / "latest").read_text().strip() == "global_step3"
+    saved = torch.load(ck / "global_step3" / "mp_rank_00_model_states.pt", map_location="cpu")["module"]
+    assert saved and all(("mask_decoder" in k or "text_hidden_fcs" in k) for k in saved)       # DeepSpeed-style module names
+    hist2 = _main(argv + ["--epochs", "2"])                # auto-resume: epoch 0 is done, one more epoch runs
+    assert len(hist2) == 3
+
+
+def test_reference_driver_lora_dense(dev, tmp_path):
+    """scripts/train_stage3.sh's shape: LISA class, LoRA r=8 on gate/up/down through find_linear_layers + get_peft_model, --sft_modules
+    lm_head,embed_tokens,mask_decoder,text_hidden_fcs (the driver default)."""
+    cfg, W, base = _write_base(tmp_path, dev)
+    hist = _main(COMMON + ["--version", base, "--lora_r", "8", "--lora_alpha", "16", "--lora_dropout", "0.05", "--lora_target_modules",
+                           "gate_proj,up_proj,down_proj", "--log_base_dir", str(tmp_path), "--exp_name", "lora"])
+    assert len(hist) == 3 and all(h == h for h in hist)
+    saved = torch.load(tmp_path / "lora" / "ckpt_model" / "global_step3" / "mp_rank_00_model_states.pt", map_location="cpu")["module"]
+    assert "base_model.model.model.layers.0.mlp.gate_proj.lora_A.default.weight" in saved and "base_model.model.lm_head.weight" in saved
+
+
+def test_reference_driver_lora_moe_stage4(dev, tmp_path):
+    """scripts/train_stage4.sh's shape: MoE class from a dense base, adapters on gate/up/down + q/v, initialize_moe_modules (E = 2, top-1,
+    all layers, experts seeded from two stage checkpoints on disk) after get_peft_model, --sft_modules wg,lm_head,embed_tokens,
+    mask_decoder,text_hidden_fcs, MoE optimizer param groups (:422-434)."""
+    cfg, W, base = _write_base(tmp_path, dev)
+    hist = _main(COMMON + ["--version", base, "--moe_enable", "True", "--moe_mode", "dense", "--num_experts", "2", "--top_k_experts", "1",
+                           "--capacity_factor", "1.5", "--router_aux_loss_coef", "0.0", "--expert_pretrained_path", f"{base},{base}",
+                           "--lora_r", "8", "--lora_target_modules", "gate_proj,up_proj,down_proj,q_proj,v_proj",
+                           "--sft_modules", "wg,lm_head,embed_tokens,mask_decoder,text_hidden_fcs",
+                           "--log_base_dir", str(tmp_path), "--exp_name", "moe"])
+    assert len(hist) == 3 and all(h == h for h in hist)
+    saved = torch.load(tmp_path / "moe" / "ckpt_model" / "global_step3" / "mp_rank_00_model_states.pt", map_location="cpu")["module"]
+    assert "base_model.model.model.layers.1.mlp.deepspeed_moe.experts.deepspeed_experts.1.up_proj.lora_B.default.weight" in saved
+    assert "base_model.model.model.layers.0.mlp.deepspeed_moe.gate.wg.weight" in saved
