@@ -55,10 +55,12 @@ def test_reference_driver_dense_lora_off(dev, tmp_path):
     ref = LISAForCausalLM(MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, dice_loss_weight=5.0, bce_loss_weight=1.0, iou_loss_weight=0.5,
                                              focal_loss_weight=1.0, ce_loss_weight=1.0), device=dev).train()
     ref.load_hf_state_dict(W)
-    b = T.dict_to_cuda(synth_batch(ref.config, 2, 42, tiny=True), dev)
-    b["images"], b["images_clip"] = b["images"].bfloat16(), b["images_clip"].bfloat16()
-    first = float(ref(**b)["loss"])
-    assert abs(first - hist[0]) < 1e-6, (first, hist[0])
+    firsts = []
+    for seed in (42, 43, 44):                              # the loader shuffles the three seeded micro-batches
+        b = T.dict_to_cuda(synth_batch(ref.config, 2, seed, tiny=True), dev)
+        b["images"], b["images_clip"] = b["images"].bfloat16(), b["images_clip"].bfloat16()
+        firsts.append(float(ref(**b)["loss"]))
+    assert min(abs(f - hist[0]) for f in firsts) < 1e-6, (firsts, hist[0])
     ck = tmp_path / "dense" / "ckpt_model"
     assert (ck / "latest").read_text().strip() == "global_step3"
     saved = torch.load(ck / "global_step3" / "mp_rank_00_model_states.pt", map_location="cpu")["module"]
