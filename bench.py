@@ -58,36 +58,24 @@ def synthetic_batch(cfg, B, device, seed):
     }
 
 
-def cpu_baseline(cfg, steps=2):
+def cpu_baseline(cfg, device, warmup=3, timed=5):
     """The oracle (CPU fp32 port of the reference path) timed on the host cores on a bounded sample of the same workload:
-    B=1 training step (forward of the whole path + backward through mask decoder / text_hidden_fcs).  To bound host memory
-    and initialisation time the 32 decoder layers alias ONE layer's random weights (arithmetic and memory traffic per
-    layer are unchanged: a layer's 1.6 GB of fp32 weights do not fit in cache)."""
-    from oracle import model as OM
-    import copy
+    B=1 training step (forward of the whole path + backward through mask decoder / text_hidden_fcs), 3 warm-ups + 5 timed
+    (SURVEY §8d).  To bound host memory and initialisation time the 32 decoder layers alias ONE layer's random weights
+    (arithmetic and memory traffic per layer are unchanged: a layer's 1.6 GB of fp32 weights do not fit in cache).
+    The same leg then loads the SAME weights into a second, un-timed HIP model and reports how far the two forwards are apart
+    (`parity`: |dloss|, Dice, per-layer routing agreement at the full 32-layer depth) — oracle/parity.py."""
+    from oracle.parity import full_size_parity
     # 32 threads is the fastest setting measured on the GPU box's 2 x EPYC 9575F (one llama layer: 0.29 s @32, 0.40 s @64,
     # 0.61 s @128 — the oracle's eager ops stop scaling past one CCD group); `cores` reports what was used.
-    torch.set_num_threads(min(32, os.cpu_count()))
-    cfg1 = copy.deepcopy(cfg)
-    cfg1.num_hidden_layers = 1
-    W = OM.init_hf_weights(cfg1, seed=0)
-    for i in range(1, cfg.num_hidden_layers):
-        for k in [k for k in W if k.startswith("model.layers.0.")]:
-            W[k.replace("model.layers.0.", f"model.layers.{i}.")] = W[k]
-    train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
-    for k in train:
-        W[k] = W[k].clone().requires_grad_()
-    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=42)
-    times = []
-    for _ in range(steps + 1):
-        t0 = time.time()
-        out = OM.model_forward(batch, W, cfg, training=True)
-        out["loss"].backward()
-        times.append(time.time() - t0)
-    t = float(np.median(times[1:]))
-    return {"value": 1.0 / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 training step at B=1 (1 of the 8 per-GPU samples), true dims, median of {steps} after 1 warm-up, "
-                      f"{t:.2f} s/step; decoder-layer weights aliased across the 32 layers"}
+    threads = min(32, os.cpu_count())
+    r = full_size_parity(cfg, device, cpu_threads=threads, time_oracle=(warmup, timed))
+    ts = r.pop("oracle_step_seconds")
+    t = float(np.median(ts))
+    base = {"value": 1.0 / t, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 training step at B=1 (1 of the 8 per-GPU samples), true dims, median of {timed} after {warmup} warm-ups, "
+                      f"{t:.2f} s/step (min {min(ts):.2f}); decoder-layer weights aliased across the {cfg.num_hidden_layers} layers"}
+    return base, r
 
 
 def main():
@@ -227,7 +215,8 @@ def main():
         print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg)
+                # (the parity model is a second set of weights in HBM beside the benchmarked one: 2 x 23 GB of 288)
+                res["cpu_baseline"], res["parity"] = cpu_baseline(cfg, device)
             except Exception as e:   # the GPU number stands on its own; say why the host leg is missing
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -45,6 +45,8 @@ def parse_args(argv=None):
                           ("bce_loss_weight", float, 2.0), ("iou_loss_weight", float, 2.0), ("focal_loss_weight", float, 2.0), ("ep_size", int, 1), ("use_residual", bool, False)):
         p.add_argument("--" + name, type=typ, default=dv)
     p.add_argument("--train_mask_decoder", action="store_true", default=True)
+    from .train import add_layout_flags
+    add_layout_flags(p)
     return p.parse_args(argv)
 
 

@@ -145,6 +145,9 @@ class LoRAState(torch.nn.Module):
         Trainable norm weights are fp32 in the model already: its tensors are re-pointed to the parameters."""
         for (i, short), n in self.norm_names.items():
             llm.layers[i][short] = self.params[self.index[n]].data
+        if self.train_gate:                                   # a trained gate: merge / export run without a training forward
+            for i in self.moe_layers:
+                self.gate_weight(i, llm)
         p = self.full_param("lm_head.weight")
         if p is not None:
             llm.lm_head.copy_(p.detach())

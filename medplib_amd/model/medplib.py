@@ -461,7 +461,7 @@ class MedPLIBForCausalLM(nn.Module):
             # model; the KV-cache decode paths want them merged (merge_and_unload())
             lora_train = getattr(m.llm, "lora", None) is not None
             if not lora_train:
-                last_hidden, aux, _ = m.llm.forward(embeds, key_valid)
+                last_hidden, aux, self._routing = m.llm.forward(embeds, key_valid, collect_routing=self.capture_intermediates)
                 ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, aux)
         if lora_train and torch.is_grad_enabled() and self.training and not inference:
             last_hidden, ce = self._lora_training_forward(plan, feats, src, embeds, key_valid, sup_rows_d, sup_labels_d, region_masks,
@@ -512,7 +512,8 @@ class MedPLIBForCausalLM(nn.Module):
         cfg, dev, m = self.config, self.device_, self.model
         with torch.no_grad():
             if self.capture_intermediates:
-                self.captured = {"last_hidden": last_hidden, "image_tokens": image_tokens, "ce": ce}
+                self.captured = {"last_hidden": last_hidden, "image_tokens": image_tokens, "ce": ce,
+                                 "routing": getattr(self, "_routing", None)}
             assert image_tokens.shape[0] == B
             if exp_d is not None:
                 image_tokens = ops.gather_rows_f32(image_tokens, exp_d)

@@ -78,8 +78,19 @@ def parse_args(argv=None):
     p.add_argument("--use_residual", type=bool, default=False)        # argparse bool as in train_ds_medplib.py:131
     p.add_argument("--router_aux_loss_coef", type=float, default=0.0)
     p.add_argument("--ep_size", type=int, default=1)
+    add_layout_flags(p)
     p.add_argument("--seed", default=42, type=int)
     return p.parse_args(argv)
+
+
+def add_layout_flags(p):
+    """The ICL front-end and MoE layout flags of the reference (train_ds_medplib.py:73-76, 125-126, 134, 97); shared with infer.py."""
+    p.add_argument("--mask_encoder_token_count", type=int, default=64)
+    p.add_argument("--mm_token_compress", action="store_true", default=False)
+    p.add_argument("--mm_compressed_token_count", type=int, default=256)
+    p.add_argument("--moe_mode", type=str, default="dense", choices=["first_half", "second_half", "sparse", "dense"])
+    p.add_argument("--moe_layers_idx", type=lambda s: [int(x) for x in s.split(",")] if s else None, default=None)
+    p.add_argument("--out_dim", default=256, type=int)
 
 
 class SyntheticDataset(torch.utils.data.Dataset):
@@ -140,8 +151,16 @@ def build_model(args, device):
               use_residual=getattr(args, "use_residual", False),
               router_aux_loss_coef=args.router_aux_loss_coef, ce_loss_weight=args.ce_loss_weight, dice_loss_weight=args.dice_loss_weight,
               bce_loss_weight=args.bce_loss_weight, iou_loss_weight=args.iou_loss_weight, focal_loss_weight=args.focal_loss_weight,
-              train_mask_decoder=args.train_mask_decoder)
+              train_mask_decoder=args.train_mask_decoder,
+              icl_mask_encoder=bool(getattr(args, "icl_mask_encoder", False)), mask_encoder_token_count=getattr(args, "mask_encoder_token_count", 64),
+              mm_token_compress=bool(getattr(args, "mm_token_compress", False)),
+              mm_compressed_token_count=getattr(args, "mm_compressed_token_count", 256), out_dim=getattr(args, "out_dim", 256))
+    n_layers = 2 if args.model_size == "tiny" else 32
+    if kw["moe_enable"] and (getattr(args, "moe_layers_idx", None) is not None or getattr(args, "moe_mode", "dense") != "dense"):
+        from .checkpoint import moe_layer_indices                       # medplib_moe_llama.py:575-596
+        kw["moe_layers_idx"] = moe_layer_indices(n_layers, getattr(args, "moe_mode", "dense"), getattr(args, "moe_layers_idx", None))
     cfg = MedPLIBConfig.tiny(sam_depth=2, **kw) if args.model_size == "tiny" else MedPLIBConfig.medplib_7b(**kw)
+    assert cfg.num_hidden_layers == n_layers
     model = (LISAForCausalLM if args.lisa else MedPLIBForCausalLM)(cfg, device=device)
     if args.version:
         model.load_hf_state_dict(torch.load(args.version, map_location="cpu"))
@@ -193,7 +212,7 @@ def main(argv=None):
             print(f"resume training from {resume}, start from epoch {start_epoch} (global step {eng.global_steps})")
     if args.eval_only:
         return validate(val, eng, device, rank)
-    it = 0
+    it = eng.micro_steps                 # a resumed run continues with the micro-batches after the ones it already consumed
     history = []
     for epoch in range(start_epoch, args.epochs):
         eng.train()

@@ -112,6 +112,22 @@ def decoder_layer_inputs(cfg, g, B=2, S=639):
     return emb, kv
 
 
+def init_hf_weights_aliased(cfg, seed=0):
+    """True-dims weights with bounded host memory: ONE decoder layer's seeded weights referenced by all `cfg.num_hidden_layers`
+    layers (the same tensor objects: 1.6 GB of fp32 instead of 52 GB for 32 layers; arithmetic and memory traffic per layer are what
+    distinct weights would cost).  Used by bench.py's cpu_baseline leg and the full-depth parity check (oracle/parity.py)."""
+    import copy
+    cfg1 = copy.deepcopy(cfg)
+    cfg1.num_hidden_layers = 1
+    if cfg1.moe_layers_idx is not None:
+        cfg1.moe_layers_idx = [0] if 0 in cfg.moe_layers_idx else []
+    W = init_hf_weights(cfg1, seed=seed)
+    for i in range(1, cfg.num_hidden_layers):
+        for k in [k for k in W if k.startswith("model.layers.0.")]:
+            W[k.replace("model.layers.0.", f"model.layers.{i}.")] = W[k]
+    return W
+
+
 def make_batch(cfg, B, L=64, H=96, Wd=80, seed=0, ragged=False, sam_size=256):
     """Synthetic batch in the collator's contract (datasets/DataCollatorForSupervisedDataset.py:11-138):
     one IMAGE placeholder bracketed by im_start/im_end, <SEG> near the end, labels supervised on the tail."""
@@ -208,7 +224,7 @@ def make_batch_multimask(cfg, L=64, seed=0, sam_size=256, sizes=((96, 80), (64, 
     return b
 
 
-def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None, llm_grad=False):
+def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=False, override=None, llm_grad=False, collect=None):
     """model/MedPLIB.py:364-572 end to end on the CPU in fp32.  `override` (tests only) may inject `hidden` [B,S,d],
     `image_emb` [B,256,16,16] and `ce` so the trainable tail can be checked on exactly the trunk outputs another
     implementation produced."""
@@ -245,7 +261,7 @@ def model_forward(batch, W, cfg, training=True, rts=None, return_intermediates=F
         kv = None if att2.all() else att2
     # llm_grad (LoRA training): the decoder and the CE stay on the autograd tape so `loss.backward()` reaches the adapters in W
     with (contextlib.nullcontext() if llm_grad else torch.no_grad()):
-        hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts)
+        hidden, aux = llm.llama_forward(embeds, kv, W, cfg, training=training, rts=rts, collect=collect)
         ce, logits = llm.causal_lm_loss(hidden, lab2, W, cfg, aux)
         if override:
             hidden = override.get("hidden", hidden); image_emb = override.get("image_emb", image_emb); ce = override.get("ce", ce)

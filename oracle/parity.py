@@ -1,0 +1,86 @@
+"""ORACLE-SIDE TEST INFRASTRUCTURE ONLY (see oracle/ops.py header): the full-depth, true-dimension parity check.
+
+`full_size_parity(cfg, device)` runs the WHOLE `model_forward` (CLIP tower -> splice -> `cfg.num_hidden_layers` Llama / MoE decoder
+layers at 7B dims -> CE; SAM-Med2D encoder -> <SEG> projection -> mask decoder -> postprocess -> 4 mask losses) once on the CPU oracle
+(fp32) and once on the HIP path (bf16 trunk, fp32 tail) from the same seeded weights and the same B = 1 batch, and reports how far
+apart they are: the 10 losses, the last hidden state, per-layer routing agreement, the thresholded-mask Dice.  Weights: one decoder
+layer's seeded weights aliased over all layers on BOTH sides (`init_hf_weights_aliased`), which bounds host memory at true dims.
+Gate sampling (DeepSpeed's RTS draws) is off on both sides so the routing is a function of the gate alone.
+Called by tests/test_gpu_model.py (8 layers) and by bench.py's cpu_baseline leg (32 layers, un-timed), never by the product."""
+import copy
+import time
+
+import torch
+
+from . import model as OM
+from . import ops as O
+
+
+def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None):
+    """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
+    through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline)."""
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
+    if cpu_threads:
+        torch.set_num_threads(cpu_threads)
+    cfg = copy.deepcopy(cfg)
+    cfg.moe_gate_sampling = False
+    W = OM.init_hf_weights_aliased(cfg, seed=seed)
+    batch = OM.make_batch(cfg, 1, L=64, H=H, Wd=Wd, seed=batch_seed)
+    batch["images"] = batch["images"].to(torch.bfloat16).float()
+    batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
+    train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
+    Wt = dict(W)
+    for k in train:
+        Wt[k] = W[k].clone().requires_grad_()
+    times = []
+    if time_oracle:
+        for _ in range(time_oracle[0] + time_oracle[1]):
+            for k in train:
+                Wt[k].grad = None
+            t0 = time.time()
+            out = OM.model_forward(batch, Wt, cfg, training=True)
+            out["loss"].backward()
+            times.append(time.time() - t0)
+        times = times[time_oracle[0]:]
+    coll = []
+    with torch.no_grad():
+        ref, inter = OM.model_forward(batch, W, cfg, training=True, return_intermediates=True, collect=coll)
+
+    cls = MedPLIBForCausalLM if cfg.moe_enable else LISAForCausalLM
+    m = cls(cfg, device=device).train()
+    m.load_hf_state_dict(W)
+    m.capture_intermediates = True
+    gb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(device) for x in batch["masks_list"]]
+    with torch.no_grad():
+        out = m(**gb)
+        losses_gpu = {k: float(out[k]) for k in O.LOSS_KEYS}
+        cap = m.captured
+        hid = cap["last_hidden"].float().cpu()
+        routing = cap.get("routing") or []
+        agree = []
+        for (e_ref, _, _), r in zip(coll, routing):
+            agree.append(float((r[0].cpu().long() == e_ref).float().mean()))
+        masks = m(**dict(gb, inference=True))["pred_masks"]
+    losses_cpu = {k: float(ref[k]) for k in O.LOSS_KEYS}
+    _, _, _, dice_cpu = O.threshold_iou(inter["pred_masks"][0][0], batch["masks_list"][0])
+    _, _, _, dice_gpu = O.threshold_iou(masks[0][0].float().cpu(), batch["masks_list"][0])
+    href = inter["hidden"]
+    res = {"layers": cfg.num_hidden_layers, "moe": bool(cfg.moe_enable), "batch": 1, "seq_len": int(href.shape[1]),
+           "abs_dloss": abs(losses_gpu["loss"] - losses_cpu["loss"]),
+           "max_abs_dloss_over_10": max(abs(losses_gpu[k] - losses_cpu[k]) for k in O.LOSS_KEYS),
+           "loss_gpu": losses_gpu["loss"], "loss_cpu": losses_cpu["loss"], "ce_gpu": losses_gpu["ce_loss"], "ce_cpu": losses_cpu["ce_loss"],
+           "mask_loss_gpu": losses_gpu["mask_loss"], "mask_loss_cpu": losses_cpu["mask_loss"],
+           "hidden_rel_err": float((hid - href).abs().max() / href.abs().max()),
+           "hidden_mean_rel_err": float((hid - href).abs().mean() / href.abs().mean()),
+           "dice_gpu": dice_gpu, "dice_cpu": dice_cpu, "abs_ddice": abs(dice_gpu - dice_cpu),
+           "mask_logit_max_abs_err": float((masks[0][0].float().cpu() - inter["pred_masks"][0][0]).abs().max()),
+           "routing_agreement_min": min(agree) if agree else None,
+           "routing_agreement_mean": (sum(agree) / len(agree)) if agree else None,
+           "routing_agreement_per_layer": [round(a, 4) for a in agree],
+           "weights": "one decoder layer's seeded weights aliased over all layers, both sides; gate sampling off"}
+    if times:
+        res["oracle_step_seconds"] = times
+    del m
+    torch.cuda.empty_cache()
+    return res

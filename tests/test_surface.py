@@ -128,3 +128,19 @@ def test_trainable_flag_on_a_frozen_tensor_is_an_error():
         p.requires_grad = "q_proj" in n
     with pytest.raises(NotImplementedError, match="frozen"):
         model.resolve_training_plan(model.parameters())
+
+
+def test_trained_gate_reaches_the_model_without_a_forward():
+    """merge.py's directory mode is build -> load checkpoint params -> sync_model -> merge_and_unload -> export with no
+    forward in between; a trained `wg` (stage IV --sft_modules wg) must be in the exported state dict."""
+    from model.MedPLIB import MedPLIBForCausalLM
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2)
+    m = MedPLIBForCausalLM(cfg, device="cpu")
+    lo = m.enable_lora(8, 16, 0.0, ("gate_proj", "up_proj", "down_proj"), train_gate=True, sft_modules=("wg",))
+    name = "model.layers.1.mlp.deepspeed_moe.gate.wg.weight"
+    with torch.no_grad():
+        lo.full_param(name).add_(0.25)
+    want = lo.full_param(name).detach().clone()
+    lo.sync_model(m.model.llm)
+    m.merge_and_unload()
+    assert torch.equal(m.state_dict()[name].float(), want)
