@@ -65,8 +65,10 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1 + 256, dtype=torch.float32, device=dev)      # [0] = the norm^2, [1:] = block partials
         off = 0
+        self.offsets = {}                                       # id(param) -> (offset, numel) in the flat buffers
         for p in self.params:                                   # re-home every parameter (and its grad) into the flat buffers
             k = p.numel()
+            self.offsets[id(p)] = (off, k)
             self.flat_param[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + k].view(p.shape)
             p.grad = self.flat_grad[off:off + k].view(p.shape)
@@ -110,7 +112,6 @@ class Engine:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
-        self._pending = None
         if self.world > 1:
             # every replica starts from rank 0's trainable parameters (DeepSpeed engine._broadcast_model): one broadcast of the flat
             # fp32 buffer.  The frozen trunk is loaded / seeded identically on every rank and is not sent.
@@ -126,6 +127,14 @@ class Engine:
             tail_only = all(("mask_decoder" in names.get(id(p), "") or "text_hidden_fcs" in names.get(id(p), ""))
                             for p in self.optimizer.params)
             model.tail_side_stream = bool(tail_only)
+        # Backward-overlapped, bucketed gradient reduction (DeepSpeed overlap_comm / reduce_bucket_size, train_ds_medplib.py:412-419):
+        # with decoder adapters training, each layer's gradients are all-reduced from INSIDE the decoder backward as soon as the
+        # layer is done (LoRAState.grad_sink), on the communication stream, while the layers below are still computing; what
+        # is left (the fp32 tail, lm_head / embed_tokens, front-end modules) goes in one last bucket after backward returns.
+        self._pendings, self._reduced, self._layer_ranges = [], [], {}
+        lora = getattr(getattr(model, "model", None), "lora", None)
+        if lora is not None and (self.world > 1 or self.reduce_single_rank) and int(config.get("overlap_comm", 1)):
+            self._setup_layer_buckets(lora)
         self.training_dataloader = None
         if training_data is not None:
             sampler = None
@@ -167,23 +176,63 @@ class Engine:
         if hasattr(self.core, "sync_side_streams") and torch.cuda.is_available():
             self.core.sync_side_streams()
 
-    def launch_grad_reduce(self):
-        """SUM all-reduce of the flat gradient bucket (averaged by grad_scale = 1/world inside the AdamW kernel)."""
-        if self.world == 1 and not self.reduce_single_rank:
-            return
+    def _setup_layer_buckets(self, lora):
+        """Flat-buffer ranges of every decoder layer's trainable tensors (contiguous runs merged), and the sink that fills them."""
+        by_layer = {}
+        for n, p in zip(lora.names, lora.params):
+            if n.startswith("model.layers.") and id(p) in self.optimizer.offsets:
+                by_layer.setdefault(int(n.split(".")[2]), []).append(self.optimizer.offsets[id(p)])
+        for i, spans in by_layer.items():
+            merged = []
+            for off, k in sorted(spans):
+                if merged and merged[-1][1] == off:
+                    merged[-1][1] = off + k
+                else:
+                    merged.append([off, off + k])
+            self._layer_ranges[i] = [tuple(m) for m in merged]
+        self._lora = lora
+        lora.grad_sink = self._sink
+
+    def _sink(self, layer, named_grads):
+        """LoRAState.grad_sink: accumulate layer `layer`'s gradients into the flat buffer (they add up over the micro-steps of a
+        gradient-accumulation window) and, at the boundary micro-step, start their all-reduce."""
+        lo = self._lora
+        for n, g in named_grads.items():
+            p = lo.params[lo.index[n]]
+            p.grad.add_(g.reshape(p.grad.shape))
+        if self.is_gradient_accumulation_boundary():
+            for s, e in self._layer_ranges.get(layer, ()):
+                self._reduce_range(s, e)
+
+    def _reduce_range(self, s, e):
+        buf = self.optimizer.flat_grad[s:e]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self._pending = dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+                self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
         else:                                                   # gloo (CPU tests of the multi-rank plumbing)
-            self._pending = dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+            self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        self._reduced.append((s, e))
+
+    def launch_grad_reduce(self):
+        """SUM all-reduce of whatever part of the flat gradient buffer no layer bucket has covered yet — all of it (one bucket)
+        when nothing in the decoder trains.  Averaged by grad_scale = 1/world inside the AdamW kernel."""
+        if self.world == 1 and not self.reduce_single_rank:
+            return
+        pos = 0
+        for s, e in sorted(self._reduced) + [(self.optimizer.numel, self.optimizer.numel)]:
+            if s > pos:
+                self._reduce_range(pos, s)
+            pos = max(pos, e)
+        self._reduced = []
 
     def wait_grad_reduce(self):
-        if self._pending is not None:
-            self._pending.wait()
+        if self._pendings:
+            for w in self._pendings:
+                w.wait()
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
-            self._pending = None
+            self._pendings = []
 
     def step(self):
         boundary = self.is_gradient_accumulation_boundary()

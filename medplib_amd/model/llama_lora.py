@@ -26,6 +26,16 @@ ALL_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj") + MLP_TARGETS
 GROUPS = {"qkv": ("q_proj", "k_proj", "v_proj"), "o": ("o_proj",), "gu": ("gate_proj", "up_proj"), "down": ("down_proj",)}
 
 
+# trainable tensors OUTSIDE the decoder stack (their gradients come from other autograd Functions than LlamaLoRAFn)
+FRONT_PREFIXES = ("lm_head.weight", "model.embed_tokens.weight", "model.mm_projector.", "model.mm_token_compressor.", "model.region_fea_adapter.",
+                  "model.mask_encoder.")
+
+
+def decoder_param_names(lora):
+    """The parameters LlamaLoRAFn takes (and returns gradients for), in `lora.names` order."""
+    return [n for n in lora.names if not n.startswith(FRONT_PREFIXES)]
+
+
 def _module(t):
     return ("self_attn." if t in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp.") + t
 
@@ -80,6 +90,9 @@ class LoRAState(torch.nn.Module):
                      "down_proj": ar}
         self.width = {"qkv": 3 * d, "o": d, "gu": 2 * ff, "down": d}
         self.step = 0
+        # set by the engine for data-parallel runs: callable(layer, {name: gradient}) invoked by backward() as soon as a layer's
+        # gradients are complete, so their all-reduce overlaps the dgrad of the layers below (engine.Engine._sink)
+        self.grad_sink = None
         self._bufs = {}
         self.p_active = self.p                                  # dropout in effect: p while training, 0 in eval (set per forward)
 
@@ -473,6 +486,9 @@ def backward(llm, saved, d_hidden, d_aux=None):
             dx, grads[lora.norm_names[(i, "ln1")]] = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid, want_wgrad=True)
         else:
             dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
+        if lora.grad_sink is not None:                              # hand layer i's finished gradients over (bucketed all-reduce)
+            pre = f"model.layers.{i}."
+            lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
     grads["__d_embeds__"] = dx                                     # gradient of the decoder's input rows (for embed_tokens)
     return grads
 
@@ -490,8 +506,8 @@ class LlamaLoRAFn(torch.autograd.Function):
         grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous())
         d_emb = grads.pop("__d_embeds__").view(ctx.saved["B"], ctx.saved["S"], -1) if ctx.needs_input_grad[1] else None
         ctx.saved = None
-        own = [n for n in llm.lora.names if n in grads]
-        return (None, d_emb, None) + tuple(grads[n].contiguous() for n in own)
+        # one slot per parameter forward() took; None where the engine's grad sink already accumulated the gradient
+        return (None, d_emb, None) + tuple((grads[n].contiguous() if n in grads else None) for n in decoder_param_names(llm.lora))
 
 
 class CrossEntropyFn(torch.autograd.Function):

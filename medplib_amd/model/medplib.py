@@ -378,9 +378,7 @@ class MedPLIBForCausalLM(nn.Module):
         from . import llama_lora as LL
         cfg, m, dev = self.config, self.model, self.device_
         lo = m.llm.lora
-        front = ("lm_head.weight", "model.embed_tokens.weight", "model.mm_projector.", "model.mm_token_compressor.", "model.region_fea_adapter.",
-                 "model.mask_encoder.")
-        decoder_params = [p_ for n_, p_ in zip(lo.names, lo.params) if not n_.startswith(front)]
+        decoder_params = [lo.params[lo.index[n_]] for n_ in LL.decoder_param_names(lo)]
         feats_on_tape = False
         proj_p = [lo.full_param(f"model.mm_projector.{k}") for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
         if proj_p[0] is not None:                                   # mm_projector trains (stage II)

@@ -59,8 +59,11 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
         hid = cap["last_hidden"].float().cpu()
         routing = cap.get("routing") or []
         agree = []
+        same = torch.ones(hid.shape[0] * hid.shape[1], dtype=torch.bool)
         for (e_ref, _, _), r in zip(coll, routing):
-            agree.append(float((r[0].cpu().long() == e_ref).float().mean()))
+            eq = r[0].cpu().long()[: same.numel()] == e_ref[: same.numel()]
+            agree.append(float(eq.float().mean()))
+            same &= eq
         masks = m(**dict(gb, inference=True))["pred_masks"]
     losses_cpu = {k: float(ref[k]) for k in O.LOSS_KEYS}
     _, _, _, dice_cpu = O.threshold_iou(inter["pred_masks"][0][0], batch["masks_list"][0])
@@ -73,6 +76,10 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "mask_loss_gpu": losses_gpu["mask_loss"], "mask_loss_cpu": losses_cpu["mask_loss"],
            "hidden_rel_err": float((hid - href).abs().max() / href.abs().max()),
            "hidden_mean_rel_err": float((hid - href).abs().mean() / href.abs().mean()),
+           # a token that picked the other expert somewhere is a different computation from there on: bound the rest
+           "hidden_rel_err_agreeing_rows": float((hid.view(-1, hid.shape[-1])[same] - href.view(-1, href.shape[-1])[same]).abs().max()
+                                                 / href.abs().max()),
+           "rows_agreeing_in_every_layer": float(same.float().mean()),
            "dice_gpu": dice_gpu, "dice_cpu": dice_cpu, "abs_ddice": abs(dice_gpu - dice_cpu),
            "mask_logit_max_abs_err": float((masks[0][0].float().cpu() - inter["pred_masks"][0][0]).abs().max()),
            "routing_agreement_min": min(agree) if agree else None,

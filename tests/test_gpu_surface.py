@@ -54,7 +54,7 @@ def test_reference_driver_dense_lora_off(dev, tmp_path):
     import train_ds_medplib as T
     ref = LISAForCausalLM(MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, dice_loss_weight=5.0, bce_loss_weight=1.0, iou_loss_weight=0.5,
                                              focal_loss_weight=1.0, ce_loss_weight=1.0), device=dev).train()
-    ref.load_hf_state_dict(W)
+    ref.load_hf_state_dict(torch.load(os.path.join(base, "pytorch_model.bin"), map_location="cpu"))   # what --version holds (bf16 export)
     firsts = []
     for seed in (42, 43, 44):                              # the loader shuffles the three seeded micro-batches
         b = T.dict_to_cuda(synth_batch(ref.config, 2, seed, tiny=True), dev)

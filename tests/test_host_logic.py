@@ -140,6 +140,89 @@ print("RANK_OK", rank)
 '''
 
 
+_WORKER_OVERLAP = r"""
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from medplib_amd import engine
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['PORT']}", rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+# a stand-in with the structure the engine looks at: model.model.lora with names / params / index / grad_sink, plus a 'tail'
+class Lora(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.names, ps = [], []
+        for i in range(3):
+            for t in ("q_proj", "v_proj"):
+                self.names += [f"model.layers.{i}.self_attn.{t}.lora_A.default.weight", f"model.layers.{i}.self_attn.{t}.lora_B.default.weight"]
+                ps += [torch.nn.Parameter(torch.zeros(2, 5)), torch.nn.Parameter(torch.zeros(7, 2))]
+        for i in range(3):                                      # norm weights sit BEHIND all adapters in the flat order (a second range per layer)
+            self.names.append(f"model.layers.{i}.input_layernorm.weight"); ps.append(torch.nn.Parameter(torch.zeros(5)))
+        self.names.append("lm_head.weight"); ps.append(torch.nn.Parameter(torch.zeros(4, 5)))
+        self.params = torch.nn.ParameterList(ps)
+        self.index = {n: k for k, n in enumerate(self.names)}
+        self.grad_sink = None
+class Inner(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.tail = torch.nn.Linear(3, 2)
+        self.lora = Lora()
+class Model(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = Inner()
+m = Model()
+params = list(m.model.tail.parameters()) + list(m.model.lora.parameters())
+eng, opt, _, _ = engine.initialize(model=m, model_parameters=params, config={"optimizer": {"params": {"lr": 1e-2}}, "gradient_accumulation_steps": 2})
+lo = m.model.lora
+assert lo.grad_sink is not None and sorted(eng._layer_ranges) == [0, 1, 2] and all(len(r) == 2 for r in eng._layer_ranges.values())
+def micro_step(k):
+    # what LlamaLoRAFn.backward does: layers from the top down, each handing its finished gradients to the sink
+    for i in (2, 1, 0):
+        g = {n: torch.full_like(p, float((rank + 1) * (i + 1) * k)) for n, p in zip(lo.names, lo.params) if n.startswith(f"model.layers.{i}.")}
+        lo.grad_sink(i, g)
+    # ... and what autograd accumulates for everything outside the decoder
+    lo.params[lo.index["lm_head.weight"]].grad.add_(float(10 * (rank + 1) * k))
+    for p in m.model.tail.parameters():
+        p.grad.add_(float(100 * (rank + 1) * k))
+micro_step(1)
+assert not eng._pendings, "no collective before the accumulation boundary"
+if eng.is_gradient_accumulation_boundary(): eng.launch_grad_reduce()
+eng.step()                                                     # micro-step 0 of 2: no optimizer step
+micro_step(2)
+assert len(eng._pendings) == 6, len(eng._pendings)            # 3 layers x 2 ranges already in flight before backward 'returned'
+eng.launch_grad_reduce(); eng.wait_grad_reduce()
+for n, p in zip(lo.names, lo.params):
+    if n.startswith("model.layers."):
+        i = int(n.split(".")[2])
+        want = (1 + 2) * (i + 1) * (1 + 2)                     # sum over ranks x sum over the two micro-steps
+    else:
+        want = 10 * (1 + 2) * (1 + 2)
+    assert torch.all(p.grad == want), (n, p.grad.flatten()[:3], want)
+for p in m.model.tail.parameters():
+    assert torch.all(p.grad == 100 * 3 * 3)
+assert not eng._reduced and not eng._pendings
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_layer_bucketed_overlapped_allreduce_two_ranks_gloo(tmp_path):
+    """Backward-overlapped, bucketed gradient reduction (train_ds_medplib.py:412-419 overlap_comm / reduce_bucket_size): the decoder
+    backward hands each layer's gradients to the engine as the layer finishes; at the accumulation boundary their all-reduce starts
+    at once and the rest of the flat buffer follows after backward — every element reduced exactly once."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker_overlap.py"
+    script.write_text(_WORKER_OVERLAP)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
 def test_gradient_bucket_allreduce_two_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
