@@ -383,6 +383,23 @@ int mp_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* ex
                       float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_sumsq,
                       float grad_scale, hipStream_t stream);
 
+/* ---- communication over RCCL / xGMI (one process per GPU) ----------------------------------------------------------------------
+ * What the reference gets from `deepspeed.init_distributed` + ZeRO-2's bucketed gradient reduction (ds_config
+ * train_ds_medplib.py:412-419: overlap_comm, reduce_bucket_size) and from DeepSpeed MOELayer's `_AllToAll` (expert dispatch /
+ * combine, call sites medplib_moe_llama.py:604-614).  RCCL is bound with dlopen at the first call; without it these return
+ * MP_ERR_ARG.  The communicator handle belongs to the caller (no library-side registry).
+ * Bootstrap: rank 0 fills `mp_comm_unique_id_bytes()` bytes with mp_comm_unique_id and hands them to the other ranks by any means
+ * (the launcher's store); every rank then calls mp_comm_init with the same bytes.  Collectives are asynchronous on `stream`. */
+int mp_comm_unique_id_bytes(void);
+int mp_comm_unique_id(void* out, int64_t bytes);
+int mp_comm_init(int rank, int world, const void* unique_id, void** comm);
+int mp_comm_destroy(void* comm);
+/* in-place SUM all-reduce of one gradient bucket (`count` elements of MP_F32 / MP_BF16) */
+int mp_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype_tag, hipStream_t stream);
+/* equal-split all-to-all of routed token slabs: chunk p (count_per_peer elements) of `send` goes to rank p, chunk p of `recv` arrives
+ * from rank p; send != recv */
+int mp_alltoall_tokens(void* comm, const void* send, void* recv, int64_t count_per_peer, int dtype_tag, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,13 +112,19 @@ class Engine:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        # "comm_backend": "rccl_capi" -> gradient buckets go through this library's own RCCL entry point (mp_allreduce_bucket) instead
+        # of torch.distributed's collective; torch.distributed then only bootstraps the communicator (medplib_amd/comm.py)
+        self.capi_comm = None
+        if config.get("comm_backend") == "rccl_capi":
+            from .comm import RcclComm
+            self.capi_comm = RcclComm()
         if self.world > 1:
             # every replica starts from rank 0's trainable parameters (DeepSpeed engine._broadcast_model): one broadcast of the flat
             # fp32 buffer.  The frozen trunk is loaded / seeded identically on every rank and is not sent.
             dist.broadcast(self.optimizer.flat_param, src=0)
         # "reduce_single_rank": run the gradient collective even on a one-rank group (SUM over one rank is the identity), so the
         # communication-stream ordering can be exercised on a single GPU (tests/test_gpu_model.py)
-        self.reduce_single_rank = bool(config.get("reduce_single_rank", False)) and dist.is_initialized()
+        self.reduce_single_rank = bool(config.get("reduce_single_rank", False)) and (dist.is_initialized() or self.capi_comm is not None)
         # When every trainable tensor lives in the fp32 mask tail (stage-III "LoRA off": mask_decoder + text_hidden_fcs), the model
         # may run that tail on its own stream so it overlaps the next step's frozen trunk (MedPLIBForCausalLM.tail_side_stream);
         # backward / step then follow it onto that stream.
@@ -206,7 +212,12 @@ class Engine:
 
     def _reduce_range(self, s, e):
         buf = self.optimizer.flat_grad[s:e]
-        if self.comm_stream is not None:
+        if self.capi_comm is not None:                          # stream-ordered: nothing to wait on but the stream itself
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.capi_comm.all_reduce_(buf)
+            self._pendings.append(None)
+        elif self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
@@ -229,7 +240,8 @@ class Engine:
     def wait_grad_reduce(self):
         if self._pendings:
             for w in self._pendings:
-                w.wait()
+                if w is not None:
+                    w.wait()
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             self._pendings = []

@@ -23,6 +23,17 @@ def group_ranks(world: int, ep_size: int) -> Tuple[List[List[int]], List[List[in
     return ep_groups, edp_groups
 
 
+def build_host_group(ep_size: int):
+    """gloo twin of this rank's expert-parallel group (host-side scalars: ExpertParallel.exchange_capacity)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = None
+    for ranks in group_ranks(world, ep_size)[0]:
+        g = dist.new_group(ranks, backend="gloo")
+        if rank in ranks:
+            mine = g
+    return mine
+
+
 def build_groups(ep_size: int):
     """Create this rank's expert-parallel and expert-data-parallel process groups (every rank must call this)."""
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -40,30 +51,79 @@ def build_groups(ep_size: int):
 
 
 class ExpertParallel:
-    def __init__(self, group, ep_size: int, num_experts: int):
+    """One exchange per direction and MoE layer.  The dispatch buffer is `[E, capx + 1, d]`: rows 0..capx-1 of slab e are the capacity
+    slots of global expert e, row capx is a HEADER whose first 4 bytes hold the number of routed rows (int32), so the row counts ride
+    in the same all-to-all as the rows (DeepSpeed sends capacity-padded slabs too — `dispatched_input` is `[E, C, M]` — but needs no
+    counts because it multiplies all C rows; here the expert GEMMs skip the unrouted tail).  `capx` is the exchange capacity: the MAX
+    over the expert-parallel group of every rank's own capacity `ceil(T/E * cf)` — ranks of one group see different padded sequence
+    lengths T, and an equal-split all-to-all with rank-local slab sizes would hang or corrupt (the routing itself still uses the
+    rank's own capacity, like DeepSpeed).  The agreement is one scalar MAX all-reduce per forward pass on `host_group` (a gloo twin of
+    the group: host data, so it never orders the host behind the GPU queue); without one the device group is used and read back.
+    Why not "routed rows only" with variable split sizes: torch.distributed / RCCL take the split sizes from the HOST, i.e. a
+    device -> host read of the counts in every one of the 32 layers, which stops the host from running ahead of the GPU (DESIGN §3.3);
+    the padding is (cf - 1) / cf = 1/3 of the bytes at the stage-IV capacity factor."""
+
+    def __init__(self, group, ep_size: int, num_experts: int, host_group=None, capi_comm=None):
         assert num_experts % ep_size == 0, "num_experts % ep_size must be 0 (deepspeed MoE asserts the same)"
         self.group, self.ep, self.E = group, ep_size, num_experts
+        self.host_group = host_group
+        self.capi_comm = capi_comm                             # medplib_amd.comm.RcclComm over the same ranks: mp_alltoall_tokens
         self.E_local = num_experts // ep_size
         self.rank_in_group = dist.get_rank(group) if group is not None else 0
+        self._agreed = {}
 
     def local_expert_ids(self):
         return list(range(self.rank_in_group * self.E_local, (self.rank_in_group + 1) * self.E_local))
 
+    def exchange_capacity(self, cap: int, key=None) -> int:
+        """MAX of `cap` over the expert-parallel group; cached under `key` (the forward-pass counter: one agreement per pass)."""
+        if self.ep == 1:
+            return cap
+        if key is not None and key in self._agreed:
+            return self._agreed[key]
+        if self.host_group is not None:
+            t = torch.tensor([cap], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_group)
+        else:
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            t = torch.tensor([cap], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        capx = int(t.item())
+        if key is not None:
+            self._agreed = {key: capx}
+        return capx
+
+    @staticmethod
+    def write_header(buf: torch.Tensor, kept: torch.Tensor):
+        """Row counts into the header row (the last row) of every slab of buf [E, capx + 1, d]."""
+        E, rows, d = buf.shape
+        hdr = buf[:, rows - 1, :].view(torch.int32) if buf.element_size() * d % 4 == 0 else None
+        assert hdr is not None, "row bytes must be a multiple of 4"
+        hdr[:, 0] = kept.to(torch.int32)
+
     def dispatch(self, buf: torch.Tensor, kept: torch.Tensor):
-        """buf [E, cap, d], kept [E] int32 -> (recv [ep, E_local, cap, d], recv_counts [ep, E_local] int32)."""
-        E, cap, d = buf.shape
+        """buf [E, capx + 1, d] (rows written by the dispatch kernel with slab stride capx + 1), kept [E] int32 ->
+        (recv [ep, E_local, capx + 1, d], recv_counts [ep, E_local] int32): ONE all-to-all; recv[s, e, :recv_counts[s, e]] are the
+        rows source rank s routed to this rank's local expert e."""
+        E, rows, d = buf.shape
         assert E == self.E and buf.is_contiguous()
-        recv = torch.empty((self.ep, self.E_local, cap, d), dtype=buf.dtype, device=buf.device)
-        dist.all_to_all_single(recv.view(self.ep, -1), buf.view(self.ep, -1), group=self.group)
-        counts = torch.empty((self.ep, self.E_local), dtype=kept.dtype, device=kept.device)
-        dist.all_to_all_single(counts, kept.view(self.ep, self.E_local).contiguous(), group=self.group)
+        self.write_header(buf, kept)
+        recv = torch.empty((self.ep, self.E_local, rows, d), dtype=buf.dtype, device=buf.device)
+        self._a2a(recv.view(self.ep, -1), buf.view(self.ep, -1))
+        counts = recv[:, :, rows - 1, :].view(torch.int32)[:, :, 0].contiguous()
         return recv, counts
 
     def combine(self, y: torch.Tensor):
-        """y [ep, E_local, cap, d] (expert outputs, slab s = rows that came from source rank s) -> [E, cap, d] on the owner of
+        """y [ep, E_local, capx, d] (expert outputs, slab s = rows that came from source rank s) -> [E, capx, d] on the owner of
         the tokens: slab e holds the outputs of global expert e for THIS rank's tokens."""
         ep, El, cap, d = y.shape
         assert ep == self.ep and El == self.E_local and y.is_contiguous()
         out = torch.empty((self.E, cap, d), dtype=y.dtype, device=y.device)
-        dist.all_to_all_single(out.view(self.ep, -1), y.view(self.ep, -1), group=self.group)
+        self._a2a(out.view(self.ep, -1), y.view(self.ep, -1))
         return out
+
+    def _a2a(self, recv, send):
+        if self.capi_comm is not None:
+            self.capi_comm.all_to_all(recv, send)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)

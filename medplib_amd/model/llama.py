@@ -187,16 +187,22 @@ class LlamaStack:
             expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
         else:
             expert, slot, weight, kept, counts, l_aux = ops.moe_route_top2(gates, logits, cap, self._gate_draws(i, T, E, gumbel=True))
-        buf = ops.moe_dispatch(h, expert, slot, E, cap, top_k=k)
         if self.ep is not None:
-            y = self._experts_parallel(lw, buf, kept, cap)
-        else:
-            act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
-            if ops.GEMM_TIMER is not None:
-                ops.GEMM_TIMER.batched_rows = k * T      # algorithmic rows of the expert GEMMs: every token visits k experts
-            ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
-            y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
-            ops.gemm_batched(act, lw["down"], y, m_dev=kept)
+            # slabs of capx + 1 rows: capx = the capacity agreed over the expert-parallel group for this pass (ranks see different
+            # T), the extra row is the header that carries the row count through the same all-to-all (expert_parallel.py)
+            capx = self.ep.exchange_capacity(cap, key=self.gate_pass)
+            buf = ops.moe_dispatch(h, expert, slot, E, capx + 1, top_k=k)
+            y = self._experts_parallel(lw, buf, kept, capx)
+            if cfg.use_residual:
+                raise NotImplementedError("residual MoE with ep_size > 1")
+            return ops.moe_combine(y, expert, slot, weight, x, capx, top_k=k), l_aux, (expert, slot, counts)
+        buf = ops.moe_dispatch(h, expert, slot, E, cap, top_k=k)
+        act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
+        if ops.GEMM_TIMER is not None:
+            ops.GEMM_TIMER.batched_rows = k * T          # algorithmic rows of the expert GEMMs: every token visits k experts
+        ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
+        y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
+        ops.gemm_batched(act, lw["down"], y, m_dev=kept)
         if cfg.use_residual:
             # residual MoE: the routed output and a dense MLP of the same input, mixed by a learned two-way softmax
             moe = ops.moe_combine(y, expert, slot, weight, None, cap, top_k=k)
@@ -212,11 +218,11 @@ class LlamaStack:
         all-to-all the outputs back (sharded_moe.py MOELayer.forward; collectives C3 of SURVEY §2.5)."""
         cfg, ep = self.cfg, self.ep
         ff, d = cfg.intermediate_size, cfg.hidden_size
-        recv, counts = ep.dispatch(buf, kept)                      # [ep, E_local, cap, d], [ep, E_local]
+        recv, counts = ep.dispatch(buf, kept)                      # [ep, E_local, cap + 1, d] (row cap = header), [ep, E_local]
         counts_t = counts.t().contiguous()                         # [E_local, ep]: per local expert, rows from each source rank
-        y = torch.empty_like(recv)
+        y = torch.empty((ep.ep, ep.E_local, cap, d), dtype=recv.dtype, device=recv.device)
         for e in range(ep.E_local):
-            a = recv[:, e]                                         # [ep, cap, d] view, batch stride E_local*cap*d
+            a = recv[:, e, :cap]                                   # [ep, cap, d] view, batch stride E_local*(cap+1)*d
             act = torch.empty((ep.ep, cap, ff), dtype=torch.bfloat16, device=buf.device)
             ops.gemm_batched(a, lw["gu"][e].unsqueeze(0).expand(ep.ep, -1, -1), act, m_dev=counts_t[e], act=ops.ACT_SWIGLU_PAIR)
             ops.gemm_batched(act, lw["down"][e].unsqueeze(0).expand(ep.ep, -1, -1), y[:, e], m_dev=counts_t[e])

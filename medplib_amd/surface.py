@@ -372,9 +372,9 @@ class SurfaceMixin:
         self._sk["tree"] = None
         ep = int(getattr(model_args, "ep_size", 1) or 1)
         if ep > 1:
-            from .expert_parallel import ExpertParallel, build_groups
+            from .expert_parallel import ExpertParallel, build_groups, build_host_group
             group, _ = build_groups(ep)
-            self.model.llm.enable_expert_parallel(ExpertParallel(group, ep, E))
+            self.model.llm.enable_expert_parallel(ExpertParallel(group, ep, E, host_group=build_host_group(ep)))
 
     def resize_token_embeddings(self, new_num_tokens=None, **_):
         """HF resize (train_ds_medplib.py:312): the first min(old, new) rows are kept, new rows are drawn N(0, 0.02) like

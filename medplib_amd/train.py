@@ -171,9 +171,9 @@ def build_model(args, device):
         model.enable_lora(args.lora_r, args.lora_alpha, args.lora_dropout, args.lora_target_modules,
                           sft_modules=getattr(args, "sft_modules", "mask_decoder,text_hidden_fcs"))
     if args.ep_size > 1:
-        from .expert_parallel import ExpertParallel, build_groups
+        from .expert_parallel import ExpertParallel, build_groups, build_host_group
         ep_group, _ = build_groups(args.ep_size)
-        model.model.llm.enable_expert_parallel(ExpertParallel(ep_group, args.ep_size, cfg.num_experts))
+        model.model.llm.enable_expert_parallel(ExpertParallel(ep_group, args.ep_size, cfg.num_experts, host_group=build_host_group(args.ep_size)))
     return cfg, model
 
 

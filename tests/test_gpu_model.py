@@ -1415,3 +1415,42 @@ def test_full_depth_parity_at_true_dims(dev, moe):
     assert r["abs_ddice"] <= 1e-3, r
     if moe:
         assert len(r["routing_agreement_per_layer"]) == 8 and r["routing_agreement_min"] >= 0.97, r
+
+
+def test_capi_rccl_comm_single_rank(dev):
+    """The C-ABI RCCL helpers (mp_comm_unique_id / mp_comm_init / mp_allreduce_bucket / mp_alltoall_tokens, SURVEY §8b Face 2) on a
+    one-rank communicator: a SUM over one rank and an exchange with oneself are identities — this checks the binding, the stream
+    ordering and the engine / expert-parallel wiring; more than one GPU is never available to this suite (the 2-rank protocol of
+    the callers is covered on gloo in tests/test_host_logic.py)."""
+    from medplib_amd import engine
+    from medplib_amd.comm import RcclComm
+    from medplib_amd.expert_parallel import ExpertParallel
+    c = RcclComm(rank=0, world=1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1 << 20, generator=g).to(dev)
+    want = x.clone()
+    c.all_reduce_(x)
+    send = torch.randn(4, 33, 64, generator=g).to(torch.bfloat16).to(dev)
+    recv = torch.empty_like(send)
+    c.all_to_all(recv, send)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and torch.equal(recv, send)
+    # the expert-parallel layer on it: bit-equal to the replicated-experts path
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, num_experts=3, capacity_factor=1.0)
+    W = OM.init_hf_weights(cfg)
+    emb = (torch.randn(2, 90, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    ref, _, _ = _model(cfg, dev, W).model.llm.forward(emb, None)
+    m = _model(cfg, dev, W)
+    m.model.llm.enable_expert_parallel(ExpertParallel(None, 1, cfg.num_experts, capi_comm=c))
+    out, _, _ = m.model.llm.forward(emb, None)
+    assert torch.equal(out, ref)
+    # the engine's gradient buckets through mp_allreduce_bucket
+    lin = torch.nn.Linear(64, 32).to(dev)
+    eng, opt, _, _ = engine.initialize(model=lin, model_parameters=lin.parameters(),
+                                       config={"optimizer": {"params": {"lr": 1e-2}}, "comm_backend": "rccl_capi", "reduce_single_rank": True})
+    lin(torch.ones(4, 64, device=dev)).sum().backward()
+    before = opt.flat_grad.clone()
+    eng.launch_grad_reduce(); eng.wait_grad_reduce()
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_grad, before) and not eng._pendings
+    c.close()

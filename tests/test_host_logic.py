@@ -268,7 +268,7 @@ def test_splice_plan_matches_executed_reference(golden_dir, tag):
 
 
 _EP_WORKER = r'''
-import os, sys, torch, torch.distributed as dist
+import os, sys, math, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
 from medplib_amd import expert_parallel as EP
 rank = int(os.environ["RANK"])
@@ -276,32 +276,41 @@ dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['PORT'
 ep_groups, edp_groups = EP.group_ranks(8, 2)
 assert ep_groups == [[0, 1], [2, 3], [4, 5], [6, 7]] and edp_groups == [[0, 2, 4, 6], [1, 3, 5, 7]]
 group, _ = EP.build_groups(2)
-E, cap, d = 4, 6, 5
-ep = EP.ExpertParallel(group, 2, E)
+host_group = EP.build_host_group(2)
+E, d = 4, 6
+ep = EP.ExpertParallel(group, 2, E, host_group=host_group)
 assert ep.local_expert_ids() == [2 * rank, 2 * rank + 1]
 g = torch.Generator().manual_seed(100 + rank)
-T = 11
+T = 11 + 6 * rank                                    # the two ranks see DIFFERENT token counts (variable-length batches) ...
+cap = math.ceil(T / E * 1.5)                         # ... hence different capacities: 5 and 7
+capx = ep.exchange_capacity(cap, key=1)
+assert capx == 7 and ep.exchange_capacity(cap, key=1) == 7
 x = torch.randn(T, d, generator=g)
 expert = torch.randint(0, E, (T,), generator=g)
 slot = torch.full((T,), -1, dtype=torch.long); kept = torch.zeros(E, dtype=torch.int32)
-for t in range(T):                                   # first-come slots, capacity drop (what moe_route_top1 produces)
+for t in range(T):                                   # first-come slots, capacity drop at the rank's OWN capacity (moe_route_top1)
     e = int(expert[t])
     if kept[e] < cap:
         slot[t] = int(kept[e]); kept[e] += 1
-buf = torch.zeros(E, cap, d)
+buf = torch.zeros(E, capx + 1, d)                    # slab stride capx + 1: the last row of each slab is the header
 for t in range(T):
     if slot[t] >= 0:
         buf[expert[t], slot[t]] = x[t]
-recv, counts = ep.dispatch(buf, kept)                # [ep, E_local, cap, d], [ep, E_local]
-assert recv.shape == (2, 2, cap, d) and counts.shape == (2, 2)
+recv, counts = ep.dispatch(buf, kept)                # ONE all-to-all: [ep, E_local, capx + 1, d]; the counts came in the headers
+assert recv.shape == (2, 2, capx + 1, d) and counts.shape == (2, 2)
+all_kept = [torch.zeros(E, dtype=torch.int32) for _ in range(2)]
+dist.all_gather(all_kept, kept)                      # (test only) what every source rank kept per global expert
+for s in range(2):
+    for el in range(2):
+        assert int(counts[s, el]) == int(all_kept[s][2 * rank + el]), (s, el)
 f = lambda e, v: v * (e + 2.0) + e                   # expert e (global id)
-y = torch.zeros_like(recv)
+y = torch.zeros(2, 2, capx, d)
 for s in range(2):
     for el in range(2):
         n = int(counts[s, el])
         y[s, el, :n] = f(2 * rank + el, recv[s, el, :n])
-        assert recv[s, el, n:].abs().sum() == 0      # rows beyond the count are padding
-out = ep.combine(y)                                  # [E, cap, d]: outputs of every global expert for MY tokens
+        assert recv[s, el, n:capx].abs().sum() == 0  # rows beyond the count are padding
+out = ep.combine(y)                                  # [E, capx, d]: outputs of every global expert for MY tokens
 for t in range(T):
     if slot[t] >= 0:
         assert torch.allclose(out[expert[t], slot[t]], f(int(expert[t]), x[t])), (t, int(expert[t]))
@@ -311,8 +320,10 @@ print("RANK_OK", rank)
 
 
 def test_expert_parallel_all_to_all_two_ranks_gloo(tmp_path):
-    """MOELayer's two all-to-alls (dispatch / combine) with E = 4 experts sharded over ep = 2 ranks: every routed row reaches the
-    rank that owns its expert together with the per-(source, expert) row counts, and comes back to its token's slot."""
+    """MOELayer's two all-to-alls (dispatch / combine) with E = 4 experts sharded over ep = 2 ranks whose batches have DIFFERENT
+    token counts: the slab size is agreed over the group (host-side MAX), every routed row reaches the rank that owns its expert,
+    the per-(source, expert) row counts arrive in the slabs' header rows (no second collective), and every output comes back to
+    its token's slot."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ep_worker.py"
     script.write_text(_EP_WORKER)
