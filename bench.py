@@ -78,6 +78,50 @@ def cpu_baseline(cfg, device, warmup=3, timed=5):
     return base, r
 
 
+def upsampler_roofline(device):
+    """The HBM-target kernel of BASELINE.json's north_star (>= 60 % of HBM bandwidth on the SAM mask-decoder upsampler at batch 8):
+    `mp_mask_upsample_fused_bf16` timed with HIP events inside this run at batch 8 for the model's real geometry (256-px SAM:
+    16 x 16 tokens, 3.29 MB algorithmic) and the 1024-px SAM geometry (64 x 64 tokens, 50.5 MB) — SURVEY §8d.  Algorithmic bytes =
+    tokens x 256 ch x 2 B in + packed weights + tokens x 16 px x 32 ch x 2 B out.  Inputs rotate over more buffers than the 256 MiB
+    Infinity Cache holds at the large geometry."""
+    from medplib_amd import ops
+    g = torch.Generator(device=device).manual_seed(0)
+    w1 = torch.randn(256, 64, 2, 2, device=device, generator=g) * 0.06
+    w2 = torch.randn(64, 32, 2, 2, device=device, generator=g) * 0.12
+    w1p, w2p = ops.pack_upsampler_weights(w1, w2)
+    b1 = torch.randn(64, device=device, generator=g) * 0.05
+    lw, lb = torch.ones(64, device=device), torch.zeros(64, device=device)
+    b2 = torch.randn(32, device=device, generator=g) * 0.05
+    out = {"bound": "hbm", "kernel": "upsample_fused_kernel", "peak": 8000.0, "unit": "GB/s", "batch": 8, "dtype": "bf16"}
+    for grid, key in ((16, "sam256"), (64, "sam1024")):
+        B, n_buf = 8, (2 if grid == 16 else 12)
+        srcs = [torch.randn(B, grid * grid, 256, device=device, generator=g).to(torch.bfloat16) for _ in range(n_buf)]
+        ups = [torch.empty(B, 32, 4 * grid, 4 * grid, dtype=torch.bfloat16, device=device) for _ in range(n_buf)]
+
+        def run(i):
+            ops.lib().call("mp_mask_upsample_fused_bf16", srcs[i % n_buf].data_ptr(), w1p.data_ptr(), b1.data_ptr(), lw.data_ptr(),
+                           lb.data_ptr(), w2p.data_ptr(), b2.data_ptr(), None, ups[i % n_buf].data_ptr(), None, B, grid, grid, 1e-6,
+                           torch.cuda.current_stream().cuda_stream)
+        for i in range(20):
+            run(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 200
+        e0.record()
+        for i in range(n):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        tokens = B * grid * grid
+        nbytes = tokens * 256 * 2 + (256 * 256 + 128 * 64) * 2 + tokens * 16 * 32 * 2
+        out[key] = {"geometry": f"{grid}x{grid} tokens ({grid * 16}-px SAM)", "us_per_launch": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
+                    "achieved": round(nbytes / us / 1e3, 1), "frac": round(nbytes / (us * 1e-6) / 8.0e12, 4)}
+    out["achieved"], out["frac"] = out["sam1024"]["achieved"], out["sam1024"]["frac"]
+    out["note"] = ("back-to-back launches bracketed by HIP events (launch gaps included: an upper bound on the kernel time); the model runs the "
+                   "sam256 geometry, which is latency-bound at 3.29 MB")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +257,13 @@ def main():
             "roofline": roof,
         }
         print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
+        if world == 1:
+            try:
+                model.sync_side_streams()
+                torch.cuda.synchronize()
+                res["roofline_upsampler"] = upsampler_roofline(device)
+            except Exception as e:
+                res["roofline_upsampler"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # (the parity model is a second set of weights in HBM beside the benchmarked one: 2 x 23 GB of 288)

@@ -245,8 +245,14 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
     flat = xcd * q + loc;
   } else {
     const int r = bid - full;
-    flat = full + r % rem;
-    split = r / rem;
+    if (S == 1 && (rem & 7) == 0) {
+      // an unsplit tail (rem > CUs / 2: Llama qkv 192, expert gate|up 184 tiles): XCD-chunked like the full waves, so the units of one
+      // XCD are neighbours in the grouped tile order instead of every 8th tile (bid & 7 == r & 7: full is a multiple of 8)
+      flat = full + (r & 7) * (rem >> 3) + (r >> 3);
+    } else {
+      flat = full + r % rem;
+      split = r / rem;
+    }
   }
   const bool is_split = (bid >= full) && S > 1;
   int batch = 0, pbase = 0;
