@@ -402,21 +402,20 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
   if (wr == 0) MP_BAR();
   if (is_split) {
     const int tail = flat - full;
-    // Partials travel as agent-scope relaxed atomics (global_store/load ... sc1: written through to / read from the
-    // memory-side coherence point), so no L2 write-back or invalidate is needed for the other XCDs to see them -- an
-    // agent-scope fence per wave costs an L2-wide flush each and made the tail slower than the unsplit tile.
-    unsigned long long* wsu = reinterpret_cast<unsigned long long*>(g.ws + ((int64_t)tail * S) * (BM2 * BN2));
-    unsigned long long* mine = wsu + (int64_t)split * (BM2 * BN2 / 2);
+    // Partials travel WRITE-THROUGH (16-byte buffer stores / loads with sc1: written to / read from the memory-side coherence point),
+    // so no L2 write-back or invalidate is needed for the other XCDs to see them -- an agent-scope fence per wave costs an L2-wide
+    // flush each and made the tail slower than the unsplit tile.  One accumulator fragment (f32x4) per store: 8-byte sc1 stores
+    // (the first version: 64-bit relaxed atomics) cost 2.7 x the time per byte of 16-byte ones (MI355X_MICROARCH.md, stores table).
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    constexpr int SLAB = BM2 * BN2 * 4;                  // one unit's partial tile, bytes
+    float* tile_ws = g.ws + ((int64_t)tail * S) * (BM2 * BN2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ws, 0, S * SLAB, 0x00020000);
+    const int my_off = split * SLAB + tid * 16;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float lo = acc[i][j][2 * h], hi = acc[i][j][2 * h + 1];
-          const unsigned long long v = (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
-          __hip_atomic_store(mine + ((i * 4 + j) * 2 + h) * NT2 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, my_off + (i * 4 + j) * (NT2 * 16), 0, 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
@@ -433,19 +432,14 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int sp = 0; sp < S; ++sp) {
-      const unsigned long long* part = wsu + (int64_t)sp * (BM2 * BN2 / 2);
+      const int base = sp * SLAB + tid * 16;
 #pragma unroll
-      for (int ip = 0; ip < 4; ++ip) {                 // 16 loads in flight, then their adds
-        unsigned long long t[16];
+      for (int ip = 0; ip < 2; ++ip) {                 // 16 x 16-byte loads in flight, then their adds
+        u32x4 t[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          t[q] = __hip_atomic_load(part + (ip * 16 + q) * NT2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (ip * 16 + q) * (NT2 * 16), 0, 16);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int i = ip * 2 + (q >> 3), j = (q >> 1) & 3, h = q & 1;
-          acc[i][j][2 * h] += __uint_as_float((unsigned)(t[q] & 0xffffffffull));
-          acc[i][j][2 * h + 1] += __uint_as_float((unsigned)(t[q] >> 32));
-        }
+        for (int q = 0; q < 16; ++q) acc[ip * 4 + (q >> 2)][q & 3] += __builtin_bit_cast(f32x4, t[q]);
       }
     }
   }
