@@ -88,7 +88,8 @@ int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, int64_t
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
  * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */
 int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
-/* A stream that issues GEMMs concurrently with others gets its own scratch (up to 4 streams); other streams use the default. */
+/* A stream that issues GEMMs concurrently with others gets its own scratch; other streams of the device use its default entry.
+ * Both calls act on the CURRENT device (hipGetDevice); the directory is keyed by (device, stream) and has no size limit. */
 int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
 
 /* Fused attention forward; variant 0 = hardware transpose-read V path, 1 = scalar-transposed V (cross-check).

@@ -26,6 +26,9 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -450,33 +453,59 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 }  // namespace
 
 // split-K workspaces, registered by the host: >= n_cu * 256 KiB of fp32 partials + >= 256 tickets each.  One workspace serves
-// one stream at a time, so a stream that runs GEMMs concurrently with the default one registers its own
-// (mp_gemm_set_stream_workspace); launches on any other stream use the default entry.
-struct SplitWs { hipStream_t stream; float* ws; int* tickets; int64_t bytes; };
-static SplitWs g_split_default = {nullptr, nullptr, nullptr, 0};
-static SplitWs g_split_streams[4] = {};
-static int g_split_n_streams = 0;
+// one stream at a time, so a stream that runs GEMMs concurrently with others registers its own (mp_gemm_set_stream_workspace);
+// launches on any other stream of that device use the device's default entry (mp_gemm_set_workspace).  The table is keyed by
+// (device, stream) with no cap on either; it is only a directory of caller-owned buffers (the library never allocates).
+struct SplitWs { float* ws; int* tickets; int64_t bytes; };
+static std::mutex g_split_mu;
+static std::map<std::pair<int, hipStream_t>, SplitWs> g_split;          // stream == nullptr: the device's default entry
+
+static int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+
+static int register_split_ws(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  const auto key = std::make_pair(current_device(), stream);
+  if (ws) g_split[key] = SplitWs{(float*)ws, tickets, ws_bytes};
+  else g_split.erase(key);
+  return MP_OK;
+}
 
 extern "C" int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
   MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_workspace: need >= 256 zeroed int tickets");
-  g_split_default = SplitWs{nullptr, (float*)ws, tickets, ws ? ws_bytes : 0};
-  return MP_OK;
+  return register_split_ws(nullptr, ws, ws_bytes, tickets);
 }
 
 extern "C" int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
   MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_stream_workspace: need >= 256 zeroed int tickets");
-  for (int i = 0; i < g_split_n_streams; ++i)
-    if (g_split_streams[i].stream == stream) { g_split_streams[i] = SplitWs{stream, (float*)ws, tickets, ws ? ws_bytes : 0}; return MP_OK; }
-  MP_REQUIRE(g_split_n_streams < 4, MP_ERR_ARG, "mp_gemm_set_stream_workspace: at most 4 per-stream workspaces");
-  g_split_streams[g_split_n_streams++] = SplitWs{stream, (float*)ws, tickets, ws ? ws_bytes : 0};
-  return MP_OK;
+  MP_REQUIRE(stream != nullptr, MP_ERR_ARG, "mp_gemm_set_stream_workspace: the default entry is mp_gemm_set_workspace");
+  return register_split_ws(stream, ws, ws_bytes, tickets);
 }
 
 void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes) {
-  const SplitWs* e = &g_split_default;
-  for (int i = 0; i < g_split_n_streams; ++i)
-    if (g_split_streams[i].stream == stream) e = &g_split_streams[i];
-  *ws = e->ws; *tickets = e->tickets; *bytes = e->bytes;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  const int dev = current_device();
+  auto it = g_split.find(std::make_pair(dev, stream));
+  if (it == g_split.end()) it = g_split.find(std::make_pair(dev, (hipStream_t) nullptr));
+  if (it == g_split.end()) { *ws = nullptr; *tickets = nullptr; *bytes = 0; return; }
+  *ws = it->second.ws; *tickets = it->second.tickets; *bytes = it->second.bytes;
+}
+
+// CU count of the CURRENT device (immutable per device; cached per device id, not in a process-wide static)
+int mp_device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cus[dev] = n;
+  return n;
 }
 
 int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
@@ -492,12 +521,9 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   MP_REQUIRE(batch <= MAX_FLAT_BATCH, MP_ERR_SHAPE, "256x256 GEMM: at most %d batches per launch (got %d)", MAX_FLAT_BATCH, batch);
   const int tiles = (int)(mp_cdiv(g.M, BM2) * mp_cdiv(g.N, BN2));
   const dim3 blk(NT2);
-  static int n_cu = 0, max_split = -1;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    n_cu = std::min(n_cu, 256);                      // workspace / ticket sizing
+  const int n_cu = std::min(mp_device_cus(), 256);   // workspace / ticket sizing
+  static int max_split = -1;                         // environment knob, read once (immutable afterwards)
+  if (max_split < 0) {
     const char* e = getenv("MP_GEMM_MAX_SPLIT");     // 1 = no tail split (A/B), default 8
     max_split = (e && atoi(e) >= 1) ? atoi(e) : 8;
   }

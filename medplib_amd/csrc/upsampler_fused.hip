@@ -22,6 +22,7 @@
 // The kernel is bounded by VALU issue, not HBM: 768 GELUs per token; GELU is evaluated as
 //   gelu(x) = max(x,0) - |x| * Phi(-|x|),   Phi(-a) = 2^q5(a)   (degree-5 fit, |abs error| < 5e-7, all-packed v_pk_fma_f32)
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -55,7 +56,9 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 // GELU(erf), two values per lane so every multiply-add is a v_pk_fma_f32.  gelu(x) = relu(x) - a Phi(-a), a = |x| = 2 relu(x) - x,
 // log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute error of a Phi(-a) over [0, 12], 4.8e-7 in fp32; the
 // leading coefficient is negative so the tail underflows to 0 for any |x|).  One v_exp_f32 per value instead of exp + rcp.
+template <int ABL>
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  if constexpr (ABL & 1) return x;
   const f32x2 xp = __builtin_elementwise_max(x, splat2(0.f));
   const f32x2 a = __builtin_elementwise_fma(splat2(2.f), xp, -x);
   f32x2 q = __builtin_elementwise_fma(splat2(-0.0004733088717330247f), a, splat2(0.007084553129971027f));
@@ -83,7 +86,7 @@ __device__ __forceinline__ void row16_sum4(float& v0, float& v1, float& v2, floa
 
 __device__ __forceinline__ int w1_off(int n, int c) { return n * 512 + ((c ^ (n & 7)) << 4); }      // c = 16-B chunk 0..31
 
-template <bool WITH_UP, bool WITH_MASK>
+template <bool WITH_UP, bool WITH_MASK, int ABL = 0>
 __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW1 = smem;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
         const f32x2 rstd = {__builtin_amdgcn_rsqf(var.x), __builtin_amdgcn_rsqf(var.y)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x2 y = gelu2(__builtin_elementwise_fma(v[rp][j] * rstd, splat2(lwv[j]), splat2(lbv[j])));
+          const f32x2 y = gelu2<ABL>(__builtin_elementwise_fma(v[rp][j] * rstd, splat2(lwv[j]), splat2(lbv[j])));
           const int ch = j * 16 + fr;       // transposition buffer [kw*16 + token][64 ch], 16-B chunks XOR-swizzled by (token & 7)
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
 #pragma unroll
           for (int kw2 = 0; kw2 < 2; ++kw2) {
             const f32x4 c = acc2[kw][kw2 * 2 + half];
-            const f32x2 g01 = gelu2(f32x2{c[0], c[1]} + splat2(b2v[half]));
-            const f32x2 g23 = gelu2(f32x2{c[2], c[3]} + splat2(b2v[half]));
+            const f32x2 g01 = gelu2<ABL>(f32x2{c[0], c[1]} + splat2(b2v[half]));
+            const f32x2 g23 = gelu2<ABL>(f32x2{c[2], c[3]} + splat2(b2v[half]));
             px[0 * 4 + kw * 2 + kw2] = (bf16_t)g01.x;
             px[1 * 4 + kw * 2 + kw2] = (bf16_t)g01.y;
             px[2 * 4 + kw * 2 + kw2] = (bf16_t)g23.x;
@@ -255,8 +258,11 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
           bf16x8 lo, hi;
 #pragma unroll
           for (int i = 0; i < 8; ++i) { lo[i] = px[i]; hi[i] = px[8 + i]; }
-          *reinterpret_cast<bf16x8*>(dst) = lo;
-          *reinterpret_cast<bf16x8*>(dst + 8) = hi;
+          if constexpr (ABL & 2) { asm volatile("" :: "v"(lo), "v"(hi)); }
+          else {
+            *reinterpret_cast<bf16x8*>(dst) = lo;
+            *reinterpret_cast<bf16x8*>(dst + 8) = hi;
+          }
         }
         if (WITH_MASK) {      // the reference multiplies the bf16-rounded upscaled embedding: keep that rounding point
           const float hv = half ? h1 : h0;
@@ -296,7 +302,12 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), UP_LDS, stream, a);
   };
-  if (up && mask) launch(upsample_fused_kernel<true, true>);
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("MP_UPS_ABLATE"); abl = e ? atoi(e) : 0; }       // scripts/upsampler_bench.py only
+  if (up && !mask && abl == 1) launch(upsample_fused_kernel<true, false, 1>);
+  else if (up && !mask && abl == 2) launch(upsample_fused_kernel<true, false, 2>);
+  else if (up && !mask && abl == 3) launch(upsample_fused_kernel<true, false, 3>);
+  else if (up && mask) launch(upsample_fused_kernel<true, true>);
   else if (up) launch(upsample_fused_kernel<true, false>);
   else launch(upsample_fused_kernel<false, true>);
   return mp_check_launch("mp_mask_upsample_fused_bf16");

@@ -77,18 +77,19 @@ GEMM_TIMER = None     # set to a KernelTimer by bench.py
 
 
 # ------------------------------------------------------------------ bf16 trunk ------------------------------------------------
-_GEMM_WS = None
+_GEMM_WS = {}
 
 
 def _ensure_gemm_workspace(device):
-    """Register the scratch of the 256x256 GEMM's tail split-K once per process (one process drives one GPU): 64 MiB of fp32
+    """Register the scratch of the 256x256 GEMM's tail split-K once per device: 64 MiB of fp32
     partials + 256 zeroed arrival tickets.  The library itself never allocates (mp_gemm_set_workspace)."""
-    global _GEMM_WS
-    if _GEMM_WS is None:
-        ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)
-        tickets = torch.zeros(256, dtype=torch.int32, device=device)
-        lib().call("mp_gemm_set_workspace", _p(ws), ws.numel(), _p(tickets), tickets.numel())
-        _GEMM_WS = (ws, tickets)
+    key = torch.device(device).index or 0
+    if key not in _GEMM_WS:
+        with torch.cuda.device(key):                       # the library files the entry under the current device
+            ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+            tickets = torch.zeros(256, dtype=torch.int32, device=device)
+            lib().call("mp_gemm_set_workspace", _p(ws), ws.numel(), _p(tickets), tickets.numel())
+        _GEMM_WS[key] = (ws, tickets)
 
 
 _STREAM_WS = {}
