@@ -221,10 +221,10 @@ def test_model_forward_losses_and_grads(dev, moe, ragged):
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = m(**gb)
-    # CE runs through the full bf16 trunk: 2e-2 absolute on a ~6-valued loss; mask losses go through the fp32 tail but start
-    # from bf16 hidden states / image embeddings: 2e-2 as well.  (Tolerances for the 7B bench config are in DESIGN.md.)
+    # CE runs through the full bf16 trunk, the mask losses through the fp32 tail from bf16 hidden states / image embeddings:
+    # 5e-3 absolute on losses of 0.1 .. 11 (largest measured over every loss comparison of this file: 1.9e-3).
     for k in O.LOSS_KEYS:
-        _stat(f"loss[{k}]", out[k], ref[k], atol=3e-2)
+        _stat(f"loss[{k}]", out[k], ref[k], atol=5e-3)
     out["loss"].backward()
     named = dict(m.named_parameters())
     # Gradients: a ReLU unit of text_hidden_fcs whose pre-activation sits within bf16 noise of zero switches on/off between the
@@ -356,7 +356,7 @@ def test_model_forward_icl_separate_mode(dev):
     S = inter["embeds"].shape[1]
     assert m.captured["last_hidden"].shape[1] == S == batch["input_ids"].shape[1] + 3 * 7 + 2 * 3
     for k in O.LOSS_KEYS:
-        _stat(f"icl loss[{k}]", out[k], ref[k], atol=3e-2)
+        _stat(f"icl loss[{k}]", out[k], ref[k], atol=5e-3)
 
 
 def test_moe_routing_small_token_counts(dev):
@@ -583,7 +583,7 @@ def test_model_forward_mixed_mask_sizes(dev):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = m(**gb)
     for k in O.LOSS_KEYS:
-        _stat(f"mixed-size loss[{k}]", out[k], ref[k], atol=3e-2)
+        _stat(f"mixed-size loss[{k}]", out[k], ref[k], atol=5e-3)
     out["loss"].backward()
     grads = [p.grad for p in m.trainable_parameters() if p.grad is not None]      # hypernets 1-3 / their tokens get none
     assert len(grads) > 20 and all(torch.isfinite(g_).all() for g_ in grads)
@@ -658,7 +658,7 @@ def test_region_prompts_forward(dev):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     torch.manual_seed(5)
     out = m(**gb)
-    _stat("region-prompt ce_loss", out["ce_loss"], inter["ce"] * cfg.ce_loss_weight, atol=3e-2)
+    _stat("region-prompt ce_loss", out["ce_loss"], inter["ce"] * cfg.ce_loss_weight, atol=5e-3)
     assert float(out["mask_loss"]) == 0.0 and inter["embeds"].shape[1] == ids.shape[1] + NP - 1
 
 
@@ -847,7 +847,7 @@ def test_lora_training_step_vs_oracle_autograd(dev, r, alpha, targets):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = eng(**gb)
     for k in O.LOSS_KEYS:
-        _stat(f"lora loss[{k}]", out[k], ref[k], atol=3e-2)
+        _stat(f"lora loss[{k}]", out[k], ref[k], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     worst = 0.0
@@ -937,7 +937,7 @@ def test_lora_training_moe_layers_vs_oracle_autograd(dev):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = eng(**gb)
     for k in O.LOSS_KEYS:
-        _stat(f"moe-lora loss[{k}]", out[k], ref[k], atol=3e-2)
+        _stat(f"moe-lora loss[{k}]", out[k], ref[k], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     worst = 0.0
@@ -985,7 +985,7 @@ def test_lora_training_with_lm_head_and_embed_tokens(dev):
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = eng(**gb)
-    _stat("loss", out["loss"], ref["loss"], atol=3e-2)
+    _stat("loss", out["loss"], ref["loss"], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     for n in ("model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight", "model.mm_projector.0.weight",
@@ -1042,7 +1042,7 @@ def test_lora_training_ragged_batch_and_ce_only(dev):
         gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
         gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
         out = eng(**gb)
-        _stat(f"loss (ragged={ragged}, seg={seg})", out["loss"], ref_loss, atol=3e-2)
+        _stat(f"loss (ragged={ragged}, seg={seg})", out["loss"], ref_loss, atol=5e-3)
         eng.backward(out["loss"])
         torch.cuda.synchronize()
         worst = 0.0
@@ -1083,7 +1083,7 @@ def test_lora_training_icl_moe_with_trainable_token_compressor(dev):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
     out = eng(**gb)
-    _stat("icl moe lora loss", out["loss"], ref["loss"], atol=3e-2)
+    _stat("icl moe lora loss", out["loss"], ref["loss"], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     assert not any(k.endswith("wg.weight") for k in lora.names)          # `wg` is not in this script's --sft_modules: the gate stays frozen
@@ -1128,7 +1128,7 @@ def test_lora_training_with_trainable_region_adapter(dev):
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     torch.manual_seed(5)
     out = eng(**gb)
-    _stat("region-adapter training loss", out["loss"], inter["ce"] * cfg.ce_loss_weight, atol=3e-2)
+    _stat("region-adapter training loss", out["loss"], inter["ce"] * cfg.ce_loss_weight, atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     for n in ("model.region_fea_adapter.weight", "model.region_fea_adapter.bias", "model.layers.0.self_attn.q_proj.lora_B.default.weight"):
@@ -1168,7 +1168,7 @@ def test_lora_training_icl_with_trainable_mask_encoder(dev):
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
     out = eng(**gb)
-    _stat("icl mask-encoder training loss", out["loss"], ref["loss"], atol=3e-2)
+    _stat("icl mask-encoder training loss", out["loss"], ref["loss"], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     for n in [k for k in lora.names if k.startswith("model.mask_encoder.")] + ["model.mm_token_compressor.proj.weight"]:
@@ -1211,7 +1211,7 @@ def test_lora_training_top2_moe_layers(dev):
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     out = eng(**gb)
-    _stat("top-2 moe lora loss", out["loss"], ref["loss"], atol=3e-2)
+    _stat("top-2 moe lora loss", out["loss"], ref["loss"], atol=5e-3)
     eng.backward(out["loss"])
     torch.cuda.synchronize()
     worst = 0.0
