@@ -40,7 +40,10 @@ struct AttnArgs {
 
 template <int D>
 __device__ __forceinline__ int k_off(int r, int c) {  // byte offset of 16-B chunk c of row r in a [64][D] bf16 tile
-  return r * (D * 2) + ((c ^ (r & 7)) << 4);
+  // XOR over ALL chunk bits of the row (D = 128: r & 15; D = 64: r & 7).  With r & 7 at D = 128 the two 8-lane halves of a
+  // ds_read_b128 lane group (fq = 0 rows {0-3, 12-15}, fq = 1 rows {4-11}) landed on the same eight 16-byte slots: a 2-way conflict
+  // on every K fragment read (SQ_LDS_BANK_CONFLICT, scripts/attn_pmc.sh).
+  return r * (D * 2) + ((c ^ (r & (D / 8 - 1))) << 4);
 }
 
 template <int D, bool VT_SCALAR>
@@ -248,6 +251,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // K / V tiles (64 keys) arrive by LDS-DMA into a two-stage ring (K XOR-swizzled via the source address, V row-major for the
 // hardware transpose read); one barrier per tile.  exp is v_exp_f32 on scores pre-multiplied by scale*log2(e); interior tiles
 // (no causal diagonal, no padding, no bias) skip every mask test.
+// V tile swizzle of the v2 kernel.  The hardware transpose read (ds_read_b64_tr_b16) of a 32-lane group touches 8 consecutive V
+// rows x 32 bytes; with plain row-major rows of D*2 = 256 B (D = 128) all 8 rows start on the same LDS bank: an 8-way conflict on
+// every one of the 64 transpose reads of a tile (SQ_LDS_BANK_CONFLICT = 78 % of the LDS-array cycles, scripts/attn_pmc.sh).  The
+// tile is stored with its 32-byte pair-blocks XORed by a per-row key (the row index in units of 256 B, modulo the pair-blocks per
+// row) — on the DMA SOURCE address (the LDS image of an LDS-DMA is lane-linear; pairs of 16-byte chunks stay adjacent, so the global
+// read still walks whole 32-byte pieces of the same two cache lines) and on the read address: the same involution on both sides.
+template <int D>
+__device__ __forceinline__ int v_key(int row) {
+  // D = 64 (CLIP, rows of 128 B: a 4-way conflict) keeps the plain layout: the swizzled tile measured 41 vs 33 us there, while
+  // D = 128 went 75.8 -> 73.6 us at S = 639 and 160 -> 119 us at S = 1316 with SQ_LDS_BANK_CONFLICT 14.4 M -> 0 per launch
+  if constexpr (D != 128) return 0;
+  constexpr int PB = D * 2 / 32;                                   // 32-byte pair-blocks per row
+  return row & (PB - 1);
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
@@ -287,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       const int j = wave * IPW + i;
       const int row = j * RPI + dma_row;
       const int kr = min(k0 + row, a.Sk - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)kr * a.k_ss + ((dma_c ^ (row & 7)) << 3)),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)kr * a.k_ss + ((dma_c ^ (row & (CH - 1))) << 3)),
                                        (__attribute__((address_space(3))) void*)(sK + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)kr * a.v_ss + (dma_c << 3)),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)kr * a.v_ss + ((dma_c ^ (v_key<D>(row) << 1)) << 3)),
                                        (__attribute__((address_space(3))) void*)(sV + j * 1024), 16, 0, 0);
     }
   };
@@ -309,6 +327,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   for (int n = 0; n < NF; ++n)
 #pragma unroll
     for (int j = 0; j < 2; ++j) o[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // V^T fragment reads (swizzled tile, see v_key): this lane's key row inside a 32-key half, the address of d-block 0 and the
+  // signed address step of each key bit (+/- 32, 64, 128 bytes)
+  constexpr int VBITS = (D == 128) ? 3 : 2;                    // log2(pair-blocks per row) = log2(NF)
+  const int v_row = fq * 4 + (fr >> 2);
+  const int v_k = v_key<D>(v_row);                             // v_key(row + 16) == v_key(row + 32) == v_key(row)
+  const int v_a0 = v_row * (D * 2) + (v_k << 5) + (fr & 3) * 8;
+  int v_dlt[VBITS];
+#pragma unroll
+  for (int bit = 0; bit < VBITS; ++bit) v_dlt[bit] = ((v_k >> bit) & 1) ? -(32 << bit) : (32 << bit);
   float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
   const float c2 = a.scale * 1.44269504088896340736f;          // exponent of 2 per unit of raw score (softmax in the log2 domain)
   const float inv_scale = 1.f / a.scale;                       // the rel-pos bias is added to the UNSCALED score, so it is pre-divided
@@ -397,11 +424,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     }
 
     // ---- O^T += V^T P^T: A = V^T fragment (d rows) by the hardware transpose read, B = P^T from registers ----
+    // The d-blocks are walked in Gray-code order so that the swizzled address of block n, vrow_base + ((n ^ key) << 5), follows from
+    // the previous one by ONE add of a per-lane delta (the bit that flips): one running address register instead of NF of them.
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp)
+    for (int kp = 0; kp < 2; ++kp) {
+      int va = v_a0 + kp * 32 * (D * 2);
 #pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const char* p0 = sV + (kp * 32 + fq * 4 + (fr >> 2)) * (D * 2) + (n * 16 + (fr & 3) * 4) * 2;
+      for (int g = 0; g < NF; ++g) {
+        const int n = g ^ (g >> 1);
+        if (g > 0) {
+          const int bit = __builtin_ctz(g);
+          va += ((n >> bit) & 1) ? v_dlt[bit] : -v_dlt[bit];
+          asm volatile("" : "+v"(va));               // keep ONE running register (the compiler would otherwise pre-compute all NF addresses)
+        }
+        const char* p0 = sV + va;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * (D * 2)));
         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -409,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) o[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[kp][j], o[n][j], 0, 0, 0);
       }
+    }
   }
 
   // ---- normalise and store: o[n][j][r] = O[query qw0 + j*16 + fr][d = n*16 + fq*4 + r] ----
