@@ -233,14 +233,16 @@ def main():
             # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tpath):
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            tname = next((n for n in ("r02_hbm_traffic.json", "r01_hbm_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
+            tpath = os.path.join(pdir, tname or "")
+            if tname:
                 tj = json.load(open(tpath)).get("gemm256v3")
                 if tj:
                     roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
                     roof["traffic_detail"] = {"kernel": "gemm256v3_bf16_nt_kernel", "read_bytes_per_launch": tj["read_bytes_per_launch"],
                                               "write_bytes_per_launch": tj["write_bytes_per_launch"],
-                                              "source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, "
+                                              "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE over this same command, "
                                                         "read = 2 x FETCH_SIZE per the gfx950 correction)"}
         res = {
             "metric": "train samples/sec (img+64tok)", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,

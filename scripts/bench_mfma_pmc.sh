@@ -1,7 +1,7 @@
 #!/bin/bash
 # MFMA-pipe occupancy of the training step's GEMM / attention kernels from PMC counters (kernel-trace only, its own run):
 # SQ_VALU_MFMA_BUSY_CYCLES (cycles the MFMA pipe is busy, summed over the chip's 1024 SIMDs) against GRBM_GUI_ACTIVE (the launch's
-# duration in shader clocks, SUMMED over the 8 XCDs): util = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024).  -> gpurun_out/r01_mfma_pmc.json (copy to profiles/).
+# duration in shader clocks, SUMMED over the 8 XCDs): util = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024).  -> gpurun_out/${TAG:-r02}_mfma_pmc.json (copy to profiles/).
 export TMPDIR=/tmp
 out=gpurun_out/mfma_pmc; rm -rf $out; mkdir -p $out
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $out/p1 -- \
@@ -23,6 +23,6 @@ for fam, cs in res.items():
     busy, act = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
     out[fam] = {"launches": len(cs.get("GRBM_GUI_ACTIVE", [])), "avg": {k: round(v, 1) for k, v in a.items()},
                 "shader_clocks_per_launch": round(act / 8), "mfma_pipe_util": round(busy / (act / 8 * 1024), 4) if act else None}
-json.dump(out, open("gpurun_out/r01_mfma_pmc.json", "w"), indent=1, sort_keys=True)
+json.dump(out, open("gpurun_out/" + __import__("os").environ.get("TAG", "r02") + "_mfma_pmc.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))
 PY

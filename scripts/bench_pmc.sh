@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the training step's kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes
 # (kernel-trace only, no sys-trace), as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes.  Summarised per kernel family into
-# gpurun_out/r01_hbm_traffic.json (copy to profiles/).  Units: FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on
+# gpurun_out/${TAG:-r02}_hbm_traffic.json (copy to profiles/).  Units: FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on
 # gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so read bytes = 2 x FETCH_SIZE (guide's correction); WRITE_SIZE is
 # uncalibrated and reported raw.
 export TMPDIR=/tmp
@@ -26,6 +26,6 @@ out = {"note": "rocprofv3 --kernel-trace --pmc <counter> over bench.py (3 steps)
 for fam, cs in res.items():
     f, w = cs.get("FETCH_SIZE", []), cs.get("WRITE_SIZE", [])
     out[fam] = {"launches": len(f), "read_bytes_per_launch": round(2 * 1024 * sum(f) / max(len(f), 1)), "write_bytes_per_launch": round(1024 * sum(w) / max(len(w), 1))}
-json.dump(out, open("gpurun_out/r01_hbm_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump(out, open("gpurun_out/" + __import__("os").environ.get("TAG", "r02") + "_hbm_traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))
 PY
