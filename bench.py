@@ -129,6 +129,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU micro-batch (BASELINE config: 8)")
     ap.add_argument("--layers", type=int, default=32, help="debug only; the reported config is 32")
+    ap.add_argument("--lora", action="store_true",
+                    help="secondary line: scripts/train_stage3.sh's configuration (dense Llama-7B, LoRA r = 8 / alpha 16 / dropout 0.05 on "
+                         "gate/up/down_proj, mask decoder + text_hidden_fcs trainable) = the whole decoder backward in the step; the "
+                         "contract's default line is BASELINE configs[3] (LoRA off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
@@ -153,8 +157,19 @@ def main():
     from medplib_amd.model.medplib import MedPLIBForCausalLM
 
     torch.manual_seed(1234)          # the randomly initialised trainable tail is the same on every rank and in every run
-    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers)
-    model = MedPLIBForCausalLM(cfg, device=device).train()
+    if args.lora:
+        from medplib_amd.model.medplib import LISAForCausalLM
+        cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, moe_enable=False)
+        model = LISAForCausalLM(cfg, device=device).train()
+        lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules="gate_proj,up_proj,down_proj",
+                                 sft_modules="mask_decoder,text_hidden_fcs")
+        for n, p in zip(lora.names, lora.params):            # B = 0 at initialisation would make half the gradients trivially zero
+            if "lora_B" in n:
+                p.data.normal_(0, 0.01)
+        args.no_cpu_baseline = True                          # the host leg and the parity object belong to the default configuration
+    else:
+        cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers)
+        model = MedPLIBForCausalLM(cfg, device=device).train()
     ds_config = {"train_micro_batch_size_per_gpu": args.batch, "gradient_accumulation_steps": 1,
                  "optimizer": {"type": "AdamW", "params": {"lr": 3e-4, "weight_decay": 0.0, "betas": (0.9, 0.95)}},
                  "gradient_clipping": 1.0,
@@ -249,12 +264,16 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic" + (" (images / masks copied from pageable host memory every step)" if args.host_inputs else ""),
-            "config": {"workload": "MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E=2 top-1 experts x32 layers), "
+            "config": {"workload": ("MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh; "
+                                    "whole decoder backward), " if args.lora else
+                                    "MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E=2 top-1 experts x32 layers), ") +
                                    "336x336 CLIP image + 256x256 SAM image + 64-token prompt (S=639 after splice), "
                                    f"per-GPU batch {args.batch}, DP={world}",
                        "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel},
-            "model_tflops_per_gpu": round(FWD_TFLOP_PER_SAMPLE * args.batch * args.steps / dt, 1),
+            # algorithmic work per sample: the forward (9.15 TFLOP); with --lora also the decoder's dgrad (8.66: the frozen
+            # projections' input gradients + the attention backward; no wgrad for frozen weights)
+            "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1),
             "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
             "roofline": roof,
         }
