@@ -53,6 +53,13 @@ const char* mp_last_error_string(void);
 int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
                     const void* residual, int64_t ldr, int M, int N, int K, int act, int out_dtype, float alpha,
                     const int* m_dev, hipStream_t stream);
+/* Fused qkv projection + rotary embedding (HF LlamaAttention q/k/v_proj + apply_rotary_pos_emb, medplib_moe_llama.py:127-135, SURVEY
+ * A.1): C[M, 3*hidden] (standard layout: q | k | v, heads of 128) = A[M,K] @ Wi^T with q and k rotated in the GEMM epilogue at position
+ * (row % seq) + pos_offset (cos_t / sin_t: fp32 [positions, 64]).  Wi = the fused qkv weight with the rows of every q / k head
+ * interleaved in blocks of 32: [dims 0..31 | 64..95 | 32..63 | 96..127] (v rows unchanged).  Bit-identical with mp_gemm_bf16_nt on the
+ * plain weight followed by mp_rope_qk_bf16.  head_dim 128, hidden % 256 == 0. */
+int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
+                          const float* sin_t, int M, int N, int K, int seq, int pos_offset, int head_dim, hipStream_t stream);
 /* 256 or 128: the tile size of the kernel the calling thread's last mp_gemm_bf16_nt* call dispatched to (0 before the first call).
  * Measurement aid: bench.py attributes its HIP-event samples to gemm256v3_bf16_nt_kernel / gemm_bf16_nt_kernel with it. */
 int mp_gemm_last_kernel(void);

@@ -164,6 +164,38 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
     }
     return;
   }
+  if (g.act == ACT_ROPE_QK && n0 < (N / 3) * 2) {
+    // q / k tile of the fused qkv projection (N = 3 * hidden, hidden % 256 == 0: a tile never straddles two thirds).  W rows are
+    // interleaved per 128-wide head (gemm_common.h), so this wave's 64 columns are [lo 32 dims | hi 32 dims] of ONE head: fragments
+    // j = 0,1 hold x_i, fragments j + 2 the matching x_{i+64}.  Same arithmetic and rounding points as the stand-alone kernel
+    // (mp_rope_qk_bf16: the projection output is rounded to bf16 first, the rotation runs in fp32, one rounding per output).
+    const int head0 = (cw >> 7) << 7;                 // first column of the head (standard layout)
+    const int blk = (cw >> 6) & 1;                    // which 32-dim block of lo / hi this wave holds
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + wr * 128 + i * 16 + fr;
+      const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int dim = blk * 32 + j * 16 + fq * 4;   // rotary index i in [0, 64)
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)pos * 64 + dim);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)pos * 64 + dim);
+        bf16x4 olo, ohi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = (float)(bf16_t)acc[i][j][r], b = (float)(bf16_t)acc[i][j + 2][r];
+          olo[r] = (bf16_t)(a * cs[r] - b * sn[r]);
+          ohi[r] = (bf16_t)(b * cs[r] + a * sn[r]);
+        }
+        if (row < M) {
+          *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + head0 + dim) = olo;
+          *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + head0 + 64 + dim) = ohi;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   const bool vec = (g.ldc & 3) == 0 && (!R || (g.ldr & 3) == 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

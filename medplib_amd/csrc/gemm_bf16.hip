@@ -308,7 +308,7 @@ static int gemm_group_m() {
 }
 
 static bool use_256_rule(const GemmArgs& g, int batch) {
-  if (g.act == ACT_SWIGLU_PAIR) return true;          // the paired epilogue exists in the 256x256 kernel only
+  if (g.act == ACT_SWIGLU_PAIR || g.act == ACT_ROPE_QK) return true;   // the paired epilogues exist in the 256x256 kernel only
   if (batch > 8) return false;                        // its flat work decode walks at most 8 batches
   if (gemm_variant() != 2) return false;
   const int64_t tiles = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256) * batch;
@@ -389,6 +389,25 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.max_split = split128(g, 1, stream, &g.ws, &g.tickets);
   launch_gemm(g, dim3(tiles * g.max_split, 1), stream);
   return mp_check_launch("mp_gemm_bf16_nt");
+}
+
+// Fused qkv projection + RoPE (LlamaAttention: q_proj / k_proj / v_proj + apply_rotary_pos_emb): C[M, 3*hidden] =
+// A[M, K] @ Wi[3*hidden, K]^T with the rotation of the q and k thirds done in the epilogue.  Wi = the fused qkv weight with the rows
+// of every q / k head interleaved in blocks of 32 (ACT_ROPE_QK, gemm_common.h); C comes out in the standard layout.
+extern "C" int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
+                                     const float* sin_t, int M, int N, int K, int seq, int pos_offset, int head_dim, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0, MP_ERR_SHAPE, "mp_gemm_qkv_rope_bf16: K must be a multiple of %d", BK);
+  MP_REQUIRE(head_dim == 128 && N % 3 == 0 && (N / 3) % 256 == 0, MP_ERR_SHAPE,
+             "mp_gemm_qkv_rope_bf16: head_dim 128 and hidden %% 256 == 0 (got head_dim %d, N %d)", head_dim, N);
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && cos_t && sin_t && seq > 0, MP_ERR_ARG, "mp_gemm_qkv_rope_bf16: bad arguments");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wi; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.act = ACT_ROPE_QK; g.out_f32 = 0; g.alpha = 1.f;
+  g.group_m = gemm_group_m();
+  g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_seq = seq; g.rope_pos0 = pos_offset;
+  (void)use_256(g, 1);
+  return mp_launch_gemm256(g, 1, stream);
 }
 
 // batched variant: `batch` independent problems at fixed element strides (expert GEMMs: one launch over all experts,

@@ -6,7 +6,12 @@
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4,
        // fused SwiGLU: W holds gate/up rows interleaved in blocks of 32 ([g0..31 | u0..31 | g32..63 | u32..63 | ...]); the epilogue
        // writes silu(gate) * up, so C is [M, N/2] (256x256 kernel only)
-       ACT_SWIGLU_PAIR = 5 };
+       ACT_SWIGLU_PAIR = 5,
+       // fused RoPE on the q and k thirds of a fused qkv projection (256x256 kernel only): within every 128-wide head the W rows
+       // are interleaved in blocks of 32 like the SwiGLU pairs ([lo 0..31 | hi 0..31 | lo 32..63 | hi 32..63], lo = dims 0..63,
+       // hi = dims 64..127), so the two members of a rotary pair sit in fragments j and j+2 of the same lane; the rotated values
+       // are stored at their STANDARD column positions, so C has the reference's layout.  The v third is a plain store.
+       ACT_ROPE_QK = 6 };
 
 struct GemmArgs {
   const bf16_t* A;  int64_t lda;
@@ -34,6 +39,9 @@ struct GemmArgs {
   // matrix, scaled by c_scale[that row] before the residual (indexed by the same destination row) is added.  null = identity.
   const int* a_rows; const int* c_rows; const float* c_scale;
   int rows_stride;
+  // ACT_ROPE_QK: cos / sin tables [positions, 64] fp32, position of row m = m % rope_seq + rope_pos0
+  const float* rope_cos; const float* rope_sin;
+  int rope_seq, rope_pos0;
 };
 
 // GELU(erf) without erff: gelu(x) = relu(x) - a Phi(-a), a = |x|, log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute

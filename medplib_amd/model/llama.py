@@ -57,6 +57,19 @@ class LlamaStack:
         self.ep = None                     # ExpertParallel (expert_parallel.py) once enable_expert_parallel() sharded the experts
         self.fuse_moe_gather_scatter = True   # top-1, one rank: dispatch / combine folded into the expert GEMMs
         self.fuse_decode_routing = True       # decode rows: post-attention norm + gate + routing in one launch
+        # RoPE in the qkv GEMM's epilogue (mp_gemm_qkv_rope_bf16) wants the q / k head rows interleaved in blocks of 32; the plain
+        # fused qkv weight stays (decode GEMVs, the LoRA path's dgrad transposes, export), the interleaved copy (+3.2 GB of 288 at
+        # 7B) serves every multi-row forward.  Rebuilt whenever the qkv weights change (refresh_fused_qkv).
+        self.fuse_rope = cfg.head_dim == 128 and cfg.hidden_size % 256 == 0
+        self.refresh_fused_qkv()
+
+    def refresh_fused_qkv(self):
+        """(Re)build the RoPE-interleaved copies of the fused qkv weights; call after anything that writes lw["qkv"]."""
+        for lw in self.layers:
+            if self.fuse_rope:
+                lw["qkv_rope"] = ops.rope_interleave_qkv(lw["qkv"], self.cfg.num_attention_heads, self.cfg.head_dim)
+            else:
+                lw.pop("qkv_rope", None)
 
     def enable_expert_parallel(self, ep):
         """Shard the experts over an expert-parallel group (DeepSpeed `ep_size`, medplib_moe_llama.py:604-614): every rank keeps the
@@ -99,6 +112,7 @@ class LlamaStack:
             else:
                 put(lw["gu"], ops.swiglu_interleave(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
                 put(lw["down"], sd[p + "mlp.down_proj.weight"])
+        self.refresh_fused_qkv()
 
     def export_hf(self, prefix=""):
         cfg = self.cfg
@@ -251,8 +265,11 @@ class LlamaStack:
         lin = (lambda a, w, **kw: ops.gemv(a, w, **kw)) if B * S <= 8 else (lambda a, w, **kw: ops.gemm(a, w, **kw))
         for i, lw in enumerate(self.layers):
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
-            qkv = lin(h, lw["qkv"])
-            ops.rope_qk_(qkv, self.cos, self.sin, S, H, D, pos_offset=pos0)
+            if self.fuse_rope and B * S > 8:
+                qkv = ops.gemm_qkv_rope(h, lw["qkv_rope"], self.cos, self.sin, S, H, D, pos_offset=pos0)   # RoPE in the epilogue
+            else:
+                qkv = lin(h, lw["qkv"])
+                ops.rope_qk_(qkv, self.cos, self.sin, S, H, D, pos_offset=pos0)
             q5 = qkv.view(B, S, 3, H, D)
             if kv_cache is not None:
                 kv_cache["k"][i][:, pos0:pos0 + S].copy_(q5[:, :, 1])

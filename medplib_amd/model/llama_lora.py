@@ -228,6 +228,7 @@ class LoRAState(torch.nn.Module):
             for k in ("qkv", "o", "gu", "down"):
                 if k + "_T" in lw:
                     lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()
+        llm.refresh_fused_qkv()                                   # the RoPE-interleaved copies follow the merged q / k / v weights
 
     def padded(self, i):
         """bf16 GEMM operands of layer i per adapter group: (A [64, in], A^T [in, 64], B [out, 64], B^T [64, out], R, targets) — with a

@@ -458,6 +458,38 @@ def rope_qk_(qkv, cos_t, sin_t, seq, heads, head_dim, pos_offset=0):
     return qkv
 
 
+def rope_interleave_qkv(qkv_w, heads, head_dim):
+    """Fused qkv weight [3*H*D, K] -> the row order mp_gemm_qkv_rope_bf16 expects: inside every q and k head (D = 128 rows) the rows
+    are [dims 0..31 | 64..95 | 32..63 | 96..127] (blocks of 32 of the low half followed by the matching block of the high half, the
+    SwiGLU interleave applied per head); the v third is unchanged.  Pure data movement."""
+    d = heads * head_dim
+    assert head_dim == 128 and qkv_w.shape[0] == 3 * d
+    K = qkv_w.shape[1]
+    out = qkv_w.clone()
+    qk = qkv_w[:2 * d].view(2 * heads, 2, 2, 32, K)            # [head, half (lo/hi), block, 32, K]
+    out[:2 * d] = qk.permute(0, 2, 1, 3, 4).reshape(2 * d, K)   # [head, block, half, 32, K]
+    return out
+
+
+def gemm_qkv_rope(a, w_interleaved, cos_t, sin_t, seq, heads, head_dim, pos_offset=0, out=None):
+    """qkv = a @ W^T with RoPE applied to the q and k thirds in the GEMM epilogue; `w_interleaved` = rope_interleave_qkv(W).  The result
+    (standard [tokens, 3*H*D] layout) is bit-identical with gemm(a, W) followed by rope_qk_."""
+    _chk(a, torch.bfloat16, "gemm_qkv_rope.a"); _chk(w_interleaved, torch.bfloat16, "gemm_qkv_rope.w"); _chk(cos_t, torch.float32, "gemm_qkv_rope.cos")
+    M, K = a.shape
+    N = w_interleaved.shape[0]
+    assert a.stride(1) == 1 and w_interleaved.stride(1) == 1 and cos_t.is_contiguous() and sin_t.is_contiguous()
+    assert cos_t.shape[0] >= seq + pos_offset and cos_t.shape[1] == head_dim // 2 and N == 3 * heads * head_dim
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    _ensure_gemm_workspace(a.device)
+    t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
+    lib().call("mp_gemm_qkv_rope_bf16", _p(a), a.stride(0), _p(w_interleaved), w_interleaved.stride(0), _p(out), out.stride(0), _p(cos_t),
+               _p(sin_t), M, N, K, int(seq), int(pos_offset), int(head_dim), _stream())
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.end(2.0 * M * N * K, t0)
+    return out
+
+
 def argmax_rows(x):
     _chk(x, torch.float32, "argmax_rows.x"); assert x.dim() == 2 and x.stride(1) == 1
     out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)

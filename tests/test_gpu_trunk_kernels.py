@@ -411,3 +411,26 @@ def test_decoder_backward_row_kernels(dev):
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)
     keep = (y1 != 0).float().mean().item()
     assert abs(keep - 0.75) < 5e-3 and abs(float(y1.max()) - 1 / 0.75) < 1e-2
+
+
+@pytest.mark.parametrize("M,S,heads,K,pos0", [(700, 350, 4, 256, 3), (5112, 639, 32, 4096, 0), (9, 9, 2, 128, 5)])
+def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, M, S, heads, K, pos0):
+    """mp_gemm_qkv_rope_bf16 (RoPE of the q / k thirds in the 256x256 GEMM's epilogue, W rows interleaved per head) against the two-kernel
+    path it replaces, mp_gemm_bf16_nt + mp_rope_qk_bf16: same rounding points, so the [tokens, 3*H*D] result must be EQUAL bit for bit —
+    ragged M (row clamp), several sequences per batch (position = row % S + offset), the tail-split-K tiles of the 7B shape."""
+    from medplib_amd import ops
+    D = 128
+    d = heads * D
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    w = (torch.randn(3 * d, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.outer(torch.arange(S + pos0, dtype=torch.float32), inv)
+    cos_t, sin_t = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+    ref = ops.gemm(a, w)
+    ops.rope_qk_(ref, cos_t, sin_t, S, heads, D, pos_offset=pos0)
+    wi = ops.rope_interleave_qkv(w, heads, D)
+    assert torch.equal(wi[2 * d:], w[2 * d:]) and not torch.equal(wi[:D], w[:D])
+    got = ops.gemm_qkv_rope(a, wi, cos_t, sin_t, S, heads, D, pos_offset=pos0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
