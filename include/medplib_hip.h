@@ -278,6 +278,11 @@ int mp_moe_route_top2(const float* gates, const float* logits, const float* nois
 int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, int gumbel, hipStream_t stream);
 /* MOELayer dispatch / combine as index gathers (replaces einsum "sec,sm->ecm" / "sec,ecm->sm"); top_k (1 or 2) entries per
  * token in the layout above. */
+/* Post-attention RMSNorm and the MoE gate in one pass over the rows (LlamaRMSNorm + TopKGate's `logits = x.float() @ wg.float()^T`,
+ * softmax — medplib_moe_llama.py:137-147): h = rmsnorm(x) * ln_w (bf16), logits / gates fp32 [tokens, E] computed from that
+ * bf16 h.  Bit-identical with mp_rmsnorm_bf16 followed by mp_moe_gate_bf16.  n_experts = 0: the norm alone.  dim 2048 / 4096 / 8192. */
+int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg, float* logits,
+                         float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream);
 int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
                          int capacity, int top_k, hipStream_t stream);
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,

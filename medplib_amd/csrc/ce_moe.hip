@@ -83,6 +83,76 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
   moe_gate_token(x + tok * ldx, wg, d, E, lane, logits + tok * E, gates + tok * E);
 }
 
+// ---------------- post-attention RMSNorm + MoE gate in one pass (one WAVE per token row) ----------------
+// h = rmsnorm(x) * w (HF LlamaRMSNorm rounding points) and the gate of mp_moe_gate_bf16 on that h, while the row is still in
+// registers: the separate gate kernel re-read all of h (42 MB per layer at the 7B shape).  Both results are BIT-IDENTICAL with the
+// two stand-alone kernels: lane l holds the 16-byte chunks q = k*64 + l — the chunk a thread (c = q >> 8, t = q & 255) of
+// rmsnorm_bf16_kernel's 256-thread block owns — so the sum of squares is accumulated per "virtual wave" w = (q >> 6) & 3 in that
+// kernel's order (c ascending, then the wave butterfly, then red[0] + red[1] + red[2] + red[3]); and q = k*64 + l is also the chunk
+// moe_gate_token's lane l reads in its k-th iteration, so the fp32 logits follow the same fma sequence.
+template <int NCH>      // 16-byte chunks per lane: dim = NCH * 512
+__global__ __launch_bounds__(256) void rmsnorm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, float eps,
+                                                           bf16_t* __restrict__ h, int64_t ldh, const float* __restrict__ wg, int E,
+                                                           float* __restrict__ logits, float* __restrict__ gates, int64_t T) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  constexpr int dim = NCH * 512;
+  const bf16_t* xr = x + tok * ldx;
+  bf16x8 v[NCH];
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    v[k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[k][j]; part[k & 3] += f * f; }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int wv = 0; wv < 4; ++wv) ss += wave_sum(part[wv]);
+  const float rs = rsqrtf(ss / (float)dim + eps);
+  float acc[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
+  bf16_t* hr = h + tok * ldh;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int i = (k * 64 + lane) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t t = (bf16_t)((float)v[k][j] * rs);          // HF: the normalised value is cast to the input dtype first
+      o[j] = (bf16_t)(w[i + j] * (float)t);
+    }
+    *reinterpret_cast<bf16x8*>(hr + i) = o;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E) {
+        const float* wr = wg + (int64_t)e * dim + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e] = fmaf((float)o[j], wr[j], acc[e]);
+      }
+    }
+  }
+  if (E == 0) return;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e)
+    if (e < E) { acc[e] = wave_sum(acc[e]); mx = fmaxf(mx, acc[e]); }
+  if (lane == 0) {
+    float sum = 0.f, pr[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      if (e < E) { pr[e] = expf(acc[e] - mx); sum += pr[e]; }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      if (e < E) {
+        if (logits) logits[tok * E + e] = acc[e];
+        gates[tok * E + e] = pr[e] / sum;
+      }
+  }
+}
+
 // ---------------- top-1 routing (single block, 1024 threads) ----------------
 // expert[s] = argmax gates[s]; capacity drop: if an expert is over capacity keep the `capacity` tokens with the largest
 // uniform draws (DeepSpeed RTS; first-come when no draws are supplied); slot[s] = rank among KEPT tokens of that expert
@@ -596,6 +666,20 @@ extern "C" int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, flo
   hipLaunchKernelGGL(moe_gate_kernel, dim3((unsigned)mp_cdiv(tokens, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, wg, logits,
                      gates, tokens, dim, n_experts);
   return mp_check_launch("mp_moe_gate_bf16");
+}
+
+extern "C" int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg,
+                                    float* logits, float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream) {
+  MP_REQUIRE(n_experts >= 0 && n_experts <= MAXE && ldx % 8 == 0 && ldh % 8 == 0, MP_ERR_SHAPE, "mp_rmsnorm_gate_bf16: bad shape (E <= %d)", MAXE);
+  MP_REQUIRE(dim == 2048 || dim == 4096 || dim == 8192, MP_ERR_SHAPE, "mp_rmsnorm_gate_bf16: dim %d (2048, 4096 or 8192)", dim);
+  MP_REQUIRE(n_experts == 0 || (wg != nullptr && gates != nullptr), MP_ERR_ARG, "mp_rmsnorm_gate_bf16: gate outputs missing");
+  if (tokens == 0) return MP_OK;
+  const dim3 grid((unsigned)mp_cdiv(tokens, 4)), blk(256);
+#define MP_RG(N) hipLaunchKernelGGL(rmsnorm_gate_kernel<N>, grid, blk, 0, stream, (const bf16_t*)x, ldx, ln_w, eps, (bf16_t*)h, ldh, wg, \
+                                    n_experts, logits, gates, tokens)
+  if (dim == 2048) MP_RG(4); else if (dim == 4096) MP_RG(8); else MP_RG(16);
+#undef MP_RG
+  return mp_check_launch("mp_rmsnorm_gate_bf16");
 }
 
 extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,

@@ -160,8 +160,9 @@ class LlamaStack:
         off = (self.gate_pass * len(self.layers) + i) * T * E
         return ops.gate_noise(T * E, self.cfg.moe_gate_seed, off, gumbel, self.device)
 
-    def _mlp(self, i, lw, h, x):
-        """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]."""
+    def _mlp(self, i, lw, h, x, gate=None):
+        """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]; gate = (logits, gates) when the caller's fused
+        norm kernel already produced them (ops.rmsnorm_gate)."""
         cfg = self.cfg
         T = h.shape[0]
         if i not in self.moe_layers:
@@ -172,7 +173,7 @@ class LlamaStack:
         E, ff, d = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
         cap = self.capacity(T)
         k = cfg.top_k_experts
-        logits, gates = ops.moe_gate(h, lw["wg"])
+        logits, gates = gate if gate is not None else ops.moe_gate(h, lw["wg"])
         if k == 1 and self.ep is None and T <= 8 and not cfg.use_residual:
             # decode rows: each row streams its own expert's matrices (GEMV with a device-side expert index); the combine weight,
             # the capacity drop and the residual ride in the down projection's epilogue
@@ -280,8 +281,13 @@ class LlamaStack:
             else:
                 attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
             x = lin(attn.view(B * S, d), lw["o"], residual=x)
-            h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
-            x, l_aux, r = self._mlp(i, lw, h, x)
+            if i in self.moe_layers and d in ops.RMSNORM_GATE_DIMS and B * S > 8:
+                # post-attention norm and the MoE gate in one pass over the rows (bit-identical with the two kernels)
+                h, lg, gt = ops.rmsnorm_gate(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"])
+                x, l_aux, r = self._mlp(i, lw, h, x, gate=(lg, gt))
+            else:
+                h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
+                x, l_aux, r = self._mlp(i, lw, h, x)
             if l_aux is not None:
                 aux.append(l_aux)
                 if collect_routing:

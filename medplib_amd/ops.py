@@ -948,6 +948,28 @@ def moe_gate(x, wg):
     return logits, gates
 
 
+def rmsnorm_gate(x, ln_w, eps, wg=None):
+    """h = rmsnorm(x) * ln_w and, with wg [E, d] fp32, the MoE gate (logits, gates fp32 [T, E]) of that h in the same pass over the rows:
+    bit-identical with rmsnorm() followed by moe_gate().  dim 2048 / 4096 / 8192 (callers fall back to the two kernels otherwise).
+    -> (h, logits, gates) (logits / gates None without wg)."""
+    _chk(x, torch.bfloat16, "rmsnorm_gate.x"); _chk(ln_w, torch.float32, "rmsnorm_gate.w")
+    T, d = x.shape
+    assert x.stride(1) == 1
+    h = torch.empty((T, d), dtype=torch.bfloat16, device=x.device)
+    E = 0 if wg is None else wg.shape[0]
+    logits = gates = None
+    if E:
+        _chk(wg, torch.float32, "rmsnorm_gate.wg"); assert wg.is_contiguous() and wg.shape[1] == d
+        logits = torch.empty((T, E), dtype=torch.float32, device=x.device)
+        gates = torch.empty((T, E), dtype=torch.float32, device=x.device)
+    lib().call("mp_rmsnorm_gate_bf16", _p(x), x.stride(0), _p(ln_w), float(eps), _p(h), h.stride(0), _p(wg), _p(logits), _p(gates), T, d, E,
+               _stream())
+    return h, logits, gates
+
+
+RMSNORM_GATE_DIMS = (2048, 4096, 8192)
+
+
 def moe_route_top1(gates, capacity, rts_uniform=None, want_slot_token=False):
     """-> (expert, slot, weight, kept, counts, l_aux[, slot_token [E, capacity] int32: token held by each slot])."""
     T, E = gates.shape

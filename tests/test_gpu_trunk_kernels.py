@@ -434,3 +434,23 @@ def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, M, S, heads, K, pos0)
     got = ops.gemm_qkv_rope(a, wi, cos_t, sin_t, S, heads, D, pos_offset=pos0)
     torch.cuda.synchronize()
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
+
+
+@pytest.mark.parametrize("d,E,T", [(4096, 2, 1000), (2048, 3, 77), (8192, 8, 5), (4096, 0, 130)])
+def test_rmsnorm_gate_fusion_is_bit_identical(dev, d, E, T):
+    """mp_rmsnorm_gate_bf16 (post-attention RMSNorm + MoE gate in one pass, one wave per row) vs mp_rmsnorm_bf16 + mp_moe_gate_bf16:
+    the normalised rows, the fp32 logits and the softmax gates must be EQUAL bit for bit (same accumulation order by construction),
+    so routing cannot change with the fusion."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(d + E + T)
+    x = (torch.randn(T, d, generator=g) * 1.7).to(torch.bfloat16).to(dev)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
+    wg = (torch.randn(max(E, 1), d, generator=g) * 0.05).to(dev)[:E].contiguous() if E else None
+    h_ref = ops.rmsnorm(x, w, 1e-5)
+    h, lg, gt = ops.rmsnorm_gate(x, w, 1e-5, wg)
+    assert torch.equal(h, h_ref)
+    if E:
+        lg_ref, gt_ref = ops.moe_gate(h_ref, wg)
+        assert torch.equal(lg, lg_ref) and torch.equal(gt, gt_ref)
+    else:
+        assert lg is None and gt is None
