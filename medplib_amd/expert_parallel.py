@@ -113,6 +113,15 @@ class ExpertParallel:
         counts = recv[:, :, rows - 1, :].view(torch.int32)[:, :, 0].contiguous()
         return recv, counts
 
+    def exchange(self, t: torch.Tensor):
+        """Plain slab exchange without headers: t [E, rows, d] (slab e for global expert e) -> [ep, E_local, rows, d] on the owners —
+        the backward of `combine` (output gradients travel to the experts' ranks); `combine` is its inverse."""
+        E, rows, d = t.shape
+        assert E == self.E and t.is_contiguous()
+        recv = torch.empty((self.ep, self.E_local, rows, d), dtype=t.dtype, device=t.device)
+        self._a2a(recv.view(self.ep, -1), t.view(self.ep, -1))
+        return recv
+
     def combine(self, y: torch.Tensor):
         """y [ep, E_local, capx, d] (expert outputs, slab s = rows that came from source rank s) -> [E, capx, d] on the owner of
         the tokens: slab e holds the outputs of global expert e for THIS rank's tokens."""

@@ -77,8 +77,9 @@ class LlamaStack:
         ids = ep.local_expert_ids()
         for i in self.moe_layers:
             lw = self.layers[i]
-            lw["gu"] = lw["gu"][ids[0]:ids[-1] + 1].contiguous()
-            lw["down"] = lw["down"][ids[0]:ids[-1] + 1].contiguous()
+            for k in ("gu", "down", "gu_T", "down_T"):           # (+ the dgrad transposes when enable_lora() ran first)
+                if k in lw:
+                    lw[k] = lw[k][ids[0]:ids[-1] + 1].contiguous()
         self.ep = ep
 
     # ------------------------------------------------------------------ HF checkpoint layout

@@ -48,8 +48,8 @@ class LoRAState(torch.nn.Module):
         super().__init__()
         assert r % 8 == 0 and 0 < r <= 16, "lora_r must be 8 or 16 (the shipped scripts' values)"
         assert all(t in ALL_TARGETS for t in targets), f"adapters are built for {ALL_TARGETS}"
-        assert llm.ep is None and not cfg.use_residual or not llm.moe_layers, \
-            "training MoE layers: one expert-parallel rank, no residual MoE (not yet)"
+        assert not cfg.use_residual or not llm.moe_layers, "training MoE layers: no residual MoE (not yet)"
+        assert llm.ep is None or cfg.top_k_experts == 1, "expert-parallel MoE layers under training: top-1 gating"
         self.r, self.alpha, self.p = r, float(alpha), float(dropout)
         self.targets = tuple(t for t in ALL_TARGETS if t in targets)
         self.scaling = self.alpha / r
@@ -220,9 +220,12 @@ class LoRAState(torch.nn.Module):
         for i, lw in enumerate(llm.layers):
             for t in self.targets:
                 grp = next(g for g, mem in GROUPS.items() if t in mem)
+                local = llm.ep.local_expert_ids() if (llm.ep is not None and lw[grp].dim() == 3) else None
                 for e, _ in enumerate(self._modules_of(i, t)):
+                    if local is not None and e not in local:
+                        continue                                  # expert parallelism: this rank holds (and merges) its own experts only
                     delta = self.scaling * (self.get(i, t, "B", e).float() @ self.get(i, t, "A", e).float())
-                    W = lw[grp] if lw[grp].dim() == 2 else lw[grp][e]
+                    W = lw[grp] if lw[grp].dim() == 2 else lw[grp][e - (local[0] if local is not None else 0)]
                     rows = self.rows[t]
                     W[rows] = (W[rows].float() + delta).to(W.dtype)
             for k in ("qkv", "o", "gu", "down"):
@@ -323,6 +326,94 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     return ops.moe_combine(y, expert, slot, weight, x_mid, cap, top_k=k), l_aux
 
 
+def _ep_pad(ops_pad, eg, ep):
+    """The padded adapter operands of ONE global expert `eg`, broadcast (stride 0) over the `ep` source-rank slabs it serves."""
+    A, AT, B, BT, R, tg = ops_pad
+    x = lambda t: t[eg].unsqueeze(0).expand(ep, -1, -1)
+    return (x(A), x(AT), x(B), x(BT), R, tg)
+
+
+def _moe_fwd_ep(llm, lora, i, lw, pad, h2, x_mid, s, seed):
+    """_moe_fwd with the experts SHARDED over an expert-parallel group (DeepSpeed `ep_size` > 1, medplib_moe_llama.py:604-614; top-1):
+    this rank routes its own tokens, the routed rows travel to the ranks that own their experts (expert_parallel.py: one all-to-all,
+    row counts in the slab headers), every local expert runs over the `ep` slabs it received — base projections as one batched GEMM
+    per expert with the expert's matrix broadcast over the slabs, its LoRA adapters the same way — and the outputs travel back.
+    Slabs are zero where no token sits, so every row is finite and empty rows add nothing to the weight gradients."""
+    cfg, ep = llm.cfg, llm.ep
+    T, d = h2.shape
+    E, ff = cfg.num_experts, cfg.intermediate_size
+    cap = llm.capacity(T)
+    wg = lora.gate_weight(i, llm)
+    logits, gates = ops.moe_gate(h2, wg)
+    expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, llm._gate_draws(i, T, E, gumbel=False))
+    capx = ep.exchange_capacity(cap, key=llm.gate_pass)
+    buf = ops.moe_dispatch(h2, expert, slot, E, capx + 1, buf=_zeros((E, capx + 1, d), h2.device))
+    recv, rcounts = ep.dispatch(buf, kept)                                   # [ep, El, capx + 1, d], [ep, El]
+    xin = recv[:, :, :capx].permute(1, 0, 2, 3).contiguous()                 # [El, ep, capx, d]: local expert e's slabs are xin[e]
+    rc = rcounts.t().contiguous()                                            # [El, ep]
+    ids = ep.local_expert_ids()
+    y_loc = torch.empty((ep.E_local, ep.ep, capx, d), dtype=torch.bfloat16, device=h2.device)
+    loc = []
+    for e, eg in enumerate(ids):
+        w_gu = lw["gu"][e].unsqueeze(0).expand(ep.ep, -1, -1)               # lw holds this rank's E_local experts only
+        w_dn = lw["down"][e].unsqueeze(0).expand(ep.ep, -1, -1)
+        st = {}
+        gu = ops.gemm_batched(xin[e], w_gu, _zeros((ep.ep, capx, 2 * ff), h2.device), m_dev=rc[e])
+        if "gu" in pad:
+            gu, st["bufd"], st["t_gu"] = _adapter_fwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), xin[e], gu, rc[e], seed + 16 * eg)
+        act = ops.swiglu_pair_fwd(gu.view(ep.ep * capx, 2 * ff)).view(ep.ep, capx, ff)
+        y = ops.gemm_batched(act, w_dn, _zeros((ep.ep, capx, d), h2.device), m_dev=rc[e])
+        if "down" in pad:
+            y, st["actd"], st["t_d"] = _adapter_fwd_moe(lora, _ep_pad(pad["down"], eg, ep.ep), act, y, rc[e], seed + 16 * eg + 1)
+        y_loc[e] = y
+        st.update(gu=gu, x=xin[e])
+        loc.append(st)
+    y_all = ep.combine(y_loc.permute(1, 0, 2, 3).contiguous())              # [E, capx, d]: every global expert's rows for MY tokens
+    s.update(moe=True, ep=True, h2=h2, gates=gates, expert=expert, slot=slot, weight=weight, kept=kept, counts=counts, y=y_all, cap=capx,
+             wg=wg, loc=loc, rc=rc)
+    return ops.moe_combine(y_all, expert, slot, weight, x_mid, capx, top_k=1), l_aux
+
+
+def _moe_bwd_ep(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
+    """Backward of _moe_fwd_ep: the output-row gradients travel to the experts' ranks (`exchange`), each local expert's dgrad and
+    adapter gradients run over its slabs (the adapter gradients of the `ep` slabs are summed: they are ONE expert's parameters), the
+    input-row gradients travel back (`combine`), then the gate as in _moe_bwd.  Gradients of non-local experts' adapters do not
+    exist on this rank (the engine's SUM all-reduce collects each expert's from its owners)."""
+    cfg, ep = llm.cfg, llm.ep
+    E, ff, capx = cfg.num_experts, cfg.intermediate_size, s["cap"]
+    T, d = dx.shape
+    pad, rc = s["pad"], s["rc"]
+    d_y, d_w = ops.moe_combine_bwd(dx, s["y"], s["expert"], s["slot"], s["weight"], capx, top_k=1)        # [E, capx, d]
+    dy_loc = ep.exchange(d_y).permute(1, 0, 2, 3).contiguous()                                             # [El, ep, capx, d]
+    dbuf_loc = torch.empty_like(dy_loc)
+    for e, eg in enumerate(ep.local_expert_ids()):
+        st = s["loc"][e]
+        dn_T = lw["down_T"][e].unsqueeze(0).expand(ep.ep, -1, -1)
+        gu_T = lw["gu_T"][e].unsqueeze(0).expand(ep.ep, -1, -1)
+        d_act = ops.gemm_batched(dy_loc[e], dn_T, _zeros((ep.ep, capx, ff), dx.device), m_dev=rc[e])
+        if "down" in pad:
+            d_act, dB, dAT = _adapter_bwd_moe(lora, _ep_pad(pad["down"], eg, ep.ep), dy_loc[e], st["actd"], st["t_d"], d_act, rc[e],
+                                              s["seed"] + 16 * eg + 1)
+            take_e(i, pad["down"], {eg: sum(dB[1:], dB[0])}, {eg: sum(dAT[1:], dAT[0])})
+        d_gu = ops.swiglu_pair_bwd(st["gu"].view(ep.ep * capx, 2 * ff), d_act.view(ep.ep * capx, ff)).view(ep.ep, capx, 2 * ff)
+        d_in = ops.gemm_batched(d_gu, gu_T, _zeros((ep.ep, capx, d), dx.device), m_dev=rc[e])
+        if "gu" in pad:
+            d_in, dB, dAT = _adapter_bwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), d_gu, st["bufd"], st["t_gu"], d_in, rc[e], s["seed"] + 16 * eg)
+            take_e(i, pad["gu"], {eg: sum(dB[1:], dB[0])}, {eg: sum(dAT[1:], dAT[0])})
+        dbuf_loc[e] = d_in
+    d_buf = ep.combine(dbuf_loc.permute(1, 0, 2, 3).contiguous())                                          # [E, capx, d]
+    ones = torch.ones(T, dtype=torch.float32, device=dx.device)
+    d_h2 = ops.moe_combine(d_buf, s["expert"], s["slot"], ones, None, capx, top_k=1)
+    dl = ops.moe_gate_bwd(s["gates"], s["expert"], s["slot"], d_w, s["counts"], d_aux, 1.0, top_k=1)
+    ops.moe_gate_dgrad_(dl, s["wg"], d_h2)
+    name = f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight"
+    if name in lora.index:
+        dlb = torch.zeros((T, 8), dtype=torch.bfloat16, device=dx.device)
+        dlb[:, :E] = dl
+        grads[name] = ops.tn_skinny(s["h2"], dlb, 8, 1.0)[:, :E].t()
+    return d_h2
+
+
 def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
     """Per-expert adapter gradients on the slabs: (dx', [dB_e [out, R]], [dA_e^T [in, R]])."""
     A, AT, B, BT, R, _ = ops_pad
@@ -394,7 +485,7 @@ def forward_train(llm, embeds, key_valid):
         h2 = ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps)
         s.update(qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, seed=seed)
         if i in llm.moe_layers:
-            x_out, l_aux = _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed)
+            x_out, l_aux = (_moe_fwd_ep if llm.ep is not None else _moe_fwd)(llm, lora, i, lw, pad, h2, x_mid, s, seed)
             aux.append(l_aux)
         else:
             gu = ops.gemm(h2, lw["gu"])
@@ -442,9 +533,12 @@ def backward(llm, saved, d_hidden, d_aux=None):
             grads[f"model.layers.{i}.{_module(t)}.lora_A.default.weight"] = dAT[:, k * r:(k + 1) * r].t()
 
     def take_e(i, ops_pad, dB, dAT):
-        """The same for the per-expert adapters of a MoE layer."""
+        """The same for the per-expert adapters of a MoE layer; dB / dAT: a list over all experts, or {global expert id: gradient} with
+        the experts this rank owns (expert parallelism)."""
         for k, t in enumerate(ops_pad[5]):
             for e, mod in enumerate(lora._modules_of(i, t)):
+                if isinstance(dB, dict) and e not in dB:
+                    continue
                 grads[f"model.layers.{i}.{mod}.lora_B.default.weight"] = dB[e][lora.rows[t], k * r:(k + 1) * r]
                 grads[f"model.layers.{i}.{mod}.lora_A.default.weight"] = dAT[e][:, k * r:(k + 1) * r].t()
 
@@ -454,7 +548,7 @@ def backward(llm, saved, d_hidden, d_aux=None):
         pad = s["pad"]
         # ---- MLP: x_out = x_mid + down(act) [+ adapter], or the MoE layer
         if s.get("moe"):
-            d_h2 = _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e)
+            d_h2 = (_moe_bwd_ep if s.get("ep") else _moe_bwd)(llm, lora, i, lw, s, dx, d_aux, grads, take_e)
         else:
             d_act = ops.gemm(dx, lw["down_T"])
             if "down" in pad:

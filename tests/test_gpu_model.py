@@ -1455,3 +1455,49 @@ def test_capi_rccl_comm_single_rank(dev):
     torch.cuda.synchronize()
     assert torch.equal(opt.flat_grad, before) and not eng._pendings
     c.close()
+
+
+def test_lora_training_expert_parallel_path_equals_replicated(dev):
+    """MoE layers under LoRA training with the experts SHARDED over an expert-parallel group (`ep_size`, medplib_moe_llama.py:604-614;
+    llama_lora._moe_fwd_ep / _moe_bwd_ep: dispatch with in-band counts, per-local-expert batched GEMMs + adapters over the received
+    slabs, combine; in the backward the output-row gradients travel to the owners and the input-row gradients back) on a ONE-rank
+    group (the exchanges are identities: RCCL refuses two ranks on one device; the two-rank exchange protocol itself runs on gloo in
+    tests/test_host_logic.py): the 10 losses and every gradient — per-expert adapters, q / v adapters, `wg` — must equal the
+    replicated-experts path on the same weights, batch and injected gate draws (capacity factor 1.0: tokens are dropped)."""
+    from medplib_amd import engine
+    from medplib_amd.comm import RcclComm
+    from medplib_amd.expert_parallel import ExpertParallel
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_hidden_layers=2, num_experts=2, capacity_factor=1.0, router_aux_loss_coef=0.05)
+    W = OM.init_hf_weights(cfg)
+    batch = OM.make_batch(cfg, 2, seed=6)
+    g = torch.Generator().manual_seed(41)
+    T = 2 * (batch["input_ids"].shape[1] - 1 + cfg.clip_num_patches)
+    draws = {i: torch.rand(T, cfg.num_experts, generator=g).to(dev) for i in range(cfg.num_hidden_layers)}
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    comm = RcclComm(rank=0, world=1)
+    results = []
+    for use_ep in (False, True):
+        m = _model(cfg, dev, W).train()
+        if use_ep:
+            m.model.llm.enable_expert_parallel(ExpertParallel(None, 1, cfg.num_experts, capi_comm=comm))
+        lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj,q_proj,v_proj")
+        gg = torch.Generator().manual_seed(77)
+        for n, p_ in zip(lora.names, lora.params):
+            if not n.endswith("wg.weight"):
+                p_.data.copy_((torch.randn(p_.shape, generator=gg) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float().to(dev))
+        m.model.llm.rts_uniform_provider = lambda i, T_, E_: draws[i]
+        eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                         config={"optimizer": {"params": {"lr": 1e-4, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0})
+        out = eng(**gb)
+        eng.backward(out["loss"])
+        torch.cuda.synchronize()
+        results.append(({k: float(out[k]) for k in O.LOSS_KEYS}, {n: p_.grad.detach().clone() for n, p_ in zip(lora.names, lora.params)}))
+        eng.step()
+        torch.cuda.synchronize()
+    (l0, g0), (l1, g1) = results
+    assert l0 == l1, (l0, l1)
+    for n in g0:
+        assert g0[n].abs().max().item() > 0, n
+        assert torch.equal(g0[n], g1[n]), (n, (g0[n] - g1[n]).abs().max().item())
+    comm.close()

@@ -314,6 +314,17 @@ out = ep.combine(y)                                  # [E, capx, d]: outputs of 
 for t in range(T):
     if slot[t] >= 0:
         assert torch.allclose(out[expert[t], slot[t]], f(int(expert[t]), x[t])), (t, int(expert[t]))
+# the training backward's exchanges (llama_lora._moe_bwd_ep): output-row gradients [E, capx, d] travel to the experts' owners
+# (`exchange`: slab (s, el) on rank r = source rank s's gradient rows for global expert 2r + el), the input-row gradients come back
+# (`combine`): the pair is an identity round trip and `exchange` delivers to the owner
+dy = torch.arange(E * capx * d, dtype=torch.float32).view(E, capx, d) + 1000.0 * rank
+got = ep.exchange(dy.clone())
+assert got.shape == (2, 2, capx, d)
+for s_ in range(2):
+    for el in range(2):
+        want = torch.arange(E * capx * d, dtype=torch.float32).view(E, capx, d)[2 * rank + el] + 1000.0 * s_
+        assert torch.equal(got[s_, el], want), (s_, el)
+assert torch.equal(ep.combine(got), dy)
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 '''
