@@ -22,7 +22,11 @@
 // per-tile DMA bursts with vmcnt(0) (the "v1" schedule this file started with), an LDS-transposed epilogue with 16-byte stores
 // (slower than the register-direct one by 5-20 % depending on K), and persistent workgroups with the next tile's prologue
 // issued before the epilogue (+2-4 % on multi-wave shapes in isolation, -2.3 % on the training step: workgroups that never
-// leave the CUs starve the concurrent SAM-encoder and mask-tail streams).
+// leave the CUs starve the concurrent SAM-encoder and mask-tail streams).  Round 2: the buffer-descriptor form of the LDS-DMA
+// (raw_ptr_buffer_load_lds: 32-bit lane offsets computed once, the K advance in the scalar offset, no VALU per piece) measured
+// 0.5-1 % SLOWER on every Llama shape; 16-byte write-through stores / loads for the tail split-K partials changed nothing (the
+// 64 MB + 64 MB of partial traffic per N = 4096 launch is the cost, not the store width); L2 hit rate 80 % on the multi-wave
+// shapes = what a 4 x 8 block of co-resident tiles can reach (scripts/gemm_l2_pmc.sh).
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
