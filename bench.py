@@ -135,6 +135,8 @@ def main():
                          "contract's default line is BASELINE configs[3] (LoRA off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-side-streams", action="store_true",
+                    help="debug only: SAM encoder and mask tail on the decoder's stream (what the side streams buy; what they cost the GEMM launches they run beside)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="images and masks start every step in pageable host memory (the reference's dict_to_cuda per batch): the "
                          "PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the default, HBM-resident run")
@@ -176,6 +178,9 @@ def main():
                  "scheduler": {"type": "WarmupDecayLR", "params": {"total_num_steps": 10000, "warmup_min_lr": 0,
                                                                      "warmup_max_lr": 3e-4, "warmup_num_steps": 100,
                                                                      "warmup_type": "linear"}}}
+    if args.no_side_streams:
+        model.sam_side_stream = False
+        ds_config["overlap_mask_tail"] = 0
     eng, _, _, _ = engine.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
     batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
 
@@ -232,6 +237,13 @@ def main():
             a_flops, a_ms, a_sampled, a_launches, a_all = timer.summary()
             if sampled == 0:          # very short debug runs: no sampled launch went to the dominant kernel
                 flops, ms, sampled, launches, all_flops = a_flops, a_ms, a_sampled, a_launches, a_all
+            if os.environ.get("MP_BENCH_SHAPES"):       # debug: the sampled launches grouped by their algorithmic work (= by shape)
+                by = {}
+                for w, s0, e0, kern in timer.records:
+                    by.setdefault((kern, round(w / 1e9, 1)), []).append(s0.elapsed_time(e0) * 1e3)
+                for (kern, gf), v in sorted(by.items()):
+                    print(f"[bench] gemm{kern} {gf:8.1f} GFLOP: {len(v):4d} samples, avg {sum(v) / len(v):7.1f} us, "
+                          f"min {min(v):7.1f}, {gf / (sum(v) / len(v)) * 1e3 / 1e3:7.1f} TF/s", file=sys.stderr)
             achieved = flops / (max(ms, 1e-9) * 1e-3) / 1e12
             a_ach = a_flops / (max(a_ms, 1e-9) * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm256v3_bf16_nt_kernel",

@@ -27,6 +27,12 @@
 // 0.5-1 % SLOWER on every Llama shape; 16-byte write-through stores / loads for the tail split-K partials changed nothing (the
 // 64 MB + 64 MB of partial traffic per N = 4096 launch is the cost, not the store width); L2 hit rate 80 % on the multi-wave
 // shapes = what a 4 x 8 block of co-resident tiles can reach (scripts/gemm_l2_pmc.sh).
+// Round 2, what DID pay: the epilogue.  bench.py's per-shape samples showed the N = 4096 projections 20-30 us slower in the model than
+// alone; the residual epilogue was the difference (scripts/gemm_sustained.py: o 158 -> 188 us with a residual): eight dependent round
+// trips to memory, one per fragment row.  All residual pieces are now requested up front (the operand fragments' registers are dead by
+// then) and every bf16 output path stores 16-byte pieces built with v_permlane16_swap (pair_swap16): o 188 -> 165 us, down 373 -> 357
+// alone; in the model o 192 -> 172, down (expert, combine folded in) 397 -> 374, qkv + RoPE 416 -> 407; same box A/B of the whole
+// step (MP_GEMM_EP8=1 restores the 8-byte epilogue): 74.6 -> 72.7 ms.
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -52,6 +58,24 @@ __device__ __forceinline__ int lds_off2(int r, int c) { return r * 128 + ((c ^ (
     asm volatile("" ::: "memory");         \
   } while (0)
 
+// Two neighbouring fragments' bf16x4 row pieces (fragment j: columns j*16 + fq*4 .. +3, fragment j+1: 16 columns further) become one
+// 16-byte piece per lane: v_permlane16_swap exchanges the odd 16-lane rows of the first operand with the even rows of the second (lane
+// = fq*16 + fr, so a row of lanes IS an fq), after which lane (fr, fq) holds the EIGHT consecutive columns
+// (fq & 1) * 16 + (fq >> 1) * 8 .. +7 of the pair's 32 -- same matrix row as before.  Stores (and residual loads) are then 16 bytes per
+// lane and 64 contiguous bytes per matrix row per instruction instead of 8 / 32: half the store instructions (the epilogue is
+// store-ISSUE bound, MI355X_MICROARCH.md T21).  Must be executed by all 64 lanes.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ bf16x8 pair_swap16(bf16x4 a, bf16x4 b) {
+  const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+  const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+  const u32x2_t r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  return __builtin_bit_cast(bf16x8, (u32x4_t{r0[0], r1[0], r0[1], r1[1]}));
+}
+__device__ __forceinline__ int pair_col8(int fq) { return (fq & 1) * 16 + (fq >> 1) * 8; }
+__device__ __forceinline__ bf16x4 round4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // Epilogue for TRANSPOSED accumulators (v3): the MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] is
 // C[row = i*16 + fr, col = j*16 + fq*4 + r] of the wave tile — a lane owns FOUR CONSECUTIVE COLUMNS of one row per fragment.
 // Outputs leave straight from registers as 8-byte (bf16) / 16-byte (fp32) pieces, four fragments completing each 128-byte row
@@ -65,6 +89,46 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
     // the same rounding points as the separate combine kernel (expert output rounded to bf16 first)
     bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
     const int cw = n0 + wc * 64;
+    if (!g.ep8 && (g.ldc & 7) == 0 && (N & 7) == 0 && aligned16(Cb) && (!g.residual || ((g.ldr & 7) == 0 && aligned16(g.residual)))) {
+      // 16-byte pieces (pair_swap16); the row indices, scales and residual pieces of the whole wave tile are fetched before the first one
+      // is used (eight dependent round trips to memory otherwise: +25 us per launch on the N = 4096 shapes)
+      int orow[8];
+      float sc[8];
+      bf16x8 rv[8][2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wr * 128 + i * 16 + fr;
+        orow[i] = row < M ? g.c_rows[batch * g.rows_stride + row] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sc[i] = (orow[i] >= 0 && g.c_scale) ? g.c_scale[orow[i]] : 1.f;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + jp * 32 + pair_col8(fq);
+          rv[i][jp] = bf16x8{};
+          if (g.residual && orow[i] >= 0 && col < N) rv[i][jp] = *reinterpret_cast<const bf16x8*>(g.residual + (int64_t)orow[i] * g.ldr + col);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + jp * 32 + pair_col8(fq);
+          const bf16x8 p = pair_swap16(round4(acc[i][2 * jp]), round4(acc[i][2 * jp + 1]));
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = (float)p[e] * sc[i];
+            if (g.residual) v += (float)rv[i][jp][e];
+            o[e] = (bf16_t)v;
+          }
+          if (orow[i] >= 0 && col < N) *reinterpret_cast<bf16x8*>(Cb + (int64_t)orow[i] * g.ldc + col) = o;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = m0 + wr * 128 + i * 16 + fr;
@@ -149,6 +213,26 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
     // W rows are [gate 0..31 | up 0..31 | gate 32..63 | ...]: fragments j = 0,1 are gate columns, j = 2,3 the matching up columns;
     // gate and up are rounded to bf16 first, like the unfused GEMM + SwiGLU kernel pair
     const int half_n = N >> 1;
+    if (!g.ep8 && (g.ldc & 7) == 0 && (half_n & 7) == 0 && aligned16(Cb)) {
+      const int col = (cw >> 1) + pair_col8(fq);               // the lane's eight output columns (pair_swap16 of the j = 0, 1 pieces)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wr * 128 + i * 16 + fr;
+        bf16x4 o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gf = (float)(bf16_t)acc[i][j][r];
+            const float uf = (float)(bf16_t)acc[i][j + 2][r];
+            o[j][r] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+          }
+        const bf16x8 p = pair_swap16(o[0], o[1]);
+        if (row < M && col < half_n) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = m0 + wr * 128 + i * 16 + fr;
@@ -175,6 +259,48 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
     // (mp_rope_qk_bf16: the projection output is rounded to bf16 first, the rotation runs in fp32, one rounding per output).
     const int head0 = (cw >> 7) << 7;                 // first column of the head (standard layout)
     const int blk = (cw >> 6) & 1;                    // which 32-dim block of lo / hi this wave holds
+    if (!g.ep8 && (g.ldc & 7) == 0 && aligned16(Cb)) {
+      // 16-byte pieces: the lo pieces of fragments 0, 1 pair up, and the hi pieces of fragments 2, 3; the cos / sin rows of four matrix
+      // rows are fetched together (one round trip to L2 per half instead of one per row)
+      const int c8 = blk * 32 + pair_col8(fq);        // the lane's eight rotary indices after the swap
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {
+        f32x4 cs[4][2], sn[4][2];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int row = m0 + wr * 128 + (ih * 4 + ii) * 16 + fr;
+          const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int dim = blk * 32 + j * 16 + fq * 4;
+            cs[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)pos * 64 + dim);
+            sn[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)pos * 64 + dim);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = ih * 4 + ii;
+          const int row = m0 + wr * 128 + i * 16 + fr;
+          bf16x4 olo[2], ohi[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = (float)(bf16_t)acc[i][j][r], b = (float)(bf16_t)acc[i][j + 2][r];
+              olo[j][r] = (bf16_t)(a * cs[ii][j][r] - b * sn[ii][j][r]);
+              ohi[j][r] = (bf16_t)(b * cs[ii][j][r] + a * sn[ii][j][r]);
+            }
+          const bf16x8 plo = pair_swap16(olo[0], olo[1]), phi = pair_swap16(ohi[0], ohi[1]);
+          if (row < M) {
+            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + c8) = plo;
+            *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + 64 + c8) = phi;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = m0 + wr * 128 + i * 16 + fr;
@@ -197,6 +323,41 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  if (!g.ep8 && (g.ldc & 7) == 0 && (N & 7) == 0 && aligned16(Cb) && (!R || ((g.ldr & 7) == 0 && aligned16(R)))) {
+    // 16-byte pieces (pair_swap16).  All sixteen residual pieces of the lane are requested before the first is used: the operand
+    // fragments' 64 registers are dead here, and eight dependent round trips to memory (one per fragment row, the first version) cost
+    // 25-30 us per launch on the N = 4096 projections.  The activation result is rounded to bf16 before the residual add (HF's own
+    // order: act(x) is a bf16 tensor).
+    bf16x8 rv[8][2];
+    if (R) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + jp * 32 + pair_col8(fq);
+          rv[i][jp] = bf16x8{};
+          if (row < M && col < N) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int col = cw + jp * 32 + pair_col8(fq);
+        bf16x8 p = pair_swap16(round4(acc[i][2 * jp]), round4(acc[i][2 * jp + 1]));
+        if (R) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) p[e] = (bf16_t)((float)p[e] + (float)rv[i][jp][e]);
+        }
+        if (row < M && col < N) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+      }
     }
     return;
   }
@@ -564,7 +725,9 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
     max_split = (e && atoi(e) >= 1) ? atoi(e) : 8;
   }
   GemmArgs gf = g;
-  gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split;
+  static int ep8 = -1;
+  if (ep8 < 0) { const char* e = getenv("MP_GEMM_EP8"); ep8 = (e && atoi(e) == 1) ? 1 : 0; }
+  gf.n_cu = n_cu; gf.nbatch = batch; gf.max_split = max_split; gf.ep8 = ep8;
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
   if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }

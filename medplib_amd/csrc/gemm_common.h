@@ -42,6 +42,7 @@ struct GemmArgs {
   // ACT_ROPE_QK: cos / sin tables [positions, 64] fp32, position of row m = m % rope_seq + rope_pos0
   const float* rope_cos; const float* rope_sin;
   int rope_seq, rope_pos0;
+  int ep8;              // 256x256 kernel: 1 = the 8-byte epilogue of round 1 (MP_GEMM_EP8=1, A/B runs only)
 };
 
 // GELU(erf) without erff: gelu(x) = relu(x) - a Phi(-a), a = |x|, log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute
