@@ -60,9 +60,14 @@ int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void
  * plain weight followed by mp_rope_qk_bf16.  head_dim 128, hidden % 256 == 0. */
 int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
                           const float* sin_t, int M, int N, int K, int seq, int pos_offset, int head_dim, hipStream_t stream);
-/* 256 or 128: the tile size of the kernel the calling thread's last mp_gemm_bf16_nt* call dispatched to (0 before the first call).
+/* 320, 256 or 128: the tile size of the kernel the calling thread's last mp_gemm_bf16_nt* call dispatched to (0 before the first call).
  * Measurement aid: bench.py attributes its HIP-event samples to gemm256v3_bf16_nt_kernel / gemm_bf16_nt_kernel with it. */
 int mp_gemm_last_kernel(void);
+/* Tile choice of the calling thread's dense mp_gemm_bf16_nt / mp_gemm_qkv_rope_bf16 calls: 1 (default) = 320x256 tiles where the wave model
+ * says they beat 256x256 tiles (M = 5112: one whole wave instead of 1.25 for every N = 4096 projection), 0 = never, 2 = whenever the call
+ * is eligible (dense, bf16 out, N % 256 == 0, act NONE / QUICK_GELU / RoPE), -1 = back to the process default (MP_GEMM320).  A/B runs and
+ * tests; mp_gemm_last_kernel() then reports 320. */
+int mp_gemm_tile_policy(int mode);
 /* `batch` independent GEMMs at fixed strides — the per-expert SwiGLU GEMMs of DeepSpeed `Experts`
  * (call site medplib_moe_llama.py:604-614). m_dev[b] = rows routed to expert b. */
 int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,

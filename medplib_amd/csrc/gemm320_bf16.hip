@@ -1,0 +1,338 @@
+// 320x256x64 bf16 MFMA GEMM for gfx950: the 256x256 ping-pong kernel's schedule (gemm256_bf16.hip) on a taller tile, for the shapes whose
+// 256-row tiling leaves a short last wave.  The decoder runs M = batch x sequence = 8 x 639 = 5112 rows: 20 row tiles of 256 x 16 column
+// tiles = 320 tiles = 1.25 waves on 256 CUs for every N = 4096 projection (o_proj, down_proj, three of the four dgrad GEMMs of LoRA training),
+// 3.75 waves for qkv; 16 row tiles of 320 make that exactly 1 and 3 waves of 1.25 x the work each, without the split-K tail's fp32
+// partials going through memory (64 MB written + 48 MB read per N = 4096 launch).  mp_gemm_bf16_nt picks this kernel per call from the
+// two wave counts (use_320 in gemm_bf16.hip).
+//
+// 512 threads = 8 waves as 4 (M) x 2 (N); a wave owns an 80 x 128 output tile = 5 x 8 fragments of v_mfma_f32_16x16x32_bf16 (160
+// accumulator registers).  LDS: 2 stages x (A 40 KiB + B 32 KiB) = 144 KiB, one workgroup per CU, two waves per SIMD.  The two N halves
+// (waves 0-3 / 4-7, one of each per SIMD) run one barrier out of phase like the 256x256 kernel's M halves, so one wave of a SIMD is in
+// a 40-MFMA segment while its partner reads fragments and issues DMA.  A K-tile is two segments = the two 64-column halves of the wave
+// tile; the A fragments (all 80 rows) stay in registers for both, the B fragments are read per half:
+//   reads:  H0  A (5 fragments x 2) + B columns 0-63 (4 x 2)        H1  B columns 64-127 (4 x 2)
+//   DMA  :  H0  B columns 64-127 of tile t+1 (2 pieces per wave)     H1  A (5 pieces) + B columns 0-63 (2) of tile t+2
+// (A and the B columns 0-63 of a stage are free after H0's reads, the B columns 64-127 after H1's) -- the split along N rather than
+// M makes the DMA piece counts integral (40 A pieces of 8 rows over 8 waves; a split along M would need 2.5 per wave and region).
+// One counted wait (vmcnt(7)) per K-tile; the operand stream never drains.  The DMA goes through buffer descriptors (buffer_load ... lds:
+// one 32-bit lane offset per operand, everything else in the scalar offset): 2 address registers instead of 18 -- with 160 accumulators,
+// 40 A-fragment and 32 B-fragment registers there is no room for per-piece 64-bit pointers (the launcher checks the operands fit 2 GiB).
+// The MFMAs are issued as (W fragment, A fragment) = transposed accumulators (a lane owns four consecutive columns of a row); the
+// epilogue pairs neighbouring fragments with v_permlane16_swap into 16-byte pieces (gemm256_bf16.hip, pair_swap16).
+// Dense calls only (no device-side row counts, no row gather / scatter, bf16 output); no tail split: the launcher selects this kernel
+// only when its last wave is full enough to win without one.
+#include "gemm_common.h"
+#include <stdlib.h>
+#include <algorithm>
+
+namespace {
+
+constexpr int BM3 = 320, BN3 = 256, BK3 = 64, NT3 = 512;
+constexpr int A_BYTES = BM3 * 128, B_BYTES = BN3 * 128, STAGE3 = A_BYTES + B_BYTES;     // 40960 + 32768 = 73728
+
+__device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+#define MP3_BAR()                          \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+#define MP3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_3;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_3;
+__device__ __forceinline__ bf16x8 pair_swap16_3(bf16x4 a, bf16x4 b) {          // see pair_swap16 in gemm256_bf16.hip
+  const u32x2_3 ua = __builtin_bit_cast(u32x2_3, a), ub = __builtin_bit_cast(u32x2_3, b);
+  const u32x2_3 r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+  const u32x2_3 r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+  return __builtin_bit_cast(bf16x8, (u32x4_3{r0[0], r1[0], r0[1], r1[1]}));
+}
+__device__ __forceinline__ bf16x4 round4_3(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
+
+// Epilogue: alpha / bias / activation (rounded to bf16) then the residual add, or the RoPE pairing of a q / k tile (same arithmetic and
+// rounding points as gemm256_epilogue_t; 16-byte pieces only: the launcher guarantees the alignment).
+__device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int M, int N, int m0, int n0, int wr, int wc,
+                                                 int fr, int fq) {
+  bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+  const int cw = n0 + wc * 128;
+  const int c8 = (fq & 1) * 16 + (fq >> 1) * 8;              // the lane's eight columns inside a fragment pair's 32
+  if (g.act == ACT_ROPE_QK && n0 < (N / 3) * 2) {
+    // the wave's 128 columns are one head: fragments 0,1 | 2,3 hold [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63]
+    const int head0 = (cw >> 7) << 7;
+    bf16x4 qk[5][8];                                      // the projection output rounded to bf16 (its own rounding point): 80 registers for 160
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qk[i][j] = round4_3(acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+      for (int ic = 0; ic < 2; ++ic) {                   // fragment rows {0,1,2}, then {3,4}: the cos / sin pieces of a chunk are fetched together
+        f32x4 cs[3][2], sn[3][2];
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+          const int i = ic * 3 + ii;
+          if (i < 5) {
+            const int row = m0 + wr * 80 + i * 16 + fr;
+            const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int dim = jb * 32 + j * 16 + fq * 4;
+              cs[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)pos * 64 + dim);
+              sn[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)pos * 64 + dim);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+          const int i = ic * 3 + ii;
+          if (i < 5) {
+            const int row = m0 + wr * 80 + i * 16 + fr;
+            bf16x4 olo[2], ohi[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float a = (float)qk[i][jb * 4 + j][r], b = (float)qk[i][jb * 4 + j + 2][r];
+                olo[j][r] = (bf16_t)(a * cs[ii][j][r] - b * sn[ii][j][r]);
+                ohi[j][r] = (bf16_t)(b * cs[ii][j][r] + a * sn[ii][j][r]);
+              }
+            const bf16x8 plo = pair_swap16_3(olo[0], olo[1]), phi = pair_swap16_3(ohi[0], ohi[1]);
+            if (row < M) {
+              *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + jb * 32 + c8) = plo;
+              *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + 64 + jb * 32 + c8) = phi;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
+  // ---- alpha, bias, activation in place (fp32)
+  if (g.alpha != 1.f || g.bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int col = cw + j * 16 + fq * 4 + r; bv[r] = col < N ? g.bias[col] : 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[i][j] = acc[i][j] * g.alpha + bv;
+    }
+  }
+#define MP3_ACT_SWEEP(EXPR)                                                          \
+  _Pragma("unroll") for (int i = 0; i < 5; ++i) _Pragma("unroll") for (int j = 0; j < 8; ++j) {                    \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = (EXPR); }         \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  }
+  switch (g.act) {
+    case ACT_QUICK_GELU: MP3_ACT_SWEEP(v / (1.f + __expf(-1.702f * v))) break;
+    default: break;
+  }
+#undef MP3_ACT_SWEEP
+  // ---- stores, in two column halves of the wave tile (the residual pieces of a half are all requested before the first is used)
+  const bf16_t* R = g.residual;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    bf16x8 rv[5][2];
+    if (R) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int row = m0 + wr * 80 + i * 16 + fr;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + (h * 2 + jp) * 32 + c8;
+          rv[i][jp] = bf16x8{};
+          if (row < M && col < N) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int row = m0 + wr * 80 + i * 16 + fr;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int col = cw + (h * 2 + jp) * 32 + c8;
+        bf16x8 p = pair_swap16_3(round4_3(acc[i][(h * 2 + jp) * 2]), round4_3(acc[i][(h * 2 + jp) * 2 + 1]));
+        if (R) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) p[e] = (bf16_t)((float)p[e] + (float)rv[i][jp][e]);
+        }
+        if (row < M && col < N) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = g.M, N = g.N;
+  const int tiles_n = N / BN3, tiles_m = (M + BM3 - 1) / BM3;
+  const int T = tiles_m * tiles_n;
+  // ---- work decode: XCD-chunked (workgroup b runs on XCD b & 7: an XCD walks a contiguous chunk of the grouped tile order)
+  const int bid = blockIdx.x;
+  const int full = T & ~7;
+  const int flat = bid < full ? (bid & 7) * (full >> 3) + (bid >> 3) : bid;
+  const int GROUP_M = g.group_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = flat / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (flat % per_group) % gsz, tn = (flat % per_group) / gsz;
+  const int m0 = tm * BM3, n0 = tn * BN3;
+  const int nt = g.K / BK3;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 2, wr = wave & 3;               // wave group = N half (waves w and w + 4 share a SIMD)
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // DMA piece p of an operand covers its rows 8p..8p+7 (LDS image: p * 1024 + lane * 16, XOR swizzle on the source chunk).
+  //   A: 40 pieces, wave w issues p = w + 8 i (i < 5)
+  //   B: columns 0-63 of both wave groups = rows {0-63, 128-191} = pieces {0-7, 16-23}; columns 64-127 = pieces {8-15, 24-31};
+  //      wave w issues the entries 2w, 2w+1 of each list
+  const int sub_row = lane >> 3;
+  const int src_c = (lane & 7) ^ sub_row;
+  // Buffer-descriptor DMA: ONE lane offset per operand (the lane's row within a piece + its swizzled 16-byte chunk); the piece's first
+  // row, the tile origin and the K advance are a scalar offset.  Rows beyond M are beyond the descriptor's range and read as zeros (no
+  // clamping, so the A pieces are affine in i); N is a multiple of 256 (launcher), so no W row is out of range.
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (int)(((int64_t)(M - 1) * g.lda + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.W), 0, (int)(((int64_t)(N - 1) * g.ldw + g.K) * 2), 0x00020000);
+  const int a_lane = (int)((sub_row * g.lda + src_c * 8) * 2), w_lane = (int)((sub_row * g.ldw + src_c * 8) * 2);
+  const int a_row_bytes = (int)(g.lda * 2), w_row_bytes = (int)(g.ldw * 2);
+  int b_piece[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = 2 * wave + (k & 1);                    // entry 0..15 of the list
+    b_piece[k] = (e & 7) + (e >> 3) * 16 + (k >> 1) * 8; // k = 0,1: columns 0-63 (region 0); k = 2,3: columns 64-127 (region 1)
+  }
+  auto dma_a = [&](int i, int t) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + (wave + 8 * i) * 1024), 16,
+                                             a_lane, (m0 + (wave + 8 * i) * 8) * a_row_bytes + t * (BK3 * 2), 0, 0);
+  };
+  auto dma_b = [&](int k, int t) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + A_BYTES + b_piece[k] * 1024), 16,
+                                             w_lane, (n0 + b_piece[k] * 8) * w_row_bytes + t * (BK3 * 2), 0, 0);
+  };
+
+  f32x4 acc[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[5][2], fb[4][2];
+  // fragment read addresses: one lane base per operand and K half (row wr * 80 + fr resp. wc * 128 + fr; (row & 7) == (fr & 7) for every
+  // fragment row, so the swizzle term is the lane's own), everything else is an immediate
+  const int a_rd0 = (wr * 80 + fr) * 128 + ((fq ^ (fr & 7)) << 4), a_rd1 = (wr * 80 + fr) * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+  const int b_rd0 = A_BYTES + (wc * 128 + fr) * 128 + ((fq ^ (fr & 7)) << 4), b_rd1 = A_BYTES + (wc * 128 + fr) * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+  auto load_a = [&](const char* st) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(st + a_rd0 + i * 2048);
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(st + a_rd1 + i * 2048);
+    }
+  };
+  auto load_b = [&](int hn, const char* st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[j][0] = *reinterpret_cast<const bf16x8*>(st + b_rd0 + (hn * 64 + j * 16) * 128);
+      fb[j][1] = *reinterpret_cast<const bf16x8*>(st + b_rd1 + (hn * 64 + j * 16) * 128);
+    }
+  };
+// the 40 MFMAs of one segment: column half HN of the wave tile, K = 64
+#define MP3_MFMA_40(HN)                                                                                     \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+      _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+          acc[i][(HN) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][(HN) * 4 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+    MP3_BAR();                                                                                              \
+  } while (0)
+
+  // ---- prologue: all of tile 0, and what the (virtual) tile -1 would have issued for tile 1 (A + B columns 0-63)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) dma_a(i, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dma_b(k, 0);
+  if (nt > 1) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_a(i, 1);
+    dma_b(0, 1); dma_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  MP3_BAR();
+  if (wc == 1) MP3_BAR();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE3;
+    const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+    // ---------------- H0: all 80 rows x columns 0-63 of the wave tile (40 MFMAs) ----------------
+    load_b(0, st);
+    load_a(st);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1) { dma_b(2, t + 1); dma_b(3, t + 1); }
+    MP3_LGKM0();
+    MP3_BAR();
+    MP3_MFMA_40(0);
+    // ---------------- H1: columns 64-127 (40 MFMAs) ----------------
+    load_b(1, st);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) dma_a(i, t + 2);
+      dma_b(0, t + 2); dma_b(1, t + 2);
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");     // everything up to the B columns 64-127 of tile t+1 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    MP3_LGKM0();
+    MP3_BAR();
+    MP3_MFMA_40(1);
+  }
+  if (wc == 0) MP3_BAR();
+  // the epilogue's lane coordinates are derived again from the thread id (opaque to the optimiser), so nothing of the epilogue's address
+  // arithmetic is kept in registers across the K loop
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  gemm320_epilogue(g, acc, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
+}
+
+}  // namespace
+
+// Whether the 320-row tiling is eligible for this call (dense bf16-out, aligned, offsets fit 32 bits) -- the choice between the two
+// tilings is use_320() in gemm_bf16.hip.
+bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
+  if (batch != 1 || g.m_dev || g.a_rows || g.c_rows || g.out_f32) return false;
+  // (the other activations' sweeps over 40 fragments do not fit beside 160 accumulators: the allocator then spills accumulators inside the K loop)
+  if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK)) return false;
+  if (g.N % BN3 || g.K % BK3 || g.M < 1024) return false;
+  if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15)) return false;
+  if (g.residual && ((g.ldr & 7) || (reinterpret_cast<uintptr_t>(g.residual) & 15))) return false;
+  if ((int64_t)(g.M + 320) * g.lda * 2 >= (1ll << 31) || (int64_t)g.N * g.ldw * 2 >= (1ll << 31)) return false;   // 32-bit (signed) DMA offsets
+  return true;
+}
+
+int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    attr = true;
+  }
+  const int tiles = (int)(mp_cdiv(g.M, BM3) * (g.N / BN3));
+  hipLaunchKernelGGL(gemm320_bf16_nt_kernel, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
+  return mp_check_launch("mp_gemm_bf16_nt(320)");
+}

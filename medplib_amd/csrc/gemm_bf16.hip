@@ -324,7 +324,40 @@ static bool use_256_rule(const GemmArgs& g, int batch) {
   static int shortk = -1;
   if (shortk < 0) { const char* e = getenv("MP_GEMM_SHORTK_RULE"); shortk = (e && atoi(e) == 0) ? 0 : 1; }
   if (shortk && g.K <= 1024 && tiles > 256 && (tiles % 256) > 0 && (tiles % 256) < 128) return false;
+  // few tiles but a long K (CLIP fc2: 4616 x 1024 x 4096 = 76 tiles): the tail split cuts each tile into K-ranges of >= 16 K-tiles that
+  // fill the machine (3 x 76 units): 64 vs 77 us on the 128x128 kernel (scripts/tower_ab.sh)
+  if (g.M >= 1024 && g.N >= min_n && tiles >= 64 && tiles < min_tiles && g.K >= 4096 && !g.m_dev && !g.out_f32) return true;
   return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
+}
+
+// implemented in gemm256_bf16.hip (cached per device) / gemm320_bf16.hip
+int mp_device_cus();
+bool mp_gemm320_eligible(const GemmArgs& g, int batch);
+int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream);
+
+// 320-row or 256-row tiles for a dense call?  Modelled cost in units of one 256x256 tile's time on the device's CUs: the 256 tiling pays
+// floor(T / C) full waves plus a tail (a whole tile-time when more than half the CUs have a tile, else 1 / S of one for the S-way split
+// plus ~0.3 for the partials' round trip through memory: measured 0.67 at K = 4096 with S = 4, 0.5 at K = 11008); the 320 tiling pays
+// 1.35 per wave, all waves whole (it has no tail split).  MP_GEMM320 = 0 never, 2 whenever eligible, default 1 = by this model.
+static thread_local int g_tile_policy = -1;          // mp_gemm_tile_policy(): -1 = the process default (MP_GEMM320, else 1)
+static bool use_320(const GemmArgs& g, int batch) {
+  static int env_mode = -1;
+  if (env_mode < 0) { const char* e = getenv("MP_GEMM320"); env_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+  const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
+  if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
+  if (mode == 2) return true;
+  const int C = std::min(mp_device_cus(), 256);
+  const int64_t t256 = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256), t320 = mp_cdiv(g.M, 320) * (g.N / 256);
+  const int64_t rem = t256 % C;
+  double c256 = (double)(t256 / C);
+  if (rem > 0) {
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(C / rem, 8), g.K / 64 / 4));
+    c256 += (rem * 2 > C || S == 1) ? 1.0 : 1.0 / S + 0.3;
+  }
+  // 1.25 x the work per tile, and the taller tile's K loop runs ~7 % below the 256x256 one's (its second load segment carries 7 of the
+  // 9 DMA pieces): qkv at 3.0 waves of 320 measured 420 us against 393 at 3.75 waves of 256, o_proj 154 against 174, down 338 against 369
+  const double c320 = 1.35 * (double)mp_cdiv(t320, C);
+  return c320 < 0.97 * c256;
 }
 
 // which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)
@@ -335,6 +368,11 @@ static bool use_256(const GemmArgs& g, int batch) {
   return big;
 }
 extern "C" int mp_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+extern "C" int mp_gemm_tile_policy(int mode) {
+  MP_REQUIRE(mode >= -1 && mode <= 2, MP_ERR_ARG, "mp_gemm_tile_policy: mode must be -1 (default), 0 (256-row tiles only), 1 (by the wave model) or 2 (320-row tiles whenever eligible)");
+  g_tile_policy = mode;
+  return MP_OK;
+}
 
 // implemented in gemm256_bf16.hip: the registered split-K scratch (mp_gemm_set_workspace)
 void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
@@ -384,6 +422,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
+  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, stream); }
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   g.max_split = split128(g, 1, stream, &g.ws, &g.tickets);
@@ -406,6 +445,7 @@ extern "C" int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi,
   g.M = M; g.N = N; g.K = K; g.act = ACT_ROPE_QK; g.out_f32 = 0; g.alpha = 1.f;
   g.group_m = gemm_group_m();
   g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_seq = seq; g.rope_pos0 = pos_offset;
+  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, stream); }
   (void)use_256(g, 1);
   return mp_launch_gemm256(g, 1, stream);
 }

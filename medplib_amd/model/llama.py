@@ -268,11 +268,13 @@ class LlamaStack:
         for i, lw in enumerate(self.layers):
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
             if self.fuse_rope and B * S > 8:
-                qkv = ops.gemm_qkv_rope(h, lw["qkv_rope"], self.cos, self.sin, S, H, D, pos_offset=pos0)   # RoPE in the epilogue
+                # (row stride of the qkv buffer kept off multiples of 8 KiB: ops.padded_rows)
+                qkv = ops.gemm_qkv_rope(h, lw["qkv_rope"], self.cos, self.sin, S, H, D, pos_offset=pos0,
+                                        out=ops.padded_rows(B * S, 3 * d, x.device))                       # RoPE in the epilogue
             else:
                 qkv = lin(h, lw["qkv"])
                 ops.rope_qk_(qkv, self.cos, self.sin, S, H, D, pos_offset=pos0)
-            q5 = qkv.view(B, S, 3, H, D)
+            q5 = qkv.unflatten(0, (B, S)).unflatten(2, (3, H, D))
             if kv_cache is not None:
                 kv_cache["k"][i][:, pos0:pos0 + S].copy_(q5[:, :, 1])
                 kv_cache["v"][i][:, pos0:pos0 + S].copy_(q5[:, :, 2])

@@ -230,7 +230,7 @@ class LoRAState(torch.nn.Module):
                     W[rows] = (W[rows].float() + delta).to(W.dtype)
             for k in ("qkv", "o", "gu", "down"):
                 if k + "_T" in lw:
-                    lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()
+                    lw[k + "_T"] = _transposed(lw[k])
         llm.refresh_fused_qkv()                                   # the RoPE-interleaved copies follow the merged q / k / v weights
 
     def padded(self, i):
@@ -264,12 +264,22 @@ class LoRAState(torch.nn.Module):
         return out
 
 
+def _transposed(w):
+    """The transposed copy of a projection weight the dgrad GEMMs read as their W operand; 2-D copies get a row stride off multiples of
+    8 KiB (ops.padded_rows: qkv^T [d, 3d] has 24 KiB rows)."""
+    if w.dim() == 2:
+        out = ops.padded_rows(w.shape[1], w.shape[0], w.device, w.dtype)
+        out.copy_(w.t())
+        return out
+    return w.transpose(-1, -2).contiguous()
+
+
 def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True, sft_modules=()):
     """Attach adapters to a LlamaStack and make the transposed weight copies the dgrad GEMMs read."""
     llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed, train_gate, tuple(sft_modules))
     for lw in llm.layers:
         for k in ("qkv", "o", "gu", "down"):
-            lw[k + "_T"] = lw[k].transpose(-1, -2).contiguous()          # experts: [E, out, in] -> [E, in, out]
+            lw[k + "_T"] = _transposed(lw[k])                            # experts: [E, out, in] -> [E, in, out]
     V, d = llm.lm_head.shape
     vp = (V + 63) // 64 * 64
     llm.lm_head_T = torch.zeros(d, vp, dtype=torch.bfloat16, device=llm.device)
@@ -473,11 +483,11 @@ def forward_train(llm, embeds, key_valid):
         s = {"x": x, "pad": pad}
         seed = (lora.step * 4096 + i) * 4
         h1 = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
-        qkv = ops.gemm(h1, lw["qkv"])
+        qkv = ops.gemm(h1, lw["qkv"], out=ops.padded_rows(T, 3 * d, x.device))
         if "qkv" in pad:
             qkv, s["h1d"], s["t_qkv"] = _adapter_fwd(lora, pad["qkv"], h1, qkv, seed + 2)
         ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
-        q5 = qkv.view(B, S, 3, H, D)
+        q5 = qkv.unflatten(0, (B, S)).unflatten(2, (3, H, D))
         attn, lse = ops.attention_fwd_lse(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
         x_mid = ops.gemm(attn.view(T, d), lw["o"], residual=x)
         if "o" in pad:
@@ -568,10 +578,10 @@ def backward(llm, saved, d_hidden, d_aux=None):
         if "o" in pad:
             d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3)
             take(i, pad["o"], dB, dAT)
-        q5 = s["qkv"].view(B, S, 3, H, D)
+        q5 = s["qkv"].unflatten(0, (B, S)).unflatten(2, (3, H, D))
         _, _, _, dqkv = ops.attention_bwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], s["attn"], d_attn.view(B, S, d), s["lse"], causal=True,
                                           key_valid=saved["key_valid"])
-        dqkv = dqkv.view(T, 3 * d)
+        dqkv = dqkv.flatten(0, 1).flatten(1)                    # [T, 3d] view of the (row-padded) buffer
         ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)           # the transpose of a rotation is the rotation by -theta
         d_h1 = ops.gemm(dqkv, lw["qkv_T"])
         if "qkv" in pad:

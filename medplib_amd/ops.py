@@ -144,6 +144,17 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
     return out
 
 
+def gemm_tile_policy(mode):
+    """Tile choice of this thread's dense bf16 GEMM calls (mp_gemm_tile_policy): 1 = 320x256 tiles where the wave model prefers them
+    (default), 0 = 256-row tiles only, 2 = 320-row tiles whenever eligible, -1 = process default."""
+    lib().call("mp_gemm_tile_policy", int(mode))
+
+
+def gemm_last_kernel():
+    """320 / 256 / 128: the tile of the kernel the last GEMM call of this thread went to."""
+    return int(lib().raw("mp_gemm_last_kernel")())
+
+
 def gemv(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, alpha=1.0, w_index=None, row_scale=None, row_keep=None):
     """x [M <= 8, K] bf16; w [N, K] bf16 or, with w_index (int32 [M] device), [E, N, K] with row m using w[w_index[m]].
     Decode-step projections (HBM-bound weight stream)."""
@@ -243,7 +254,7 @@ def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=
     delta = torch.empty((B * H, Sq), dtype=torch.float32, device=q.device)
     lib().call("mp_attention_delta_bf16", _p(out), out.stride(0), out.stride(1), _p(d_out), d_out.stride(0), d_out.stride(1), _p(delta),
                B, H, Sq, D, _stream())
-    dqkv = torch.empty((B, Sq, 3, H, D), dtype=torch.bfloat16, device=q.device)
+    dqkv = padded_rows(B * Sq, 3 * H * D, q.device).unflatten(0, (B, Sq)).unflatten(2, (3, H, D))
     dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
     lib().call("mp_attention_bwd_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
                _p(d_out), d_out.stride(0), d_out.stride(1), _p(lse2), _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0),
@@ -469,6 +480,16 @@ def rope_interleave_qkv(qkv_w, heads, head_dim):
     qk = qkv_w[:2 * d].view(2 * heads, 2, 2, 32, K)            # [head, half (lo/hi), block, 32, K]
     out[:2 * d] = qk.permute(0, 2, 1, 3, 4).reshape(2 * d, K)   # [head, block, half, 32, K]
     return out
+
+
+def padded_rows(rows, cols, device, dtype=torch.bfloat16):
+    """A [rows, cols] view of a buffer whose row stride avoids multiples of 8 KiB: with such strides (the fused qkv output: 3 * 4096 * 2 B
+    = 24 KiB) every row starts at the same offset modulo the memory channels' interleave, and the kernels that walk rows lose 10-14 %
+    (scripts/gemm_pad_ab.py: K = 12288 GEMM 426 -> 375 us; scripts/attn_pad_ab.py: attention forward 77 -> 68 us).  320 elements of
+    padding per row; the padding is never read or written."""
+    esz = torch.empty(0, dtype=dtype).element_size()
+    pad = 320 if (cols * esz) % 8192 == 0 else 0
+    return torch.empty((rows, cols + pad), dtype=dtype, device=device)[:, :cols]
 
 
 def gemm_qkv_rope(a, w_interleaved, cos_t, sin_t, seq, heads, head_dim, pos_offset=0, out=None):

@@ -436,6 +436,65 @@ def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, M, S, heads, K, pos0)
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
 
 
+def test_gemm_320_row_tile_kernel(dev):
+    """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
+    no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
+    read as zeros through the buffer descriptor), bias + QuickGELU (CLIP fc1), the residual epilogue (o_proj / down_proj), alpha, the
+    RoPE epilogue, and which kernel the wave model picks for the decoder's shapes."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(320)
+    try:
+        for (M, N, K, exact) in [(4096, 4096, 512, True), (5112, 4096, 1024, False), (1100, 512, 256, True), (4616, 4096, 1024, False)]:
+            a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.05)
+            bias = torch.randn(N, generator=g); res = _bf(torch.randn(M, N, generator=g))
+            ad, wd, bd, rd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev)
+            base = O.linear(a.float(), w.float())
+            for kw, ref in (({}, base), ({"residual": rd}, base + res.float()), ({"alpha": 0.5}, 0.5 * base),
+                            ({"bias": bd, "act": ops.ACT_QUICK_GELU, "residual": rd},
+                             (lambda x: x * torch.sigmoid(1.702 * x))(base + bias) + res.float())):
+                ops.gemm_tile_policy(2)
+                out = ops.gemm(ad, wd, **kw)
+                assert ops.gemm_last_kernel() == 320, (M, N, K, ops.gemm_last_kernel())
+                _report(f"gemm320 {M}x{N}x{K} {sorted(kw)}", out, ref, rtol=3 * BF16_EPS, atol=3e-2)
+                for _ in range(2):
+                    assert torch.equal(ops.gemm(ad, wd, **kw), out), "non-deterministic result: LDS race in the ping-pong schedule"
+                ops.gemm_tile_policy(0)
+                out256 = ops.gemm(ad, wd, **kw)
+                assert ops.gemm_last_kernel() in (256, 128)
+                if exact and ops.gemm_last_kernel() == 256:
+                    assert torch.equal(out, out256), (out.float() - out256.float()).abs().max()
+                else:
+                    assert (out.float() - out256.float()).abs().max() <= 4 * BF16_EPS * ref.abs().max()
+        # gelu is not among the 320 kernel's epilogues: the call must fall back, not fail
+        ops.gemm_tile_policy(2)
+        ops.gemm(ad, wd, act=ops.ACT_GELU)
+        assert ops.gemm_last_kernel() != 320
+        # RoPE epilogue: equal to the 256x256 kernel's (M = 4096, N = 3 * 1024: 192 tiles of 256 = one unsplit wave)
+        M, S, heads, K, D = 4096, 512, 8, 512, 128
+        d = heads * D
+        a = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+        w = (torch.randn(3 * d, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+        fr = torch.outer(torch.arange(S + 2, dtype=torch.float32), inv)
+        cos_t, sin_t = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+        wi = ops.rope_interleave_qkv(w, heads, D)
+        got = ops.gemm_qkv_rope(a, wi, cos_t, sin_t, S, heads, D, pos_offset=2)
+        assert ops.gemm_last_kernel() == 320
+        ops.gemm_tile_policy(0)
+        ref = ops.gemm_qkv_rope(a, wi, cos_t, sin_t, S, heads, D, pos_offset=2)
+        assert ops.gemm_last_kernel() == 256 and torch.equal(got, ref), (got.float() - ref.float()).abs().max()
+        # the wave model on 256 CUs at the decoder's row count: the N = 4096 projections go to 320-row tiles, qkv and gate|up stay on 256
+        ops.gemm_tile_policy(1)
+        a = torch.zeros(5112, 4096, dtype=torch.bfloat16, device=dev)
+        picks = {}
+        for N in (4096, 12288, 22016):
+            ops.gemm(a, torch.zeros(N, 4096, dtype=torch.bfloat16, device=dev))
+            picks[N] = ops.gemm_last_kernel()
+        assert picks == {4096: 320, 12288: 256, 22016: 256}, picks
+    finally:
+        ops.gemm_tile_policy(-1)
+
+
 @pytest.mark.parametrize("d,E,T", [(4096, 2, 1000), (2048, 3, 77), (8192, 8, 5), (4096, 0, 130)])
 def test_rmsnorm_gate_fusion_is_bit_identical(dev, d, E, T):
     """mp_rmsnorm_gate_bf16 (post-attention RMSNorm + MoE gate in one pass, one wave per row) vs mp_rmsnorm_bf16 + mp_moe_gate_bf16:
