@@ -253,10 +253,16 @@ def main():
                     "avg_launch_us": round(ms * 1e3 / max(sampled, 1), 2),
                     "gemm_tflop_per_step": round(all_flops / args.steps / 1e12, 2),
                     "gemm_ms_per_step": round(all_flops / args.steps / (achieved * 1e12) * 1e3, 2),
-                    "all_bf16_gemms": {"kernels": "gemm256v3_bf16_nt_kernel + gemm_bf16_nt_kernel", "achieved": round(a_ach, 1),
+                    "all_bf16_gemms": {"kernels": "gemm256v3_bf16_nt_kernel + gemm320_bf16_nt_kernel + gemm_bf16_nt_kernel", "achieved": round(a_ach, 1),
                                        "frac": round(a_ach / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": a_launches // args.steps,
                                        "sampled_launches": a_sampled, "avg_launch_us": round(a_ms * 1e3 / max(a_sampled, 1), 2),
                                        "tflop_per_step": round(a_all / args.steps / 1e12, 2)}}
+            t_flops, t_ms, t_sampled, t_launches, t_all = timer.summary(320)
+            if t_sampled:      # the 320x256 tile kernel (the dense N = 4096 projections at 5112 rows: o_proj; with --lora also down / three dgrads)
+                t_ach = t_flops / (max(t_ms, 1e-9) * 1e-3) / 1e12
+                roof["gemm320_bf16_nt_kernel"] = {"achieved": round(t_ach, 1), "frac": round(t_ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                  "launches_per_step": t_launches // args.steps, "sampled_launches": t_sampled,
+                                                  "avg_launch_us": round(t_ms * 1e3 / t_sampled, 2)}
             # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)

@@ -87,4 +87,8 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// sigmoid(s x) of the bf16 trunk's activations (SiLU / SwiGLU: s = 1, QuickGELU: s = 1.702): v_rcp_f32 (1 ulp) instead of the correctly
+// rounded fp32 division (ten instructions per element in the GEMM epilogues); every kernel that evaluates these activations uses this
+// one expression, so the fused and unfused paths stay bit-identical with each other.  The fp32 mask tail keeps sigmoidf_.
+__device__ __forceinline__ float mp_sigmoid_fast(float x, float s = 1.f) { return __builtin_amdgcn_rcpf(1.f + __expf(-s * x)); }
 #endif

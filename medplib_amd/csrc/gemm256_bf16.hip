@@ -174,8 +174,8 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
   switch (g.act) {
     case ACT_RELU: MP_ACT_SWEEP(fmaxf(v, 0.f)) break;
     case ACT_GELU: MP_ACT_SWEEP(gelu_erf_fast(v)) break;
-    case ACT_QUICK_GELU: MP_ACT_SWEEP(v / (1.f + __expf(-1.702f * v))) break;
-    case ACT_SILU: MP_ACT_SWEEP(v / (1.f + __expf(-v))) break;
+    case ACT_QUICK_GELU: MP_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) break;
+    case ACT_SILU: MP_ACT_SWEEP(v * mp_sigmoid_fast(v)) break;
     default: break;
   }
 #undef MP_ACT_SWEEP
@@ -225,7 +225,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
           for (int r = 0; r < 4; ++r) {
             const float gf = (float)(bf16_t)acc[i][j][r];
             const float uf = (float)(bf16_t)acc[i][j + 2][r];
-            o[j][r] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+            o[j][r] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
           }
         const bf16x8 p = pair_swap16(o[0], o[1]);
         if (row < M && col < half_n) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
         for (int r = 0; r < 4; ++r) {
           const float gf = (float)(bf16_t)acc[i][j][r];
           const float uf = (float)(bf16_t)acc[i][j + 2][r];
-          o[r] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+          o[r] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
         }
         if (row < M && col + 4 <= half_n) *reinterpret_cast<bf16x4*>(Cb + (int64_t)row * g.ldc + col) = o;
       }

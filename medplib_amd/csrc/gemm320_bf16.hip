@@ -133,7 +133,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
   switch (g.act) {
-    case ACT_QUICK_GELU: MP3_ACT_SWEEP(v / (1.f + __expf(-1.702f * v))) break;
+    case ACT_QUICK_GELU: MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) break;
     default: break;
   }
 #undef MP3_ACT_SWEEP

@@ -346,6 +346,9 @@ static bool use_320(const GemmArgs& g, int batch) {
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
   if (mode == 2) return true;
+  // short K (CLIP fc1: 16 K-tiles + bias + QuickGELU): one workgroup per CU serialises prologue, K loop and a 160-accumulator epilogue;
+  // the 128x128 kernel's two co-resident workgroups overlap them (70.5 vs 73.9 us, scripts/gemm_tile_ab.py)
+  if (g.K < 2048) return false;
   const int C = std::min(mp_device_cus(), 256);
   const int64_t t256 = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256), t320 = mp_cdiv(g.M, 320) * (g.N / 256);
   const int64_t rem = t256 % C;

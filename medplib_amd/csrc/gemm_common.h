@@ -63,8 +63,8 @@ static __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);
     case ACT_GELU: return gelu_erf_fast(v);
-    case ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));
-    case ACT_SILU: return v / (1.f + __expf(-v));
+    case ACT_QUICK_GELU: return v * mp_sigmoid_fast(v, 1.702f);
+    case ACT_SILU: return v * mp_sigmoid_fast(v);
     default: return v;
   }
 }

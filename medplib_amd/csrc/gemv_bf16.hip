@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
       for (int p = 0; p < 2; ++p) {
         const float gf = (float)(bf16_t)(acc[m][p] * g.alpha), uf = (float)(bf16_t)(acc[m][2 + p] * g.alpha);
         const int col = (rows[p] >> 6) * 32 + (rows[p] & 31);
-        if (rows[p] < g.N) yo[col] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+        if (rows[p] < g.N) yo[col] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
       }
     } else {
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
       for (int p = 0; p < 2; ++p) {
         const float gf = (float)(bf16_t)acc[p], uf = (float)(bf16_t)acc[2 + p];
         const int col = (rows[p] >> 6) * 32 + (rows[p] & 31);
-        if (rows[p] < g.N) yo[col] = (bf16_t)(gf / (1.f + __expf(-gf)) * uf);
+        if (rows[p] < g.N) yo[col] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
       }
     } else {
 #pragma unroll

@@ -81,7 +81,7 @@ __global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __
   const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col + 32);
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { const float gf = (float)g[j]; o[j] = (bf16_t)(gf / (1.f + __expf(-gf)) * (float)u[j]); }
+  for (int j = 0; j < 8; ++j) { const float gf = (float)g[j]; o[j] = (bf16_t)(gf * mp_sigmoid_fast(gf) * (float)u[j]); }
   *reinterpret_cast<bf16x8*>(act + t * ff + c) = o;
 }
 
@@ -100,7 +100,7 @@ __global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float gf = (float)g[j], uf = (float)u[j], df = (float)d[j];
-    const float sg = 1.f / (1.f + __expf(-gf));
+    const float sg = mp_sigmoid_fast(gf);
     du[j] = (bf16_t)(df * gf * sg);
     dg[j] = (bf16_t)(df * uf * sg * (1.f + gf * (1.f - sg)));
   }

@@ -218,7 +218,7 @@ __global__ void swiglu_bf16_kernel(const bf16_t* __restrict__ gu, bf16_t* __rest
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float gv = (float)g[j];
-    o[j] = (bf16_t)(gv / (1.f + __expf(-gv)) * (float)u[j]);
+    o[j] = (bf16_t)(gv * mp_sigmoid_fast(gv) * (float)u[j]);
   }
   *reinterpret_cast<bf16x8*>(out + row * ldo + c) = o;
 }
