@@ -321,7 +321,7 @@ int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, int64_t ldy
                          int64_t partial_floats, int64_t rows, int dim, hipStream_t stream);
 /* silu(gate) * up and its autograd on the gate|up GEMM output [tokens, 2*ff] whose columns are interleaved in blocks of 32 (the
  * fused weight layout); act / dact [tokens, ff]. */
-int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream);
+int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, hipStream_t stream);
 int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream);
 /* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R in {8, 16, 32}): the LoRA weight gradients dB = dY^T (x A^T) and
  * dA^T = x^T (dY B) — reads X once; `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
@@ -337,7 +337,20 @@ int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int
 /* One adapter (fp32 A [r, fin], B [fout, r]) written into its group's padded bf16 GEMM operands, both orientations: A [64, fin],
  * A^T [fin, 64] at rank offset k0; B * bscale in B [W, 64], B^T [64, W] at the output rows `rows[o]` of the fused projection. */
 int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout, int k0,
-                 int W, float bscale, hipStream_t stream);
+                 int W, float bscale, void* Bx, int64_t ldbx, float xscale, hipStream_t stream);
+/* Backward of the adapter branch into the projection's input gradient in one pass: out = dx + dropout(bf16(dt A)) with the forward's mask
+ * (dt [tokens, >= R] = scaling * dY B, AT [K, 64] = A^T padded: mp_lora_pack; p = 0: no mask).  Replaces a thin GEMM, mp_dropout_bf16 and
+ * mp_add3_bf16 with the same rounding points.  R in {8, 16, 32}; out may alias dx. */
+int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
+                        int K, int R, float p, uint64_t seed, hipStream_t stream);
+/* The adapter's down-projection with lora_dropout inline, written as the K-extension of the projection's input (peft lora.Linear.forward,
+ * tuners/lora/layer.py: result + lora_B(lora_A(dropout(x))) * scaling; call sites train_ds_medplib.py:262-303): t[token, 0..63] =
+ * bf16(drop(x)[token, :] . A[j, :]) for the R rank rows of A (A: [>= 16 * ceil(R / 16), K], rows >= R zero), zeros beyond; xd (optional) =
+ * drop(x), the wgrad's operand.  With t stored in columns K..K+63 of the row-padded input and scaling * B in columns K..K+63 of the weight
+ * (mp_lora_pack's Bx), one mp_gemm_bf16_nt over K + 64 gives base + adapter.  Same mask as mp_dropout_bf16 on the contiguous tensor.
+ * t is scaled by alpha before its rounding; with p = 0 and A = B^T the same kernel is the backward's dt = scaling * dY B (reads dY once). */
+int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
+                      int K, int R, float p, uint64_t seed, float alpha, hipStream_t stream);
 /* MoE layer backward, top-1 / top-2 (autograd of DeepSpeed MOELayer + top1gating / top2gating; entries = choice * tokens +
  * token; top-2 weights are the kept pair renormalised; l_aux uses the first choices' counts): the combine's d_y[e, slot] = w d_out and
  * d_w = <d_out, y[e, slot]> (d_y pre-zeroed); the gate's d_logits from d_w (chosen expert of kept tokens) and from l_aux

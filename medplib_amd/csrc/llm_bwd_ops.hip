@@ -70,7 +70,7 @@ __global__ __launch_bounds__(RB_THREADS) void rmsnorm_bwd_kernel(const bf16_t* _
 }
 
 // gate|up interleaved in blocks of 32: column blk*64 + j = gate channel blk*32 + j, column blk*64 + 32 + j = its up channel
-__global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int64_t T, int ff) {
+__global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int64_t T, int ff, int64_t ldact) {
   const int per_row = ff / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * per_row) return;
@@ -82,7 +82,7 @@ __global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const float gf = (float)g[j]; o[j] = (bf16_t)(gf * mp_sigmoid_fast(gf) * (float)u[j]); }
-  *reinterpret_cast<bf16x8*>(act + t * ff + c) = o;
+  *reinterpret_cast<bf16x8*>(act + t * ldact + c) = o;
 }
 
 __global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu, int64_t T,
@@ -216,30 +216,194 @@ __global__ void scatter_rows_f32_bf16_kernel(const float* __restrict__ g, const 
   *reinterpret_cast<bf16x4*>(out + rows[i] * d + c) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
 }
 
-__device__ __forceinline__ uint32_t hash32(uint64_t k) {       // splitmix64 finaliser, as the gate-noise generator uses
-  k += 0x9e3779b97f4a7c15ull;
-  k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ull;
-  k = (k ^ (k >> 27)) * 0x94d049bb133111ebull;
+// lora_dropout's keep decision: one splitmix64 value per 4 consecutive elements (16 bits each: keep iff bits >= p * 65536), so the
+// generator costs a quarter of a hash per element (the 64-bit finaliser is ~25 VALU operations; at one per element it made the dropout
+// pass VALU-bound).  Index = position in the contiguous [tokens, features] tensor; every kernel that needs the mask calls this.
+__device__ __forceinline__ uint64_t hash64(uint64_t k) {
+  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27; k *= 0x94d049bb133111ebull;
   k ^= k >> 31;
-  return (uint32_t)(k >> 32);
+  return k;
 }
+__device__ __forceinline__ uint64_t dropout_bits4(uint64_t seed, uint64_t i4) { return hash64(seed * 0x100000001b3ull + i4); }   // i4 = index / 4
+__device__ __forceinline__ unsigned dropout_thresh(float p) { return (unsigned)(p * 65536.f); }
 __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, float p, uint64_t seed) {
   const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i8 >= n) return;
   const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
   if (i8 + 8 <= n) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i8);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)(i8 + j)) >> 8) * (1.f / 16777216.f);
-      o[j] = (bf16_t)(u >= p ? (float)v[j] * keep_scale : 0.f);
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t bits = dropout_bits4(seed, (uint64_t)(i8 >> 2) + h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[h * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)v[h * 4 + j] * keep_scale : 0.f);
     }
     *reinterpret_cast<bf16x8*>(y + i8) = o;
   } else {
     for (int64_t i = i8; i < n; ++i) {
-      const float u = (float)(hash32(seed * 0x100000001b3ull + (uint64_t)i) >> 8) * (1.f / 16777216.f);
-      y[i] = (bf16_t)(u >= p ? (float)x[i] * keep_scale : 0.f);
+      const uint64_t bits = dropout_bits4(seed, (uint64_t)(i >> 2));
+      y[i] = (bf16_t)(((unsigned)(bits >> (16 * (i & 3))) & 0xffffu) >= th ? (float)x[i] * keep_scale : 0.f);
+    }
+  }
+}
+
+// LoRA down-projection of one (fused) adapter group with the dropout inline: t[token, j] = bf16(sum_k drop(x)[token, k] A[j, k]) for the 64
+// padded rank columns (zeros beyond 16 * RG), and optionally the dropped activations themselves (the wgrad's operand).  t is written as
+// the K-EXTENSION of the projection's input: the base GEMM then runs over [x | t] and [W | scaling B] (K + 64 deep) and produces
+// x W^T + scaling (drop(x) A^T) B^T in one pass -- no [tokens, out] round trip for the adapter branch (peft lora.Linear.forward:
+// result + lora_B(lora_A(dropout(x))) * scaling).  A workgroup owns 16 tokens; its 8 waves split K and are summed in wave order through
+// LDS (fixed order); a lane's x fragment is 16 bytes of one token row = the MFMA operand layout, so x goes from global memory straight
+// into v_mfma_f32_16x16x32_bf16 (issued as (A rows, tokens): a lane ends up with four consecutive rank columns of a token).  Same
+// mask as mp_dropout_bf16 over the contiguous [tokens, K] tensor (index token * K + k).
+template <int RG>
+__global__ __launch_bounds__(512) void lora_down_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ A, int64_t lda,
+                                                        bf16_t* __restrict__ t, int64_t ldt, bf16_t* __restrict__ xd, int64_t ldxd, int T, int K,
+                                                        float p, uint64_t seed, float alpha) {
+  __shared__ float red[8][RG][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tok0 = blockIdx.x * 16;
+  const int nk = K / 64;                                     // 64-deep K blocks; a lane reads 32 contiguous bytes of its row per block
+  const int ks0 = (int)((int64_t)wave * nk / 8), ks1 = (int)((int64_t)(wave + 1) * nk / 8);
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  f32x4 acc[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool live = tok0 + fr < T;
+  const int tok = min(tok0 + fr, T - 1);
+  // MFMA K slot (fq, j) of the block's first / second step holds k = kb + fq * 16 + j resp. + 8 + j -- the same assignment for x and A, so
+  // the dot products are over the same k; with it a token row's 128 bytes are read by four lanes x 32 contiguous bytes (whole lines)
+  constexpr int U = 4;                                       // K blocks whose loads are in flight together
+  for (int ks = ks0; ks < ks1; ks += U) {
+    const int n = min(U, ks1 - ks);
+    bf16x8 af[U][RG][2], xv[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        const int k = (ks + u) * 64 + fq * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) af[u][rg][h] = *reinterpret_cast<const bf16x8*>(A + (int64_t)(rg * 16 + fr) * lda + k + h * 8);
+          xv[u][h] = *reinterpret_cast<const bf16x8*>(x + (int64_t)tok * ldx + k + h * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        const int k = (ks + u) * 64 + fq * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (p > 0.f) {
+            const uint64_t i4 = ((uint64_t)tok * (uint64_t)K + (uint64_t)(k + h * 8)) >> 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const uint64_t bits = dropout_bits4(seed, i4 + q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                xv[u][h][q * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)xv[u][h][q * 4 + j] * keep_scale : 0.f);
+            }
+            if (xd && live) *reinterpret_cast<bf16x8*>(xd + (int64_t)tok * ldxd + k + h * 8) = xv[u][h];
+          }
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][rg][h], xv[u][h], acc[rg], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) *reinterpret_cast<f32x4*>(&red[wave][rg][lane * 4]) = acc[rg];
+  __syncthreads();
+  // RG x 64 lane-quads to finish (summing the 8 waves in order); everyone helps with the zeros beyond the rank columns
+  for (int q = tid; q < RG * 64; q += 512) {
+    const int rg = q / 64, ln = q & 63;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += *reinterpret_cast<const f32x4*>(&red[w][rg][ln * 4]);
+    sum *= alpha;
+    const int tk = tok0 + (ln & 15);
+    if (tk < T) *reinterpret_cast<bf16x4*>(t + (int64_t)tk * ldt + rg * 16 + (ln >> 4) * 4) = bf16x4{(bf16_t)sum[0], (bf16_t)sum[1], (bf16_t)sum[2], (bf16_t)sum[3]};
+  }
+  constexpr int ZC = (64 - 16 * RG) / 4;                    // zero quads per token beyond the rank columns
+  for (int q = tid; q < 16 * ZC; q += 512) {
+    const int tk = tok0 + q / (ZC > 0 ? ZC : 1), c = 16 * RG + (q % (ZC > 0 ? ZC : 1)) * 4;
+    if (ZC > 0 && tk < T) *reinterpret_cast<bf16x4*>(t + (int64_t)tk * ldt + c) = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  }
+}
+
+// Backward of the adapter branch into the projection's input gradient, in one pass over it: out = dx + dropout(bf16(dt A)) with the
+// forward's mask -- the thin GEMM (dt A^T^T -> [tokens, in]), the dropout pass over its output and the add were six passes over a
+// [tokens, in] tensor; this is one read and one write.  A lane owns 8 consecutive input features of a 512-wide chunk (16-byte accesses,
+// 1 KiB per wave per token row) and keeps their rank vectors in registers (AT [in, 64]: a feature's rank values are contiguous, so two
+// ranks at a time go through v_dot2c_f32_bf16 against the token's (uniform) dt pairs); the four waves of a workgroup take different
+// token ranges of the same chunk.  Rounding points as the three kernels it replaces: the product rounded to bf16 (the GEMM's output),
+// scaled by 1 / (1 - p) and rounded (mp_dropout_bf16), added to dx and rounded (mp_add3_bf16).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <int RP>                                            // rank pairs: R / 2 in {4, 8, 16}
+__global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restrict__ dt, int64_t lddt, const bf16_t* __restrict__ AT,
+                                                          const bf16_t* __restrict__ dx, int64_t lddx, bf16_t* __restrict__ out, int64_t ldo,
+                                                          int T, int K, float p, uint64_t seed, int tpw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (blockIdx.x * 64 + lane) * 8;
+  const bool col_live = k0 < K;
+  const int kc = col_live ? k0 : 0;
+  bf16x2_t a[8][RP];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < RP / 4; ++q) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(AT + (int64_t)(kc + j) * 64 + q * 8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[j][q * 4 + r] = bf16x2_t{v[2 * r], v[2 * r + 1]};
+    }
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  const int t_beg = (blockIdx.y * 4 + wave) * tpw, t_end = min(T, t_beg + tpw);
+  constexpr int U = 4;                                       // tokens whose loads are in flight together
+  for (int tb = t_beg; tb < t_end; tb += U) {
+    const int n = min(U, t_end - tb);
+    bf16x8 dv[U], dtv[U][RP / 4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        dv[u] = *reinterpret_cast<const bf16x8*>(dx + (int64_t)(tb + u) * lddx + kc);
+#pragma unroll
+        for (int q = 0; q < RP / 4; ++q) dtv[u][q] = *reinterpret_cast<const bf16x8*>(dt + (int64_t)(tb + u) * lddt + q * 8);   // same address in every lane
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < RP / 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bf16x2_t d2 = bf16x2_t{dtv[u][q][2 * r], dtv[u][q][2 * r + 1]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_fdot2_f32_bf16(a[j][q * 4 + r], d2, acc[j], false);
+          }
+        bf16x8 o;
+        const uint64_t i4 = ((uint64_t)(tb + u) * (uint64_t)K + (uint64_t)kc) >> 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint64_t bits = p > 0.f ? dropout_bits4(seed, i4 + h) : ~0ull;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = (float)(bf16_t)acc[h * 4 + j];
+            if (p > 0.f) v = (((unsigned)(bits >> (16 * j)) & 0xffffu) >= th) ? (float)(bf16_t)(v * keep_scale) : 0.f;
+            o[h * 4 + j] = (bf16_t)((float)dv[u][h * 4 + j] + v);
+          }
+        }
+        if (col_live) *reinterpret_cast<bf16x8*>(out + (int64_t)(tb + u) * ldo + kc) = o;
+      }
     }
   }
 }
@@ -248,7 +412,7 @@ __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __rest
 // k0..k0+r-1, A^T [fin, 64] columns k0.., B [W, 64] rows rows[o] columns k0.., B^T [64, W] rows k0.. columns rows[o]
 __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ rows, bf16_t* __restrict__ A,
                                  bf16_t* __restrict__ AT, bf16_t* __restrict__ B, bf16_t* __restrict__ BT, int r, int fin, int fout, int k0,
-                                 int W, float bscale) {
+                                 int W, float bscale, bf16_t* __restrict__ Bx, int64_t ldbx, float xscale) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t na = (int64_t)r * fin, nb = (int64_t)fout * r;
   if (idx < na) {
@@ -263,6 +427,7 @@ __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __res
     const bf16_t v = (bf16_t)(b[e] * bscale);
     B[ro * 64 + k0 + j] = v;
     BT[(int64_t)(k0 + j) * W + ro] = v;
+    if (Bx) Bx[ro * ldbx + k0 + j] = (bf16_t)(b[e] * xscale);      // the K-extension columns of [W | scaling B] (mp_lora_down_bf16)
   }
 }
 
@@ -575,11 +740,11 @@ extern "C" int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, c
   return mp_check_launch("mp_rmsnorm_bwd_bf16");
 }
 
-extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t tokens, int ff, hipStream_t stream) {
-  MP_REQUIRE(ff % 32 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_fwd_bf16: ff %% 32 != 0");
+extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, hipStream_t stream) {
+  MP_REQUIRE(ff % 32 == 0 && ldact >= ff && ldact % 8 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_fwd_bf16: ff %% 32 != 0 or bad ldact");
   const int64_t n = tokens * (ff / 8);
   if (n == 0) return MP_OK;
-  hipLaunchKernelGGL(swiglu_pair_fwd_kernel, GRID1D(n), (const bf16_t*)gu, (bf16_t*)act, tokens, ff);
+  hipLaunchKernelGGL(swiglu_pair_fwd_kernel, GRID1D(n), (const bf16_t*)gu, (bf16_t*)act, tokens, ff, ldact);
   return mp_check_launch("mp_swiglu_pair_fwd_bf16");
 }
 
@@ -630,11 +795,38 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
   return mp_check_launch("mp_dropout_bf16");
 }
 
+extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
+                                 int K, int R, float p, uint64_t seed, float alpha, hipStream_t stream) {
+  MP_REQUIRE(tokens >= 0 && K > 0 && K % 64 == 0 && R > 0 && R <= 64, MP_ERR_SHAPE, "mp_lora_down_bf16: K %% 64 == 0 and 0 < R <= 64 (got K %d, R %d)", K, R);
+  MP_REQUIRE(ldx % 8 == 0 && lda % 8 == 0 && ldt % 4 == 0 && (!xd || ldxd % 8 == 0) && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_down_bf16: bad strides / p");
+  if (tokens == 0) return MP_OK;
+  const dim3 grid((unsigned)mp_cdiv(tokens, 16)), blk(512);
+  const int rg = (R + 15) / 16;
+#define MP_GO(RG) hipLaunchKernelGGL((lora_down_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, (bf16_t*)xd, ldxd, tokens, K, p, seed, alpha)
+  switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
+#undef MP_GO
+  return mp_check_launch("mp_lora_down_bf16");
+}
+
+extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
+                                   int K, int R, float p, uint64_t seed, hipStream_t stream) {
+  MP_REQUIRE(tokens >= 0 && K > 0 && K % 8 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_bf16: K %% 8 == 0, R in {8, 16, 32} (got K %d, R %d)", K, R);
+  MP_REQUIRE(lddt % 8 == 0 && lddx % 8 == 0 && ldo % 8 == 0 && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_up_add_bf16: bad strides / p");
+  if (tokens == 0) return MP_OK;
+  const int tpw = 32;
+  const dim3 grid((unsigned)mp_cdiv(K, 512), (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
+#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw)
+  switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
+#undef MP_GO
+  return mp_check_launch("mp_lora_up_add_bf16");
+}
+
 extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout,
-                            int k0, int W, float bscale, hipStream_t stream) {
+                            int k0, int W, float bscale, void* Bx, int64_t ldbx, float xscale, hipStream_t stream) {
   MP_REQUIRE(r > 0 && k0 >= 0 && k0 + r <= 64 && fin > 0 && fout > 0 && W >= fout, MP_ERR_SHAPE, "mp_lora_pack: bad shape");
   const int64_t n = (int64_t)r * fin + (int64_t)fout * r;
-  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W, bscale);
+  hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W, bscale,
+                     (bf16_t*)Bx, ldbx, xscale);
   return mp_check_launch("mp_lora_pack");
 }
 

@@ -94,6 +94,7 @@ class LoRAState(torch.nn.Module):
         # gradients are complete, so their all-reduce overlaps the dgrad of the layers below (engine.Engine._sink)
         self.grad_sink = None
         self._bufs = {}
+        self.ext = {}                                           # (layer, group) -> extended weight [out, in + 64] (enable_lora)
         self.p_active = self.p                                  # dropout in effect: p while training, 0 in eval (set per forward)
 
     def _modules_of(self, i, t):
@@ -231,6 +232,8 @@ class LoRAState(torch.nn.Module):
             for k in ("qkv", "o", "gu", "down"):
                 if k + "_T" in lw:
                     lw[k + "_T"] = _transposed(lw[k])
+                if k + "_x" in lw:
+                    lw[k + "_x"][:, :lw[k].shape[1]].copy_(lw[k])
         llm.refresh_fused_qkv()                                   # the RoPE-interleaved copies follow the merged q / k / v weights
 
     def padded(self, i):
@@ -258,7 +261,9 @@ class LoRAState(torch.nn.Module):
                     if batched:
                         ops.lora_pack(a, b, self.rows[t], A[e], AT[e], B[e], BT[e], k * r, bscale=self.scaling)
                     else:
-                        ops.lora_pack(a, b, self.rows[t], A, AT, B, BT, k * r)
+                        wx = self.ext.get((i, grp))                # dense group: scaling * B also lands in [W | scaling B]'s last 64 columns
+                        ops.lora_pack(a, b, self.rows[t], A, AT, B, BT, k * r, Bx=None if wx is None else wx[:, wx.shape[1] - 64:],
+                                      xscale=self.scaling)
             R = len(tg) * r
             out[grp] = (A, AT, B, BT, 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64, tg)
         return out
@@ -274,12 +279,24 @@ def _transposed(w):
     return w.transpose(-1, -2).contiguous()
 
 
+def _extended(w):
+    """[out, in] -> [out, in + 64] with the weight in the first `in` columns and zeros behind (filled with scaling * B per step)."""
+    out = torch.zeros((w.shape[0], w.shape[1] + 64), dtype=w.dtype, device=w.device)
+    out[:, :w.shape[1]].copy_(w)
+    return out
+
+
 def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=0, train_gate=True, sft_modules=()):
     """Attach adapters to a LlamaStack and make the transposed weight copies the dgrad GEMMs read."""
     llm.lora = LoRAState(cfg, llm, r, alpha, dropout, targets, seed, train_gate, tuple(sft_modules))
-    for lw in llm.layers:
+    for i, lw in enumerate(llm.layers):
         for k in ("qkv", "o", "gu", "down"):
             lw[k + "_T"] = _transposed(lw[k])                            # experts: [E, out, in] -> [E, in, out]
+            if lw[k].dim() == 2 and any(t in llm.lora.targets for t in GROUPS[k]):
+                # the adapter's up-projection as a K-extension of the frozen weight: [W | scaling B] (ops.lora_down writes the matching
+                # 64 columns of the activations), so base + adapter is ONE GEMM over K + 64
+                lw[k + "_x"] = _extended(lw[k])
+                llm.lora.ext[(i, k)] = lw[k + "_x"]
     V, d = llm.lm_head.shape
     vp = (V + 63) // 64 * 64
     llm.lm_head_T = torch.zeros(d, vp, dtype=torch.bfloat16, device=llm.device)
@@ -294,6 +311,20 @@ def _adapter_fwd(lora, ops_pad, x, y, seed):
     xd = ops.dropout_bf16(x, lora.p_active, seed) if lora.p_active > 0 else x
     t = ops.gemm(xd, A)                                           # [T, 64] (columns >= R are zero)
     return ops.gemm(t, B, residual=y, alpha=lora.scaling), xd, t
+
+
+def _ext_rows(T, K, dev):
+    """The row-padded input of an extended projection: (whole [T, K + 64] buffer, its [T, K] activation part, its [T, 64] adapter part)."""
+    buf = torch.empty((T, K + 64), dtype=torch.bfloat16, device=dev)
+    return buf, buf[:, :K], buf[:, K:]
+
+
+def _adapter_down(lora, ops_pad, x, t, seed):
+    """t = bf16(dropout(x) A^T) into the extension columns -> the dropped x (the wgrad's operand; x itself without dropout)."""
+    A, _, _, _, R, _ = ops_pad
+    xd = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lora.p_active > 0 else None
+    ops.lora_down(x, A, t, R, lora.p_active, seed, xd=xd)
+    return x if xd is None else xd
 
 
 def _zeros(shape, dev):
@@ -482,29 +513,46 @@ def forward_train(llm, embeds, key_valid):
         pad = lora.padded(i)
         s = {"x": x, "pad": pad}
         seed = (lora.step * 4096 + i) * 4
-        h1 = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
-        qkv = ops.gemm(h1, lw["qkv"], out=ops.padded_rows(T, 3 * d, x.device))
-        if "qkv" in pad:
-            qkv, s["h1d"], s["t_qkv"] = _adapter_fwd(lora, pad["qkv"], h1, qkv, seed + 2)
+        if "qkv_x" in lw:
+            h1x, h1, t1 = _ext_rows(T, d, x.device)
+            ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps, out=h1)
+            s["h1d"], s["t_qkv"] = _adapter_down(lora, pad["qkv"], h1, t1, seed + 2), t1
+            qkv = ops.gemm(h1x, lw["qkv_x"], out=ops.padded_rows(T, 3 * d, x.device))
+        else:
+            h1 = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
+            qkv = ops.gemm(h1, lw["qkv"], out=ops.padded_rows(T, 3 * d, x.device))
         ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
         q5 = qkv.unflatten(0, (B, S)).unflatten(2, (3, H, D))
-        attn, lse = ops.attention_fwd_lse(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
-        x_mid = ops.gemm(attn.view(T, d), lw["o"], residual=x)
-        if "o" in pad:
-            x_mid, s["attnd"], s["t_o"] = _adapter_fwd(lora, pad["o"], attn.view(T, d), x_mid, seed + 3)
-        h2 = ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps)
+        if "o_x" in lw:
+            ax, a2, t2 = _ext_rows(T, d, x.device)
+            attn, lse = ops.attention_fwd_lse(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid, out=a2.unflatten(0, (B, S)))
+            s["attnd"], s["t_o"] = _adapter_down(lora, pad["o"], a2, t2, seed + 3), t2
+            x_mid = ops.gemm(ax, lw["o_x"], residual=x)
+        else:
+            attn, lse = ops.attention_fwd_lse(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
+            x_mid = ops.gemm(attn.view(T, d), lw["o"], residual=x)
+        if "gu_x" in lw:
+            h2x, h2, t3 = _ext_rows(T, d, x.device)
+            ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps, out=h2)
+        else:
+            h2 = ops.rmsnorm(x_mid, lw["ln2"], cfg.rms_norm_eps)
         s.update(qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, seed=seed)
         if i in llm.moe_layers:
             x_out, l_aux = (_moe_fwd_ep if llm.ep is not None else _moe_fwd)(llm, lora, i, lw, pad, h2, x_mid, s, seed)
             aux.append(l_aux)
         else:
-            gu = ops.gemm(h2, lw["gu"])
-            if "gu" in pad:
-                gu, s["h2d"], s["t_gu"] = _adapter_fwd(lora, pad["gu"], h2, gu, seed)
-            act = ops.swiglu_pair_fwd(gu)
-            x_out = ops.gemm(act, lw["down"], residual=x_mid)
-            if "down" in pad:
-                x_out, s["actd"], s["t_d"] = _adapter_fwd(lora, pad["down"], act, x_out, seed + 1)
+            if "gu_x" in lw:
+                s["h2d"], s["t_gu"] = _adapter_down(lora, pad["gu"], h2, t3, seed), t3
+                gu = ops.gemm(h2x, lw["gu_x"])
+            else:
+                gu = ops.gemm(h2, lw["gu"])
+            if "down_x" in lw:
+                actx, act, t4 = _ext_rows(T, cfg.intermediate_size, x.device)
+                ops.swiglu_pair_fwd(gu, out=act)
+                s["actd"], s["t_d"] = _adapter_down(lora, pad["down"], act, t4, seed + 1), t4
+                x_out = ops.gemm(actx, lw["down_x"], residual=x_mid)
+            else:
+                x_out = ops.gemm(ops.swiglu_pair_fwd(gu), lw["down"], residual=x_mid)
             s["gu"] = gu
         saved.append(s)
         x = x_out
@@ -516,11 +564,14 @@ def forward_train(llm, embeds, key_valid):
 def _adapter_bwd(lora, ops_pad, dy, xd, t, dx, seed):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout)."""
     A, AT, B, BT, R, _ = ops_pad
-    dt = ops.gemm(dy, BT, alpha=lora.scaling)                      # [T, 64] = scaling * dy B
+    # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
+    dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
     dB = ops.tn_skinny(dy, t, R, lora.scaling)                     # [out, R] = scaling * dy^T t
     dAT = ops.tn_skinny(xd, dt, R, 1.0)                            # [in, R]  = x_d^T (scaling * dy B)
-    if lora.p_active > 0:
-        dxa = ops.dropout_bf16(ops.gemm(dt, AT), lora.p_active, seed)    # the same mask and 1/(1-p) as the forward
+    if R <= 32 and dx.stride(0) % 8 == 0:
+        dx = ops.lora_up_add(dt, AT, dx, R, lora.p_active, seed)       # dx += dropout(dt A): the same mask and 1/(1-p) as the forward
+    elif lora.p_active > 0:
+        dxa = ops.dropout_bf16(ops.gemm(dt, AT), lora.p_active, seed)
         dx = ops.add3(dx, dxa)
     else:
         dx = ops.gemm(dt, AT, residual=dx)

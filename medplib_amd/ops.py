@@ -225,7 +225,7 @@ def attention(q, k, v, out=None, causal=False, key_valid=None, rel_h=None, rel_w
     return out
 
 
-def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None):
+def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None, out=None):
     """Attention forward that also returns the row log-sum-exp (log2 domain) for the backward.  q,k,v: [B,S,H,D] bf16 views.
     -> (out [B,Sq,H*D] bf16, lse2 [B*H, Sq] fp32)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
@@ -233,7 +233,9 @@ def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None):
         assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
-    out = torch.empty((B, Sq, H * D), dtype=torch.bfloat16, device=q.device)
+    if out is None:
+        out = torch.empty((B, Sq, H * D), dtype=torch.bfloat16, device=q.device)
+    assert out.shape == (B, Sq, H * D) and out.stride(2) == 1
     lse2 = torch.empty((B * H, Sq), dtype=torch.float32, device=q.device)
     if key_valid is not None:
         _chk(key_valid, torch.uint8, "attention_fwd_lse.key_valid"); assert key_valid.is_contiguous()
@@ -280,10 +282,11 @@ def rmsnorm_bwd(x, w, dy, eps, add=None, want_wgrad=False):
     return out, dw
 
 
-def swiglu_pair_fwd(gu):
+def swiglu_pair_fwd(gu, out=None):
     T, ff2 = gu.shape
-    act = torch.empty((T, ff2 // 2), dtype=torch.bfloat16, device=gu.device)
-    lib().call("mp_swiglu_pair_fwd_bf16", _p(gu), _p(act), T, ff2 // 2, _stream())
+    act = torch.empty((T, ff2 // 2), dtype=torch.bfloat16, device=gu.device) if out is None else out
+    assert gu.is_contiguous() and act.shape == (T, ff2 // 2) and act.stride(1) == 1
+    lib().call("mp_swiglu_pair_fwd_bf16", _p(gu), _p(act), act.stride(0), T, ff2 // 2, _stream())
     return act
 
 
@@ -325,12 +328,38 @@ def scatter_rows_f32_bf16(g, rows, T):
     return out
 
 
-def lora_pack(a, b, rows, A, AT, B, BT, k0, bscale=1.0):
-    """fp32 adapter (a [r, fin], b [fout, r]) -> its slices of the padded bf16 operands (both orientations); B is stored * bscale."""
+def lora_pack(a, b, rows, A, AT, B, BT, k0, bscale=1.0, Bx=None, xscale=1.0):
+    """fp32 adapter (a [r, fin], b [fout, r]) -> its slices of the padded bf16 operands (both orientations); B is stored * bscale.  Bx
+    (optional): a [W, 64] view (any row stride) that receives b * xscale as well -- the K-extension columns of an extended weight."""
     r, fin = a.shape
     fout = b.shape[0]
     lib().call("mp_lora_pack", _p(a), _p(b), _p(rows), _p(A), _p(AT), _p(B), _p(BT), r, fin, fout, int(k0), B.shape[0], float(bscale),
+               _p(Bx), Bx.stride(0) if Bx is not None else 0, float(xscale), _stream())
+
+
+def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0):
+    """t[:, :64] = bf16(dropout(x) @ A[:R]^T) (zeros beyond R), the dropped x into xd when given (mp_lora_down_bf16).  x [T, K] bf16 (any row
+    stride), A [>= 16 * ceil(R / 16), K] bf16, t a [T, 64] view (typically columns K.. of x's own row-padded buffer)."""
+    _chk(x, torch.bfloat16, "lora_down.x"); _chk(A, torch.bfloat16, "lora_down.A"); _chk(t, torch.bfloat16, "lora_down.t")
+    T, K = x.shape
+    assert x.stride(1) == 1 and A.stride(1) == 1 and t.stride(1) == 1 and t.shape == (T, 64) and A.shape[1] == K and A.shape[0] >= (R + 15) // 16 * 16
+    if xd is not None:
+        assert xd.shape == (T, K) and xd.stride(1) == 1
+    lib().call("mp_lora_down_bf16", _p(x), x.stride(0), _p(A), A.stride(0), _p(t), t.stride(0), _p(xd), xd.stride(0) if xd is not None else 0,
+               T, K, int(R), float(p), int(seed), float(alpha), _stream())
+    return t
+
+
+def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None):
+    """dx + dropout(bf16(dt @ AT^T)) with mp_dropout_bf16's mask (mp_lora_up_add_bf16): dt [T, >= R] bf16, AT [K, 64] bf16 (A^T, padded),
+    dx [T, K] bf16; in place on dx unless `out` is given."""
+    _chk(dt, torch.bfloat16, "lora_up_add.dt"); _chk(AT, torch.bfloat16, "lora_up_add.AT"); _chk(dx, torch.bfloat16, "lora_up_add.dx")
+    T, K = dx.shape
+    assert AT.shape == (K, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dx.stride(1) == 1
+    out = dx if out is None else out
+    lib().call("mp_lora_up_add_bf16", _p(dt), dt.stride(0), _p(AT), _p(dx), dx.stride(0), _p(out), out.stride(0), T, K, int(R), float(p), int(seed),
                _stream())
+    return out
 
 
 def moe_combine_bwd(dout, y, expert, slot, weight, capacity, top_k=1):

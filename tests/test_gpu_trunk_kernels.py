@@ -436,6 +436,60 @@ def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, M, S, heads, K, pos0)
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
 
 
+@pytest.mark.parametrize("T,K,N,R,p", [(5112, 4096, 2048, 16, 0.05), (1000, 11008, 1024, 8, 0.0), (77, 256, 512, 48, 0.25)])
+def test_lora_down_and_k_extension(dev, T, K, N, R, p):
+    """mp_lora_down_bf16: t = bf16(dropout(x) A^T) in the 64 extension columns (zeros beyond R), the dropped x equal to mp_dropout_bf16's,
+    and the GEMM over [x | t] x [W | s B] equal to base + s * (t B^T) up to the one rounding the fp32 accumulation saves."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(T + R)
+    buf = torch.zeros(T, K + 64, dtype=torch.bfloat16, device=dev) + 7.0          # the extension columns must be overwritten
+    x = (torch.randn(T, K, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    buf[:, :K] = x
+    A = torch.zeros(64, K, dtype=torch.bfloat16, device=dev)
+    A[:R] = (torch.randn(R, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    xd = torch.empty(T, K, dtype=torch.bfloat16, device=dev) if p > 0 else None
+    t = ops.lora_down(buf[:, :K], A, buf[:, K:], R, p, 99, xd=xd)
+    xd_ref = ops.dropout_bf16(x, p, 99) if p > 0 else x
+    if p > 0:
+        assert torch.equal(xd, xd_ref)
+    ref = xd_ref.float() @ A[:R].float().T
+    _report("lora_down", t[:, :R], ref, rtol=2 * BF16_EPS, atol=2e-3 * ref.abs().max().item())
+    assert float(t[:, R:].float().abs().max()) == 0.0 and torch.equal(buf[:, :K], x)
+    assert torch.equal(ops.lora_down(buf[:, :K], A, buf[:, K:], R, p, 99, xd=xd), t)       # fixed summation order
+    # [x | t] [W | s B]^T against the two-GEMM form
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    Bm = torch.zeros(N, 64, dtype=torch.bfloat16, device=dev)
+    Bm[:, :R] = (torch.randn(N, R, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    Wx = torch.cat([W, (2.0 * Bm.float()).to(torch.bfloat16)], dim=1).contiguous()
+    got = ops.gemm(buf, Wx)
+    ref = x.float() @ W.float().T + 2.0 * (t.float() @ Bm.float().T)
+    _report("K-extension GEMM", got, ref, rtol=2 * BF16_EPS, atol=2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T,K,R,p", [(5112, 4096, 16, 0.05), (777, 11008, 8, 0.05), (130, 1000, 32, 0.0)])
+def test_lora_up_add_equals_the_three_kernels(dev, T, K, R, p):
+    """mp_lora_up_add_bf16 against the path it replaces -- thin GEMM dt A^T^T, mp_dropout_bf16 on the product, mp_add3_bf16 onto dx: same
+    mask, same rounding points; the fp32 sums differ only in their order (v_dot2c pairs vs MFMA), so all but a handful of outputs are
+    EQUAL and the rest differ by one bf16 rounding of the adapter term."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(K + R)
+    dt = torch.zeros(T, 64, dtype=torch.bfloat16, device=dev)
+    dt[:, :R] = (torch.randn(T, R, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    AT = torch.zeros(K, 64, dtype=torch.bfloat16, device=dev)
+    AT[:, :R] = (torch.randn(K, R, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    dx = torch.randn(T, K, generator=g).to(torch.bfloat16).to(dev)
+    prod = ops.gemm(dt, AT) if K % 64 == 0 else (dt.float() @ AT.float().T).to(torch.bfloat16)
+    ref = ops.add3(dx, ops.dropout_bf16(prod, p, 4242)) if p > 0 else ops.add3(dx, prod)
+    got = ops.lora_up_add(dt, AT, dx.clone(), R, p, 4242)
+    diff = (got.float() - ref.float()).abs()
+    frac = float((diff > 0).float().mean())
+    print(f"lora_up_add T={T} K={K} R={R} p={p}: {frac * 100:.4f} % of outputs differ, max {float(diff.max()):.3e}")
+    assert frac < 2e-3 and float(diff.max()) <= 2 * BF16_EPS * float(ref.float().abs().max())
+    if p > 0:                                             # dropped positions carry dx through untouched
+        dropped = ops.dropout_bf16(torch.ones(T, K, dtype=torch.bfloat16, device=dev), p, 4242) == 0
+        assert torch.equal(got[dropped], dx[dropped]) and 0.8 * p < float(dropped.float().mean()) < 1.2 * p
+
+
 def test_gemm_320_row_tile_kernel(dev):
     """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
     no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
