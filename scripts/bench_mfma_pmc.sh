@@ -12,7 +12,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/mfma_pmc/p1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        fam = ("gemm256v3" if "gemm256v3" in n else "gemm128" if "gemm_bf16_nt_kernel" in n else "attn_fwd2" if "attn_fwd2" in n else None)
+        fam = ("gemm256v3" if "gemm256v3" in n else "gemm320" if "gemm320" in n else "gemm128" if "gemm_bf16_nt_kernel" in n else "attn_fwd2" if "attn_fwd2" in n else None)
         if fam:
             res[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 over bench.py (3 steps, kernels "

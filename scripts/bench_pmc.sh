@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != c:
                 continue
             n = r["Kernel_Name"]
-            fam = ("gemm256v3" if "gemm256v3" in n else "gemm128" if "gemm_bf16_nt_kernel" in n else "attn_fwd2" if "attn_fwd2" in n else
+            fam = ("gemm256v3" if "gemm256v3" in n else "gemm320" if "gemm320" in n else "gemm128" if "gemm_bf16_nt_kernel" in n else "attn_fwd2" if "attn_fwd2" in n else
                    "rmsnorm" if "rmsnorm" in n else "moe_combine" if "moe_combine" in n else "rope" if "rope_qk" in n else None)
             if fam:
                 res[fam][c].append(float(r["Counter_Value"]))
