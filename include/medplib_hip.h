@@ -60,6 +60,11 @@ int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void
  * plain weight followed by mp_rope_qk_bf16.  head_dim 128, hidden % 256 == 0. */
 int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
                           const float* sin_t, int M, int N, int K, int seq, int pos_offset, int head_dim, hipStream_t stream);
+/* The gate|up projection of a training forward (HF LlamaMLP, medplib_moe_llama.py:127-141, with peft adapters folded into K: see
+ * mp_lora_down_bf16): act_out[M, N/2] = silu(gate) * up as with MP_ACT_SWIGLU_PAIR, and gu_out[M, N] = the bf16 gate|up values in W's
+ * interleaved row order (what mp_swiglu_pair_bwd_bf16 reads).  Same values as mp_gemm_bf16_nt + mp_swiglu_pair_fwd_bf16. */
+int mp_gemm_swiglu_keep_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* act_out, int64_t ld_act, void* gu_out,
+                             int64_t ld_gu, int M, int N, int K, hipStream_t stream);
 /* 320, 256 or 128: the tile size of the kernel the calling thread's last mp_gemm_bf16_nt* call dispatched to (0 before the first call).
  * Measurement aid: bench.py attributes its HIP-event samples to gemm256v3_bf16_nt_kernel / gemm_bf16_nt_kernel with it. */
 int mp_gemm_last_kernel(void);
@@ -324,10 +329,11 @@ int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, int64_t ldy
 int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, hipStream_t stream);
 int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream);
 /* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R in {8, 16, 32}): the LoRA weight gradients dB = dY^T (x A^T) and
- * dA^T = x^T (dY B) — reads X once; `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
+ * dA^T = x^T (dY B) — reads X once (p > 0: X is the UNdropped adapter input and mp_dropout_bf16's mask over the contiguous [tokens, N]
+ * tensor is applied on the way; G must be readable for 16 columns per 16 ranks: the padded [tokens, 64] adapter tensors are); `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
  * order (fixed summation order). */
 int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                     int64_t tokens, int N, int R, float scale, hipStream_t stream);
+                     int64_t tokens, int N, int R, float scale, float p, uint64_t seed, hipStream_t stream);
 /* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
  * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
 int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,
@@ -336,6 +342,10 @@ int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, cons
 int mp_scatter_rows_f32_bf16(const float* g, const int64_t* rows, void* out, int64_t n, int dim, hipStream_t stream);
 /* One adapter (fp32 A [r, fin], B [fout, r]) written into its group's padded bf16 GEMM operands, both orientations: A [64, fin],
  * A^T [fin, 64] at rank offset k0; B * bscale in B [W, 64], B^T [64, W] at the output rows `rows[o]` of the fused projection. */
+/* Gradient counterpart of mp_lora_pack: gB[fout, r] += dB[rows[o], k0 + j], gA[r, fin] += dAT[c, k0 + i] (dB [W, R], dAT [fin, R] fp32: the fused
+ * group's padded weight gradients from mp_tn_skinny_f32) -- accumulates one adapter's gradients where the optimizer reads them. */
+int mp_lora_grad_unpack_f32(const float* dB, const float* dAT, const int64_t* rows, int R, int k0, int r, int fin, int fout, float* gB, float* gA,
+                            hipStream_t stream);
 int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout, int k0,
                  int W, float bscale, void* Bx, int64_t ldbx, float xscale, hipStream_t stream);
 /* Backward of the adapter branch into the projection's input gradient in one pass: out = dx + dropout(bf16(dt A)) with the forward's mask

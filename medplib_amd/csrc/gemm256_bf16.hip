@@ -229,6 +229,13 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
           }
         const bf16x8 p = pair_swap16(o[0], o[1]);
         if (row < M && col < half_n) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+        if (g.keep_gu) {                                     // the bf16 gate / up values the product was formed from, in the GEMM's own column order
+          const bf16x8 pg = pair_swap16(round4(acc[i][0]), round4(acc[i][1])), pu = pair_swap16(round4(acc[i][2]), round4(acc[i][3]));
+          if (row < M && cw + 64 <= N) {
+            *reinterpret_cast<bf16x8*>(g.keep_gu + (int64_t)row * g.ld_gu + cw + pair_col8(fq)) = pg;
+            *reinterpret_cast<bf16x8*>(g.keep_gu + (int64_t)row * g.ld_gu + cw + 32 + pair_col8(fq)) = pu;
+          }
+        }
         if (i & 1) __builtin_amdgcn_sched_barrier(0);
       }
       return;

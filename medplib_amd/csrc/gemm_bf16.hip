@@ -453,6 +453,24 @@ extern "C" int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi,
   return mp_launch_gemm256(g, 1, stream);
 }
 
+// gate|up projection of a TRAINING forward: act = silu(gate) * up from the fused epilogue AND the bf16 gate|up values themselves (the
+// backward's operands), one launch instead of GEMM + mp_swiglu_pair_fwd_bf16 (which re-read the [tokens, 2 ff] tensor).
+extern "C" int mp_gemm_swiglu_keep_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* act_out, int64_t ld_act, void* gu_out,
+                                        int64_t ld_gu, int M, int N, int K, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 64 == 0, MP_ERR_SHAPE, "mp_gemm_swiglu_keep_bf16: K %% %d == 0 and N %% 64 == 0", BK);
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ld_act % 8 == 0 && ld_gu % 8 == 0 && act_out && gu_out &&
+                 (reinterpret_cast<uintptr_t>(act_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(gu_out) & 15) == 0,
+             MP_ERR_ARG, "mp_gemm_swiglu_keep_bf16: strides must be multiples of 8, outputs 16-byte aligned");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = act_out; g.ldc = ld_act;
+  g.M = M; g.N = N; g.K = K; g.act = ACT_SWIGLU_PAIR; g.out_f32 = 0; g.alpha = 1.f;
+  g.group_m = gemm_group_m();
+  g.keep_gu = (bf16_t*)gu_out; g.ld_gu = ld_gu;
+  (void)use_256(g, 1);
+  return mp_launch_gemm256(g, 1, stream);
+}
+
 // batched variant: `batch` independent problems at fixed element strides (expert GEMMs: one launch over all experts,
 // with per-expert device-side row counts m_dev[b]).
 extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,

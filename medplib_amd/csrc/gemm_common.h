@@ -43,6 +43,9 @@ struct GemmArgs {
   const float* rope_cos; const float* rope_sin;
   int rope_seq, rope_pos0;
   int ep8;              // 256x256 kernel: 1 = the 8-byte epilogue of round 1 (MP_GEMM_EP8=1, A/B runs only)
+  // ACT_SWIGLU_PAIR with keep_gu: the rounded gate|up values are ALSO stored (interleaved [M, N] layout, ld_gu) -- training keeps them for
+  // the backward, and the stand-alone SwiGLU pass over the [tokens, 2 ff] tensor disappears (mp_gemm_swiglu_keep_bf16)
+  bf16_t* keep_gu; int64_t ld_gu;
 };
 
 // GELU(erf) without erff: gelu(x) = relu(x) - a Phi(-a), a = |x|, log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute

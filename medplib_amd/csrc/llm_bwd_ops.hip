@@ -11,6 +11,7 @@
 //   mp_scatter_rows_f32_bf16   out[rows[i], :] = bf16(g[i, :])  (backward of the row gather in front of text_hidden_fcs / lm_head)
 //   mp_dropout_bf16            y = x * keep / (1 - p) with keep from the stateless hash generator (peft lora_dropout on the adapter input)
 #include "common.h"
+#include <stdlib.h>
 #include "gemm_common.h"
 
 namespace {
@@ -108,6 +109,17 @@ __global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16
   *reinterpret_cast<bf16x8*>(dgu + t * 2 * ff + col + 32) = du;
 }
 
+// lora_dropout's keep decision: one splitmix64 value per 4 consecutive elements (16 bits each: keep iff bits >= p * 65536), so the
+// generator costs a quarter of a hash per element (the 64-bit finaliser is ~25 VALU operations; at one per element it made the dropout
+// pass VALU-bound).  Index = position in the contiguous [tokens, features] tensor; every kernel that needs the mask calls this.
+__device__ __forceinline__ uint64_t hash64(uint64_t k) {
+  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27; k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return k;
+}
+__device__ __forceinline__ uint64_t dropout_bits4(uint64_t seed, uint64_t i4) { return hash64(seed * 0x100000001b3ull + i4); }   // i4 = index / 4
+__device__ __forceinline__ unsigned dropout_thresh(float p) { return (unsigned)(p * 65536.f); }
 // out[n, j] = scale * sum_t X[t, n] * G[t, j]   (j < R <= 32).  Pass 1: a workgroup owns 256 columns x a chunk of 256 token rows;
 // the chunk's G rows sit in LDS as fp32 (every lane reads the same row: broadcast), a thread owns 4 columns (8-byte loads of X) and
 // R accumulators per column, the 4 waves take the chunk's rows round-robin and meet in LDS in wave order -> partial[chunk][n][R].
@@ -174,6 +186,116 @@ __global__ __launch_bounds__(256) void tn_skinny_partial_kernel(const bf16_t* __
   }
 }
 
+// The same partial sums on the matrix cores (round 2): at R = 16 the scalar form above issues T * N * R fmas -- VALU-bound, 91 us on the
+// gate|up gradient [5112, 22016] where the read alone is ~50 us.  Both MFMA operands are reductions over the TOKEN axis, i.e. transposes of
+// the row-major X and G tiles: a workgroup stages 64 tokens x 256 columns of X (coalesced 16-byte loads, lora_dropout applied on the way
+// when p > 0, so the forward need not store its dropped activations) and the 64 x R tile of G in XOR-swizzled LDS images and reads
+// both as transposed fragments with ds_read_b64_tr_b16 (the attention backward's X^T recipe: lane (fr, fq), element e <-> token
+// fq * 4 + (e & 3) + (e >> 2) * 16 of a 32-token block -- the same assignment on both operands).  A wave owns 64 columns x R; chunks of
+// 256 tokens per workgroup as before, added by tn_skinny_reduce_kernel in ascending order.
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
+typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
+template <int RB>                                           // row bytes of the tile
+__device__ __forceinline__ bf16x8 tn_tr_frag(const char* tile, int kp, int n, int fr, int fq) {
+  const int row = kp * 32 + fq * 4 + (fr >> 2);
+  const int cb = n * 32 + (fr & 3) * 8;
+  const char* p0 = tile + row * RB + ((((cb >> 4) ^ (row & 7)) << 4) | (cb & 15));
+  const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(p0));
+  const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(p0 + 16 * RB));
+  const tn_s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, both);
+}
+template <int RG>                                           // 16-wide rank groups: R <= 16 * RG
+__global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
+                                                             float* __restrict__ partial, int64_t T, int N, int R, float p, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) char xt[64 * 512];      // [64 tokens][256 columns] bf16, 16-byte chunk c of row r at (c ^ (r & 7))
+  __shared__ __attribute__((aligned(16))) char gt[64 * 128];      // [64 tokens][64 columns] bf16 (columns >= 16 * RG never read)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n_base = blockIdx.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
+  const int rows = (int)min((int64_t)TN_CHUNK, T - t0);
+  const int nsteps = (rows + 63) / 64;
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  f32x4 acc[4][RG];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging roles: X chunk (row i * 8 + tid / 32, 16-byte chunk tid % 32); G chunk idx = tid (+ 256): (row idx / (2 RG), chunk idx % (2 RG))
+  const int xr = tid >> 5, xc = tid & 31;
+  const int xn = n_base + xc * 8;
+  bf16x8 xv[8], gv[(64 * 2 * RG + 255) / 256];
+  auto load_step = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = step * 64 + i * 8 + xr;
+      xv[i] = bf16x8{};
+      if (r < rows && xn < N) {
+        xv[i] = *reinterpret_cast<const bf16x8*>(X + (t0 + r) * ldx + xn);
+        if (p > 0.f) {
+          const uint64_t i4 = ((uint64_t)(t0 + r) * (uint64_t)N + (uint64_t)xn) >> 2;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint64_t bits = dropout_bits4(seed, i4 + q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              xv[i][q * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)xv[i][q * 4 + j] * keep_scale : 0.f);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = step * 64 + idx / (2 * RG), c = idx % (2 * RG);
+      gv[u] = bf16x8{};
+      if (idx < 64 * 2 * RG && r < rows) gv[u] = *reinterpret_cast<const bf16x8*>(G + (t0 + r) * ldg + c * 8);
+    }
+  };
+  load_step(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();                                       // the previous step's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + xr;
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = xv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = idx / (2 * RG), c = idx % (2 * RG);
+      if (idx < 64 * 2 * RG) *reinterpret_cast<bf16x8*>(gt + r * 128 + ((c ^ (r & 7)) << 4)) = gv[u];
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) load_step(step + 1);            // in flight under this step's MFMAs
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 gf[RG];
+#pragma unroll
+      for (int jf = 0; jf < RG; ++jf) gf[jf] = tn_tr_frag<128>(gt, kp, jf, fr, fq);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const bf16x8 xf = tn_tr_frag<512>(xt, kp, wave * 4 + nf, fr, fq);
+#pragma unroll
+        for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[jf], acc[nf][jf], 0, 0, 0);
+      }
+    }
+  }
+  // acc[nf][jf][r] = sum_t X[t, n] G[t, j] with n = n_base + (wave * 4 + nf) * 16 + fq * 4 + r, j = jf * 16 + fr
+  float* po = partial + ((int64_t)blockIdx.y * N) * R;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_base + (wave * 4 + nf) * 16 + fq * 4 + r, j = jf * 16 + fr;
+        if (n < N && j < R) po[(int64_t)n * R + j] = acc[nf][jf][r];
+      }
+}
+
 __global__ void tn_skinny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t NR, int chunks, float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NR) return;
@@ -216,17 +338,6 @@ __global__ void scatter_rows_f32_bf16_kernel(const float* __restrict__ g, const 
   *reinterpret_cast<bf16x4*>(out + rows[i] * d + c) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
 }
 
-// lora_dropout's keep decision: one splitmix64 value per 4 consecutive elements (16 bits each: keep iff bits >= p * 65536), so the
-// generator costs a quarter of a hash per element (the 64-bit finaliser is ~25 VALU operations; at one per element it made the dropout
-// pass VALU-bound).  Index = position in the contiguous [tokens, features] tensor; every kernel that needs the mask calls this.
-__device__ __forceinline__ uint64_t hash64(uint64_t k) {
-  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
-  k ^= k >> 27; k *= 0x94d049bb133111ebull;
-  k ^= k >> 31;
-  return k;
-}
-__device__ __forceinline__ uint64_t dropout_bits4(uint64_t seed, uint64_t i4) { return hash64(seed * 0x100000001b3ull + i4); }   // i4 = index / 4
-__device__ __forceinline__ unsigned dropout_thresh(float p) { return (unsigned)(p * 65536.f); }
 __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, float p, uint64_t seed) {
   const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i8 >= n) return;
@@ -405,6 +516,23 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
         if (col_live) *reinterpret_cast<bf16x8*>(out + (int64_t)(tb + u) * ldo + kc) = o;
       }
     }
+  }
+}
+
+// The inverse of lora_pack for gradients: one adapter's slices of the fused group's padded gradients (dB [W, R] rows rows[o] columns k0..,
+// dA^T [fin, R] columns k0..) ADDED into the parameter-shaped gradient tensors (lora_B.grad [fout, r], lora_A.grad [r, fin]) -- the engine's
+// flat buffer; one launch instead of a gather, a transpose-copy and two adds per adapter (192 adapters' worth of 5-us kernels per step).
+__global__ void lora_grad_unpack_kernel(const float* __restrict__ dB, const float* __restrict__ dAT, const int64_t* __restrict__ rows, int R, int k0, int r,
+                                        int fin, int fout, float* __restrict__ gB, float* __restrict__ gA) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nb = (int64_t)fout * r, na = (int64_t)r * fin;
+  if (idx < nb) {
+    const int o = (int)(idx / r), j = (int)(idx % r);
+    gB[idx] += dB[rows[o] * R + k0 + j];
+  } else if (idx < nb + na) {
+    const int64_t e = idx - nb;
+    const int i = (int)(e / fin), c = (int)(e % fin);
+    gA[e] += dAT[(int64_t)c * R + k0 + i];
   }
 }
 
@@ -757,14 +885,22 @@ extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* d
 }
 
 extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                                int64_t tokens, int N, int R, float scale, hipStream_t stream) {
-  MP_REQUIRE(N > 0 && tokens > 0 && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 4 == 0, MP_ERR_SHAPE,
-             "mp_tn_skinny_f32: R must be 8, 16 or 32; ldx %% 4, ldg %% 8");
+                                int64_t tokens, int N, int R, float scale, float p, uint64_t seed, hipStream_t stream) {
+  MP_REQUIRE(N > 0 && tokens > 0 && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 4 == 0 && p >= 0.f && p < 1.f, MP_ERR_SHAPE,
+             "mp_tn_skinny_f32: R must be 8, 16 or 32; ldx %% 4, ldg %% 8; 0 <= p < 1");
   const int chunks = (int)mp_cdiv(tokens, TN_CHUNK);
   MP_REQUIRE(partial && partial_floats >= (int64_t)chunks * N * R, MP_ERR_WORKSPACE, "mp_tn_skinny_f32: partial needs %lld floats",
              (long long)((int64_t)chunks * N * R));
   const dim3 grid((unsigned)mp_cdiv(N, 256), (unsigned)chunks);
-  if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("MP_TN_SKINNY_MFMA"); use_mfma = (e && atoi(e) == 0) ? 0 : 1; }     // 0: the scalar kernel (A/B)
+  const bool mfma = ldx % 8 == 0 && N % 8 == 0 && (use_mfma || p > 0.f);
+  MP_REQUIRE(mfma || p == 0.f, MP_ERR_ARG, "mp_tn_skinny_f32: inline dropout needs ldx %% 8 == 0 and N %% 8 == 0");
+  if (mfma) {
+    // G must be readable for 16 columns per rank group (the padded [tokens, 64] adapter tensors are)
+    if (R <= 16) hipLaunchKernelGGL(tn_skinny_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed);
+    else hipLaunchKernelGGL(tn_skinny_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed);
+  } else if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
   else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
   else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
   const int64_t NR = (int64_t)N * R;
@@ -819,6 +955,14 @@ extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT,
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
   return mp_check_launch("mp_lora_up_add_bf16");
+}
+
+extern "C" int mp_lora_grad_unpack_f32(const float* dB, const float* dAT, const int64_t* rows, int R, int k0, int r, int fin, int fout, float* gB,
+                                       float* gA, hipStream_t stream) {
+  MP_REQUIRE(R > 0 && r > 0 && k0 >= 0 && k0 + r <= R && fin > 0 && fout > 0 && dB && dAT && rows && gB && gA, MP_ERR_ARG, "mp_lora_grad_unpack_f32: bad arguments");
+  const int64_t n = (int64_t)fout * r + (int64_t)r * fin;
+  hipLaunchKernelGGL(lora_grad_unpack_kernel, GRID1D(n), dB, dAT, rows, R, k0, r, fin, fout, gB, gA);
+  return mp_check_launch("mp_lora_grad_unpack_f32");
 }
 
 extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout,

@@ -139,7 +139,8 @@ class Engine:
         # is left (the fp32 tail, lm_head / embed_tokens, front-end modules) goes in one last bucket after backward returns.
         self._pendings, self._reduced, self._layer_ranges = [], [], {}
         lora = getattr(getattr(model, "model", None), "lora", None)
-        if lora is not None and (self.world > 1 or self.reduce_single_rank) and int(config.get("overlap_comm", 1)):
+        # (attached on one rank as well: the sink is also how the decoder backward writes adapter gradients straight into the flat buffer)
+        if lora is not None and int(config.get("overlap_comm", 1)):
             self._setup_layer_buckets(lora)
         self.training_dataloader = None
         if training_data is not None:
@@ -206,7 +207,7 @@ class Engine:
         for n, g in named_grads.items():
             p = lo.params[lo.index[n]]
             p.grad.add_(g.reshape(p.grad.shape))
-        if self.is_gradient_accumulation_boundary():
+        if (self.world > 1 or self.reduce_single_rank) and self.is_gradient_accumulation_boundary():
             for s, e in self._layer_ranges.get(layer, ()):
                 self._reduce_range(s, e)
 

@@ -15,11 +15,13 @@ fp32 tail); everything inside them is this library's kernels.  Targets: any of q
 MoE layers (top-1, one rank): per-expert adapters on the capacity slabs, the routed dgrad, the gate-probability and l_aux gradients
 into the gate and a trainable `wg` (scripts/train_stage4.sh's `--sft_modules wg,...`)."""
 import math
+import os
 
 import torch
 
 from .. import ops
 
+_SWIGLU_KEEP = os.environ.get("MP_LORA_SWIGLU_KEEP", "1") != "0"     # 0: GEMM + mp_swiglu_pair_fwd_bf16 (A/B runs)
 MLP_TARGETS = ("gate_proj", "up_proj", "down_proj")
 ALL_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj") + MLP_TARGETS
 # adapter groups: targets that share an input and whose outputs are row blocks of one fused projection get ONE pair of thin GEMMs
@@ -305,14 +307,6 @@ def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=
     return llm.lora
 
 
-def _adapter_fwd(lora, ops_pad, x, y, seed):
-    """y + scaling * (dropout(x) A^T) B^T  -> (y', x_dropped, t)."""
-    A, _, B, _, _, _ = ops_pad
-    xd = ops.dropout_bf16(x, lora.p_active, seed) if lora.p_active > 0 else x
-    t = ops.gemm(xd, A)                                           # [T, 64] (columns >= R are zero)
-    return ops.gemm(t, B, residual=y, alpha=lora.scaling), xd, t
-
-
 def _ext_rows(T, K, dev):
     """The row-padded input of an extended projection: (whole [T, K + 64] buffer, its [T, K] activation part, its [T, 64] adapter part)."""
     buf = torch.empty((T, K + 64), dtype=torch.bfloat16, device=dev)
@@ -320,11 +314,10 @@ def _ext_rows(T, K, dev):
 
 
 def _adapter_down(lora, ops_pad, x, t, seed):
-    """t = bf16(dropout(x) A^T) into the extension columns -> the dropped x (the wgrad's operand; x itself without dropout)."""
+    """t = bf16(dropout(x) A^T) into the extension columns -> x (the wgrad regenerates the mask from the seed: nothing dropped is stored)."""
     A, _, _, _, R, _ = ops_pad
-    xd = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lora.p_active > 0 else None
-    ops.lora_down(x, A, t, R, lora.p_active, seed, xd=xd)
-    return x if xd is None else xd
+    ops.lora_down(x, A, t, R, lora.p_active, seed)
+    return x
 
 
 def _zeros(shape, dev):
@@ -518,10 +511,14 @@ def forward_train(llm, embeds, key_valid):
             ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps, out=h1)
             s["h1d"], s["t_qkv"] = _adapter_down(lora, pad["qkv"], h1, t1, seed + 2), t1
             qkv = ops.gemm(h1x, lw["qkv_x"], out=ops.padded_rows(T, 3 * d, x.device))
+            ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
         else:
             h1 = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
-            qkv = ops.gemm(h1, lw["qkv"], out=ops.padded_rows(T, 3 * d, x.device))
-        ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
+            if "qkv_rope" in lw:                                    # no adapters on q / k / v: RoPE in the GEMM's epilogue as in the frozen forward
+                qkv = ops.gemm_qkv_rope(h1, lw["qkv_rope"], llm.cos, llm.sin, S, H, D, out=ops.padded_rows(T, 3 * d, x.device))
+            else:
+                qkv = ops.gemm(h1, lw["qkv"], out=ops.padded_rows(T, 3 * d, x.device))
+                ops.rope_qk_(qkv, llm.cos, llm.sin, S, H, D)
         q5 = qkv.unflatten(0, (B, S)).unflatten(2, (3, H, D))
         if "o_x" in lw:
             ax, a2, t2 = _ext_rows(T, d, x.device)
@@ -541,18 +538,26 @@ def forward_train(llm, embeds, key_valid):
             x_out, l_aux = (_moe_fwd_ep if llm.ep is not None else _moe_fwd)(llm, lora, i, lw, pad, h2, x_mid, s, seed)
             aux.append(l_aux)
         else:
-            if "gu_x" in lw:
-                s["h2d"], s["t_gu"] = _adapter_down(lora, pad["gu"], h2, t3, seed), t3
-                gu = ops.gemm(h2x, lw["gu_x"])
-            else:
-                gu = ops.gemm(h2, lw["gu"])
+            # gate|up: silu(gate) * up from the GEMM's epilogue, which also stores the gate|up values the backward reads
             if "down_x" in lw:
                 actx, act, t4 = _ext_rows(T, cfg.intermediate_size, x.device)
-                ops.swiglu_pair_fwd(gu, out=act)
+            else:
+                act = None
+            if "gu_x" in lw:
+                s["h2d"], s["t_gu"] = _adapter_down(lora, pad["gu"], h2, t3, seed), t3
+                gin, gw = h2x, lw["gu_x"]
+            else:
+                gin, gw = h2, lw["gu"]
+            if _SWIGLU_KEEP:
+                act, gu = ops.gemm_swiglu_keep(gin, gw, act_out=act)
+            else:                                                  # A/B: the two-kernel form
+                gu = ops.gemm(gin, gw)
+                act = ops.swiglu_pair_fwd(gu, out=act)
+            if "down_x" in lw:
                 s["actd"], s["t_d"] = _adapter_down(lora, pad["down"], act, t4, seed + 1), t4
                 x_out = ops.gemm(actx, lw["down_x"], residual=x_mid)
             else:
-                x_out = ops.gemm(ops.swiglu_pair_fwd(gu), lw["down"], residual=x_mid)
+                x_out = ops.gemm(act, lw["down"], residual=x_mid)
             s["gu"] = gu
         saved.append(s)
         x = x_out
@@ -561,13 +566,14 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, xd, t, dx, seed):
-    """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout)."""
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed):
+    """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
+    adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed."""
     A, AT, B, BT, R, _ = ops_pad
     # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
     dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
     dB = ops.tn_skinny(dy, t, R, lora.scaling)                     # [out, R] = scaling * dy^T t
-    dAT = ops.tn_skinny(xd, dt, R, 1.0)                            # [in, R]  = x_d^T (scaling * dy B)
+    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed)        # [in, R]  = dropout(x)^T (scaling * dy B)
     if R <= 32 and dx.stride(0) % 8 == 0:
         dx = ops.lora_up_add(dt, AT, dx, R, lora.p_active, seed)       # dx += dropout(dt A): the same mask and 1/(1-p) as the forward
     elif lora.p_active > 0:
@@ -588,10 +594,17 @@ def backward(llm, saved, d_hidden, d_aux=None):
     grads = {}
 
     def take(i, ops_pad, dB, dAT):
-        """Unpack the fused pair's gradients into the per-target parameters."""
+        """Unpack the fused pair's gradients into the per-target parameters -- straight into the parameters' .grad (the engine's flat
+        buffer) when a gradient sink is attached, one launch per adapter."""
         for k, t in enumerate(ops_pad[5]):
-            grads[f"model.layers.{i}.{_module(t)}.lora_B.default.weight"] = dB[lora.rows[t], k * r:(k + 1) * r]
-            grads[f"model.layers.{i}.{_module(t)}.lora_A.default.weight"] = dAT[:, k * r:(k + 1) * r].t()
+            nb, na = f"model.layers.{i}.{_module(t)}.lora_B.default.weight", f"model.layers.{i}.{_module(t)}.lora_A.default.weight"
+            pb, pa = lora.params[lora.index[nb]], lora.params[lora.index[na]]
+            if (lora.grad_sink is not None and pb.grad is not None and pa.grad is not None and pb.grad.is_contiguous() and pa.grad.is_contiguous()
+                    and pb.grad.dtype == torch.float32 and dB.is_contiguous() and dAT.is_contiguous()):
+                ops.lora_grad_unpack(dB, dAT, lora.rows[t], k * r, pb.grad, pa.grad)
+            else:
+                grads[nb] = dB[lora.rows[t], k * r:(k + 1) * r]
+                grads[na] = dAT[:, k * r:(k + 1) * r].t()
 
     def take_e(i, ops_pad, dB, dAT):
         """The same for the per-expert adapters of a MoE layer; dB / dAT: a list over all experts, or {global expert id: gradient} with

@@ -144,6 +144,23 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16,
     return out
 
 
+def gemm_swiglu_keep(a, w, act_out=None):
+    """(act [M, N/2] = silu(gate) * up, gu [M, N] bf16 gate|up in w's interleaved row order) from one GEMM launch (mp_gemm_swiglu_keep_bf16)."""
+    _chk(a, torch.bfloat16, "gemm_swiglu_keep.a"); _chk(w, torch.bfloat16, "gemm_swiglu_keep.w")
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=a.device) if act_out is None else act_out
+    gu = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    assert act.shape == (M, N // 2) and act.stride(1) == 1
+    _ensure_gemm_workspace(a.device)
+    t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
+    lib().call("mp_gemm_swiglu_keep_bf16", _p(a), a.stride(0), _p(w), w.stride(0), _p(act), act.stride(0), _p(gu), gu.stride(0), M, N, K, _stream())
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.end(2.0 * M * N * K, t0)
+    return act, gu
+
+
 def gemm_tile_policy(mode):
     """Tile choice of this thread's dense bf16 GEMM calls (mp_gemm_tile_policy): 1 = 320x256 tiles where the wave model prefers them
     (default), 0 = 256-row tiles only, 2 = 320-row tiles whenever eligible, -1 = process default."""
@@ -297,17 +314,23 @@ def swiglu_pair_bwd(gu, dact):
     return dgu
 
 
-def tn_skinny(x, g, R, scale=1.0):
-    """out[n, j] = scale * sum_t x[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= R] bf16."""
+def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0):
+    """out[n, j] = scale * sum_t drop(x)[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= 16 * ceil(R / 16)] bf16; p > 0: x is the
+    undropped tensor and the lora_dropout mask (mp_dropout_bf16 over the contiguous [T, N]) is applied on the way."""
     _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
     T, N = x.shape
     if R > 32:                      # wider than the kernel's register budget: two passes over column halves of g
-        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale) for j in range(0, R, 32)], dim=1)
+        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale, p, seed) for j in range(0, R, 32)], dim=1)
+    need = (R + 15) // 16 * 16                                  # the MFMA kernel reads g in 16-column groups
+    if g.shape[1] < need:
+        gp = torch.zeros((T, need), dtype=torch.bfloat16, device=g.device)
+        gp[:, :g.shape[1]] = g
+        g = gp
     out = torch.empty((N, R), dtype=torch.float32, device=x.device)
     chunks = (T + 255) // 256
     partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
     lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), T, N, int(R), float(scale),
-               _stream())
+               float(p), int(seed), _stream())
     return out
 
 
@@ -335,6 +358,16 @@ def lora_pack(a, b, rows, A, AT, B, BT, k0, bscale=1.0, Bx=None, xscale=1.0):
     fout = b.shape[0]
     lib().call("mp_lora_pack", _p(a), _p(b), _p(rows), _p(A), _p(AT), _p(B), _p(BT), r, fin, fout, int(k0), B.shape[0], float(bscale),
                _p(Bx), Bx.stride(0) if Bx is not None else 0, float(xscale), _stream())
+
+
+def lora_grad_unpack(dB, dAT, rows, k0, gB, gA):
+    """gB [fout, r] += dB[rows, k0:k0 + r], gA [r, fin] += dAT[:, k0:k0 + r].T in one launch (mp_lora_grad_unpack_f32); all fp32, contiguous."""
+    for t_, n_ in ((dB, "dB"), (dAT, "dAT"), (gB, "gB"), (gA, "gA")):
+        _chk(t_, torch.float32, "lora_grad_unpack." + n_); assert t_.is_contiguous()
+    fout, r = gB.shape
+    fin = gA.shape[1]
+    assert gA.shape[0] == r and dAT.shape[0] == fin and dB.shape[1] == dAT.shape[1] and rows.numel() == fout
+    lib().call("mp_lora_grad_unpack_f32", _p(dB), _p(dAT), _p(rows), dB.shape[1], int(k0), r, fin, fout, _p(gB), _p(gA), _stream())
 
 
 def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0):

@@ -490,6 +490,42 @@ def test_lora_up_add_equals_the_three_kernels(dev, T, K, R, p):
         assert torch.equal(got[dropped], dx[dropped]) and 0.8 * p < float(dropped.float().mean()) < 1.2 * p
 
 
+@pytest.mark.parametrize("T,N,R,p", [(5112, 4096, 16, 0.05), (700, 1000, 8, 0.25), (300, 22016, 32, 0.0), (64, 40, 8, 0.0)])
+def test_tn_skinny_mfma_and_inline_dropout(dev, T, N, R, p):
+    """mp_tn_skinny_f32 on the matrix cores (transposed LDS fragment reads) against the fp32 reference, with the lora_dropout mask
+    regenerated inline: equal, bit for bit, to the same kernel on mp_dropout_bf16's output (the same values enter the same MFMAs)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(T + N)
+    x = (torch.randn(T, N, generator=g)).to(torch.bfloat16).to(dev)
+    gm = torch.zeros(T, 64, dtype=torch.bfloat16, device=dev)
+    gm[:, :R] = (torch.randn(T, R, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    xd = ops.dropout_bf16(x, p, 77) if p > 0 else x
+    ref = 0.5 * (xd.float().T @ gm[:, :R].float())
+    got = ops.tn_skinny(x, gm, R, 0.5, p, 77)
+    _report(f"tn_skinny T={T} N={N} R={R} p={p}", got, ref, rtol=1e-4, atol=1e-3 * ref.abs().max().item())
+    assert torch.equal(got, ops.tn_skinny(xd, gm, R, 0.5)) and torch.equal(got, ops.tn_skinny(x, gm, R, 0.5, p, 77))
+    # a narrow G (the gate's d_logits: 8 columns) is padded by the wrapper
+    g8 = gm[:, :8].contiguous()
+    _report("tn_skinny narrow G", ops.tn_skinny(xd, g8, 8, 1.0), xd.float().T @ g8.float(), rtol=1e-4, atol=1e-3 * ref.abs().max().item())
+
+
+def test_gemm_swiglu_keep_equals_gemm_plus_swiglu_kernel(dev):
+    """mp_gemm_swiglu_keep_bf16 (training forward of gate|up: act from the epilogue + the gate|up values kept for the backward) against
+    mp_gemm_bf16_nt followed by mp_swiglu_pair_fwd_bf16: both outputs EQUAL, incl. a row-padded act destination and a K-extended operand."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in [(5112, 2048, 4096 + 64), (1100, 512, 256)]:
+        a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+        gu_ref = ops.gemm(a, w)
+        act_ref = ops.swiglu_pair_fwd(gu_ref)
+        buf = torch.zeros(M, N // 2 + 64, dtype=torch.bfloat16, device=dev)
+        act, gu = ops.gemm_swiglu_keep(a, w, act_out=buf[:, :N // 2])
+        torch.cuda.synchronize()
+        assert torch.equal(gu, gu_ref), (gu.float() - gu_ref.float()).abs().max()
+        assert torch.equal(act, act_ref) and float(buf[:, N // 2:].float().abs().max()) == 0.0
+
+
 def test_gemm_320_row_tile_kernel(dev):
     """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
     no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
