@@ -293,8 +293,8 @@ int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, int
  * bf16 h.  Bit-identical with mp_rmsnorm_bf16 followed by mp_moe_gate_bf16.  n_experts = 0: the norm alone.  dim 2048 / 4096 / 8192. */
 int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg, float* logits,
                          float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream);
-int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
-                         int capacity, int top_k, hipStream_t stream);
+int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t ldbuf, int64_t tokens, int dim,
+                         int capacity, int top_k, hipStream_t stream);   /* buf: [E, capacity, ldbuf >= dim] slabs (ldbuf > dim: row-padded, e.g. a K-extension) */
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,
                         int64_t tokens, int dim, int capacity, int top_k, hipStream_t stream);
 
@@ -333,7 +333,7 @@ int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t
  * tensor is applied on the way; G must be readable for 16 columns per 16 ranks: the padded [tokens, 64] adapter tensors are); `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
  * order (fixed summation order). */
 int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                     int64_t tokens, int N, int R, float scale, float p, uint64_t seed, hipStream_t stream);
+                     int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, hipStream_t stream);   /* rows_dev (optional): device-side row count <= tokens */
 /* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
  * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
 int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,

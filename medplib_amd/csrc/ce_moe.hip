@@ -482,7 +482,7 @@ __global__ void moe_residual_mix_kernel(const bf16_t* __restrict__ x, const bf16
 
 // buf[expert[j*T + s], slot[j*T + s], :] = x[s, :]   for the top_k choices j of token s
 __global__ void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int* __restrict__ expert, const int* __restrict__ slot,
-                                    bf16_t* __restrict__ buf, int64_t T, int d, int capacity, int top_k) {
+                                    bf16_t* __restrict__ buf, int64_t ldbuf, int64_t T, int d, int capacity, int top_k) {
   const int per_row = d / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * top_k * per_row) return;
@@ -491,7 +491,7 @@ __global__ void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, c
   const int c = (int)(idx % per_row) * 8;
   const int sl = slot[en];
   if (sl < 0) return;
-  *reinterpret_cast<bf16x8*>(buf + ((int64_t)expert[en] * capacity + sl) * d + c) = *reinterpret_cast<const bf16x8*>(x + s * ldx + c);
+  *reinterpret_cast<bf16x8*>(buf + ((int64_t)expert[en] * capacity + sl) * ldbuf + c) = *reinterpret_cast<const bf16x8*>(x + s * ldx + c);
 }
 
 // out[s, :] = residual[s, :] + sum_j weight[j*T + s] * y[expert[j*T + s], slot[j*T + s], :]     (dropped choices contribute nothing)
@@ -765,13 +765,13 @@ extern "C" int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t 
   return mp_check_launch("mp_gate_noise_f32");
 }
 
-extern "C" int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t tokens, int dim,
+extern "C" int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t ldbuf, int64_t tokens, int dim,
                                     int capacity, int top_k, hipStream_t stream) {
-  MP_REQUIRE(dim % 8 == 0 && ldx % 8 == 0 && top_k >= 1 && top_k <= 2, MP_ERR_SHAPE, "mp_moe_dispatch_bf16: bad shape");
+  MP_REQUIRE(dim % 8 == 0 && ldx % 8 == 0 && ldbuf % 8 == 0 && ldbuf >= dim && top_k >= 1 && top_k <= 2, MP_ERR_SHAPE, "mp_moe_dispatch_bf16: bad shape");
   const int64_t n = tokens * top_k * (dim / 8);
   if (n == 0) return MP_OK;
   hipLaunchKernelGGL(moe_dispatch_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, expert, slot,
-                     (bf16_t*)buf, tokens, dim, capacity, top_k);
+                     (bf16_t*)buf, ldbuf, tokens, dim, capacity, top_k);
   return mp_check_launch("mp_moe_dispatch_bf16");
 }
 

@@ -566,8 +566,12 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 #define MP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
   // ---- prologue: all of tile 0 and what the (virtual) tile -1 would have issued for tile 1
+  // (the W pieces first: with gathered A rows -- the experts' dispatch -- the A addresses wait for the row-index loads, and the W fetch
+  //  can be in flight meanwhile)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { dma_a(i, 0); dma_w(i, 0); }
+  for (int i = 0; i < 4; ++i) dma_w(i, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_a(i, 0);
   if (nt > 1) {
     dma_a(0, 1); dma_a(2, 1);
 #pragma unroll

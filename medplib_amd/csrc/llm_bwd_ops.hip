@@ -127,13 +127,14 @@ __device__ __forceinline__ unsigned dropout_thresh(float p) { return (unsigned)(
 constexpr int TN_MAXR = 32, TN_CHUNK = 256;
 template <int R>
 __global__ __launch_bounds__(256) void tn_skinny_partial_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G,
-                                                                int64_t ldg, float* __restrict__ partial, int64_t T, int N) {
+                                                                int64_t ldg, float* __restrict__ partial, int64_t T, int N, const int* __restrict__ rows_dev) {
+  if (rows_dev) T = min(T, (int64_t)*rows_dev);
   __shared__ float gs[TN_CHUNK][R];
   __shared__ float red[3][64][4 * R + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 256 + lane * 4;
   const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
-  const int rows = (int)min((int64_t)TN_CHUNK, T - t0);
+  const int rows = (int)max((int64_t)0, min((int64_t)TN_CHUNK, T - t0));
   for (int i = threadIdx.x; i < rows * (R / 8); i += 256) {
     const int rr = i / (R / 8), c8 = (i % (R / 8)) * 8;
     const bf16x8 gv = *reinterpret_cast<const bf16x8*>(G + (t0 + rr) * ldg + c8);
@@ -207,14 +208,15 @@ __device__ __forceinline__ bf16x8 tn_tr_frag(const char* tile, int kp, int n, in
 }
 template <int RG>                                           // 16-wide rank groups: R <= 16 * RG
 __global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
-                                                             float* __restrict__ partial, int64_t T, int N, int R, float p, uint64_t seed) {
+                                                             float* __restrict__ partial, int64_t T, int N, int R, float p, uint64_t seed, const int* __restrict__ rows_dev) {
+  if (rows_dev) T = min(T, (int64_t)*rows_dev);        // device-side row count (an expert's routed rows): chunks beyond it write zeros
   __shared__ __attribute__((aligned(16))) char xt[64 * 512];      // [64 tokens][256 columns] bf16, 16-byte chunk c of row r at (c ^ (r & 7))
   __shared__ __attribute__((aligned(16))) char gt[64 * 128];      // [64 tokens][64 columns] bf16 (columns >= 16 * RG never read)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n_base = blockIdx.x * 256;
   const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
-  const int rows = (int)min((int64_t)TN_CHUNK, T - t0);
+  const int rows = (int)max((int64_t)0, min((int64_t)TN_CHUNK, T - t0));
   const int nsteps = (rows + 63) / 64;
   const float keep_scale = 1.f / (1.f - p);
   const unsigned th = dropout_thresh(p);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __res
       if (idx < 64 * 2 * RG && r < rows) gv[u] = *reinterpret_cast<const bf16x8*>(G + (t0 + r) * ldg + c * 8);
     }
   };
-  load_step(0);
+  if (nsteps > 0) load_step(0);
   for (int step = 0; step < nsteps; ++step) {
     __syncthreads();                                       // the previous step's fragment reads are done
 #pragma unroll
@@ -885,7 +887,7 @@ extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* d
 }
 
 extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                                int64_t tokens, int N, int R, float scale, float p, uint64_t seed, hipStream_t stream) {
+                                int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, hipStream_t stream) {
   MP_REQUIRE(N > 0 && tokens > 0 && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 4 == 0 && p >= 0.f && p < 1.f, MP_ERR_SHAPE,
              "mp_tn_skinny_f32: R must be 8, 16 or 32; ldx %% 4, ldg %% 8; 0 <= p < 1");
   const int chunks = (int)mp_cdiv(tokens, TN_CHUNK);
@@ -898,11 +900,11 @@ extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64
   MP_REQUIRE(mfma || p == 0.f, MP_ERR_ARG, "mp_tn_skinny_f32: inline dropout needs ldx %% 8 == 0 and N %% 8 == 0");
   if (mfma) {
     // G must be readable for 16 columns per rank group (the padded [tokens, 64] adapter tensors are)
-    if (R <= 16) hipLaunchKernelGGL(tn_skinny_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed);
-    else hipLaunchKernelGGL(tn_skinny_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed);
-  } else if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
-  else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
-  else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N);
+    if (R <= 16) hipLaunchKernelGGL(tn_skinny_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev);
+    else hipLaunchKernelGGL(tn_skinny_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev);
+  } else if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
+  else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
+  else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
   const int64_t NR = (int64_t)N * R;
   hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
   return mp_check_launch("mp_tn_skinny_f32");

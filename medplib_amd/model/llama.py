@@ -80,6 +80,10 @@ class LlamaStack:
             for k in ("gu", "down", "gu_T", "down_T"):           # (+ the dgrad transposes when enable_lora() ran first)
                 if k in lw:
                     lw[k] = lw[k][ids[0]:ids[-1] + 1].contiguous()
+            for k in ("gu", "down"):                             # the expert-parallel training path keeps the unfused adapter kernels
+                lw.pop(k + "_x", None)
+                if getattr(self, "lora", None) is not None:
+                    self.lora.ext.pop((i, k), None)
         self.ep = ep
 
     # ------------------------------------------------------------------ HF checkpoint layout

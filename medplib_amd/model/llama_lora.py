@@ -235,7 +235,7 @@ class LoRAState(torch.nn.Module):
                 if k + "_T" in lw:
                     lw[k + "_T"] = _transposed(lw[k])
                 if k + "_x" in lw:
-                    lw[k + "_x"][:, :lw[k].shape[1]].copy_(lw[k])
+                    lw[k + "_x"][..., :lw[k].shape[-1]].copy_(lw[k])
         llm.refresh_fused_qkv()                                   # the RoPE-interleaved copies follow the merged q / k / v weights
 
     def padded(self, i):
@@ -261,7 +261,9 @@ class LoRAState(torch.nn.Module):
                 for e in range(self.E if batched else 1):
                     a, b = self.get(i, t, "A", e).detach(), self.get(i, t, "B", e).detach()
                     if batched:
-                        ops.lora_pack(a, b, self.rows[t], A[e], AT[e], B[e], BT[e], k * r, bscale=self.scaling)
+                        wx = self.ext.get((i, grp))                # [E, out, in + 64]: expert e's scaling * B behind its frozen weight
+                        ops.lora_pack(a, b, self.rows[t], A[e], AT[e], B[e], BT[e], k * r, bscale=self.scaling,
+                                      Bx=None if wx is None else wx[e][:, wx.shape[2] - 64:], xscale=self.scaling)
                     else:
                         wx = self.ext.get((i, grp))                # dense group: scaling * B also lands in [W | scaling B]'s last 64 columns
                         ops.lora_pack(a, b, self.rows[t], A, AT, B, BT, k * r, Bx=None if wx is None else wx[:, wx.shape[1] - 64:],
@@ -283,8 +285,8 @@ def _transposed(w):
 
 def _extended(w):
     """[out, in] -> [out, in + 64] with the weight in the first `in` columns and zeros behind (filled with scaling * B per step)."""
-    out = torch.zeros((w.shape[0], w.shape[1] + 64), dtype=w.dtype, device=w.device)
-    out[:, :w.shape[1]].copy_(w)
+    out = torch.zeros(w.shape[:-1] + (w.shape[-1] + 64,), dtype=w.dtype, device=w.device)      # experts: [E, out, in + 64]
+    out[..., :w.shape[-1]].copy_(w)
     return out
 
 
@@ -294,7 +296,7 @@ def enable_lora(llm, cfg, r=8, alpha=16, dropout=0.0, targets=MLP_TARGETS, seed=
     for i, lw in enumerate(llm.layers):
         for k in ("qkv", "o", "gu", "down"):
             lw[k + "_T"] = _transposed(lw[k])                            # experts: [E, out, in] -> [E, in, out]
-            if lw[k].dim() == 2 and any(t in llm.lora.targets for t in GROUPS[k]):
+            if (lw[k].dim() == 2 or llm.ep is None) and any(t in llm.lora.targets for t in GROUPS[k]):
                 # the adapter's up-projection as a K-extension of the frozen weight: [W | scaling B] (ops.lora_down writes the matching
                 # 64 columns of the activations), so base + adapter is ONE GEMM over K + 64
                 lw[k + "_x"] = _extended(lw[k])
@@ -348,14 +350,37 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     else:
         expert, slot, weight, kept, _, l_aux = ops.moe_route_top2(gates, logits, cap, llm._gate_draws(i, T, E, gumbel=True))
         counts = torch.bincount(expert[:T].long(), minlength=E)    # l_aux is built on the FIRST choices (top2gating's mask1)
-    buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=_zeros((E, cap, d), h2.device), top_k=k)
-    gu = ops.gemm_batched(buf, lw["gu"], _zeros((E, cap, 2 * ff), h2.device), m_dev=kept)
-    if "gu" in pad:
-        gu, s["bufd"], s["t_gu"] = _adapter_fwd_moe(lora, pad["gu"], buf, gu, kept, seed)
-    act = ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
-    y = ops.gemm_batched(act, lw["down"], _zeros((E, cap, d), h2.device), m_dev=kept)
-    if "down" in pad:
-        y, s["actd"], s["t_d"] = _adapter_fwd_moe(lora, pad["down"], act, y, kept, seed + 1)
+    dev = h2.device
+    empty = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+    if "gu_x" in lw:
+        # fused adapter branch on the capacity slabs (as the dense layers, per expert): nothing is zero-filled -- rows beyond an expert's
+        # count hold whatever the allocator left, every reduction over rows is limited by the device-side count (GEMMs: m_dev, weight
+        # gradients: rows_dev) and the combine only reads routed slots
+        bufx = empty(E, cap, d + 64)
+        buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=bufx[:, :, :d], top_k=k)
+        for e in range(E):
+            ops.lora_down(buf[e], pad["gu"][0][e], bufx[e][:, d:], pad["gu"][4], lora.p_active, seed * 16 + e)
+        gu = ops.gemm_batched(bufx, lw["gu_x"], empty(E, cap, 2 * ff), m_dev=kept)
+        s["bufd"], s["t_gu"] = buf, bufx[:, :, d:]
+    else:
+        buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=_zeros((E, cap, d), dev), top_k=k)
+        gu = ops.gemm_batched(buf, lw["gu"], _zeros((E, cap, 2 * ff), dev), m_dev=kept)
+        if "gu" in pad:
+            gu, s["bufd"], s["t_gu"] = _adapter_fwd_moe(lora, pad["gu"], buf, gu, kept, seed)
+    if "down_x" in lw:
+        actx = empty(E, cap, ff + 64)
+        act = actx[:, :, :ff]
+        ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff), out=actx.view(E * cap, ff + 64)[:, :ff])
+        for e in range(E):
+            ops.lora_down(act[e], pad["down"][0][e], actx[e][:, ff:], pad["down"][4], lora.p_active, (seed + 1) * 16 + e)
+        y = ops.gemm_batched(actx, lw["down_x"], empty(E, cap, d), m_dev=kept)
+        s["actd"], s["t_d"] = act, actx[:, :, ff:]
+    else:
+        act = ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff)).view(E, cap, ff)
+        y = ops.gemm_batched(act, lw["down"], _zeros((E, cap, d), dev), m_dev=kept)
+        if "down" in pad:
+            y, s["actd"], s["t_d"] = _adapter_fwd_moe(lora, pad["down"], act, y, kept, seed + 1)
+    s["fused_moe"] = ("gu_x" in lw, "down_x" in lw)
     s.update(moe=True, h2=h2, gates=gates, expert=expert, slot=slot, weight=weight, kept=kept, counts=counts, gu=gu, y=y, cap=cap, wg=wg)
     return ops.moe_combine(y, expert, slot, weight, x_mid, cap, top_k=k), l_aux
 
@@ -461,6 +486,25 @@ def _adapter_bwd_moe(lora, ops_pad, dy, xd, t, dx, kept, seed):
     return ops.gemm_batched_res(dt, AT, dx, _zeros(dx.shape, dy.device), m_dev=kept), dB, dAT
 
 
+def _adapter_bwd_moe_fused(lora, ops_pad, dy, x, t, dx, kept, seed):
+    """Per-expert adapter gradients for the fused forward (x = the UNdropped slabs, t = their extension columns): dt = dY (scaling B)
+    by the down-projection kernel, weight gradients limited to each expert's routed rows, dx += dropout(dt A) in place."""
+    A, AT, B, BT, R, _ = ops_pad
+    E, cap, _ = dy.shape
+    dB, dAT = [], []
+    for e in range(E):
+        dt = ops.lora_down(dy[e], BT[e], torch.empty((cap, 64), dtype=torch.bfloat16, device=dy.device), R)    # scaling rides in the packed B
+        cnt = kept[e:e + 1]
+        dB.append(ops.tn_skinny(dy[e], t[e], R, lora.scaling, rows_dev=cnt))
+        dAT.append(ops.tn_skinny(x[e], dt, R, 1.0, lora.p_active, seed * 16 + e, rows_dev=cnt))
+        if R <= 32:
+            ops.lora_up_add(dt, AT[e], dx[e], R, lora.p_active, seed * 16 + e)
+        else:
+            dxa = ops.gemm(dt, AT[e])
+            dx[e].copy_(ops.add3(dx[e].contiguous(), ops.dropout_bf16(dxa, lora.p_active, seed * 16 + e) if lora.p_active > 0 else dxa))
+    return dx, dB, dAT
+
+
 def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
     """Backward of _moe_fwd: routed dgrad through the experts (+ their adapters), the combine weights' gradient into the gate
     (softmax probability of the chosen expert) together with l_aux's, the gate's input gradient, and d wg.  -> d_h2 [T, d]."""
@@ -470,14 +514,16 @@ def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
     pad, kept = s["pad"], s["kept"]
     k = cfg.top_k_experts
     d_y, d_w = ops.moe_combine_bwd(dx, s["y"], s["expert"], s["slot"], s["weight"], cap, top_k=k)
-    d_act = ops.gemm_batched(d_y, lw["down_T"], _zeros((E, cap, ff), dx.device), m_dev=kept)
+    fused_gu, fused_down = s.get("fused_moe", (False, False))
+    slab = (lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dx.device)) if fused_gu and fused_down else (lambda *shape: _zeros(shape, dx.device))
+    d_act = ops.gemm_batched(d_y, lw["down_T"], slab(E, cap, ff), m_dev=kept)
     if "down" in pad:
-        d_act, dB, dAT = _adapter_bwd_moe(lora, pad["down"], d_y, s["actd"], s["t_d"], d_act, kept, s["seed"] + 1)
+        d_act, dB, dAT = (_adapter_bwd_moe_fused if fused_down else _adapter_bwd_moe)(lora, pad["down"], d_y, s["actd"], s["t_d"], d_act, kept, s["seed"] + 1)
         take_e(i, pad["down"], dB, dAT)
     d_gu = ops.swiglu_pair_bwd(s["gu"].view(E * cap, 2 * ff), d_act.view(E * cap, ff)).view(E, cap, 2 * ff)
-    d_buf = ops.gemm_batched(d_gu, lw["gu_T"], _zeros((E, cap, d), dx.device), m_dev=kept)
+    d_buf = ops.gemm_batched(d_gu, lw["gu_T"], slab(E, cap, d), m_dev=kept)
     if "gu" in pad:
-        d_buf, dB, dAT = _adapter_bwd_moe(lora, pad["gu"], d_gu, s["bufd"], s["t_gu"], d_buf, kept, s["seed"])
+        d_buf, dB, dAT = (_adapter_bwd_moe_fused if fused_gu else _adapter_bwd_moe)(lora, pad["gu"], d_gu, s["bufd"], s["t_gu"], d_buf, kept, s["seed"])
         take_e(i, pad["gu"], dB, dAT)
     ones = torch.ones(T * k, dtype=torch.float32, device=dx.device)
     d_h2 = ops.moe_combine(d_buf, s["expert"], s["slot"], ones, None, cap, top_k=k)        # rows back to their tokens (dropped: 0)

@@ -314,13 +314,14 @@ def swiglu_pair_bwd(gu, dact):
     return dgu
 
 
-def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0):
+def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None):
     """out[n, j] = scale * sum_t drop(x)[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= 16 * ceil(R / 16)] bf16; p > 0: x is the
-    undropped tensor and the lora_dropout mask (mp_dropout_bf16 over the contiguous [T, N]) is applied on the way."""
+    undropped tensor and the lora_dropout mask (mp_dropout_bf16 over the contiguous [T, N]) is applied on the way.  rows_dev: int32 device
+    scalar, only the first min(T, rows_dev) rows count (an expert's routed rows on its capacity slab)."""
     _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
     T, N = x.shape
     if R > 32:                      # wider than the kernel's register budget: two passes over column halves of g
-        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale, p, seed) for j in range(0, R, 32)], dim=1)
+        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale, p, seed, rows_dev) for j in range(0, R, 32)], dim=1)
     need = (R + 15) // 16 * 16                                  # the MFMA kernel reads g in 16-column groups
     if g.shape[1] < need:
         gp = torch.zeros((T, need), dtype=torch.bfloat16, device=g.device)
@@ -330,7 +331,7 @@ def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0):
     chunks = (T + 255) // 256
     partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
     lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), T, N, int(R), float(scale),
-               float(p), int(seed), _stream())
+               float(p), int(seed), _p(rows_dev), _stream())
     return out
 
 
@@ -1137,7 +1138,8 @@ def moe_dispatch(x, expert, slot, n_experts, capacity, buf=None, top_k=1):
     T, d = x.shape
     if buf is None:
         buf = torch.empty((n_experts, capacity, d), dtype=torch.bfloat16, device=x.device)
-    lib().call("mp_moe_dispatch_bf16", _p(x), x.stride(0), _p(expert), _p(slot), _p(buf), T, d, capacity, top_k, _stream())
+    assert buf.dim() == 3 and buf.shape[2] == d and buf.stride(2) == 1 and buf.stride(0) == capacity * buf.stride(1)
+    lib().call("mp_moe_dispatch_bf16", _p(x), x.stride(0), _p(expert), _p(slot), _p(buf), buf.stride(1), T, d, capacity, top_k, _stream())
     return buf
 
 

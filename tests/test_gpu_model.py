@@ -1496,8 +1496,11 @@ def test_lora_training_expert_parallel_path_equals_replicated(dev):
         eng.step()
         torch.cuda.synchronize()
     (l0, g0), (l1, g1) = results
-    assert l0 == l1, (l0, l1)
+    # (not bit-equal any more: the replicated path folds the experts' adapters into the projections' K -- one rounding of base + adapter --
+    #  while the expert-parallel path keeps the two-GEMM form; the two agree to bf16 rounding of single activations)
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 2e-3 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
     for n in g0:
         assert g0[n].abs().max().item() > 0, n
-        assert torch.equal(g0[n], g1[n]), (n, (g0[n] - g1[n]).abs().max().item())
+        assert (g0[n] - g1[n]).abs().max().item() <= 0.03 * g0[n].abs().max().item(), (n, (g0[n] - g1[n]).abs().max().item(), g0[n].abs().max().item())
     comm.close()
