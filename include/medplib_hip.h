@@ -352,7 +352,7 @@ int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, v
  * (dt [tokens, >= R] = scaling * dY B, AT [K, 64] = A^T padded: mp_lora_pack; p = 0: no mask).  Replaces a thin GEMM, mp_dropout_bf16 and
  * mp_add3_bf16 with the same rounding points.  R in {8, 16, 32}; out may alias dx. */
 int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
-                        int K, int R, float p, uint64_t seed, hipStream_t stream);
+                        int K, int R, float p, uint64_t seed, const int* rows_dev, hipStream_t stream);   /* rows_dev (optional, both kernels): device-side row count */
 /* The adapter's down-projection with lora_dropout inline, written as the K-extension of the projection's input (peft lora.Linear.forward,
  * tuners/lora/layer.py: result + lora_B(lora_A(dropout(x))) * scaling; call sites train_ds_medplib.py:262-303): t[token, 0..63] =
  * bf16(drop(x)[token, :] . A[j, :]) for the R rank rows of A (A: [>= 16 * ceil(R / 16), K], rows >= R zero), zeros beyond; xd (optional) =
@@ -360,7 +360,7 @@ int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void
  * (mp_lora_pack's Bx), one mp_gemm_bf16_nt over K + 64 gives base + adapter.  Same mask as mp_dropout_bf16 on the contiguous tensor.
  * t is scaled by alpha before its rounding; with p = 0 and A = B^T the same kernel is the backward's dt = scaling * dY B (reads dY once). */
 int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
-                      int K, int R, float p, uint64_t seed, float alpha, hipStream_t stream);
+                      int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, hipStream_t stream);
 /* MoE layer backward, top-1 / top-2 (autograd of DeepSpeed MOELayer + top1gating / top2gating; entries = choice * tokens +
  * token; top-2 weights are the kept pair renormalised; l_aux uses the first choices' counts): the combine's d_y[e, slot] = w d_out and
  * d_w = <d_out, y[e, slot]> (d_y pre-zeroed); the gate's d_logits from d_w (chosen expert of kept tokens) and from l_aux

@@ -374,7 +374,9 @@ __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __rest
 template <int RG>
 __global__ __launch_bounds__(512) void lora_down_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ A, int64_t lda,
                                                         bf16_t* __restrict__ t, int64_t ldt, bf16_t* __restrict__ xd, int64_t ldxd, int T, int K,
-                                                        float p, uint64_t seed, float alpha) {
+                                                        float p, uint64_t seed, float alpha, const int* __restrict__ rows_dev) {
+  if (rows_dev) T = min(T, *rows_dev);                     // device-side row count (an expert's routed rows on its capacity slab)
+  if ((int)blockIdx.x * 16 >= T) return;
   __shared__ float red[8][RG][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -460,8 +462,10 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 template <int RP>                                            // rank pairs: R / 2 in {4, 8, 16}
 __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restrict__ dt, int64_t lddt, const bf16_t* __restrict__ AT,
                                                           const bf16_t* __restrict__ dx, int64_t lddx, bf16_t* __restrict__ out, int64_t ldo,
-                                                          int T, int K, float p, uint64_t seed, int tpw) {
+                                                          int T, int K, float p, uint64_t seed, int tpw, const int* __restrict__ rows_dev) {
+  if (rows_dev) T = min(T, *rows_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)(blockIdx.y * 4 + wave) * tpw >= T) return;
   const int k0 = (blockIdx.x * 64 + lane) * 8;
   const bool col_live = k0 < K;
   const int kc = col_live ? k0 : 0;
@@ -934,26 +938,26 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
 }
 
 extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
-                                 int K, int R, float p, uint64_t seed, float alpha, hipStream_t stream) {
+                                 int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, hipStream_t stream) {
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 64 == 0 && R > 0 && R <= 64, MP_ERR_SHAPE, "mp_lora_down_bf16: K %% 64 == 0 and 0 < R <= 64 (got K %d, R %d)", K, R);
   MP_REQUIRE(ldx % 8 == 0 && lda % 8 == 0 && ldt % 4 == 0 && (!xd || ldxd % 8 == 0) && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_down_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
   const dim3 grid((unsigned)mp_cdiv(tokens, 16)), blk(512);
   const int rg = (R + 15) / 16;
-#define MP_GO(RG) hipLaunchKernelGGL((lora_down_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, (bf16_t*)xd, ldxd, tokens, K, p, seed, alpha)
+#define MP_GO(RG) hipLaunchKernelGGL((lora_down_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, (bf16_t*)xd, ldxd, tokens, K, p, seed, alpha, rows_dev)
   switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
 #undef MP_GO
   return mp_check_launch("mp_lora_down_bf16");
 }
 
 extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
-                                   int K, int R, float p, uint64_t seed, hipStream_t stream) {
+                                   int K, int R, float p, uint64_t seed, const int* rows_dev, hipStream_t stream) {
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 8 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_bf16: K %% 8 == 0, R in {8, 16, 32} (got K %d, R %d)", K, R);
   MP_REQUIRE(lddt % 8 == 0 && lddx % 8 == 0 && ldo % 8 == 0 && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_up_add_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
   const int tpw = 32;
   const dim3 grid((unsigned)mp_cdiv(K, 512), (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
-#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw)
+#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw, rows_dev)
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
   return mp_check_launch("mp_lora_up_add_bf16");

@@ -359,7 +359,7 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
         bufx = empty(E, cap, d + 64)
         buf = ops.moe_dispatch(h2, expert, slot, E, cap, buf=bufx[:, :, :d], top_k=k)
         for e in range(E):
-            ops.lora_down(buf[e], pad["gu"][0][e], bufx[e][:, d:], pad["gu"][4], lora.p_active, seed * 16 + e)
+            ops.lora_down(buf[e], pad["gu"][0][e], bufx[e][:, d:], pad["gu"][4], lora.p_active, seed * 16 + e, rows_dev=kept[e:e + 1])
         gu = ops.gemm_batched(bufx, lw["gu_x"], empty(E, cap, 2 * ff), m_dev=kept)
         s["bufd"], s["t_gu"] = buf, bufx[:, :, d:]
     else:
@@ -372,7 +372,7 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
         act = actx[:, :, :ff]
         ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff), out=actx.view(E * cap, ff + 64)[:, :ff])
         for e in range(E):
-            ops.lora_down(act[e], pad["down"][0][e], actx[e][:, ff:], pad["down"][4], lora.p_active, (seed + 1) * 16 + e)
+            ops.lora_down(act[e], pad["down"][0][e], actx[e][:, ff:], pad["down"][4], lora.p_active, (seed + 1) * 16 + e, rows_dev=kept[e:e + 1])
         y = ops.gemm_batched(actx, lw["down_x"], empty(E, cap, d), m_dev=kept)
         s["actd"], s["t_d"] = act, actx[:, :, ff:]
     else:
@@ -493,12 +493,12 @@ def _adapter_bwd_moe_fused(lora, ops_pad, dy, x, t, dx, kept, seed):
     E, cap, _ = dy.shape
     dB, dAT = [], []
     for e in range(E):
-        dt = ops.lora_down(dy[e], BT[e], torch.empty((cap, 64), dtype=torch.bfloat16, device=dy.device), R)    # scaling rides in the packed B
         cnt = kept[e:e + 1]
+        dt = ops.lora_down(dy[e], BT[e], torch.empty((cap, 64), dtype=torch.bfloat16, device=dy.device), R, rows_dev=cnt)    # scaling rides in the packed B
         dB.append(ops.tn_skinny(dy[e], t[e], R, lora.scaling, rows_dev=cnt))
         dAT.append(ops.tn_skinny(x[e], dt, R, 1.0, lora.p_active, seed * 16 + e, rows_dev=cnt))
         if R <= 32:
-            ops.lora_up_add(dt, AT[e], dx[e], R, lora.p_active, seed * 16 + e)
+            ops.lora_up_add(dt, AT[e], dx[e], R, lora.p_active, seed * 16 + e, rows_dev=cnt)
         else:
             dxa = ops.gemm(dt, AT[e])
             dx[e].copy_(ops.add3(dx[e].contiguous(), ops.dropout_bf16(dxa, lora.p_active, seed * 16 + e) if lora.p_active > 0 else dxa))
@@ -659,8 +659,14 @@ def backward(llm, saved, d_hidden, d_aux=None):
             for e, mod in enumerate(lora._modules_of(i, t)):
                 if isinstance(dB, dict) and e not in dB:
                     continue
-                grads[f"model.layers.{i}.{mod}.lora_B.default.weight"] = dB[e][lora.rows[t], k * r:(k + 1) * r]
-                grads[f"model.layers.{i}.{mod}.lora_A.default.weight"] = dAT[e][:, k * r:(k + 1) * r].t()
+                nb, na = f"model.layers.{i}.{mod}.lora_B.default.weight", f"model.layers.{i}.{mod}.lora_A.default.weight"
+                pb, pa = lora.params[lora.index[nb]], lora.params[lora.index[na]]
+                if (lora.grad_sink is not None and pb.grad is not None and pa.grad is not None and pb.grad.is_contiguous() and pa.grad.is_contiguous()
+                        and pb.grad.dtype == torch.float32 and dB[e].is_contiguous() and dAT[e].is_contiguous()):
+                    ops.lora_grad_unpack(dB[e], dAT[e], lora.rows[t], k * r, pb.grad, pa.grad)
+                else:
+                    grads[nb] = dB[e][lora.rows[t], k * r:(k + 1) * r]
+                    grads[na] = dAT[e][:, k * r:(k + 1) * r].t()
 
     dx = ops.rmsnorm_bwd(saved["x_last"], llm.norm_w, d_hidden.reshape(T, d).contiguous(), cfg.rms_norm_eps)
     for i in range(len(llm.layers) - 1, -1, -1):

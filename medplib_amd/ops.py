@@ -371,7 +371,7 @@ def lora_grad_unpack(dB, dAT, rows, k0, gB, gA):
     lib().call("mp_lora_grad_unpack_f32", _p(dB), _p(dAT), _p(rows), dB.shape[1], int(k0), r, fin, fout, _p(gB), _p(gA), _stream())
 
 
-def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0):
+def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0, rows_dev=None):
     """t[:, :64] = bf16(dropout(x) @ A[:R]^T) (zeros beyond R), the dropped x into xd when given (mp_lora_down_bf16).  x [T, K] bf16 (any row
     stride), A [>= 16 * ceil(R / 16), K] bf16, t a [T, 64] view (typically columns K.. of x's own row-padded buffer)."""
     _chk(x, torch.bfloat16, "lora_down.x"); _chk(A, torch.bfloat16, "lora_down.A"); _chk(t, torch.bfloat16, "lora_down.t")
@@ -380,11 +380,11 @@ def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0):
     if xd is not None:
         assert xd.shape == (T, K) and xd.stride(1) == 1
     lib().call("mp_lora_down_bf16", _p(x), x.stride(0), _p(A), A.stride(0), _p(t), t.stride(0), _p(xd), xd.stride(0) if xd is not None else 0,
-               T, K, int(R), float(p), int(seed), float(alpha), _stream())
+               T, K, int(R), float(p), int(seed), float(alpha), _p(rows_dev), _stream())
     return t
 
 
-def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None):
+def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None, rows_dev=None):
     """dx + dropout(bf16(dt @ AT^T)) with mp_dropout_bf16's mask (mp_lora_up_add_bf16): dt [T, >= R] bf16, AT [K, 64] bf16 (A^T, padded),
     dx [T, K] bf16; in place on dx unless `out` is given."""
     _chk(dt, torch.bfloat16, "lora_up_add.dt"); _chk(AT, torch.bfloat16, "lora_up_add.AT"); _chk(dx, torch.bfloat16, "lora_up_add.dx")
@@ -392,7 +392,7 @@ def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None):
     assert AT.shape == (K, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dx.stride(1) == 1
     out = dx if out is None else out
     lib().call("mp_lora_up_add_bf16", _p(dt), dt.stride(0), _p(AT), _p(dx), dx.stride(0), _p(out), out.stride(0), T, K, int(R), float(p), int(seed),
-               _stream())
+               _p(rows_dev), _stream())
     return out
 
 
