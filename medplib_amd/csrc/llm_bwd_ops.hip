@@ -11,6 +11,7 @@
 //   mp_scatter_rows_f32_bf16   out[rows[i], :] = bf16(g[i, :])  (backward of the row gather in front of text_hidden_fcs / lm_head)
 //   mp_dropout_bf16            y = x * keep / (1 - p) with keep from the stateless hash generator (peft lora_dropout on the adapter input)
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 #include "gemm_common.h"
 
@@ -955,8 +956,10 @@ extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT,
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 8 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_bf16: K %% 8 == 0, R in {8, 16, 32} (got K %d, R %d)", K, R);
   MP_REQUIRE(lddt % 8 == 0 && lddx % 8 == 0 && ldo % 8 == 0 && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_up_add_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
-  const int tpw = 32;
-  const dim3 grid((unsigned)mp_cdiv(K, 512), (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
+  // tokens per wave: enough waves to hide the loads' latency (~4 per SIMD) without re-reading the chunk's rank vectors too often
+  const int64_t chunks = mp_cdiv(K, 512);
+  const int tpw = (int)std::min<int64_t>(32, std::max<int64_t>(8, (chunks * tokens / 4096 + 3) / 4 * 4));
+  const dim3 grid((unsigned)chunks, (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
 #define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw, rows_dev)
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
