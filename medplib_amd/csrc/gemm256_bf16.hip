@@ -58,24 +58,6 @@ __device__ __forceinline__ int lds_off2(int r, int c) { return r * 128 + ((c ^ (
     asm volatile("" ::: "memory");         \
   } while (0)
 
-// Two neighbouring fragments' bf16x4 row pieces (fragment j: columns j*16 + fq*4 .. +3, fragment j+1: 16 columns further) become one
-// 16-byte piece per lane: v_permlane16_swap exchanges the odd 16-lane rows of the first operand with the even rows of the second (lane
-// = fq*16 + fr, so a row of lanes IS an fq), after which lane (fr, fq) holds the EIGHT consecutive columns
-// (fq & 1) * 16 + (fq >> 1) * 8 .. +7 of the pair's 32 -- same matrix row as before.  Stores (and residual loads) are then 16 bytes per
-// lane and 64 contiguous bytes per matrix row per instruction instead of 8 / 32: half the store instructions (the epilogue is
-// store-ISSUE bound, MI355X_MICROARCH.md T21).  Must be executed by all 64 lanes.
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-__device__ __forceinline__ bf16x8 pair_swap16(bf16x4 a, bf16x4 b) {
-  const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
-  const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-  const u32x2_t r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-  return __builtin_bit_cast(bf16x8, (u32x4_t{r0[0], r1[0], r0[1], r1[1]}));
-}
-__device__ __forceinline__ int pair_col8(int fq) { return (fq & 1) * 16 + (fq >> 1) * 8; }
-__device__ __forceinline__ bf16x4 round4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
-__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 // Epilogue for TRANSPOSED accumulators (v3): the MFMAs are issued as (W fragment, A fragment), so acc[i][j][r] is
 // C[row = i*16 + fr, col = j*16 + fq*4 + r] of the wave tile — a lane owns FOUR CONSECUTIVE COLUMNS of one row per fragment.
 // Outputs leave straight from registers as 8-byte (bf16) / 16-byte (fp32) pieces, four fragments completing each 128-byte row

@@ -18,7 +18,7 @@
 // one 32-bit lane offset per operand, everything else in the scalar offset): 2 address registers instead of 18 -- with 160 accumulators,
 // 40 A-fragment and 32 B-fragment registers there is no room for per-piece 64-bit pointers (the launcher checks the operands fit 2 GiB).
 // The MFMAs are issued as (W fragment, A fragment) = transposed accumulators (a lane owns four consecutive columns of a row); the
-// epilogue pairs neighbouring fragments with v_permlane16_swap into 16-byte pieces (gemm256_bf16.hip, pair_swap16).
+// epilogue pairs neighbouring fragments with v_permlane16_swap into 16-byte pieces (gemm_common.h, pair_swap16).
 // Dense calls only (no device-side row counts, no row gather / scatter, bf16 output); no tail split: the launcher selects this kernel
 // only when its last wave is full enough to win without one.
 #include "gemm_common.h"
@@ -42,23 +42,13 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
   } while (0)
 #define MP3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_3;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_3;
-__device__ __forceinline__ bf16x8 pair_swap16_3(bf16x4 a, bf16x4 b) {          // see pair_swap16 in gemm256_bf16.hip
-  const u32x2_3 ua = __builtin_bit_cast(u32x2_3, a), ub = __builtin_bit_cast(u32x2_3, b);
-  const u32x2_3 r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-  const u32x2_3 r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-  return __builtin_bit_cast(bf16x8, (u32x4_3{r0[0], r1[0], r0[1], r1[1]}));
-}
-__device__ __forceinline__ bf16x4 round4_3(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
-
 // Epilogue: alpha / bias / activation (rounded to bf16) then the residual add, or the RoPE pairing of a q / k tile (same arithmetic and
 // rounding points as gemm256_epilogue_t; 16-byte pieces only: the launcher guarantees the alignment).
 __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int M, int N, int m0, int n0, int wr, int wc,
                                                  int fr, int fq) {
   bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
   const int cw = n0 + wc * 128;
-  const int c8 = (fq & 1) * 16 + (fq >> 1) * 8;              // the lane's eight columns inside a fragment pair's 32
+  const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
   if (g.act == ACT_ROPE_QK && n0 < (N / 3) * 2) {
     // the wave's 128 columns are one head: fragments 0,1 | 2,3 hold [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63]
     const int head0 = (cw >> 7) << 7;
@@ -66,7 +56,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qk[i][j] = round4_3(acc[i][j]);
+      for (int j = 0; j < 8; ++j) qk[i][j] = round4(acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
@@ -102,7 +92,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
                 olo[j][r] = (bf16_t)(a * cs[ii][j][r] - b * sn[ii][j][r]);
                 ohi[j][r] = (bf16_t)(b * cs[ii][j][r] + a * sn[ii][j][r]);
               }
-            const bf16x8 plo = pair_swap16_3(olo[0], olo[1]), phi = pair_swap16_3(ohi[0], ohi[1]);
+            const bf16x8 plo = pair_swap16(olo[0], olo[1]), phi = pair_swap16(ohi[0], ohi[1]);
             if (row < M) {
               *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + jb * 32 + c8) = plo;
               *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + 64 + jb * 32 + c8) = phi;
@@ -161,7 +151,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const int col = cw + (h * 2 + jp) * 32 + c8;
-        bf16x8 p = pair_swap16_3(round4_3(acc[i][(h * 2 + jp) * 2]), round4_3(acc[i][(h * 2 + jp) * 2 + 1]));
+        bf16x8 p = pair_swap16(round4(acc[i][(h * 2 + jp) * 2]), round4(acc[i][(h * 2 + jp) * 2 + 1]));
         if (R) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) p[e] = (bf16_t)((float)p[e] + (float)rv[i][jp][e]);
