@@ -195,7 +195,7 @@ def main():
             out = eng(**b)
         else:
             out = eng(**batch)
-        eng.backward(out["loss"])
+        eng.backward(out)                 # the output dict: its loss tensors live on the mask tail's stream, nothing here reads them
         eng.step()
         return out
 

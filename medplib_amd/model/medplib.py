@@ -71,6 +71,42 @@ class _Inner(nn.Module):
                                                             nn.Dropout(0.0))])
 
 
+class StreamOrderedLosses(dict):
+    """The loss dict of a step whose mask tail ran on its own stream.  Reading a value (out[k], .get, .items, .values) first makes the
+    READER's current stream wait for the event recorded behind the tail forward -- once per stream -- so any use of the tensors is
+    ordered exactly as if model_forward had waited itself; `raw(k)` hands a tensor out without the wait (for consumers that run on the
+    tail stream themselves: Engine.backward)."""
+
+    def __init__(self, values, event):
+        super().__init__(values)
+        self._event, self._ordered = event, set()
+
+    def _order(self):
+        st = torch.cuda.current_stream()
+        if st.cuda_stream not in self._ordered:
+            st.wait_event(self._event)
+            self._ordered.add(st.cuda_stream)
+
+    def raw(self, key):
+        return dict.__getitem__(self, key)
+
+    def __getitem__(self, key):
+        self._order()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._order()
+        return dict.get(self, key, default)
+
+    def items(self):
+        self._order()
+        return dict.items(self)
+
+    def values(self):
+        self._order()
+        return dict.values(self)
+
+
 class MedPLIBForCausalLM(nn.Module):
     moe_default = True
 
@@ -502,9 +538,14 @@ class MedPLIBForCausalLM(nn.Module):
         with torch.cuda.stream(tail):
             out = self._mask_tail(plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list,
                                   inference, B)
-        main.wait_event(tail.record_event())                        # the loss dict is complete for the caller's stream
+        # The loss tensors are produced on the tail stream.  Nothing on the caller's stream needs them unless the caller reads one, so the
+        # cross-stream wait is attached to the READ (StreamOrderedLosses) instead of being paid by the next step's CLIP tower and decoder:
+        # engine.backward(out) takes the dict as it is; out["loss"] / float(out["loss"]) / the reference driver's loss.item() wait first.
         self.active_tail_stream = tail
-        return out
+        res = StreamOrderedLosses(out, tail.record_event())
+        if os.environ.get("MP_TAIL_WAIT") == "1":              # A/B: the calling stream waits here, as before round 2
+            res._order()
+        return res
 
     def _mask_tail(self, plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list, inference, B):
         cfg, dev, m = self.config, self.device_, self.model
