@@ -199,6 +199,11 @@ def main():
         eng.step()
         return out
 
+    # debug: run the step's main stream at high priority, so the CLIP tower / decoder get the CUs before the side streams' kernels
+    hp_ctx = torch.cuda.stream(torch.cuda.Stream(device=device, priority=-1)) if os.environ.get("MP_BENCH_HIPRIO") == "1" else None
+    if hp_ctx is not None:
+        torch.cuda.synchronize()
+        hp_ctx.__enter__()
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
