@@ -168,8 +168,8 @@ class Engine:
         """autograd backward (grads accumulate straight into the flat buffer; `loss` = the loss tensor as with DeepSpeed, or the model's
         output dict, whose "loss" is then taken without ordering the caller's stream behind the mask tail), then — at an accumulation boundary — one
         bucketed all-reduce of the flat gradient on the communication stream (collective C1)."""
-        if hasattr(loss, "raw") and isinstance(loss, dict):       # the step's loss dict itself (medplib.StreamOrderedLosses): no cross-stream wait
-            loss = loss.raw("loss")
+        if isinstance(loss, dict):                                # the step's output dict itself (medplib.StreamOrderedLosses: no cross-stream wait)
+            loss = loss.raw("loss") if hasattr(loss, "raw") else loss["loss"]
         with self._tail_ctx():
             if self.grad_accum > 1:
                 loss = loss / self.grad_accum
