@@ -213,7 +213,7 @@ def main():
 
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.KernelTimer()
+        timer = ops.KernelTimer(sample_every=23)         # every 23rd GEMM launch (coprime to the layer's GEMM period): ~290 samples over 20 steps
         ops.GEMM_TIMER = timer
     if world > 1:
         dist.barrier()
@@ -236,7 +236,7 @@ def main():
         value = samples / dt
         roof = None
         if timer is not None:
-            # every 11th GEMM launch of the timed steps is bracketed by HIP events on the launch stream (ops.KernelTimer)
+            # every 23rd GEMM launch of the timed steps is bracketed by HIP events on the launch stream (ops.KernelTimer)
             # the dominant kernel alone (mp_gemm_last_kernel tells which kernel a launch went to), then all bf16 GEMM launches
             flops, ms, sampled, launches, all_flops = timer.summary(256)
             a_flops, a_ms, a_sampled, a_launches, a_all = timer.summary()
