@@ -138,6 +138,13 @@ class MedPLIBForCausalLM(nn.Module):
         self.inference_threshold = 0.1
         self.sam_side_stream = True             # run the SAM encoder beside the LLM stack (model_forward)
         self._sam_stream = None
+        # Opt-in (the caller guarantees the image tensors of a step are COMPLETE when it calls model_forward -- resident, or copied on
+        # another stream and already synchronised with): the frozen CLIP tower and SAM encoder of the step start on their own streams
+        # without queueing behind whatever the calling stream still has in flight, i.e. beside the PREVIOUS step's decoder layers
+        # (the host issues a step tens of milliseconds before the GPU reaches it).  The calling stream waits for the CLIP features
+        # before the splice, the mask tail for the SAM embedding.  Only while every module in front of the decoder is frozen.
+        self.towers_run_ahead = False
+        self._vision_stream_obj = None
         # Training only, switched on by engine.initialize(): the fp32 mask tail (forward, and through autograd its backward; the
         # engine adds the optimizer) runs on its own stream, so its ~700 tiny launches overlap the NEXT step's CLIP tower / LLM
         # instead of holding the machine at a few percent occupancy.  The calling stream waits for the tail FORWARD before
@@ -156,6 +163,11 @@ class MedPLIBForCausalLM(nn.Module):
             self._sam_stream = ops.side_stream(self.device_, "sam_encoder", with_gemm_workspace=True)   # own split-K scratch
         return self._sam_stream
 
+    def _vision_stream(self):
+        if self._vision_stream_obj is None:
+            self._vision_stream_obj = ops.side_stream(self.device_, "clip_tower", with_gemm_workspace=True)
+        return self._vision_stream_obj
+
     def _tail_stream(self):
         if self._tail_stream_obj is None:
             self._tail_stream_obj = ops.side_stream(self.device_, "mask_tail")      # fp32 tail: no bf16 GEMMs, no scratch needed
@@ -163,10 +175,10 @@ class MedPLIBForCausalLM(nn.Module):
 
     def sync_side_streams(self):
         """Order the calling stream behind everything the side streams have been given (tail backward / optimizer, SAM encoder)."""
-        if self._tail_stream_obj is None and self._sam_stream is None:
+        if self._tail_stream_obj is None and self._sam_stream is None and self._vision_stream_obj is None:
             return                                            # nothing was ever put on a side stream (also: host-only surface tests)
         cur = torch.cuda.current_stream()
-        for st in (self._tail_stream_obj, self._sam_stream):
+        for st in (self._tail_stream_obj, self._sam_stream, self._vision_stream_obj):
             if st is not None:
                 cur.wait_stream(st)
 
@@ -464,16 +476,30 @@ class MedPLIBForCausalLM(nn.Module):
         # launches (windowed attention, adapter convolutions on 64-token maps) fill in beside the LLM's GEMMs instead of
         # occupying the machine alone.  Joined again before the mask tail.
         image_tokens = None
+        ahead = (self.towers_run_ahead and getattr(m.llm, "lora", None) is None and not (region_masks is not None and len(region_masks) > 0)
+                 and kwargs.get("mask_images") is None and torch.is_tensor(images_clip))
         if seg_flag and self.sam_side_stream:
             main = torch.cuda.current_stream()
             side = self._side_stream()
-            side.wait_stream(main)
+            if not ahead:
+                side.wait_stream(main)
+            else:
+                images.record_stream(side)
             with torch.cuda.stream(side), torch.no_grad():
                 image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
+        if ahead:
+            main, vis = torch.cuda.current_stream(), self._vision_stream()
+            images_clip.record_stream(vis)
+            with torch.cuda.stream(vis), torch.no_grad():
+                plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, None, kwargs.get("image_token_types"),
+                                                    kwargs.get("image_token_lengths"))
+            main.wait_stream(vis)
+            feats.record_stream(main)
         with torch.no_grad():
-            plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, kwargs.get("mask_images"),
-                                                kwargs.get("image_token_types"), kwargs.get("image_token_lengths"),
-                                                region_masks=region_masks, valid_region_masks_bool=valid_region_masks_bool)
+            if not ahead:
+                plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, kwargs.get("mask_images"),
+                                                    kwargs.get("image_token_types"), kwargs.get("image_token_lengths"),
+                                                    region_masks=region_masks, valid_region_masks_bool=valid_region_masks_bool)
             # every host-built index tensor of the step goes to the device NOW (see _h2d)
             src = _h2d(plan.src_code.reshape(-1), dev)
             key_valid = None
