@@ -360,7 +360,8 @@ int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void
  * (mp_lora_pack's Bx), one mp_gemm_bf16_nt over K + 64 gives base + adapter.  Same mask as mp_dropout_bf16 on the contiguous tensor.
  * t is scaled by alpha before its rounding; with p = 0 and A = B^T the same kernel is the backward's dt = scaling * dY B (reads dY once). */
 int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
-                      int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, hipStream_t stream);
+                      int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, float* partial, int64_t partial_floats,
+                      hipStream_t stream);   /* partial (optional, >= 8 * tokens * 16 * ceil(R / 16) floats): room for the K-split sums of the LDS-staged kernel (K % 256 == 0) */
 /* MoE layer backward, top-1 / top-2 (autograd of DeepSpeed MOELayer + top1gating / top2gating; entries = choice * tokens +
  * token; top-2 weights are the kept pair renormalised; l_aux uses the first choices' counts): the combine's d_y[e, slot] = w d_out and
  * d_w = <d_out, y[e, slot]> (d_y pre-zeroed); the gate's d_logits from d_w (chosen expert of kept tokens) and from l_aux

@@ -452,6 +452,113 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const bf16_t* __restrict
   }
 }
 
+// The same down-projection with the x tile STAGED THROUGH LDS (K % 256 == 0): the kernel above feeds the MFMA from global memory with
+// fragment-shaped loads (16 bytes of sixteen different rows per instruction: nothing coalesces, 2.5-3 TB/s); here a workgroup loads a
+// [64 tokens x 256] tile with whole-row 16-byte accesses (the dropout and the optional store of the dropped values happen on the way,
+// also coalesced), writes it and the [16 RG x 256] piece of A into XOR-swizzled LDS images and reads both as plain ds_read_b128
+// fragments.  One token group per wave; K is split over gridDim.y workgroups (80 token blocks alone would leave two thirds of the chip
+// idle) whose fp32 partials are added in split order by lora_down_finish_kernel (scaling, rounding, zero padding to 64 columns).
+template <int RG>
+__global__ __launch_bounds__(256) void lora_down_staged_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ A, int64_t lda,
+                                                               float* __restrict__ partial, bf16_t* __restrict__ xd, int64_t ldxd, int T, int K,
+                                                               float p, uint64_t seed, const int* __restrict__ rows_dev) {
+  __shared__ __attribute__((aligned(16))) char xt[64 * 512];            // [64 tokens][256 k] bf16, chunk c of row r at c ^ (r & 7)
+  __shared__ __attribute__((aligned(16))) char at[16 * RG * 512];       // [16 RG rank rows][256 k]
+  if (rows_dev) T = min(T, *rows_dev);
+  const int tok0 = blockIdx.x * 64;
+  if (tok0 >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nsteps_all = K / 256;
+  const int st0 = (int)((int64_t)blockIdx.y * nsteps_all / gridDim.y), st1 = (int)((int64_t)(blockIdx.y + 1) * nsteps_all / gridDim.y);
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  const int xr = tid >> 5, xc = tid & 31;                                // staging role: row i * 8 + xr, 16-byte chunk xc
+  f32x4 acc[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xv[8], av[(16 * RG * 32 + 255) / 256];
+  auto load_step = [&](int st) {
+    const int k = st * 256 + xc * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = tok0 + i * 8 + xr;
+      xv[i] = bf16x8{};
+      if (tok < T) {
+        xv[i] = *reinterpret_cast<const bf16x8*>(x + (int64_t)tok * ldx + k);
+        if (p > 0.f) {
+          const uint64_t i4 = ((uint64_t)tok * (uint64_t)K + (uint64_t)k) >> 2;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint64_t bits = dropout_bits4(seed, i4 + q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              xv[i][q * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)xv[i][q * 4 + j] * keep_scale : 0.f);
+          }
+          if (xd) *reinterpret_cast<bf16x8*>(xd + (int64_t)tok * ldxd + k) = xv[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * RG * 32 + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      av[u] = bf16x8{};
+      if (idx < 16 * RG * 32) av[u] = *reinterpret_cast<const bf16x8*>(A + (int64_t)(idx >> 5) * lda + st * 256 + (idx & 31) * 8);
+    }
+  };
+  if (st0 < st1) load_step(st0);
+  for (int st = st0; st < st1; ++st) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + xr;
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = xv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * RG * 32 + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < 16 * RG * 32) {
+        const int r = idx >> 5, c = idx & 31;
+        *reinterpret_cast<bf16x8*>(at + r * 512 + ((c ^ (r & 7)) << 4)) = av[u];
+      }
+    }
+    __syncthreads();
+    if (st + 1 < st1) load_step(st + 1);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int c = kk * 4 + fq;
+      const int xrow = wave * 16 + fr;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + xrow * 512 + ((c ^ (xrow & 7)) << 4));
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        const int arow = rg * 16 + fr;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(at + arow * 512 + ((c ^ (arow & 7)) << 4));
+        acc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, acc[rg], 0, 0, 0);
+      }
+    }
+  }
+  // acc[rg][r] = partial t[token tok0 + wave * 16 + fr][rank rg * 16 + fq * 4 + r]
+  const int tok = tok0 + wave * 16 + fr;
+  if (tok < T) {
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+      *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.y * T + tok) * (16 * RG) + rg * 16 + fq * 4) = acc[rg];
+  }
+}
+
+__global__ void lora_down_finish_kernel(const float* __restrict__ partial, bf16_t* __restrict__ t, int64_t ldt, int T, int RW, int splits, float alpha,
+                                        const int* __restrict__ rows_dev) {
+  if (rows_dev) T = min(T, *rows_dev);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (token, 4-column group of the 64)
+  if (idx >= (int64_t)T * 16) return;
+  const int tok = (int)(idx >> 4), c = (int)(idx & 15) * 4;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  if (c < RW)
+    for (int sp = 0; sp < splits; ++sp) sum += *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * T + tok) * RW + c);
+  sum *= alpha;
+  *reinterpret_cast<bf16x4*>(t + (int64_t)tok * ldt + c) = bf16x4{(bf16_t)sum[0], (bf16_t)sum[1], (bf16_t)sum[2], (bf16_t)sum[3]};
+}
+
 // Backward of the adapter branch into the projection's input gradient, in one pass over it: out = dx + dropout(bf16(dt A)) with the
 // forward's mask -- the thin GEMM (dt A^T^T -> [tokens, in]), the dropout pass over its output and the add were six passes over a
 // [tokens, in] tensor; this is one read and one write.  A lane owns 8 consecutive input features of a 512-wide chunk (16-byte accesses,
@@ -939,12 +1046,25 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
 }
 
 extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
-                                 int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, hipStream_t stream) {
+                                 int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, float* partial, int64_t partial_floats,
+                                 hipStream_t stream) {
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 64 == 0 && R > 0 && R <= 64, MP_ERR_SHAPE, "mp_lora_down_bf16: K %% 64 == 0 and 0 < R <= 64 (got K %d, R %d)", K, R);
   MP_REQUIRE(ldx % 8 == 0 && lda % 8 == 0 && ldt % 4 == 0 && (!xd || ldxd % 8 == 0) && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_down_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
-  const dim3 grid((unsigned)mp_cdiv(tokens, 16)), blk(512);
   const int rg = (R + 15) / 16;
+  // staged form (coalesced x loads through LDS) when K is a multiple of 256 and the caller brought room for the K-split partials
+  const int splits = (int)std::min<int64_t>(std::min<int64_t>(8, K / 256), std::max<int64_t>(1, 1024 / mp_cdiv(tokens, 64)));     // ~1024 workgroups
+  static int staged = -1;
+  if (staged < 0) { const char* e = getenv("MP_LORA_DOWN_STAGED"); staged = (e && atoi(e) == 0) ? 0 : 1; }                // 0: fragment-shaped loads (A/B)
+  if (staged && K % 256 == 0 && partial && partial_floats >= (int64_t)splits * tokens * 16 * rg) {
+    const dim3 grid((unsigned)mp_cdiv(tokens, 64), (unsigned)splits), blk(256);
+#define MP_GO(RG) hipLaunchKernelGGL((lora_down_staged_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, partial, (bf16_t*)xd, ldxd, tokens, K, p, seed, rows_dev)
+    switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
+#undef MP_GO
+    hipLaunchKernelGGL(lora_down_finish_kernel, GRID1D((int64_t)tokens * 16), partial, (bf16_t*)t, ldt, tokens, 16 * rg, splits, alpha, rows_dev);
+    return mp_check_launch("mp_lora_down_bf16(staged)");
+  }
+  const dim3 grid((unsigned)mp_cdiv(tokens, 16)), blk(512);
 #define MP_GO(RG) hipLaunchKernelGGL((lora_down_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, (bf16_t*)xd, ldxd, tokens, K, p, seed, alpha, rows_dev)
   switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
 #undef MP_GO

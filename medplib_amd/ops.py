@@ -379,8 +379,9 @@ def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0, rows_dev=None):
     assert x.stride(1) == 1 and A.stride(1) == 1 and t.stride(1) == 1 and t.shape == (T, 64) and A.shape[1] == K and A.shape[0] >= (R + 15) // 16 * 16
     if xd is not None:
         assert xd.shape == (T, K) and xd.stride(1) == 1
+    partial = torch.empty(8 * T * 16 * ((R + 15) // 16), dtype=torch.float32, device=x.device) if K % 256 == 0 else None
     lib().call("mp_lora_down_bf16", _p(x), x.stride(0), _p(A), A.stride(0), _p(t), t.stride(0), _p(xd), xd.stride(0) if xd is not None else 0,
-               T, K, int(R), float(p), int(seed), float(alpha), _p(rows_dev), _stream())
+               T, K, int(R), float(p), int(seed), float(alpha), _p(rows_dev), _p(partial), partial.numel() if partial is not None else 0, _stream())
     return t
 
 
