@@ -14,6 +14,8 @@
 //   DMA  :  H0  B columns 64-127 of tile t+1 (2 pieces per wave)     H1  A (5 pieces) + B columns 0-63 (2) of tile t+2
 // (A and the B columns 0-63 of a stage are free after H0's reads, the B columns 64-127 after H1's) -- the split along N rather than
 // M makes the DMA piece counts integral (40 A pieces of 8 rows over 8 waves; a split along M would need 2.5 per wave and region).
+// (Issuing two of the five A pieces one segment later -- 4 + 5 DMA pieces per K-tile instead of 2 + 7, the load segments' fragment reads being 18
+// + 8 -- measured the same on every shape: the DMA issue split is not what holds this tile ~7 % below the 256x256 one per flop.)
 // One counted wait (vmcnt(7)) per K-tile; the operand stream never drains.  The DMA goes through buffer descriptors (buffer_load ... lds:
 // one 32-bit lane offset per operand, everything else in the scalar offset): 2 address registers instead of 18 -- with 160 accumulators,
 // 40 A-fragment and 32 B-fragment registers there is no room for per-piece 64-bit pointers (the launcher checks the operands fit 2 GiB).
