@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm256_epilogue_t(const GemmArgs& g, f32x4 (&ac
     // W rows are [gate 0..31 | up 0..31 | gate 32..63 | ...]: fragments j = 0,1 are gate columns, j = 2,3 the matching up columns;
     // gate and up are rounded to bf16 first, like the unfused GEMM + SwiGLU kernel pair
     const int half_n = N >> 1;
-    if (!g.ep8 && (g.ldc & 7) == 0 && (half_n & 7) == 0 && aligned16(Cb)) {
+    if ((!g.ep8 || g.keep_gu) && (g.ldc & 7) == 0 && (half_n & 7) == 0 && aligned16(Cb)) {      // (keep_gu exists in the 16-byte form only: its entry point checks the alignment)
       const int col = (cw >> 1) + pair_col8(fq);               // the lane's eight output columns (pair_swap16 of the j = 0, 1 pieces)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

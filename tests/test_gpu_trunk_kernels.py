@@ -4,6 +4,7 @@ Tolerances (stated per test): the HIP path computes on bf16 inputs with fp32 acc
 once; the oracle computes in fp32 on the SAME bf16-rounded inputs, so the bound is one bf16 rounding of the output
 (2^-8 relative) plus fp32 accumulation-order noise."""
 import math
+import os
 
 import pytest
 import torch
@@ -503,7 +504,9 @@ def test_tn_skinny_mfma_and_inline_dropout(dev, T, N, R, p):
     ref = 0.5 * (xd.float().T @ gm[:, :R].float())
     got = ops.tn_skinny(x, gm, R, 0.5, p, 77)
     _report(f"tn_skinny T={T} N={N} R={R} p={p}", got, ref, rtol=1e-4, atol=1e-3 * ref.abs().max().item())
-    assert torch.equal(got, ops.tn_skinny(xd, gm, R, 0.5)) and torch.equal(got, ops.tn_skinny(x, gm, R, 0.5, p, 77))
+    assert torch.equal(got, ops.tn_skinny(x, gm, R, 0.5, p, 77))
+    if os.environ.get("MP_TN_SKINNY_MFMA") != "0":        # (the A/B knob sends the mask-free call to the scalar kernel: another summation order)
+        assert torch.equal(got, ops.tn_skinny(xd, gm, R, 0.5))
     # a narrow G (the gate's d_logits: 8 columns) is padded by the wrapper
     g8 = gm[:, :8].contiguous()
     _report("tn_skinny narrow G", ops.tn_skinny(xd, g8, 8, 1.0), xd.float().T @ g8.float(), rtol=1e-4, atol=1e-3 * ref.abs().max().item())
