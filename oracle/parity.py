@@ -91,3 +91,52 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     del m
     torch.cuda.empty_cache()
     return res
+
+
+def lora_grad_parity(cfg, device, r=8, alpha=16, targets="gate_proj,up_proj,down_proj", seed=0, batch_seed=42, cpu_threads=None):
+    """LoRA training step at the TRUE layer dimensions (dense decoder of cfg.num_hidden_layers layers, B = 1, S = 639): every adapter
+    gradient of the HIP path (the whole decoder backward: attention backward, RMSNorm / SwiGLU backward, dgrad GEMMs on 320- / 256-row
+    tiles, the fused adapter branch, MFMA weight gradients) against torch autograd of the oracle with the same adapters in fp32
+    (dropout 0: the two sides cannot share a mask stream).  -> {"worst_rel": max over adapters of max|g_hip - g_ref| / max|g_ref|, ...}."""
+    from medplib_amd import engine
+    from medplib_amd.model.medplib import LISAForCausalLM
+    if cpu_threads:
+        torch.set_num_threads(cpu_threads)
+    cfg = copy.deepcopy(cfg)
+    assert not cfg.moe_enable
+    W = OM.init_hf_weights_aliased(cfg, seed=seed)
+    m = LISAForCausalLM(cfg, device=device).train()
+    m.load_hf_state_dict(W)
+    lora = m.enable_lora(lora_r=r, lora_alpha=alpha, lora_dropout=0.0, lora_target_modules=targets)
+    g = torch.Generator().manual_seed(seed + 31)
+    Wl = dict(W)
+    Wl["lora_scaling"] = alpha / r
+    for n, p_ in zip(lora.names, lora.params):
+        v = (torch.randn(p_.shape, generator=g) * (0.02 if "lora_A" in n else 0.01)).to(torch.bfloat16).float()
+        p_.data.copy_(v.to(device))
+        Wl[n] = v.clone().requires_grad_(True)
+    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=batch_seed)
+    batch["images"] = batch["images"].to(torch.bfloat16).float()
+    batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
+    t0 = time.time()
+    ref = OM.model_forward(batch, Wl, cfg, training=True, llm_grad=True)
+    ref["loss"].backward()
+    t_ref = time.time() - t0
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                     config={"optimizer": {"params": {"lr": 1e-4, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0})
+    gb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(device) for x in batch["masks_list"]]
+    out = eng(**gb)
+    losses = {k: (float(out[k].detach()), float(ref[k])) for k in O.LOSS_KEYS}
+    eng.backward(out["loss"])
+    torch.cuda.synchronize()
+    per, worst = {}, 0.0
+    for n, p_ in zip(lora.names, lora.params):
+        want = Wl[n].grad
+        rel = (p_.grad.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+        per[n] = rel
+        worst = max(worst, rel)
+    return {"layers": cfg.num_hidden_layers, "adapters": len(per), "worst_rel": worst, "per_param": per, "losses_hip_vs_oracle": losses,
+            "max_abs_dloss": max(abs(a - b) for a, b in losses.values()), "oracle_seconds": t_ref,
+            "grad_absmax_min": min(Wl[n].grad.abs().max().item() for n in lora.names)}
+

@@ -1449,6 +1449,23 @@ def test_full_depth_parity_at_true_dims(dev, moe):
         assert len(r["routing_agreement_per_layer"]) == 8 and r["routing_agreement_min"] >= 0.97, r
 
 
+@pytest.mark.parametrize("layers,r_,targets", [(2, 8, "gate_proj,up_proj,down_proj"), (3, 16, "q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj")])
+def test_lora_gradients_at_true_dims(dev, layers, r_, targets):
+    """LoRA training at the 7B layer dimensions (dense decoder layers, B = 1, S = 639; scripts/train_stage3.sh's adapters -- r = 8 on
+    gate / up / down_proj -- and train_stage2.sh's -- r = 16 on all seven projections): every adapter gradient of the HIP path's decoder
+    backward against the oracle's fp32 autograd (oracle/parity.py::lora_grad_parity).  Bound: 5 % of each gradient's largest entry
+    (bf16 trunk; measured 1.6 % on the stage-III set), losses within 2e-2."""
+    from oracle.parity import lora_grad_parity
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=layers, vocab_size=4096, seg_token_idx=4000, moe_enable=False)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    r = lora_grad_parity(cfg, dev, r=r_, targets=targets)
+    print({k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items() if k != "per_param"})
+    for n, e in r["per_param"].items():
+        print(f"  {n}: {e:.4f}")
+    assert r["adapters"] == 2 * layers * len(targets.split(",")) and r["grad_absmax_min"] > 0 and r["worst_rel"] < 0.05, r
+    assert r["max_abs_dloss"] < 2e-2, r["losses_hip_vs_oracle"]
+
+
 def test_capi_rccl_comm_single_rank(dev):
     """The C-ABI RCCL helpers (mp_comm_unique_id / mp_comm_init / mp_allreduce_bucket / mp_alltoall_tokens, SURVEY §8b Face 2) on a
     one-rank communicator: a SUM over one rank and an exchange with oneself are identities — this checks the binding, the stream
