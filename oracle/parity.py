@@ -93,27 +93,31 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     return res
 
 
-def lora_grad_parity(cfg, device, r=8, alpha=16, targets="gate_proj,up_proj,down_proj", seed=0, batch_seed=42, cpu_threads=None):
+def lora_grad_parity(cfg, device, r=8, alpha=16, targets="gate_proj,up_proj,down_proj", seed=0, batch_seed=42, cpu_threads=None,
+                     sft_modules="mask_decoder,text_hidden_fcs"):
     """LoRA training step at the TRUE layer dimensions (dense decoder of cfg.num_hidden_layers layers, B = 1, S = 639): every adapter
     gradient of the HIP path (the whole decoder backward: attention backward, RMSNorm / SwiGLU backward, dgrad GEMMs on 320- / 256-row
     tiles, the fused adapter branch, MFMA weight gradients) against torch autograd of the oracle with the same adapters in fp32
     (dropout 0: the two sides cannot share a mask stream).  -> {"worst_rel": max over adapters of max|g_hip - g_ref| / max|g_ref|, ...}."""
     from medplib_amd import engine
-    from medplib_amd.model.medplib import LISAForCausalLM
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
     if cpu_threads:
         torch.set_num_threads(cpu_threads)
     cfg = copy.deepcopy(cfg)
-    assert not cfg.moe_enable
+    cfg.moe_gate_sampling = False                  # MoE: routing is a function of the gate alone on both sides (as in full_size_parity)
     W = OM.init_hf_weights_aliased(cfg, seed=seed)
-    m = LISAForCausalLM(cfg, device=device).train()
+    m = (MedPLIBForCausalLM if cfg.moe_enable else LISAForCausalLM)(cfg, device=device).train()
     m.load_hf_state_dict(W)
-    lora = m.enable_lora(lora_r=r, lora_alpha=alpha, lora_dropout=0.0, lora_target_modules=targets)
+    lora = m.enable_lora(lora_r=r, lora_alpha=alpha, lora_dropout=0.0, lora_target_modules=targets, sft_modules=sft_modules)
     g = torch.Generator().manual_seed(seed + 31)
     Wl = dict(W)
     Wl["lora_scaling"] = alpha / r
     for n, p_ in zip(lora.names, lora.params):
-        v = (torch.randn(p_.shape, generator=g) * (0.02 if "lora_A" in n else 0.01)).to(torch.bfloat16).float()
-        p_.data.copy_(v.to(device))
+        if "lora_" in n:
+            v = (torch.randn(p_.shape, generator=g) * (0.02 if "lora_A" in n else 0.01)).to(torch.bfloat16).float()
+            p_.data.copy_(v.to(device))
+        else:                                      # e.g. a trainable gate `wg`: the checkpoint's own values
+            v = p_.detach().float().cpu()
         Wl[n] = v.clone().requires_grad_(True)
     batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=batch_seed)
     batch["images"] = batch["images"].to(torch.bfloat16).float()
@@ -138,5 +142,6 @@ def lora_grad_parity(cfg, device, r=8, alpha=16, targets="gate_proj,up_proj,down
         worst = max(worst, rel)
     return {"layers": cfg.num_hidden_layers, "adapters": len(per), "worst_rel": worst, "per_param": per, "losses_hip_vs_oracle": losses,
             "max_abs_dloss": max(abs(a - b) for a, b in losses.values()), "oracle_seconds": t_ref,
-            "grad_absmax_min": min(Wl[n].grad.abs().max().item() for n in lora.names)}
+            "grad_absmax_min": min(Wl[n].grad.abs().max().item() for n in lora.names),
+            "zero_gradients": [n for n in lora.names if Wl[n].grad.abs().max().item() == 0.0]}
 
