@@ -16,7 +16,7 @@ from . import model as OM
 from . import ops as O
 
 
-def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None):
+def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0):
     """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
     through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline)."""
     from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
@@ -25,9 +25,13 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     cfg = copy.deepcopy(cfg)
     cfg.moe_gate_sampling = False
     W = OM.init_hf_weights_aliased(cfg, seed=seed)
-    batch = OM.make_batch(cfg, 1, L=64, H=H, Wd=Wd, seed=batch_seed)
+    if icl_ctx:                                   # BASELINE config 5 shape: icl_ctx in-context (image, mask) pairs + the query, separate mode
+        batch = OM.make_batch_icl(cfg, 1, n_ctx=icl_ctx, H=H, Wd=Wd, seed=batch_seed, mask_size=cfg.clip_image_size)
+        batch["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]
+    else:
+        batch = OM.make_batch(cfg, 1, L=64, H=H, Wd=Wd, seed=batch_seed)
+        batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
     batch["images"] = batch["images"].to(torch.bfloat16).float()
-    batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
     train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
     Wt = dict(W)
     for k in train:
@@ -51,7 +55,9 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     m.load_hf_state_dict(W)
     m.capture_intermediates = True
     gb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-    gb["masks_list"] = [x.to(device) for x in batch["masks_list"]]
+    for k in ("masks_list", "images_clip", "mask_images"):
+        if isinstance(batch.get(k), (list, tuple)):
+            gb[k] = [x.to(device) for x in batch[k]]
     with torch.no_grad():
         out = m(**gb)
         losses_gpu = {k: float(out[k]) for k in O.LOSS_KEYS}

@@ -1492,6 +1492,23 @@ def test_lora_gradients_moe_at_true_dims(dev, cf):
     assert r["max_abs_dloss"] < 2e-2, r["losses_hip_vs_oracle"]
 
 
+def test_icl_separate_mode_parity_at_true_dims(dev):
+    """BASELINE config 5 at the true dimensions: ICL separate mode -- three in-context (image, mask) pairs + the query (four 336 x 336
+    CLIP images through the tower and the 576 -> 256 token compressor, three masks through the mask encoder to 64 tokens each), seven
+    placeholders spliced (S = 1250-1320), E = 2 top-1 MoE decoder layers, SAM-Med2D mask head -- whole model_forward, HIP vs the CPU
+    oracle from the same weights (4 decoder layers).  Same bounds as test_full_depth_parity_at_true_dims."""
+    from oracle.parity import full_size_parity
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=4, vocab_size=4096, seg_token_idx=4000, moe_enable=True, mm_token_compress=True,
+                                   mm_compressed_token_count=256, icl_mask_encoder=True, mask_encoder_token_count=64)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    r = full_size_parity(cfg, dev, icl_ctx=3)
+    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
+    assert 1250 <= r["seq_len"] <= 1320, r["seq_len"]
+    assert r["max_abs_dloss_over_10"] < 5e-2, r
+    assert r["hidden_rel_err_agreeing_rows"] < 0.1 and r["hidden_mean_rel_err"] < 2 ** -6, r
+    assert r["abs_ddice"] <= 1e-3 and r["routing_agreement_min"] >= 0.97, r
+
+
 def test_capi_rccl_comm_single_rank(dev):
     """The C-ABI RCCL helpers (mp_comm_unique_id / mp_comm_init / mp_allreduce_bucket / mp_alltoall_tokens, SURVEY §8b Face 2) on a
     one-rank communicator: a SUM over one rank and an exchange with oneself are identities — this checks the binding, the stream
