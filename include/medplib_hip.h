@@ -326,8 +326,9 @@ int mp_rmsnorm_wgrad_f32(const void* x, int64_t ldx, const void* dy, int64_t ldy
                          int64_t partial_floats, int64_t rows, int dim, hipStream_t stream);
 /* silu(gate) * up and its autograd on the gate|up GEMM output [tokens, 2*ff] whose columns are interleaved in blocks of 32 (the
  * fused weight layout); act / dact [tokens, ff]. */
-int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, hipStream_t stream);
-int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream);
+/* (counts / cap, optional: the rows are capacity slabs [E, cap, .]; only the first counts[e] rows of slab e are processed) */
+int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, const int* counts, int cap, hipStream_t stream);
+int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, const int* counts, int cap, hipStream_t stream);
 /* out[n, j] = scale * sum_t X[t, n] * G[t, j] (fp32 [N, R], R in {8, 16, 32}): the LoRA weight gradients dB = dY^T (x A^T) and
  * dA^T = x^T (dY B) — reads X once (p > 0: X is the UNdropped adapter input and mp_dropout_bf16's mask over the contiguous [tokens, N]
  * tensor is applied on the way; G must be readable for 16 columns per 16 ranks: the padded [tokens, 64] adapter tensors are); `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending

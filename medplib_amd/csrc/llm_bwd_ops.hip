@@ -72,11 +72,14 @@ __global__ __launch_bounds__(RB_THREADS) void rmsnorm_bwd_kernel(const bf16_t* _
 }
 
 // gate|up interleaved in blocks of 32: column blk*64 + j = gate channel blk*32 + j, column blk*64 + 32 + j = its up channel
-__global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int64_t T, int ff, int64_t ldact) {
+// (counts / cap, optional: the rows are capacity slabs [E, cap, .] of which only the first counts[e] of slab e hold routed tokens -- the rest is skipped)
+__global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int64_t T, int ff, int64_t ldact,
+                                       const int* __restrict__ counts, int cap) {
   const int per_row = ff / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * per_row) return;
   const int64_t t = idx / per_row;
+  if (counts && (int)(t % cap) >= counts[t / cap]) return;
   const int c = (int)(idx % per_row) * 8;                 // act channel (8 consecutive, inside one block of 32)
   const int64_t col = (int64_t)(c >> 5) * 64 + (c & 31);
   const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col);
@@ -88,11 +91,12 @@ __global__ void swiglu_pair_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __
 }
 
 __global__ void swiglu_pair_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu, int64_t T,
-                                       int ff) {
+                                       int ff, const int* __restrict__ counts, int cap) {
   const int per_row = ff / 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * per_row) return;
   const int64_t t = idx / per_row;
+  if (counts && (int)(t % cap) >= counts[t / cap]) return;
   const int c = (int)(idx % per_row) * 8;
   const int64_t col = (int64_t)(c >> 5) * 64 + (c & 31);
   const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * 2 * ff + col);
@@ -982,19 +986,19 @@ extern "C" int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, c
   return mp_check_launch("mp_rmsnorm_bwd_bf16");
 }
 
-extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, hipStream_t stream) {
-  MP_REQUIRE(ff % 32 == 0 && ldact >= ff && ldact % 8 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_fwd_bf16: ff %% 32 != 0 or bad ldact");
+extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, const int* counts, int cap, hipStream_t stream) {
+  MP_REQUIRE(ff % 32 == 0 && ldact >= ff && ldact % 8 == 0 && (!counts || cap > 0), MP_ERR_SHAPE, "mp_swiglu_pair_fwd_bf16: ff %% 32 != 0 or bad ldact / cap");
   const int64_t n = tokens * (ff / 8);
   if (n == 0) return MP_OK;
-  hipLaunchKernelGGL(swiglu_pair_fwd_kernel, GRID1D(n), (const bf16_t*)gu, (bf16_t*)act, tokens, ff, ldact);
+  hipLaunchKernelGGL(swiglu_pair_fwd_kernel, GRID1D(n), (const bf16_t*)gu, (bf16_t*)act, tokens, ff, ldact, counts, cap);
   return mp_check_launch("mp_swiglu_pair_fwd_bf16");
 }
 
-extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, hipStream_t stream) {
+extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t tokens, int ff, const int* counts, int cap, hipStream_t stream) {
   MP_REQUIRE(ff % 32 == 0, MP_ERR_SHAPE, "mp_swiglu_pair_bwd_bf16: ff %% 32 != 0");
   const int64_t n = tokens * (ff / 8);
   if (n == 0) return MP_OK;
-  hipLaunchKernelGGL(swiglu_pair_bwd_kernel, GRID1D(n), (const bf16_t*)gu, (const bf16_t*)dact, (bf16_t*)dgu, tokens, ff);
+  hipLaunchKernelGGL(swiglu_pair_bwd_kernel, GRID1D(n), (const bf16_t*)gu, (const bf16_t*)dact, (bf16_t*)dgu, tokens, ff, counts, cap);
   return mp_check_launch("mp_swiglu_pair_bwd_bf16");
 }
 

@@ -370,7 +370,7 @@ def _moe_fwd(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     if "down_x" in lw:
         actx = empty(E, cap, ff + 64)
         act = actx[:, :, :ff]
-        ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff), out=actx.view(E * cap, ff + 64)[:, :ff])
+        ops.swiglu_pair_fwd(gu.view(E * cap, 2 * ff), out=actx.view(E * cap, ff + 64)[:, :ff], counts=kept, cap=cap)
         for e in range(E):
             ops.lora_down(act[e], pad["down"][0][e], actx[e][:, ff:], pad["down"][4], lora.p_active, (seed + 1) * 16 + e, rows_dev=kept[e:e + 1])
         y = ops.gemm_batched(actx, lw["down_x"], empty(E, cap, d), m_dev=kept)
@@ -520,7 +520,8 @@ def _moe_bwd(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
     if "down" in pad:
         d_act, dB, dAT = (_adapter_bwd_moe_fused if fused_down else _adapter_bwd_moe)(lora, pad["down"], d_y, s["actd"], s["t_d"], d_act, kept, s["seed"] + 1)
         take_e(i, pad["down"], dB, dAT)
-    d_gu = ops.swiglu_pair_bwd(s["gu"].view(E * cap, 2 * ff), d_act.view(E * cap, ff)).view(E, cap, 2 * ff)
+    d_gu = ops.swiglu_pair_bwd(s["gu"].view(E * cap, 2 * ff), d_act.view(E * cap, ff), counts=kept if (fused_gu and fused_down) else None,
+                               cap=cap).view(E, cap, 2 * ff)
     d_buf = ops.gemm_batched(d_gu, lw["gu_T"], slab(E, cap, d), m_dev=kept)
     if "gu" in pad:
         d_buf, dB, dAT = (_adapter_bwd_moe_fused if fused_gu else _adapter_bwd_moe)(lora, pad["gu"], d_gu, s["bufd"], s["t_gu"], d_buf, kept, s["seed"])

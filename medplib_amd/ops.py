@@ -299,18 +299,19 @@ def rmsnorm_bwd(x, w, dy, eps, add=None, want_wgrad=False):
     return out, dw
 
 
-def swiglu_pair_fwd(gu, out=None):
+def swiglu_pair_fwd(gu, out=None, counts=None, cap=0):
+    """counts / cap: the rows are capacity slabs [E * cap, .]; only the first counts[e] rows of slab e are processed (the rest is left alone)."""
     T, ff2 = gu.shape
     act = torch.empty((T, ff2 // 2), dtype=torch.bfloat16, device=gu.device) if out is None else out
     assert gu.is_contiguous() and act.shape == (T, ff2 // 2) and act.stride(1) == 1
-    lib().call("mp_swiglu_pair_fwd_bf16", _p(gu), _p(act), act.stride(0), T, ff2 // 2, _stream())
+    lib().call("mp_swiglu_pair_fwd_bf16", _p(gu), _p(act), act.stride(0), T, ff2 // 2, _p(counts), int(cap), _stream())
     return act
 
 
-def swiglu_pair_bwd(gu, dact):
+def swiglu_pair_bwd(gu, dact, counts=None, cap=0):
     T, ff2 = gu.shape
     dgu = torch.empty_like(gu)
-    lib().call("mp_swiglu_pair_bwd_bf16", _p(gu), _p(dact), _p(dgu), T, ff2 // 2, _stream())
+    lib().call("mp_swiglu_pair_bwd_bf16", _p(gu), _p(dact), _p(dgu), T, ff2 // 2, _p(counts), int(cap), _stream())
     return dgu
 
 
