@@ -476,8 +476,11 @@ class MedPLIBForCausalLM(nn.Module):
         # launches (windowed attention, adapter convolutions on 64-token maps) fill in beside the LLM's GEMMs instead of
         # occupying the machine alone.  Joined again before the mask tail.
         image_tokens = None
-        ahead = (self.towers_run_ahead and getattr(m.llm, "lora", None) is None and not (region_masks is not None and len(region_masks) > 0)
-                 and kwargs.get("mask_images") is None and torch.is_tensor(images_clip))
+        lo_ = getattr(m.llm, "lora", None)
+        front_frozen = lo_ is None or not any(n.startswith(("model.mm_projector.", "model.mm_token_compressor.", "model.region_fea_adapter.",
+                                                             "model.mask_encoder.")) for n in lo_.names)
+        ahead = (self.towers_run_ahead and front_frozen and not getattr(self, "_want_raw_feats", False)
+                 and not (region_masks is not None and len(region_masks) > 0) and kwargs.get("mask_images") is None and torch.is_tensor(images_clip))
         if seg_flag and self.sam_side_stream:
             main = torch.cuda.current_stream()
             side = self._side_stream()
