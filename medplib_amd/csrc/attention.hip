@@ -13,6 +13,7 @@
 // hardware transpose read ds_read_b64_tr_b16 (VT_SCALAR=true keeps a scalar-transposed staging as a cross-check path).
 // The [S,S] score matrix is never materialised (the reference materialises [B,32,S,S] fp32).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -36,6 +37,7 @@ struct AttnArgs {
   float scale;
   const int* sk_dev;         // optional: number of valid keys read from device memory (<= Sk); decode steps inside a HIP graph
   float* lse2;               // optional [B*H, Sq]: row log-sum-exp of the scaled scores in the log2 domain (for the backward; v2 kernel)
+  int bh_chunk;              // v2 kernel: (batch, head) pairs per chunk of the workgroup order (0 = all: the plain order)
 };
 
 template <int D>
@@ -280,8 +282,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   // grid = (batch*heads, query blocks): the dispatcher walks x fastest, so with the query-block index REVERSED every (batch, head)'s
   // heaviest causal block (most key tiles) starts first and the 2-tile blocks fill the tail (longest-processing-time order)
-  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
-  const int q0 = (a.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * 128;
+  // Round 2: ... inside CHUNKS of 64 (batch, head) pairs.  With all of a query-block rank's 256 (batch, head) pairs ahead of the next rank, the
+  // five blocks of one (batch, head) ran a whole round of workgroups apart and each re-fetched its K / V (327 KB) through an L2 that had seen
+  // 255 other heads in between; now they are 64 workgroup ids apart -- the same XCD (ids equal modulo 8), the same round -- and an XCD
+  // holds the K / V of the 8 heads of a chunk it is working on (2.6 MB of its 4 MiB L2).  MP_ATTN_CHUNK=0 restores the plain order (A/B).
+  int bh, qrank;
+  {
+    const int BH = gridDim.x, nqb = gridDim.y;
+    const int L = blockIdx.y * BH + blockIdx.x;               // dispatch order
+    const int CH = a.bh_chunk > 0 ? a.bh_chunk : BH;
+    const int nch = (BH + CH - 1) / CH;
+    const int chunk = min(L / (CH * nqb), nch - 1);
+    const int cs = min(CH, BH - chunk * CH);
+    const int rem = L - chunk * CH * nqb;
+    qrank = rem / cs;
+    bh = chunk * CH + rem % cs;
+  }
+  const int b = bh / a.H, h = bh % a.H;
+  const int q0 = (a.causal ? (int)(gridDim.y - 1 - qrank) : qrank) * 128;
   const int qw0 = q0 + wave * 32;
 
   const bf16_t* Qb = a.Q + b * a.q_sb + (int64_t)h * D;
@@ -474,8 +492,12 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  static int chunk = -1;
+  if (chunk < 0) { const char* e = getenv("MP_ATTN_CHUNK"); chunk = e ? atoi(e) : 64; }
+  AttnArgs ac = a;
+  ac.bh_chunk = chunk;
   dim3 grid(a.B * a.H, (a.Sq + 127) / 128);
-  hipLaunchKernelGGL((attn_fwd2_kernel<D>), grid, dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((attn_fwd2_kernel<D>), grid, dim3(256), LDS, stream, ac);
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }
 
