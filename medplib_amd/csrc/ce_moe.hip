@@ -194,23 +194,51 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
   const int chunk = (T + 1023) / 1024;
   const int s0 = min(T, tid * chunk), s1 = min(T, s0 + chunk);
   int ex[FAST ? 16 : 1];
-  for (int s = FAST ? s0 : tid; s < (FAST ? s1 : T); s += FAST ? 1 : 1024) {
-    int best = 0;
-    float bv = gates[(int64_t)s * E];
+  if constexpr (FAST) {
+    // expert by expert with the whole chunk's gate values of that expert in flight together: E round trips to memory instead of one per
+    // token (a runtime-length token loop is not unrolled, and each of its iterations waited for its own loads)
+    float bvv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { bvv[i] = 0.f; ex[i] = 0; }
     for (int e = 0; e < E; ++e) {
-      const float g = gates[(int64_t)s * E + e];
-      if (e > 0 && g > bv) { bv = g; best = e; }
+      float gcol[16];
 #pragma unroll
-      for (int k = 0; k < MAXE; ++k) if (k == e) me[k] += g;
+      for (int i = 0; i < 16; ++i) gcol[i] = (s0 + i < s1) ? gates[(int64_t)(s0 + i) * E + e] : 0.f;
+      float msum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (s0 + i < s1) {
+          if (e == 0 || gcol[i] > bvv[i]) { bvv[i] = gcol[i]; ex[i] = e; }
+          msum += gcol[i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) if (k == e) me[k] = msum;
     }
-    expert[s] = best;
-    weight[s] = bv;
-    if constexpr (FAST) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) if (i == s - s0) ex[i] = best;
+    for (int i = 0; i < 16; ++i) {
+      if (s0 + i < s1) {
+        expert[s0 + i] = ex[i];
+        weight[s0 + i] = bvv[i];
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) if (k == ex[i]) cnt[k] += 1;
+      }
     }
+  } else {
+    for (int s = tid; s < T; s += 1024) {
+      int best = 0;
+      float bv = gates[(int64_t)s * E];
+      for (int e = 0; e < E; ++e) {
+        const float g = gates[(int64_t)s * E + e];
+        if (e > 0 && g > bv) { bv = g; best = e; }
 #pragma unroll
-    for (int k = 0; k < MAXE; ++k) if (k == best) cnt[k] += 1;
+        for (int k = 0; k < MAXE; ++k) if (k == e) me[k] += g;
+      }
+      expert[s] = best;
+      weight[s] = bv;
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) if (k == best) cnt[k] += 1;
+    }
   }
   float aux = 0.f;
   for (int e = 0; e < E; ++e) {
