@@ -33,6 +33,17 @@ def _stale(src, obj, deps):
     return any(os.path.getmtime(d) > t for d in [src] + deps)
 
 
+def _file_flags(src):
+    """Extra hipcc flags a source asks for itself with a `// build-flags: ...` line in its header comment (e.g. the MFMA
+    register-form switch of the attention backward, which is a per-translation-unit LLVM option)."""
+    flags = []
+    with open(src) as f:
+        for _, line in zip(range(60), f):
+            if line.startswith("// build-flags:"):
+                flags += line.split(":", 1)[1].split()
+    return flags
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -47,7 +58,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + _file_flags(src) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return src, r.returncode, r.stdout
 

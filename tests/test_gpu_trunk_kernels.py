@@ -327,7 +327,8 @@ def test_decode_norm_gate_route_equals_separate_kernels(dev):
             assert torch.equal(a, b), (name, T, E, d, a, b)
 
 
-@pytest.mark.parametrize("B,H,S,D,ragged", [(2, 3, 150, 128, True), (1, 2, 300, 128, False), (2, 2, 200, 64, True), (1, 1, 64, 128, False)])
+@pytest.mark.parametrize("B,H,S,D,ragged", [(2, 3, 150, 128, True), (1, 2, 300, 128, False), (2, 2, 200, 64, True), (1, 1, 64, 128, False),
+                                            (1, 2, 639, 128, False), (1, 1, 449, 64, False)])
 def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
     """mp_attention_bwd_bf16 (+ the forward's log-sum-exp, delta) vs torch autograd of the eager fp32 attention on the same
     bf16-rounded q, k, v, dO: causal mask + key padding (HF-4.31 LlamaAttention semantics).  Tolerance: the kernel
@@ -353,14 +354,16 @@ def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
     _report("attention fwd (lse variant)", out, ref.detach(), rtol=3 * BF16_EPS, atol=2e-2)
     lse_ref = torch.logsumexp(sc.detach(), dim=-1).reshape(B * H, S) * 1.4426950408889634
     assert (lse2.cpu() - lse_ref).abs().max().item() < 2e-2
-    dq, dk, dv, _ = ops.attention_bwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], out, d_out.to(dev), lse2, causal=True, key_valid=kvd)
-    torch.cuda.synchronize()
-    for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
-        err = (got.float().cpu() - want).abs().max().item()
-        print(f"attention bwd {name}: max|err| {err:.3e}, ref absmax {want.abs().max().item():.3e}")
-        assert err <= 2e-2 * want.abs().max().item() + 1e-3, name
-    if ragged:                                  # padded keys receive no gradient
-        assert float(dk[0, S - 17:].abs().max()) == 0.0 and float(dv[0, S - 17:].abs().max()) == 0.0
+    for fused in (True, False):                 # delta inside the dQ kernel (mp_attention_bwd_fused_bf16) / the separate delta pass
+        dq, dk, dv, _ = ops.attention_bwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], out, d_out.to(dev), lse2, causal=True, key_valid=kvd,
+                                          fused_delta=fused)
+        torch.cuda.synchronize()
+        for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
+            err = (got.float().cpu() - want).abs().max().item()
+            print(f"attention bwd (fused_delta={fused}) {name}: max|err| {err:.3e}, ref absmax {want.abs().max().item():.3e}")
+            assert err <= 2e-2 * want.abs().max().item() + 1e-3, name
+        if ragged:                                  # padded keys receive no gradient
+            assert float(dk[0, S - 17:].abs().max()) == 0.0 and float(dv[0, S - 17:].abs().max()) == 0.0
 
 
 def test_decoder_backward_row_kernels(dev):
