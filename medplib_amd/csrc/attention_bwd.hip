@@ -262,6 +262,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
             dsb[f >> 1][j][(f & 1) * 4 + r] = (bf16_t)ds;
           }
       }
+    } else if (a.causal && (kv == nullptr) && (s0 + TT <= Sstr) && (rw0 + 32 <= Sres)) {
+      // diagonal tile, everything in range: key <= query is ONE compare of a per-lane constant against a wave-uniform threshold
+      //   dK/dV: key = rw0 + j*16 + fr, query = s0 + f*16 + fq*4 + r   <=>   fr - fq*4 <= (s0 - rw0) + (f - j)*16 + r
+      //   dQ   : key = s0 + f*16 + fq*4 + r, query = rw0 + j*16 + fr   <=>   fq*4 - fr <= (rw0 - s0) + (j - f)*16 - r
+      const int dl = DKV ? (fr - fq * 4) : (fq * 4 - fr);
+      const int base = DKV ? (s0 - rw0) : (rw0 - s0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 Lr = {0.f, 0.f, 0.f, 0.f}, Dr = {0.f, 0.f, 0.f, 0.f};
+        if (DKV) {
+          const float* st = reinterpret_cast<const float*>(sStat + stage * STAT_BYTES + f * 256);
+          Lr = *reinterpret_cast<const f32x4*>(st + fq * 4);
+          Dr = *reinterpret_cast<const f32x4*>(st + 16 + fq * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = dl <= base + (DKV ? (f - j) * 16 + r : (j - f) * 16 - r);
+            const float L = DKV ? Lr[r] : Lq[j], dl2 = DKV ? Dr[r] : Dq[j];
+            const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[f][j][r], c2, -L)) : 0.f;
+            const float ds = p * (dp[f][j][r] - dl2);
+            pb[f >> 1][j][(f & 1) * 4 + r] = (bf16_t)p;
+            dsb[f >> 1][j][(f & 1) * 4 + r] = (bf16_t)ds;
+          }
+      }
     } else {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {

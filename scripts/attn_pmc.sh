@@ -18,6 +18,7 @@ torch.cuda.synchronize()
 PY
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU --output-format csv -d $out/p1 -- python /tmp/attn_one.py > $out/p1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $out/p2 -- python /tmp/attn_one.py > $out/p2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY --output-format csv -d $out/p3 -- python /tmp/attn_one.py > $out/p3.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 res = collections.defaultdict(list)
