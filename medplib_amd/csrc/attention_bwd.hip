@@ -17,6 +17,15 @@
 // AGPRs; every score / dP value the VALU then touches, and everything spilled around the 256-register accumulator sets, travels through
 // v_accvgpr_read / _write: 854 of the dK/dV kernel's ~1170 VALU instructions per tile were such moves (rocprofv3: 9.1 VALU instructions
 // per MFMA).  The VGPR form keeps the products where the VALU reads them; ~100 moves remain in the whole kernel.
+//
+// Round-2 accounting (B 8, H 32, S 639, D 128; rocprofv3 counters, scripts/attn_bwd_pmc.sh): 374 -> 272 us for the whole backward (VGPR-form
+// MFMAs -4 %, conflict-free swizzle + interior-tile path -10 %, delta inside the dQ kernel -5 %, one-compare diagonal tiles -5 %, two dQ
+// workgroups per CU -2 %).  What is left per streamed tile of the dK/dV kernel: 2048 MFMA-pipe cycles, ~3000 VALU cycles (754 instructions:
+// exp2, fma, two bf16 roundings per element and the register traffic around the 256 accumulator + resident registers), ~4000 LDS-pipe cycles
+// for the workgroup (every wave reads the whole X and Y tile twice, once row-major, once transposed: 64 KB per wave and tile), and with one
+// wave per SIMD the three follow each other instead of overlapping: ~12 K cycles per tile against the 2 K of the MFMA pipe.  A four-stage
+// ring (MP_ATTN_BWD_STAGES=4) does not help (the DMA wait is 6 % of the time); halving the resident columns per wave to fit two waves per
+// SIMD doubles the LDS traffic per MFMA, which is already level with the MFMA time.
 #include "common.h"
 
 namespace {
@@ -66,8 +75,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kp, int n, int f
   return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int D, bool DKV, int NST>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
+template <int D, bool DKV, int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(AttnBwdArgs a) {
   constexpr int TT = 64, CH = D / 8, NF = D / 16, KS = D / 32;
   constexpr int TILE_BYTES = TT * D * 2;
   constexpr int PD = NST - 1;                     // prefetch distance in tiles: the ring holds the tile in use + PD tiles in flight
@@ -380,12 +389,18 @@ int launch_bwd_n(const AttnBwdArgs& a, hipStream_t stream) {
   constexpr int LDS = NST * 2 * 64 * D * 2 + NST * 1024;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, false, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, true, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, false, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, false, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<D, true, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<D, false, NST>), dim3(a.B * a.H, (a.Sq + 127) / 128), dim3(256), LDS, stream, a);
-  hipLaunchKernelGGL((attn_bwd_kernel<D, true, NST>), dim3(a.B * a.H, (a.Sk + 127) / 128), dim3(256), LDS, stream, a);
+  // the dQ kernel (one accumulator set) fits 256 registers with 17 spilled: two workgroups per CU hide some of the LDS / DMA latency that a
+  // single wave per SIMD exposes -- 279 -> 272.5 us for the whole backward at B 8, S 639, same box.  MP_ATTN_BWD_OCC2=0: one per CU (A/B).
+  static int occ2 = -1;
+  if (occ2 < 0) { const char* e = getenv("MP_ATTN_BWD_OCC2"); occ2 = (e && atoi(e) == 0) ? 0 : 1; }
+  if (occ2 && NST == 2) hipLaunchKernelGGL((attn_bwd_kernel<D, false, NST, 2>), dim3(a.B * a.H, (a.Sq + 127) / 128), dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((attn_bwd_kernel<D, false, NST, 1>), dim3(a.B * a.H, (a.Sq + 127) / 128), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<D, true, NST, 1>), dim3(a.B * a.H, (a.Sk + 127) / 128), dim3(256), LDS, stream, a);
   return mp_check_launch("mp_attention_bwd_bf16");
 }
 

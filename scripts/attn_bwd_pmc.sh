@@ -32,3 +32,12 @@ for kname, cs in res.items():
     for k, v in sorted(cs.items()):
         print(f"   {k:28s} {sum(v) / len(v):16.1f}")
 PY
+python - <<'PY'
+import csv, glob, collections
+d = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/attn_bwd_pmc/p1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        d[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in d.items():
+    if "attn" in k: print(f"{k:72s} n={len(v)} avg {sum(v)/len(v):8.1f} us  min {min(v):8.1f}")
+PY
