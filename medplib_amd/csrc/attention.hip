@@ -268,7 +268,9 @@ __device__ __forceinline__ int v_key(int row) {
   return row & (PB - 1);
 }
 
-template <int D>
+// GENERAL = false: no key-padding mask and no rel-pos bias (the un-padded Llama batch, CLIP) -- the masked tiles (causal diagonal, last
+// partial key tile) then need no per-element index arithmetic: both tests compare a per-lane constant with a wave-uniform threshold.
+template <int D, bool GENERAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
   constexpr int KT = 64, CH = D / 8, NF = D / 16, KS = D / 32;
@@ -305,9 +307,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   const bf16_t* Qb = a.Q + b * a.q_sb + (int64_t)h * D;
   const bf16_t* Kb = a.K + b * a.k_sb + (int64_t)h * D;
   const bf16_t* Vb = a.V + b * a.v_sb + (int64_t)h * D;
-  const uint8_t* kv = a.key_valid ? a.key_valid + (int64_t)b * a.Sk : nullptr;
-  const float* relh = a.rel_h ? a.rel_h + (int64_t)bh * a.Sq * a.kh : nullptr;
-  const float* relw = a.rel_w ? a.rel_w + (int64_t)bh * a.Sq * a.kw : nullptr;
+  const uint8_t* kv = (GENERAL && a.key_valid) ? a.key_valid + (int64_t)b * a.Sk : nullptr;
+  const float* relh = (GENERAL && a.rel_h) ? a.rel_h + (int64_t)bh * a.Sq * a.kh : nullptr;
+  const float* relw = (GENERAL && a.rel_w) ? a.rel_w + (int64_t)bh * a.Sq * a.kw : nullptr;
 
   int n_tiles = (a.Sk + KT - 1) / KT;
   if (a.causal) n_tiles = min(n_tiles, (min(q0 + 128, a.Sq) + KT - 1) / KT);
@@ -393,6 +395,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
         // interior tile: the max is taken on the raw scores (c2 > 0 commutes with max) and the scaling rides in the exp's fma
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
+        mx *= c2;
+      } else if (!GENERAL) {
+        // key kj = k0 + kf*16 + fq*4 + r, query qi = qw0 + j*16 + fr:
+        //   kj < Sk    <=>  fq*4      <= (Sk - 1 - k0) - kf*16 - r
+        //   kj <= qi   <=>  fq*4 - fr <= (qw0 - k0 + j*16) - kf*16 - r
+        const int fb = fq * 4, bb = a.Sk - 1 - k0;
+        const int dl = a.causal ? fq * 4 - fr : 0, cb = a.causal ? qw0 - k0 + j * 16 : 1 << 20;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (fb <= bb - kf * 16 - r) && (dl <= cb - kf * 16 - r);
+            const float v = ok ? s[kf][j][r] : -INFINITY;
+            s[kf][j][r] = v;
+            mx = fmaxf(mx, v);
+          }
         mx *= c2;
       } else {
         const int qc = min(qi, a.Sq - 1);
@@ -491,13 +509,20 @@ template <int D>
 int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
   static int chunk = -1;
   if (chunk < 0) { const char* e = getenv("MP_ATTN_CHUNK"); chunk = e ? atoi(e) : 64; }
   AttnArgs ac = a;
   ac.bh_chunk = chunk;
   dim3 grid(a.B * a.H, (a.Sq + 127) / 128);
-  hipLaunchKernelGGL((attn_fwd2_kernel<D>), grid, dim3(256), LDS, stream, ac);
+  static int plain = -1;
+  if (plain < 0) { const char* e = getenv("MP_ATTN_PLAIN"); plain = (e && atoi(e) == 0) ? 0 : 1; }      // 0: always the general kernel (A/B)
+  if (plain && !a.key_valid && !a.rel_h) hipLaunchKernelGGL((attn_fwd2_kernel<D, false>), grid, dim3(256), LDS, stream, ac);
+  else hipLaunchKernelGGL((attn_fwd2_kernel<D, true>), grid, dim3(256), LDS, stream, ac);
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }
 
