@@ -46,12 +46,16 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
 
 // Epilogue: alpha / bias / activation (rounded to bf16) then the residual add, or the RoPE pairing of a q / k tile (same arithmetic and
 // rounding points as gemm256_epilogue_t; 16-byte pieces only: the launcher guarantees the alignment).
+// ROPE: the kernel is instantiated once per epilogue family -- with both in one function the register allocator sized the epilogue for the
+// RoPE path and spilled 362 VGPRs; the PLAIN path then wrote and re-read its accumulators through scratch (K sweep at 256 tiles: 35 us of
+// fixed cost per launch, 28 of them the epilogue).
+template <bool ROPE>
 __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int M, int N, int m0, int n0, int wr, int wc,
                                                  int fr, int fq) {
   bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
   const int cw = n0 + wc * 128;
   const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
-  if (g.act == ACT_ROPE_QK && n0 < (N / 3) * 2) {
+  if (ROPE && n0 < (N / 3) * 2) {
     // the wave's 128 columns are one head: fragments 0,1 | 2,3 hold [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63]
     const int head0 = (cw >> 7) << 7;
     bf16x4 qk[5][8];                                      // the projection output rounded to bf16 (its own rounding point): 80 registers for 160
@@ -124,10 +128,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = (EXPR); }         \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-  switch (g.act) {
-    case ACT_QUICK_GELU: MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) break;
-    default: break;
-  }
+  if (!ROPE && g.act == ACT_QUICK_GELU) { MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) }
 #undef MP3_ACT_SWEEP
   // ---- stores, in two column halves of the wave tile (the residual pieces of a half are all requested before the first is used)
   const bf16_t* R = g.residual;
@@ -165,6 +166,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
   }
 }
 
+template <bool ROPE>
 __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = g.M, N = g.N;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   // arithmetic is kept in registers across the K loop
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
-  gemm320_epilogue(g, acc, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
+  gemm320_epilogue<ROPE>(g, acc, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
 }
 
 }  // namespace
@@ -321,10 +323,12 @@ bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
 int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
     attr = true;
   }
   const int tiles = (int)(mp_cdiv(g.M, BM3) * (g.N / BN3));
-  hipLaunchKernelGGL(gemm320_bf16_nt_kernel, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
+  if (g.act == ACT_ROPE_QK) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<true>, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
+  else hipLaunchKernelGGL(gemm320_bf16_nt_kernel<false>, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
   return mp_check_launch("mp_gemm_bf16_nt(320)");
 }

@@ -330,15 +330,21 @@ static bool use_256_rule(const GemmArgs& g, int batch) {
   return g.M >= 1024 && g.N >= min_n && tiles >= min_tiles;
 }
 
+// what the RoPE epilogue of the 320-row kernel costs on top of the plain one, in microseconds per wave of tiles (see gemm320_bf16.hip)
+#define MP_GEMM320_ROPE_EXTRA_US 28.0
 // implemented in gemm256_bf16.hip (cached per device) / gemm320_bf16.hip
 int mp_device_cus();
 bool mp_gemm320_eligible(const GemmArgs& g, int batch);
 int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream);
 
-// 320-row or 256-row tiles for a dense call?  Modelled cost in units of one 256x256 tile's time on the device's CUs: the 256 tiling pays
-// floor(T / C) full waves plus a tail (a whole tile-time when more than half the CUs have a tile, else 1 / S of one for the S-way split
-// plus ~0.3 for the partials' round trip through memory: measured 0.67 at K = 4096 with S = 4, 0.5 at K = 11008); the 320 tiling pays
-// 1.35 per wave, all waves whole (it has no tail split).  MP_GEMM320 = 0 never, 2 whenever eligible, default 1 = by this model.
+// 320-row tiles, or the kernel the call would otherwise get?  Modelled time in microseconds, from K sweeps at one full wave of tiles
+// (scripts/gemm_ksweep.py, same box): a wave of 256x256 tiles costs 8.5 + 1.45 per 64-deep K step (prologue + epilogue, then 1480-1530
+// TFLOP/s in the loop), a wave of 320x256 tiles 4.5 + 1.685 per step (1590-1640 TFLOP/s in the loop; the fixed part was 30 us until the
+// kernel was split by epilogue family, see gemm320_bf16.hip); a residual epilogue adds ~8 to either, QuickGELU ~6.  The 256 tiling pays
+// floor(T / C) whole waves plus a tail (a whole wave when more than half the CUs have a tile, else 1 / S of one for the S-way split
+// plus ~0.3 for the partials' round trip through memory); the 320 tiling has no tail split: all its waves are whole.  Where the 256x256
+// rule does not apply (short K with a small second wave, narrow N) the alternative is the 128x128 kernel at the ~560 TFLOP/s it reaches
+// on such shapes (CLIP fc1: 72 us against 43.5 on 320-row tiles).  MP_GEMM320 = 0 never, 2 whenever eligible, default 1 = by this model.
 static thread_local int g_tile_policy = -1;          // mp_gemm_tile_policy(): -1 = the process default (MP_GEMM320, else 1)
 static bool use_320(const GemmArgs& g, int batch) {
   static int env_mode = -1;
@@ -346,21 +352,26 @@ static bool use_320(const GemmArgs& g, int batch) {
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
   if (mode == 2) return true;
-  // short K (CLIP fc1: 16 K-tiles + bias + QuickGELU): one workgroup per CU serialises prologue, K loop and a 160-accumulator epilogue;
-  // the 128x128 kernel's two co-resident workgroups overlap them (70.5 vs 73.9 us, scripts/gemm_tile_ab.py)
-  if (g.K < 2048) return false;
   const int C = std::min(mp_device_cus(), 256);
   const int64_t t256 = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256), t320 = mp_cdiv(g.M, 320) * (g.N / 256);
-  const int64_t rem = t256 % C;
-  double c256 = (double)(t256 / C);
-  if (rem > 0) {
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(C / rem, 8), g.K / 64 / 4));
-    c256 += (rem * 2 > C || S == 1) ? 1.0 : 1.0 / S + 0.3;
+  if (t320 * 2 < C) return false;                     // fewer workgroups than half the CUs: the smaller tiles (or a K split) fill the machine better
+  const double k = g.K / 64.0;
+  const double epi = (g.residual ? 8.0 : 0.0) + (g.act == ACT_QUICK_GELU ? 6.0 : 0.0);
+  const double rope320 = g.act == ACT_ROPE_QK ? MP_GEMM320_ROPE_EXTRA_US : 0.0;
+  const double c320 = (double)mp_cdiv(t320, C) * (4.5 + epi + rope320 + 1.685 * k);
+  double other;
+  if (use_256_rule(g, batch)) {
+    const int64_t rem = t256 % C;
+    double w256 = (double)(t256 / C);
+    if (rem > 0) {
+      const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(C / rem, 8), g.K / 64 / 4));
+      w256 += (rem * 2 > C || S == 1) ? 1.0 : 1.0 / S + 0.3;
+    }
+    other = w256 * (8.5 + epi + 1.45 * k);
+  } else {
+    other = 2.0 * g.M * g.N * g.K / 560e6;
   }
-  // 1.25 x the work per tile, and the taller tile's K loop runs ~7 % below the 256x256 one's (its second load segment carries 7 of the
-  // 9 DMA pieces): qkv at 3.0 waves of 320 measured 420 us against 393 at 3.75 waves of 256, o_proj 154 against 174, down 338 against 369
-  const double c320 = 1.35 * (double)mp_cdiv(t320, C);
-  return c320 < 0.97 * c256;
+  return c320 < 0.98 * other;
 }
 
 // which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)
