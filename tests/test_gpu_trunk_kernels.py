@@ -579,14 +579,17 @@ def test_gemm_320_row_tile_kernel(dev):
         ops.gemm_tile_policy(0)
         ref = ops.gemm_qkv_rope(a, wi, cos_t, sin_t, S, heads, D, pos_offset=2)
         assert ops.gemm_last_kernel() == 256 and torch.equal(got, ref), (got.float() - ref.float()).abs().max()
-        # the wave model on 256 CUs at the decoder's row count: the N = 4096 projections go to 320-row tiles, qkv and gate|up stay on 256
+        # the wave model on 256 CUs at the decoder's row count: the dense projections go to 320-row tiles (16 row tiles of 320 are whole
+        # waves where 20 of 256 leave a tail); 2304 rows (9 x 16 tiles of 256 in one wave, 8 x 16 of 320 at 1.25 x the work) stay on 256
         ops.gemm_tile_policy(1)
         a = torch.zeros(5112, 4096, dtype=torch.bfloat16, device=dev)
         picks = {}
         for N in (4096, 12288, 22016):
             ops.gemm(a, torch.zeros(N, 4096, dtype=torch.bfloat16, device=dev))
             picks[N] = ops.gemm_last_kernel()
-        assert picks == {4096: 320, 12288: 256, 22016: 256}, picks
+        assert picks == {4096: 320, 12288: 320, 22016: 320}, picks
+        ops.gemm(a[:2304], torch.zeros(4096, 4096, dtype=torch.bfloat16, device=dev))
+        assert ops.gemm_last_kernel() == 256, ops.gemm_last_kernel()
     finally:
         ops.gemm_tile_policy(-1)
 
