@@ -55,58 +55,59 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
   bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
   const int cw = n0 + wc * 128;
   const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
-  if (ROPE && n0 < (N / 3) * 2) {
-    // the wave's 128 columns are one head: fragments 0,1 | 2,3 hold [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63]
+  if constexpr (ROPE) {
+    // mp_gemm_qkv_rope_bf16 (no bias / residual / alpha).  q and k tiles: the wave's 128 columns are one head, fragments 0,1 | 2,3 hold
+    // [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63].  v tiles (n0 >= 2N/3) go through the SAME loop with the rotation
+    // switched off and the standard column order -- a second, plain store path beside this one in the same function made the register
+    // allocator spill 212 VGPRs (~28 us per wave of tiles), each path alone spills none.
+    // One fragment row (16 tile rows) at a time; the cos / sin pieces of the NEXT row are requested before this row's arithmetic, so the
+    // five table round trips overlap the work and only 64 registers sit beside the accumulators.
+    const bool is_v = n0 >= (N / 3) * 2;                  // wave-uniform
     const int head0 = (cw >> 7) << 7;
-    bf16x4 qk[5][8];                                      // the projection output rounded to bf16 (its own rounding point): 80 registers for 160
+    f32x4 cs[2][2][2], sn[2][2][2];                       // [buffer][jb][j]
+    auto fetch = [&](int i, int buf) {
+      const int row = m0 + wr * 80 + i * 16 + fr;
+      const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+      for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qk[i][j] = round4(acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int jj = 0; jj < 2; ++jj) {
+          const int dim = jb * 32 + jj * 16 + fq * 4;
+          cs[buf][jb][jj] = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)pos * 64 + dim);
+          sn[buf][jb][jj] = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)pos * 64 + dim);
+        }
+    };
+    fetch(0, 0);
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    for (int i = 0; i < 5; ++i) {
+      if (i + 1 < 5) fetch(i + 1, (i + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int row = m0 + wr * 80 + i * 16 + fr;
 #pragma unroll
-      for (int ic = 0; ic < 2; ++ic) {                   // fragment rows {0,1,2}, then {3,4}: the cos / sin pieces of a chunk are fetched together
-        f32x4 cs[3][2], sn[3][2];
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x4 olo[2], ohi[2];
 #pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-          const int i = ic * 3 + ii;
-          if (i < 5) {
-            const int row = m0 + wr * 80 + i * 16 + fr;
-            const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
+        for (int jj = 0; jj < 2; ++jj) {
+          const bf16x4 qa = round4(acc[i][jb * 4 + jj]), qb = round4(acc[i][jb * 4 + jj + 2]);   // the projection output's own rounding point
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int dim = jb * 32 + j * 16 + fq * 4;
-              cs[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)pos * 64 + dim);
-              sn[ii][j] = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)pos * 64 + dim);
-            }
+          for (int r = 0; r < 4; ++r) {
+            const float a = (float)qa[r], b = (float)qb[r];
+            const bf16_t rlo = (bf16_t)(a * cs[i & 1][jb][jj][r] - b * sn[i & 1][jb][jj][r]);
+            const bf16_t rhi = (bf16_t)(b * cs[i & 1][jb][jj][r] + a * sn[i & 1][jb][jj][r]);
+            olo[jj][r] = is_v ? qa[r] : rlo;
+            ohi[jj][r] = is_v ? qb[r] : rhi;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-          const int i = ic * 3 + ii;
-          if (i < 5) {
-            const int row = m0 + wr * 80 + i * 16 + fr;
-            bf16x4 olo[2], ohi[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float a = (float)qk[i][jb * 4 + j][r], b = (float)qk[i][jb * 4 + j + 2][r];
-                olo[j][r] = (bf16_t)(a * cs[ii][j][r] - b * sn[ii][j][r]);
-                ohi[j][r] = (bf16_t)(b * cs[ii][j][r] + a * sn[ii][j][r]);
-              }
-            const bf16x8 plo = pair_swap16(olo[0], olo[1]), phi = pair_swap16(ohi[0], ohi[1]);
-            if (row < M) {
-              *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + jb * 32 + c8) = plo;
-              *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + head0 + 64 + jb * 32 + c8) = phi;
-            }
-          }
+        const bf16x8 plo = pair_swap16(olo[0], olo[1]), phi = pair_swap16(ohi[0], ohi[1]);
+        // q / k: lo half at head0 + jb*32, hi half 64 further; v: fragments 4jb, 4jb+1 are columns cw + 64jb .. +31, fragments 4jb+2, +3 the next 32
+        const int col_lo = (is_v ? cw + jb * 64 : head0 + jb * 32) + c8;
+        const int col_hi = (is_v ? cw + jb * 64 + 32 : head0 + 64 + jb * 32) + c8;
+        if (row < M) {
+          *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col_lo) = plo;
+          *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col_hi) = phi;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }

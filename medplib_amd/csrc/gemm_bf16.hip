@@ -331,7 +331,7 @@ static bool use_256_rule(const GemmArgs& g, int batch) {
 }
 
 // what the RoPE epilogue of the 320-row kernel costs on top of the plain one, in microseconds per wave of tiles (see gemm320_bf16.hip)
-#define MP_GEMM320_ROPE_EXTRA_US 28.0
+#define MP_GEMM320_ROPE_EXTRA_US 6.0
 // implemented in gemm256_bf16.hip (cached per device) / gemm320_bf16.hip
 int mp_device_cus();
 bool mp_gemm320_eligible(const GemmArgs& g, int batch);
