@@ -49,13 +49,84 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
 // ROPE: the kernel is instantiated once per epilogue family -- with both in one function the register allocator sized the epilogue for the
 // RoPE path and spilled 362 VGPRs; the PLAIN path then wrote and re-read its accumulators through scratch (K sweep at 256 tiles: 35 us of
 // fixed cost per launch, 28 of them the epilogue).
-template <bool ROPE>
-__device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int M, int N, int m0, int n0, int wr, int wc,
+// EPI: 0 = alpha / bias / QuickGELU / residual, 1 = RoPE pairing (fused qkv), 2 = SwiGLU pairing (gate|up), 3 = MoE combine (row scatter)
+constexpr int EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_COMBINE = 3;
+template <int EPI>
+__device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int batch, int M, int N, int m0, int n0, int wr, int wc,
                                                  int fr, int fq) {
-  bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+  bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
   const int cw = n0 + wc * 128;
   const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
-  if constexpr (ROPE) {
+  if constexpr (EPI == EPI_SWIGLU) {
+    // W rows are [gate 0..31 | up 0..31 | gate 32..63 | up 32..63 | ...]: of the wave's 8 fragments 0,1 / 4,5 are gate columns and 2,3 / 6,7
+    // the matching up columns; gate and up are rounded to bf16 first, like the unfused GEMM + SwiGLU kernel pair (and gemm256_epilogue_t)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int row = m0 + wr * 80 + i * 16 + fr;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x4 o[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gf = (float)(bf16_t)acc[i][jb * 4 + jj][r];
+            const float uf = (float)(bf16_t)acc[i][jb * 4 + jj + 2][r];
+            o[jj][r] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
+          }
+        const bf16x8 p = pair_swap16(o[0], o[1]);
+        if (row < M) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + (cw >> 1) + jb * 32 + c8) = p;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_COMBINE) {
+    // combine folded into the epilogue (top-1 MoE down projection): out[token] = residual[token] + weight[token] * bf16(acc), the rounding
+    // points of the separate combine kernel (and of gemm256_epilogue_t).  Row indices and weights of the wave tile first, then per column
+    // half all residual pieces before the first is used.
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(g.C);          // the shared [tokens, N] output
+    int orow[5];
+    float sc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int row = m0 + wr * 80 + i * 16 + fr;
+      orow[i] = row < M ? g.c_rows[batch * g.rows_stride + row] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc[i] = (orow[i] >= 0 && g.c_scale) ? g.c_scale[orow[i]] : 1.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 rv[5][2];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + (h * 2 + jp) * 32 + c8;
+          rv[i][jp] = bf16x8{};
+          if (g.residual && orow[i] >= 0) rv[i][jp] = *reinterpret_cast<const bf16x8*>(g.residual + (int64_t)orow[i] * g.ldr + col);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = cw + (h * 2 + jp) * 32 + c8;
+          const bf16x8 p = pair_swap16(round4(acc[i][(h * 2 + jp) * 2]), round4(acc[i][(h * 2 + jp) * 2 + 1]));
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = (float)p[e] * sc[i];
+            if (g.residual) v += (float)rv[i][jp][e];
+            o[e] = (bf16_t)v;
+          }
+          if (orow[i] >= 0) *reinterpret_cast<bf16x8*>(Cs + (int64_t)orow[i] * g.ldc + col) = o;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_ROPE) {
     // mp_gemm_qkv_rope_bf16 (no bias / residual / alpha).  q and k tiles: the wave's 128 columns are one head, fragments 0,1 | 2,3 hold
     // [lo 0..31 | hi 0..31], fragments 4,5 | 6,7 [lo 32..63 | hi 32..63].  v tiles (n0 >= 2N/3) go through the SAME loop with the rotation
     // switched off and the standard column order -- a second, plain store path beside this one in the same function made the register
@@ -112,13 +183,14 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     return;
   }
   // ---- alpha, bias, activation in place (fp32)
-  if (g.alpha != 1.f || g.bias) {
+  const float* bias0 = g.bias ? g.bias + batch * g.sBias : nullptr;
+  if (g.alpha != 1.f || bias0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias) {
+      if (bias0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int col = cw + j * 16 + fq * 4 + r; bv[r] = col < N ? g.bias[col] : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int col = cw + j * 16 + fq * 4 + r; bv[r] = col < N ? bias0[col] : 0.f; }
       }
 #pragma unroll
       for (int i = 0; i < 5; ++i) acc[i][j] = acc[i][j] * g.alpha + bv;
@@ -129,10 +201,10 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = (EXPR); }         \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-  if (!ROPE && g.act == ACT_QUICK_GELU) { MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) }
+  if (g.act == ACT_QUICK_GELU) { MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) }
 #undef MP3_ACT_SWEEP
   // ---- stores, in two column halves of the wave tile (the residual pieces of a half are all requested before the first is used)
-  const bf16_t* R = g.residual;
+  const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     bf16x8 rv[5][2];
@@ -167,22 +239,40 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
   }
 }
 
-template <bool ROPE>
+constexpr int MAX_FLAT_BATCH3 = 8;
+template <int EPI>
 __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int M = g.M, N = g.N;
-  const int tiles_n = N / BN3, tiles_m = (M + BM3 - 1) / BM3;
-  const int T = tiles_m * tiles_n;
+  const int N = g.N;
+  const int tiles_n = N / BN3;
+  // ---- tile counts per batch from the effective (device-side) row counts; the grid is sized for the host-side bound, surplus workgroups exit
+  int T = 0;
+  int pre[MAX_FLAT_BATCH3];
+#pragma unroll
+  for (int b = 0; b < MAX_FLAT_BATCH3; ++b) {
+    pre[b] = T;
+    if (b < g.nbatch) {
+      const int Mb = g.m_dev ? min(g.M, g.m_dev[b * g.m_dev_stride]) : g.M;
+      T += ((Mb + BM3 - 1) / BM3) * tiles_n;
+    }
+  }
   // ---- work decode: XCD-chunked (workgroup b runs on XCD b & 7: an XCD walks a contiguous chunk of the grouped tile order)
   const int bid = blockIdx.x;
+  if (bid >= T) return;
   const int full = T & ~7;
   const int flat = bid < full ? (bid & 7) * (full >> 3) + (bid >> 3) : bid;
+  int batch = 0, pbase = 0;
+#pragma unroll
+  for (int b = 1; b < MAX_FLAT_BATCH3; ++b) if (b < g.nbatch && flat >= pre[b]) { batch = b; pbase = pre[b]; }
+  const int lid = flat - pbase;
+  const int M = g.m_dev ? min(g.M, g.m_dev[batch * g.m_dev_stride]) : g.M;
+  const int tiles_m = (M + BM3 - 1) / BM3;
   const int GROUP_M = g.group_m;
   const int per_group = GROUP_M * tiles_n;
-  const int grp = flat / per_group;
+  const int grp = lid / per_group;
   const int first_m = grp * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (flat % per_group) % gsz, tn = (flat % per_group) / gsz;
+  const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
   const int m0 = tm * BM3, n0 = tn * BN3;
   const int nt = g.K / BK3;
 
@@ -201,10 +291,20 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   // Buffer-descriptor DMA: ONE lane offset per operand (the lane's row within a piece + its swizzled 16-byte chunk); the piece's first
   // row, the tile origin and the K advance are a scalar offset.  Rows beyond M are beyond the descriptor's range and read as zeros (no
   // clamping, so the A pieces are affine in i); N is a multiple of 256 (launcher), so no W row is out of range.
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (int)(((int64_t)(M - 1) * g.lda + g.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.W), 0, (int)(((int64_t)(N - 1) * g.ldw + g.K) * 2), 0x00020000);
-  const int a_lane = (int)((sub_row * g.lda + src_c * 8) * 2), w_lane = (int)((sub_row * g.ldw + src_c * 8) * 2);
-  const int a_row_bytes = (int)(g.lda * 2), w_row_bytes = (int)(g.ldw * 2);
+  // A: one 32-bit lane offset PER PIECE (the row of the piece this lane fetches + its swizzled chunk): with the MoE dispatch folded into
+  // the operand fetch (a_rows) the rows of a piece are arbitrary rows of the shared activation matrix; only the K advance is scalar.
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A + batch * g.sA), 0,
+                                          g.a_rows ? 0x7ffffff0 : (int)(((int64_t)(M - 1) * g.lda + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.W + batch * g.sW), 0, (int)(((int64_t)(N - 1) * g.ldw + g.K) * 2), 0x00020000);
+  const int w_lane = (int)((sub_row * g.ldw + src_c * 8) * 2);
+  const int w_row_bytes = (int)(g.ldw * 2);
+  int a_off[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int row = m0 + (wave + 8 * i) * 8 + sub_row;                  // rows beyond M: past the descriptor's range (zeros), or any valid row (gather)
+    if (g.a_rows) row = g.a_rows[batch * g.rows_stride + min(row, M - 1)];
+    a_off[i] = (int)(((int64_t)row * g.lda + src_c * 8) * 2);
+  }
   int b_piece[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -213,7 +313,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   }
   auto dma_a = [&](int i, int t) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + (wave + 8 * i) * 1024), 16,
-                                             a_lane, (m0 + (wave + 8 * i) * 8) * a_row_bytes + t * (BK3 * 2), 0, 0);
+                                             a_off[i], t * (BK3 * 2), 0, 0);
   };
   auto dma_b = [&](int k, int t) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + A_BYTES + b_piece[k] * 1024), 16,
@@ -303,7 +403,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   // arithmetic is kept in registers across the K loop
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
-  gemm320_epilogue<ROPE>(g, acc, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
+  gemm320_epilogue<EPI>(g, acc, batch, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
 }
 
 }  // namespace
@@ -311,25 +411,39 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
 // Whether the 320-row tiling is eligible for this call (dense bf16-out, aligned, offsets fit 32 bits) -- the choice between the two
 // tilings is use_320() in gemm_bf16.hip.
 bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
-  if (batch != 1 || g.m_dev || g.a_rows || g.c_rows || g.out_f32) return false;
+  if (batch < 1 || batch > MAX_FLAT_BATCH3 || g.out_f32 || g.keep_gu) return false;
   // (the other activations' sweeps over 40 fragments do not fit beside 160 accumulators: the allocator then spills accumulators inside the K loop)
-  if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK)) return false;
+  if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK || g.act == ACT_SWIGLU_PAIR)) return false;
+  if (g.act == ACT_ROPE_QK && (batch != 1 || g.m_dev || g.a_rows || g.c_rows)) return false;
+  if (g.act == ACT_SWIGLU_PAIR && (g.c_rows || g.residual || g.bias || g.alpha != 1.f || ((g.N >> 1) & 7))) return false;
+  if (g.c_rows && (g.act != ACT_NONE || g.bias || g.alpha != 1.f)) return false;
   if (g.N % BN3 || g.K % BK3 || g.M < 1024) return false;
-  if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15)) return false;
-  if (g.residual && ((g.ldr & 7) || (reinterpret_cast<uintptr_t>(g.residual) & 15))) return false;
-  if ((int64_t)(g.M + 320) * g.lda * 2 >= (1ll << 31) || (int64_t)g.N * g.ldw * 2 >= (1ll << 31)) return false;   // 32-bit (signed) DMA offsets
+  if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || (g.sC & 7)) return false;
+  if (g.residual && ((g.ldr & 7) || (reinterpret_cast<uintptr_t>(g.residual) & 15) || (g.sR & 7))) return false;
+  // 32-bit DMA offsets inside one batch's operand; a gathered A is addressed through the whole shared matrix, whose row count the call does
+  // not carry: every routed token is a row of it, so batch * M * 4 rows bound it for any capacity factor >= 1/4
+  const int64_t a_rows_bound = g.a_rows ? (int64_t)batch * g.M * 4 : (int64_t)g.M + 320;
+  if (a_rows_bound * g.lda * 2 >= (1ll << 31) || (int64_t)g.N * g.ldw * 2 >= (1ll << 31)) return false;
   return true;
 }
 
-int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream) {
+int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
-    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_COMBINE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
     attr = true;
   }
-  const int tiles = (int)(mp_cdiv(g.M, BM3) * (g.N / BN3));
-  if (g.act == ACT_ROPE_QK) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<true>, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
-  else hipLaunchKernelGGL(gemm320_bf16_nt_kernel<false>, dim3(tiles), dim3(NT3), 2 * STAGE3, stream, g);
+  GemmArgs g = g0;
+  g.nbatch = batch;
+  const dim3 grid((unsigned)(mp_cdiv(g.M, BM3) * (g.N / BN3) * batch));     // the host-side bound; workgroups beyond the device-side tile count exit
+#define MP3_GO(E) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<E>, grid, dim3(NT3), 2 * STAGE3, stream, g)
+  if (g.act == ACT_ROPE_QK) MP3_GO(EPI_ROPE);
+  else if (g.act == ACT_SWIGLU_PAIR) MP3_GO(EPI_SWIGLU);
+  else if (g.c_rows) MP3_GO(EPI_COMBINE);
+  else MP3_GO(EPI_PLAIN);
+#undef MP3_GO
   return mp_check_launch("mp_gemm_bf16_nt(320)");
 }

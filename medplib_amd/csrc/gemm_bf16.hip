@@ -335,7 +335,7 @@ static bool use_256_rule(const GemmArgs& g, int batch) {
 // implemented in gemm256_bf16.hip (cached per device) / gemm320_bf16.hip
 int mp_device_cus();
 bool mp_gemm320_eligible(const GemmArgs& g, int batch);
-int mp_launch_gemm320(const GemmArgs& g, hipStream_t stream);
+int mp_launch_gemm320(const GemmArgs& g, int batch, hipStream_t stream);
 
 // 320-row tiles, or the kernel the call would otherwise get?  Modelled time in microseconds, from K sweeps at one full wave of tiles
 // (scripts/gemm_ksweep.py, same box): a wave of 256x256 tiles costs 8.5 + 1.45 per 64-deep K step (prologue + epilogue, then 1480-1530
@@ -372,6 +372,20 @@ static bool use_320(const GemmArgs& g, int batch) {
     other = 2.0 * g.M * g.N * g.K / 560e6;
   }
   return c320 < 0.98 * other;
+}
+
+// Batched calls (the MoE expert projections: per-expert device-side row counts, rows gathered / scattered through the routing tables).  The
+// host does not know the row counts, so there is no wave model here: the 320-row tiles take every eligible call with a long K and a wide N
+// (gate|up: N = 22016, K = 4096; down: N = 4096, K = 11008) -- their K loop runs ~5 % faster and a wave of tiles costs 4 us less in prologue
+// and epilogue than a wave of 256x256 tiles; 2556 rows per expert are 8 row tiles of 320 (10 of 256).  MP_GEMM320_BATCHED=0: never (A/B).
+static bool use_320_batched(const GemmArgs& g, int batch) {
+  static int env_b = -1, env_mode = -1;
+  if (env_b < 0) { const char* e = getenv("MP_GEMM320_BATCHED"); env_b = (e && atoi(e) == 0) ? 0 : 1; }
+  if (env_mode < 0) { const char* e = getenv("MP_GEMM320"); env_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+  const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
+  if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
+  if (mode == 2) return true;
+  return env_b && g.K >= 2048 && g.N >= 2048;
 }
 
 // which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)
@@ -436,7 +450,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
-  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, stream); }
+  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, 1, stream); }
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   g.max_split = split128(g, 1, stream, &g.ws, &g.tickets);
@@ -459,7 +473,7 @@ extern "C" int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi,
   g.M = M; g.N = N; g.K = K; g.act = ACT_ROPE_QK; g.out_f32 = 0; g.alpha = 1.f;
   g.group_m = gemm_group_m();
   g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_seq = seq; g.rope_pos0 = pos_offset;
-  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, stream); }
+  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, 1, stream); }
   (void)use_256(g, 1);
   return mp_launch_gemm256(g, 1, stream);
 }
@@ -502,6 +516,7 @@ extern "C" int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strid
   g.bias = bias; g.residual = nullptr; g.ldr = 0; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = 1.f;
   g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = 0; g.sBias = strideBias; g.m_dev_stride = 1; g.group_m = gemm_group_m();
+  if (use_320_batched(g, batch)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, batch, stream); }
   if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);
@@ -522,6 +537,7 @@ extern "C" int mp_gemm_bf16_nt_batched_res(const void* A, int64_t lda, int64_t s
   g.bias = nullptr; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = ACT_NONE; g.out_f32 = 0; g.alpha = 1.f;
   g.sA = strideA; g.sW = strideW; g.sC = strideC; g.sR = strideR; g.sBias = 0; g.m_dev_stride = 1; g.group_m = gemm_group_m();
+  if (use_320_batched(g, batch)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, batch, stream); }
   if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);
@@ -549,6 +565,7 @@ extern "C" int mp_gemm_bf16_nt_batched_rows(const void* A, int64_t lda, int64_t 
   g.sA = a_rows ? 0 : strideA; g.sW = strideW; g.sC = c_rows ? 0 : strideC; g.sR = 0; g.sBias = 0; g.m_dev_stride = 1;
   g.group_m = gemm_group_m();
   g.a_rows = a_rows; g.c_rows = c_rows; g.c_scale = c_scale; g.rows_stride = rows_stride;
+  if (use_320_batched(g, batch)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, batch, stream); }
   if (use_256(g, batch)) return mp_launch_gemm256(g, batch, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   launch_gemm(g, dim3(tiles, batch), stream);

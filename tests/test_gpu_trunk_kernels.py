@@ -102,6 +102,56 @@ def test_gemm_batched_experts(dev):
         assert (out[e, c:].float() == 0).all()
 
 
+def test_gemm320_expert_paths_match_256(dev):
+    """The 320-row tile kernel on the MoE expert calls -- per-expert device-side row counts, the dispatch gather (a_rows) with the SwiGLU
+    pairing, the combine scatter (c_rows, routing weight, residual), the batched residual form -- must equal the 256x256 kernel bit for
+    bit (same K order per output element, same rounding points); rows beyond an expert's count stay untouched."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(31)
+    E, cap, d, ff = 2, 1500, 256, 512
+    T = 2300
+    counts = torch.tensor([1300, 777], dtype=torch.int32)
+    x = _bf(torch.randn(T, d, generator=g)).to(dev)
+    perm = torch.randperm(T, generator=g)
+    slot_token = torch.full((E, cap), -1, dtype=torch.int32)
+    slot_token[0, :1300] = perm[:1300].int(); slot_token[1, :777] = perm[1300:2077].int()
+    slot_token = slot_token.clamp_min(0).to(dev)                                  # entries beyond the counts are never used
+    w_gu = _bf(torch.randn(E, 2 * ff, d, generator=g) * 0.1).to(dev)
+    w_dn = _bf(torch.randn(E, 256, ff, generator=g) * 0.1).to(dev)
+    weight = torch.rand(T, generator=g).to(dev)
+    res = _bf(torch.randn(T, 256, generator=g)).to(dev)
+    cd = counts.to(dev)
+    outs = {}
+    try:
+        for pol in (0, 2):
+            ops.gemm_tile_policy(pol)
+            act = torch.full((E, cap, ff), 7.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm_batched_rows(x, w_gu, act, cd, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
+            k1 = ops.gemm_last_kernel()
+            out = torch.full((T, 256), 3.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm_batched_rows(act, w_dn, out, cd, c_rows=slot_token, c_scale=weight, residual=res, rows_stride=cap)
+            k2 = ops.gemm_last_kernel()
+            plain = torch.full((E, cap, 256), 5.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm_batched(act, w_dn, plain, m_dev=cd)
+            k3 = ops.gemm_last_kernel()
+            withres = torch.full((E, cap, 256), 5.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm_batched_res(act, w_dn, plain.clone(), withres, m_dev=cd)
+            k4 = ops.gemm_last_kernel()
+            assert ({k1, k2, k3, k4} == {320}) if pol == 2 else (320 not in {k1, k2, k3, k4}), (pol, k1, k2, k3, k4)
+            outs[pol] = (act, out, plain, withres)
+    finally:
+        ops.gemm_tile_policy(-1)
+    torch.cuda.synchronize()
+    for name, a0, a2 in zip(("swiglu+gather", "combine", "batched", "batched_res"), outs[0], outs[2]):
+        assert torch.equal(a0, a2), (name, (a0.float() - a2.float()).abs().max())
+    act = outs[2][0]
+    assert (act[0, 1300:] == 7.0).all() and (act[1, 777:] == 7.0).all()          # rows beyond the counts untouched
+    ref = x[slot_token[0, :1300].long()].float() @ w_gu[0].float().T               # spot check against fp32: expert 0
+    gate = torch.cat([ref[:, i:i + 32] for i in range(0, 2 * ff, 64)], 1).to(torch.bfloat16).float()
+    up = torch.cat([ref[:, i + 32:i + 64] for i in range(0, 2 * ff, 64)], 1).to(torch.bfloat16).float()
+    _report("gemm320 experts: swiglu(gathered rows)", act[0, :1300], torch.nn.functional.silu(gate) * up, rtol=2 * BF16_EPS, atol=2e-2)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("B,S,H,D,causal,ragged", [(2, 639, 4, 128, True, True), (1, 64, 2, 128, True, False),
                                                    (2, 577, 3, 64, False, False), (1, 200, 2, 64, False, True),
