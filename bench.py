@@ -245,9 +245,16 @@ def main():
         if timer is not None:
             # every 23rd GEMM launch of the timed steps is bracketed by HIP events on the launch stream (ops.KernelTimer)
             # the dominant kernel alone (mp_gemm_last_kernel tells which kernel a launch went to), then all bf16 GEMM launches
-            flops, ms, sampled, launches, all_flops = timer.summary(256)
+            fams = {256: "gemm256v3_bf16_nt_kernel", 320: "gemm320_bf16_nt_kernel"}
+            summ = {k: timer.summary(k) for k in fams}
             a_flops, a_ms, a_sampled, a_launches, a_all = timer.summary()
-            if sampled == 0:          # very short debug runs: no sampled launch went to the dominant kernel
+
+            def est_ms(k):            # time per run estimated from the sampled launches: all launches x the sampled average
+                f, m, n, l, _ = summ[k]
+                return l * m / n if n else 0.0
+            dom = max(fams, key=est_ms)                 # the dominant kernel = the family with the most GPU time in the timed steps
+            flops, ms, sampled, launches, all_flops = summ[dom]
+            if sampled == 0:          # very short debug runs: no sampled launch went to either tile kernel
                 flops, ms, sampled, launches, all_flops = a_flops, a_ms, a_sampled, a_launches, a_all
             if os.environ.get("MP_BENCH_SHAPES"):       # debug: the sampled launches grouped by their algorithmic work (= by shape)
                 by = {}
@@ -258,7 +265,7 @@ def main():
                           f"min {min(v):7.1f}, {gf / (sum(v) / len(v)) * 1e3 / 1e3:7.1f} TF/s", file=sys.stderr)
             achieved = flops / (max(ms, 1e-9) * 1e-3) / 1e12
             a_ach = a_flops / (max(a_ms, 1e-9) * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm256v3_bf16_nt_kernel",
+            roof = {"bound": "mfma", "kernel": fams[dom],
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": launches // args.steps, "sampled_launches": sampled,
@@ -269,23 +276,27 @@ def main():
                                        "frac": round(a_ach / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": a_launches // args.steps,
                                        "sampled_launches": a_sampled, "avg_launch_us": round(a_ms * 1e3 / max(a_sampled, 1), 2),
                                        "tflop_per_step": round(a_all / args.steps / 1e12, 2)}}
-            t_flops, t_ms, t_sampled, t_launches, t_all = timer.summary(320)
-            if t_sampled:      # the 320x256 tile kernel (the dense N = 4096 projections at 5112 rows: o_proj; with --lora also down / three dgrads)
-                t_ach = t_flops / (max(t_ms, 1e-9) * 1e-3) / 1e12
-                roof["gemm320_bf16_nt_kernel"] = {"achieved": round(t_ach, 1), "frac": round(t_ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                                                  "launches_per_step": t_launches // args.steps, "sampled_launches": t_sampled,
-                                                  "avg_launch_us": round(t_ms * 1e3 / t_sampled, 2)}
+            for k in fams:             # the other tile kernel beside the dominant one (320-row tiles: the dense projections and the experts'
+                if k == dom:           # gate|up; 256x256 tiles: the experts' down projection with the combine epilogue, CLIP's qkv / fc2)
+                    continue
+                t_flops, t_ms, t_sampled, t_launches, t_all = summ[k]
+                if t_sampled:
+                    t_ach = t_flops / (max(t_ms, 1e-9) * 1e-3) / 1e12
+                    roof[fams[k]] = {"achieved": round(t_ach, 1), "frac": round(t_ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                     "launches_per_step": t_launches // args.steps, "sampled_launches": t_sampled,
+                                     "avg_launch_us": round(t_ms * 1e3 / t_sampled, 2), "tflop_per_step": round(t_all / args.steps / 1e12, 2)}
             # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            tname = next((n for n in ("r02h_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
+            tname = next((n for n in ("r02s_hbm_traffic.json", "r02h_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+                          if os.path.exists(os.path.join(pdir, n))), None)
             tpath = os.path.join(pdir, tname or "")
             if tname:
-                tj = json.load(open(tpath)).get("gemm256v3")
-                if tj:
+                tj = json.load(open(tpath)).get({256: "gemm256v3", 320: "gemm320"}[dom])
+                if tj and not args.lora:
                     roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
-                    roof["traffic_detail"] = {"kernel": "gemm256v3_bf16_nt_kernel", "read_bytes_per_launch": tj["read_bytes_per_launch"],
+                    roof["traffic_detail"] = {"kernel": fams[dom], "read_bytes_per_launch": tj["read_bytes_per_launch"],
                                               "write_bytes_per_launch": tj["write_bytes_per_launch"],
                                               "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE over this same command, "
                                                         "read = 2 x FETCH_SIZE per the gfx950 correction)"}

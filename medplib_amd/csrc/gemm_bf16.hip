@@ -375,9 +375,12 @@ static bool use_320(const GemmArgs& g, int batch) {
 }
 
 // Batched calls (the MoE expert projections: per-expert device-side row counts, rows gathered / scattered through the routing tables).  The
-// host does not know the row counts, so there is no wave model here: the 320-row tiles take every eligible call with a long K and a wide N
-// (gate|up: N = 22016, K = 4096; down: N = 4096, K = 11008) -- their K loop runs ~5 % faster and a wave of tiles costs 4 us less in prologue
-// and epilogue than a wave of 256x256 tiles; 2556 rows per expert are 8 row tiles of 320 (10 of 256).  MP_GEMM320_BATCHED=0: never (A/B).
+// host does not know the row counts, so there is no wave model here: the 320-row tiles take the eligible calls with a long K and N >= 8192
+// (gate|up: N = 22016, K = 4096: 86 column tiles, so a row tile more or less moves the wave count by a few percent) -- their K loop runs
+// ~5 % faster and a wave of tiles costs 4 us less in prologue and epilogue than a wave of 256x256 tiles: 665-677 us against 722-787 for
+// E = 2 at 5112 tokens (scripts/expert_gemm_ab.py).  The down projection (N = 4096: 16 column tiles) stays on 256x256 tiles: 2556 + 2556
+// rows are 8 + 8 row tiles of 320 = exactly one wave (308 us against 365), but 2500 + 2612 are 8 + 9 = 1.06 waves and this kernel has no
+// tail split (531 us against 380).  MP_GEMM320_BATCHED=0: never (A/B).
 static bool use_320_batched(const GemmArgs& g, int batch) {
   static int env_b = -1, env_mode = -1;
   if (env_b < 0) { const char* e = getenv("MP_GEMM320_BATCHED"); env_b = (e && atoi(e) == 0) ? 0 : 1; }
@@ -385,7 +388,7 @@ static bool use_320_batched(const GemmArgs& g, int batch) {
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
   if (mode == 2) return true;
-  return env_b && g.K >= 2048 && g.N >= 2048;
+  return env_b && g.K >= 2048 && g.N >= 8192;
 }
 
 // which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)
