@@ -27,6 +27,9 @@
 #include <stdlib.h>
 #include <algorithm>
 
+int mp_device_cus();
+void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
+
 namespace {
 
 constexpr int BM3 = 320, BN3 = 256, BK3 = 64, NT3 = 512;
@@ -256,11 +259,30 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
       T += ((Mb + BM3 - 1) / BM3) * tiles_n;
     }
   }
-  // ---- work decode: XCD-chunked (workgroup b runs on XCD b & 7: an XCD walks a contiguous chunk of the grouped tile order)
+  // ---- work decode.  The first full = floor(T / CUs) * CUs tiles are whole-K units, XCD-chunked (workgroup b runs on XCD b & 7: an XCD
+  // walks a contiguous chunk of the grouped tile order).  TAIL SPLIT-K as in the 256x256 kernel: when the remaining rem tiles would occupy
+  // at most half the CUs for a whole tile-time, each is cut into S K-ranges (S * rem <= CUs units); the fp32 partials meet in the registered
+  // workspace (write-through 16-byte stores, a ticket per tile, the last arriver sums them in split order and runs the epilogue).
+  const int C = g.n_cu;
+  const int full = (T / C) * C, rem = T - full;
+  const int nt_all = g.K / BK3;
+  int S = 1;
+  if (g.ws && rem > 0 && rem * 2 <= C) S = max(1, min(min(C / rem, g.max_split), nt_all / 4));
   const int bid = blockIdx.x;
-  if (bid >= T) return;
-  const int full = T & ~7;
-  const int flat = bid < full ? (bid & 7) * (full >> 3) + (bid >> 3) : bid;
+  if (bid >= full + rem * S) return;
+  int flat, split = 0;
+  if (bid < full) {
+    flat = (bid & 7) * (full >> 3) + (bid >> 3);            // full is a multiple of the CU count, hence of 8
+  } else {
+    const int r = bid - full;
+    if (S == 1 && (rem & 7) == 0) {
+      flat = full + (r & 7) * (rem >> 3) + (r >> 3);        // an unsplit tail: XCD-chunked like the full waves
+    } else {
+      flat = full + r % rem;
+      split = r / rem;
+    }
+  }
+  const bool is_split = (bid >= full) && S > 1;
   int batch = 0, pbase = 0;
 #pragma unroll
   for (int b = 1; b < MAX_FLAT_BATCH3; ++b) if (b < g.nbatch && flat >= pre[b]) { batch = b; pbase = pre[b]; }
@@ -274,7 +296,13 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   const int gsz = min(tiles_m - first_m, GROUP_M);
   const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
   const int m0 = tm * BM3, n0 = tn * BN3;
-  const int nt = g.K / BK3;
+  int kt0 = 0, nt = nt_all;                               // K range of this unit (in BK3 tiles)
+  if (is_split) {
+    const int base = nt_all / S, extra = nt_all % S;
+    kt0 = split * base + min(split, extra);
+    nt = base + (split < extra ? 1 : 0);
+  }
+  const int k_byte0 = kt0 * (BK3 * 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -313,11 +341,11 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   }
   auto dma_a = [&](int i, int t) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + (wave + 8 * i) * 1024), 16,
-                                             a_off[i], t * (BK3 * 2), 0, 0);
+                                             a_off[i], k_byte0 + t * (BK3 * 2), 0, 0);
   };
   auto dma_b = [&](int k, int t) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + (t & 1) * STAGE3 + A_BYTES + b_piece[k] * 1024), 16,
-                                             w_lane, (n0 + b_piece[k] * 8) * w_row_bytes + t * (BK3 * 2), 0, 0);
+                                             w_lane, (n0 + b_piece[k] * 8) * w_row_bytes + k_byte0 + t * (BK3 * 2), 0, 0);
   };
 
   f32x4 acc[5][8];
@@ -399,6 +427,45 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     MP3_MFMA_40(1);
   }
   if (wc == 0) MP3_BAR();
+  if (is_split) {
+    // (see gemm256_bf16.hip: partials travel write-through to the memory-side coherence point, so no L2 flush is needed for the other
+    // XCDs to see them; the sum runs in ascending split order whichever unit arrives last, so the rounding does not depend on the order)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    constexpr int SLAB = BM3 * BN3 * 4;                  // one unit's partial tile, bytes
+    const int tail = flat - full;
+    float* tile_ws = g.ws + ((int64_t)tail * S) * (BM3 * BN3);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tile_ws, 0, S * SLAB, 0x00020000);
+    const int my_off = split * SLAB + tid * 16;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, my_off + (i * 8 + j) * (NT3 * 16), 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(g.tickets + tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *flag;
+    __syncthreads();
+    if (ticket != S - 1) return;
+    if (tid == 0) __hip_atomic_store(g.tickets + tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; ++sp) {
+      const int base = sp * SLAB + tid * 16;
+#pragma unroll
+      for (int ip = 0; ip < 5; ++ip) {                 // 8 x 16-byte loads in flight, then their adds
+        u32x4 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (ip * 8 + q) * (NT3 * 16), 0, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[ip][q] += __builtin_bit_cast(f32x4, t[q]);
+      }
+    }
+  }
   // the epilogue's lane coordinates are derived again from the thread id (opaque to the optimiser), so nothing of the epilogue's address
   // arithmetic is kept in registers across the K loop
   int tid2 = threadIdx.x;
@@ -438,7 +505,17 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   }
   GemmArgs g = g0;
   g.nbatch = batch;
-  const dim3 grid((unsigned)(mp_cdiv(g.M, BM3) * (g.N / BN3) * batch));     // the host-side bound; workgroups beyond the device-side tile count exit
+  g.n_cu = std::min(mp_device_cus(), 256);
+  static int max_split = -1;
+  if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 8; }     // 1 = no tail split (A/B)
+  // dense calls keep whole waves and one accumulation order per shape (the selection model counts whole waves; a gemm() must not differ
+  // from the kept-gate|up form of the same product by a split's extra fp32 rounding); the tail split serves the batched expert calls
+  g.max_split = (batch > 1 || g.m_dev) ? max_split : 1;
+  int64_t ws_bytes = 0;
+  mp_gemm_split_workspace(stream, &g.ws, &g.tickets, &ws_bytes);
+  if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }
+  // the host-side bound on the tile count plus one unit per CU for a split tail; workgroups beyond the device-side unit count exit at once
+  const dim3 grid((unsigned)(mp_cdiv(g.M, BM3) * (g.N / BN3) * batch + g.n_cu));
 #define MP3_GO(E) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<E>, grid, dim3(NT3), 2 * STAGE3, stream, g)
   if (g.act == ACT_ROPE_QK) MP3_GO(EPI_ROPE);
   else if (g.act == ACT_SWIGLU_PAIR) MP3_GO(EPI_SWIGLU);

@@ -358,7 +358,8 @@ static bool use_320(const GemmArgs& g, int batch) {
   const double k = g.K / 64.0;
   const double epi = (g.residual ? 8.0 : 0.0) + (g.act == ACT_QUICK_GELU ? 6.0 : 0.0);
   const double rope320 = g.act == ACT_ROPE_QK ? MP_GEMM320_ROPE_EXTRA_US : 0.0;
-  const double c320 = (double)mp_cdiv(t320, C) * (4.5 + epi + rope320 + 1.685 * k);
+  const double w320 = (double)mp_cdiv(t320, C);          // dense calls run whole waves (the kernel's tail split is for the batched expert calls)
+  const double c320 = w320 * (4.5 + epi + rope320 + 1.685 * k);
   double other;
   if (use_256_rule(g, batch)) {
     const int64_t rem = t256 % C;
@@ -379,8 +380,9 @@ static bool use_320(const GemmArgs& g, int batch) {
 // (gate|up: N = 22016, K = 4096: 86 column tiles, so a row tile more or less moves the wave count by a few percent) -- their K loop runs
 // ~5 % faster and a wave of tiles costs 4 us less in prologue and epilogue than a wave of 256x256 tiles: 665-677 us against 722-787 for
 // E = 2 at 5112 tokens (scripts/expert_gemm_ab.py).  The down projection (N = 4096: 16 column tiles) stays on 256x256 tiles: 2556 + 2556
-// rows are 8 + 8 row tiles of 320 = exactly one wave (308 us against 365), but 2500 + 2612 are 8 + 9 = 1.06 waves and this kernel has no
-// tail split (531 us against 380).  MP_GEMM320_BATCHED=0: never (A/B).
+// rows are 8 + 8 row tiles of 320 = exactly one wave (308 us against 365), but 2500 + 2612 are 8 + 9 = 1.06 waves and this kernel had no
+// tail split then (531 us against 380); with the tail split the kernel has since got (16 tiles cut 8 ways) it measures 375-381 against
+// 380-383 alone but loses ~35 us per layer inside the step, so the rule stays N >= 8192.  MP_GEMM320_BATCHED=0: never (A/B).
 static bool use_320_batched(const GemmArgs& g, int batch) {
   static int env_b = -1, env_mode = -1;
   if (env_b < 0) { const char* e = getenv("MP_GEMM320_BATCHED"); env_b = (e && atoi(e) == 0) ? 0 : 1; }

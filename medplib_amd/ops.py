@@ -81,12 +81,12 @@ _GEMM_WS = {}
 
 
 def _ensure_gemm_workspace(device):
-    """Register the scratch of the 256x256 GEMM's tail split-K once per device: 64 MiB of fp32
+    """Register the scratch of the 256x256 GEMM's tail split-K once per device: 96 MiB of fp32
     partials + 256 zeroed arrival tickets.  The library itself never allocates (mp_gemm_set_workspace)."""
     key = torch.device(device).index or 0
     if key not in _GEMM_WS:
         with torch.cuda.device(key):                       # the library files the entry under the current device
-            ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+            ws = torch.empty(96 << 20, dtype=torch.uint8, device=device)
             tickets = torch.zeros(256, dtype=torch.int32, device=device)
             lib().call("mp_gemm_set_workspace", _p(ws), ws.numel(), _p(tickets), tickets.numel())
         _GEMM_WS[key] = (ws, tickets)
@@ -114,7 +114,7 @@ def register_stream_workspace(stream):
     key = stream.cuda_stream
     if key not in _STREAM_WS:
         import ctypes
-        ws = torch.empty(64 << 20, dtype=torch.uint8, device=stream.device)
+        ws = torch.empty(96 << 20, dtype=torch.uint8, device=stream.device)
         tickets = torch.zeros(256, dtype=torch.int32, device=stream.device)
         lib().call("mp_gemm_set_stream_workspace", ctypes.c_void_p(key), _p(ws), ws.numel(), _p(tickets), tickets.numel())
         _STREAM_WS[key] = (ws, tickets)

@@ -104,8 +104,9 @@ def test_gemm_batched_experts(dev):
 
 def test_gemm320_expert_paths_match_256(dev):
     """The 320-row tile kernel on the MoE expert calls -- per-expert device-side row counts, the dispatch gather (a_rows) with the SwiGLU
-    pairing, the combine scatter (c_rows, routing weight, residual), the batched residual form -- must equal the 256x256 kernel bit for
-    bit (same K order per output element, same rounding points); rows beyond an expert's count stay untouched."""
+    pairing, the combine scatter (c_rows, routing weight, residual), the batched residual form -- must equal the other kernels: bit for
+    bit where neither side splits K (same accumulation order, same rounding points), to two bf16 ulps where the tail split adds an fp32
+    rounding; rows beyond an expert's count stay untouched."""
     from medplib_amd import ops
     g = torch.Generator().manual_seed(31)
     E, cap, d, ff = 2, 1500, 256, 512
@@ -143,7 +144,10 @@ def test_gemm320_expert_paths_match_256(dev):
         ops.gemm_tile_policy(-1)
     torch.cuda.synchronize()
     for name, a0, a2 in zip(("swiglu+gather", "combine", "batched", "batched_res"), outs[0], outs[2]):
-        assert torch.equal(a0, a2), (name, (a0.float() - a2.float()).abs().max())
+        if name == "swiglu+gather":       # K = 256: no K split on either tiling -> the same accumulation order, bit for bit
+            assert torch.equal(a0, a2), (name, (a0.float() - a2.float()).abs().max())
+        else:                             # K = 512, 32 tiles: the 320-row kernel's tail split sums two fp32 K-halves (one more fp32 rounding)
+            _report(f"gemm320 experts: {name} vs the other tiling", a2, a0.float(), rtol=2 * BF16_EPS, atol=2e-2)
     act = outs[2][0]
     assert (act[0, 1300:] == 7.0).all() and (act[1, 777:] == 7.0).all()          # rows beyond the counts untouched
     ref = x[slot_token[0, :1300].long()].float() @ w_gu[0].float().T               # spot check against fp32: expert 0
