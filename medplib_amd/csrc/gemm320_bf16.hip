@@ -21,8 +21,16 @@
 // 40 A-fragment and 32 B-fragment registers there is no room for per-piece 64-bit pointers (the launcher checks the operands fit 2 GiB).
 // The MFMAs are issued as (W fragment, A fragment) = transposed accumulators (a lane owns four consecutive columns of a row); the
 // epilogue pairs neighbouring fragments with v_permlane16_swap into 16-byte pieces (gemm_common.h, pair_swap16).
-// Dense calls only (no device-side row counts, no row gather / scatter, bf16 output); no tail split: the launcher selects this kernel
-// only when its last wave is full enough to win without one.
+// Round 2, late: ONE INSTANTIATION PER EPILOGUE FAMILY (plain / RoPE / SwiGLU / MoE combine).  With the RoPE and the plain store paths in
+// one function the register allocator spilled 362 VGPRs and the plain path wrote and re-read its accumulators through scratch: a K sweep
+// at one wave of tiles (scripts/gemm_ksweep.py) showed 35 us of fixed cost per launch, 28 of them the epilogue (K = 128: 38.1 us with, 10.8
+// without it); each family alone compiles to 241-253 VGPRs with no spill and the fixed cost is 10 us -- below the 256x256 kernel's 14.
+// The kernel then beat the 256-row tiling on every dense decoder shape (o_proj 131 vs 180 us, down 301 vs 362, qkv+RoPE 355 vs 383, CLIP
+// fc1 43.5 vs 72 on the 128x128 kernel), so the selection model in gemm_bf16.hip was recalibrated from the K sweeps.
+// Batched expert calls too: flat tile decode over the experts' device-side row counts, the MoE dispatch folded into the A fetch (one
+// 32-bit lane offset per DMA piece instead of one per operand: 5 registers), SwiGLU pairing and the combine scatter as epilogue families,
+// and the 256x256 kernel's tail split-K (batched calls only; dense calls keep whole waves and one accumulation order per shape).
+// bf16 output only.
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
