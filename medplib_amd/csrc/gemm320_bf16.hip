@@ -87,6 +87,13 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
           }
         const bf16x8 p = pair_swap16(o[0], o[1]);
         if (row < M) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + (cw >> 1) + jb * 32 + c8) = p;
+        if (g.keep_gu) {                                   // the bf16 gate / up values the product was formed from, in the GEMM's own column order (training keeps them)
+          const bf16x8 pg = pair_swap16(round4(acc[i][jb * 4]), round4(acc[i][jb * 4 + 1])), pu = pair_swap16(round4(acc[i][jb * 4 + 2]), round4(acc[i][jb * 4 + 3]));
+          if (row < M) {
+            *reinterpret_cast<bf16x8*>(g.keep_gu + (int64_t)row * g.ld_gu + cw + jb * 64 + c8) = pg;
+            *reinterpret_cast<bf16x8*>(g.keep_gu + (int64_t)row * g.ld_gu + cw + jb * 64 + 32 + c8) = pu;
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -486,7 +493,8 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
 // Whether the 320-row tiling is eligible for this call (dense bf16-out, aligned, offsets fit 32 bits) -- the choice between the two
 // tilings is use_320() in gemm_bf16.hip.
 bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
-  if (batch < 1 || batch > MAX_FLAT_BATCH3 || g.out_f32 || g.keep_gu) return false;
+  if (batch < 1 || batch > MAX_FLAT_BATCH3 || g.out_f32) return false;
+  if (g.keep_gu && (batch != 1 || (g.ld_gu & 7) || (reinterpret_cast<uintptr_t>(g.keep_gu) & 15))) return false;
   // (the other activations' sweeps over 40 fragments do not fit beside 160 accumulators: the allocator then spills accumulators inside the K loop)
   if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK || g.act == ACT_SWIGLU_PAIR)) return false;
   if (g.act == ACT_ROPE_QK && (batch != 1 || g.m_dev || g.a_rows || g.c_rows)) return false;

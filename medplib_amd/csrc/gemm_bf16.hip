@@ -382,7 +382,7 @@ static bool use_320(const GemmArgs& g, int batch) {
 // E = 2 at 5112 tokens (scripts/expert_gemm_ab.py).  The down projection (N = 4096: 16 column tiles) stays on 256x256 tiles: 2556 + 2556
 // rows are 8 + 8 row tiles of 320 = exactly one wave (308 us against 365), but 2500 + 2612 are 8 + 9 = 1.06 waves and this kernel had no
 // tail split then (531 us against 380); with the tail split the kernel has since got (16 tiles cut 8 ways) it measures 375-381 against
-// 380-383 alone but loses ~35 us per layer inside the step, so the rule stays N >= 8192.  MP_GEMM320_BATCHED=0: never (A/B).
+// 380-383: the routing is never balanced to the row, so there is nothing to win and the rule stays N >= 8192.  MP_GEMM320_BATCHED=0: never (A/B).
 static bool use_320_batched(const GemmArgs& g, int batch) {
   static int env_b = -1, env_mode = -1;
   if (env_b < 0) { const char* e = getenv("MP_GEMM320_BATCHED"); env_b = (e && atoi(e) == 0) ? 0 : 1; }
@@ -497,6 +497,7 @@ extern "C" int mp_gemm_swiglu_keep_bf16(const void* A, int64_t lda, const void* 
   g.M = M; g.N = N; g.K = K; g.act = ACT_SWIGLU_PAIR; g.out_f32 = 0; g.alpha = 1.f;
   g.group_m = gemm_group_m();
   g.keep_gu = (bf16_t*)gu_out; g.ld_gu = ld_gu;
+  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, 1, stream); }
   (void)use_256(g, 1);
   return mp_launch_gemm256(g, 1, stream);
 }
