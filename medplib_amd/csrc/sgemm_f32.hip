@@ -24,8 +24,14 @@ struct SgemmArgs {
   int split_k;         // >1: gridDim.y encodes (tile_n, split) and C is accumulated with atomics (beta must be 1, C pre-initialised)
 };
 
+// BK = the K depth of one staged slab.  BK = 64 keeps 32 loads per thread in flight and walks K in a quarter of the steps of BK = 16:
+// measured over the LoRA step's 768 launches 13.3 -> 12.6 ms (rocprofv3), i.e. the per-slab load latency is NOT what these launches lose
+// their time to -- the 504 launches with K >= 64 average 21 us because a 2048 x 256 x 256 product is 128 workgroups of 4 x 4 register
+// tiles (LDS-read bound, ~10 % of the fp32 FMA peak), the 264 shorter ones 7 us.  Accumulation order over k is unchanged (ascending), so
+// results are bit-identical between the two depths.  MP_SGEMM_BK=16 selects the first version (A/B).
+template <int BK>
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-  constexpr int BM = 64, BN = 64, BK = 16;
+  constexpr int BM = 64, BN = 64, NL = BK / 4;             // NL loads per thread and operand per slab
   __shared__ float sA[BK][BM + 4];
   __shared__ float sB[BK][BN + 4];
   const int tid = threadIdx.x;
@@ -46,30 +52,30 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
   }
   float acc[4][4] = {};
   // global -> register prefetch of the NEXT K-slab overlaps the FMA loop on the current one
-  float ra[4], rb[4];
+  float ra[NL], rb[NL];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + i * 256;  // 0..1023
+    for (int i = 0; i < NL; ++i) {
+      const int id = tid + i * 256;  // 0 .. 64 * BK - 1
       int m, k;
-      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & 15; m = id >> 4; }
+      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & (BK - 1); m = id / BK; }
       const int gm = m0 + m, gk = k0 + k;
       ra[i] = (gm < g.M && gk < kend) ? (g.transA ? A[(int64_t)gk * g.lda + gm] : A[(int64_t)gm * g.lda + gk]) : 0.f;
       int n, kb;
-      if (g.transB) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      if (g.transB) { kb = id & (BK - 1); n = id / BK; } else { n = id & 63; kb = id >> 6; }
       const int gn = n0 + n, gkb = k0 + kb;
       rb[i] = (gn < g.N && gkb < kend) ? (g.transB ? B[(int64_t)gn * g.ldb + gkb] : B[(int64_t)gkb * g.ldb + gn]) : 0.f;
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int id = tid + i * 256;
       int m, k;
-      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & 15; m = id >> 4; }
+      if (g.transA) { m = id & 63; k = id >> 6; } else { k = id & (BK - 1); m = id / BK; }
       sA[k][m] = ra[i];
       int n, kb;
-      if (g.transB) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      if (g.transB) { kb = id & (BK - 1); n = id / BK; } else { n = id & 63; kb = id >> 6; }
       sB[kb][n] = rb[i];
     }
   };
@@ -130,6 +136,10 @@ extern "C" int mp_sgemm_f32(const float* A, int64_t lda, int transA, const float
   SgemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, nb0, nb1, sA0, sA1, sB0, sB1, sC0, sC1,
               alpha, beta, act, split_k < 1 ? 1 : split_k};
   dim3 grid((unsigned)mp_cdiv(M, 64), (unsigned)(mp_cdiv(N, 64) * g.split_k), (unsigned)(nb0 * nb1));
-  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, stream, g);
+  static int bk = -1;
+  if (bk < 0) { const char* e = getenv("MP_SGEMM_BK"); bk = (e && atoi(e) == 16) ? 16 : 64; }      // 16: the first version (A/B)
+  const int k_unit = g.split_k > 1 ? (K + g.split_k - 1) / g.split_k : K;
+  if (bk == 64 && k_unit >= 64) hipLaunchKernelGGL(sgemm_kernel<64>, grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(sgemm_kernel<16>, grid, dim3(256), 0, stream, g);
   return mp_check_launch("mp_sgemm_f32");
 }
