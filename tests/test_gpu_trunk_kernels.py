@@ -102,7 +102,8 @@ def test_gemm_batched_experts(dev):
         assert (out[e, c:].float() == 0).all()
 
 
-def test_gemm320_expert_paths_match_256(dev):
+@pytest.mark.parametrize("c0,c1", [(1300, 777), (0, 1500), (1500, 1), (320, 640), (1281, 959)])
+def test_gemm320_expert_paths_match_256(dev, c0, c1):
     """The 320-row tile kernel on the MoE expert calls -- per-expert device-side row counts, the dispatch gather (a_rows) with the SwiGLU
     pairing, the combine scatter (c_rows, routing weight, residual), the batched residual form -- must equal the other kernels: bit for
     bit where neither side splits K (same accumulation order, same rounding points), to two bf16 ulps where the tail split adds an fp32
@@ -111,11 +112,11 @@ def test_gemm320_expert_paths_match_256(dev):
     g = torch.Generator().manual_seed(31)
     E, cap, d, ff = 2, 1500, 256, 512
     T = 2300
-    counts = torch.tensor([1300, 777], dtype=torch.int32)
+    counts = torch.tensor([c0, c1], dtype=torch.int32)       # an empty expert, a full slab, whole row tiles, a row past a tile edge
     x = _bf(torch.randn(T, d, generator=g)).to(dev)
     perm = torch.randperm(T, generator=g)
     slot_token = torch.full((E, cap), -1, dtype=torch.int32)
-    slot_token[0, :1300] = perm[:1300].int(); slot_token[1, :777] = perm[1300:2077].int()
+    slot_token[0, :c0] = perm[:c0].int(); slot_token[1, :c1] = perm[c0:c0 + c1].int()
     slot_token = slot_token.clamp_min(0).to(dev)                                  # entries beyond the counts are never used
     w_gu = _bf(torch.randn(E, 2 * ff, d, generator=g) * 0.1).to(dev)
     w_dn = _bf(torch.randn(E, 256, ff, generator=g) * 0.1).to(dev)
@@ -149,11 +150,14 @@ def test_gemm320_expert_paths_match_256(dev):
         else:                             # K = 512, 32 tiles: the 320-row kernel's tail split sums two fp32 K-halves (one more fp32 rounding)
             _report(f"gemm320 experts: {name} vs the other tiling", a2, a0.float(), rtol=2 * BF16_EPS, atol=2e-2)
     act = outs[2][0]
-    assert (act[0, 1300:] == 7.0).all() and (act[1, 777:] == 7.0).all()          # rows beyond the counts untouched
-    ref = x[slot_token[0, :1300].long()].float() @ w_gu[0].float().T               # spot check against fp32: expert 0
+    assert (act[0, c0:] == 7.0).all() and (act[1, c1:] == 7.0).all()             # rows beyond the counts untouched
+    untouched = torch.ones(T, dtype=torch.bool); untouched[perm[:c0 + c1]] = False
+    assert (outs[2][1][untouched.to(dev)] == 3.0).all()                            # the combine writes the routed tokens' rows only
+    e, c = (0, c0) if c0 else (1, c1)                                               # spot check against fp32: one non-empty expert
+    ref = x[slot_token[e, :c].long()].float() @ w_gu[e].float().T
     gate = torch.cat([ref[:, i:i + 32] for i in range(0, 2 * ff, 64)], 1).to(torch.bfloat16).float()
     up = torch.cat([ref[:, i + 32:i + 64] for i in range(0, 2 * ff, 64)], 1).to(torch.bfloat16).float()
-    _report("gemm320 experts: swiglu(gathered rows)", act[0, :1300], torch.nn.functional.silu(gate) * up, rtol=2 * BF16_EPS, atol=2e-2)
+    _report("gemm320 experts: swiglu(gathered rows)", act[e, :c], torch.nn.functional.silu(gate) * up, rtol=2 * BF16_EPS, atol=2e-2)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
