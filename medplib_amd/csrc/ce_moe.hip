@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
 // LDSW: the norm weight and the gate matrix ((1 + E) * dim floats) are staged in LDS once per workgroup, which then walks rows with
 // stride gridDim.x * 4 -- read per row from global memory they were 48 KB of L1 traffic beside the row's own 8 KB (32.7 us per launch at
 // the 7B shape against 17.8 for the RMSNorm alone); same values, same order of operations.
+// (Requesting the NEXT row's chunks before this row's arithmetic -- a wave walks 2-3 rows here -- measured 22.5 -> 32.9 us on the same box:
+// the second row buffer's registers cost more occupancy than the overlap returns.)
 template <int NCH, bool LDSW>      // 16-byte chunks per lane: dim = NCH * 512
 __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, float eps,
                                                            bf16_t* __restrict__ h, int64_t ldh, const float* __restrict__ wg, int E,
