@@ -162,8 +162,14 @@ class LlamaStack:
             return self.rts_uniform_provider(i, T, E)
         if not self.cfg.moe_gate_sampling:
             return None
-        off = (self.gate_pass * len(self.layers) + i) * T * E
-        return ops.gate_noise(T * E, self.cfg.moe_gate_seed, off, gumbel, self.device)
+        # the generator is keyed by (seed, offset + index) and a pass's layers occupy consecutive offsets: ONE launch per forward pass draws
+        # for all layers (the same numbers as a launch per layer, which sat between every layer's routing kernel and its expert GEMMs)
+        L = len(self.layers)
+        key = (self.gate_pass, T, E, bool(gumbel))
+        if getattr(self, "_draws_key", None) != key:
+            self._draws_all = ops.gate_noise(L * T * E, self.cfg.moe_gate_seed, self.gate_pass * L * T * E, gumbel, self.device)
+            self._draws_key = key
+        return self._draws_all[i * T * E:(i + 1) * T * E]
 
     def _mlp(self, i, lw, h, x, gate=None):
         """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]; gate = (logits, gates) when the caller's fused
