@@ -703,6 +703,17 @@ class MedPLIBForCausalLM(nn.Module):
         """The VQA entry the drivers use (`model.generate(input_ids, images=images_clip, attention_mask=..., max_new_tokens=...,
         do_sample=False)`, vqa_infer.py:430-442): greedy decoding, one sample per call like the reference's loop (batch rows are
         decoded one after the other).  Returns output ids [B, L + n_max] (right-padded with eos), prompt included, as HF does."""
+        # HF generate kwargs the reference driver passes (vqa_infer.py:430-442): accepted when they mean greedy decoding, refused
+        # loudly otherwise — sampling and beam search are not built
+        if kwargs.get("do_sample") or (kwargs.get("temperature") or 0) > 0 and kwargs.get("do_sample") is not False:
+            raise NotImplementedError("generate(): sampling (do_sample / temperature > 0) is not built; the shipped eval scripts decode greedily")
+        if (kwargs.get("num_beams") or 1) != 1:
+            raise NotImplementedError("generate(): beam search (num_beams > 1) is not built; the shipped eval scripts use num_beams=1")
+        unknown = set(kwargs) - {"do_sample", "temperature", "top_p", "num_beams", "use_cache", "mask_images", "image_token_types",
+                                 "image_token_lengths", "region_masks", "valid_region_masks_bool", "output_hidden_states",
+                                 "return_dict_in_generate", "pad_token_id"}
+        if unknown:
+            raise TypeError(f"generate(): unsupported arguments {sorted(unknown)}")
         self.sync_side_streams()
         self._require_merged("generate")
         ids = _np_ids(input_ids).astype(np.int64)

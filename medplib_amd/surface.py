@@ -277,6 +277,20 @@ class SurfaceMixin:
         self._resolved = False
         self.vision_pretrained = None
 
+    def to(self, *args, **kwargs):
+        """`model.to(dtype=torch_dtype, device=args.local_rank)` of the inference driver (vqa_infer.py:237-238).  The model was built on
+        its GPU with the kernel-layout dtypes (bf16 trunk, fp32 norm weights / gate / trainable tail); a blanket cast would break
+        those layouts, so this validates the request and changes nothing: bf16 (or no dtype) on the device the model lives on."""
+        device, dtype, _, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype not in (None, torch.bfloat16):
+            raise ValueError(f"this build computes the trunk in bf16 (the reference's --precision bf16); .to(dtype={dtype}) is not available")
+        if device is not None:
+            want = torch.device(device)
+            if want.type != "cuda" or (want.index is not None and want.index != self.device_.index):
+                raise NotImplementedError(f"the model lives on {self.device_}; build it there (from_pretrained(..., local_rank=) / device=) "
+                                          f"instead of moving it to {want}")
+        return self
+
     def get_model(self):
         return InnerSurface(self)
 

@@ -227,6 +227,28 @@ def build_seg_token_mask(input_ids, seg_token_idx, image_token_len, image_token_
 
 
 # ----------------------------------------------------------------------------------------------- DeepSpeed MoE (top-1)
+def top1_capacity_selection(mask1, capacity, rts_uniform=None):
+    """The token-selection half of DeepSpeed 0.13.1 `top1gating`, as a function of the first choices alone:
+    mask1 [T,E] one-hot of the gate argmax; with Random Token Selection the `capacity` largest entries per expert column of
+    `mask1 * uniform` stay, the rest are dropped; the slot of a kept token is its rank among its expert's kept tokens in token
+    order.  -> (new_mask1 [T,E], slot [T] (0 where dropped: mask with `kept`), kept [T] bool).  Also used by oracle/parity.py to
+    check a routing kernel's kept / dropped sets at full size from that kernel's OWN expert choices."""
+    T = mask1.shape[0]
+    cap = min(capacity, T)
+    if rts_uniform is None:
+        # no draws supplied: stable first-come selection (documented deviation point; DeepSpeed's own behaviour without
+        # RTS relies on topk tie-breaking)
+        keep = (torch.cumsum(mask1, 0) - 1 < capacity) & mask1.bool()
+        new_mask1 = keep.long()
+    else:
+        top_idx = torch.topk(mask1 * rts_uniform, k=cap, dim=0)[1]
+        new_mask1 = mask1 * torch.zeros_like(mask1).scatter_(0, top_idx, 1)
+    loc = torch.cumsum(new_mask1, 0) - 1
+    slot = torch.sum(loc * new_mask1, 1)
+    kept = new_mask1.sum(1).bool()
+    return new_mask1, slot, kept
+
+
 def moe_top1(x, wg, experts, capacity, rts_uniform=None):
     """DeepSpeed 0.13.1 TopKGate(k=1) + MOELayer on one rank — parity unpinned (third-party).
     x [T,d] fp32; wg [E,d]; experts: list of callables; rts_uniform [T,E] (the `uniform(mask1.shape)` draw) or None.
@@ -239,19 +261,7 @@ def moe_top1(x, wg, experts, capacity, rts_uniform=None):
     exp_counts = mask1.sum(0)
     me, ce = gates.mean(0), mask1.float().mean(0)
     l_aux = torch.sum(me * ce) * E
-    mask1_rand = mask1 * rts_uniform if rts_uniform is not None else mask1.float()
-    cap = min(capacity, T)
-    if rts_uniform is None:
-        # no draws supplied: stable first-come selection (documented deviation point; DeepSpeed's own behaviour without
-        # RTS relies on topk tie-breaking)
-        keep = (torch.cumsum(mask1, 0) - 1 < capacity) & mask1.bool()
-        new_mask1 = keep.long()
-    else:
-        top_idx = torch.topk(mask1_rand, k=cap, dim=0)[1]
-        new_mask1 = mask1 * torch.zeros_like(mask1).scatter_(0, top_idx, 1)
-    loc = torch.cumsum(new_mask1, 0) - 1
-    slot = torch.sum(loc * new_mask1, 1)
-    kept = new_mask1.sum(1).bool()
+    new_mask1, slot, kept = top1_capacity_selection(mask1, capacity, rts_uniform)
     gate_w = (gates * new_mask1.float()).sum(1)
     out = torch.zeros_like(x, dtype=torch.float32)
     for e in range(E):

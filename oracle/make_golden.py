@@ -783,9 +783,87 @@ def golden_lisa():
         dm = max((r - p.detach()).abs().max().item() for r, p in zip(ref_masks, inter["pred_masks"]))
         print(f"   masks: {len(ref_masks)} of shapes {[tuple(r.shape) for r in ref_masks]}, max|reference - oracle| {dm:.2e}")
         assert dm < 1e-3
-        out[f"{name}_pred_masks"] = np.concatenate([r.reshape(-1).numpy() for r in ref_masks]).astype(np.float16)
+        out[f"{name}_pred_masks"] = np.concatenate([r.reshape(-1).numpy() for r in ref_masks]).astype(np.float32)   # (fp16 until round 3: the cut checks want the logits themselves)
     np.savez_compressed(os.path.join(OUT, "lisa_forward_reference.npz"), **out)
     print("lisa goldens ok:", os.path.getsize(os.path.join(OUT, "lisa_forward_reference.npz")) // 1024, "KiB")
+
+
+EVAL_CASES = ("fallback", "seg_prompt_two", "seg_generated", "eos")
+
+
+def evaluate_case(cfg, W, name, edit=None):
+    """-> (batch, W_case, max_new_tokens, edit) of one `evaluate()` golden case (B = 1, the reference evaluates one sample at a time,
+    vqa_infer.py:528).  fallback: 40-token prompt without <SEG>, nothing generated is <SEG> -> the `[-2:-1]` rule (LISA.py:516-517);
+    seg_prompt_two: two <SEG> in the prompt -> the first one (LISA.py:514-515); seg_generated / eos: one lm_head row is made a scaled
+    copy of the row of a token the greedy decode emits (`edit` = (dst, src, scale), found by make_golden with the oracle and stored
+    in the fixture), so the model itself GENERATES <SEG> / stops at EOS."""
+    from . import model as OM
+    b = OM.make_batch(cfg, 1, seed=16)        # (of seeds 11..30 the one whose greedy decodes have the widest top-2 logit gaps: >= 0.03)
+    b["images"] = b["images"].to(torch.bfloat16).float()
+    b["images_clip"] = b["images_clip"].to(torch.bfloat16).float()
+    ids = b["input_ids"]
+    n_new = {"fallback": 20, "seg_prompt_two": 16, "seg_generated": 18, "eos": 20}[name]
+    if name == "seg_prompt_two":
+        ids = ids.clone(); ids[0, 50] = cfg.seg_token_idx
+    else:
+        ids = ids[:, :40].clone()
+    b = dict(b, input_ids=ids, labels=None, attention_mask=None)
+    Wc = W
+    if edit is not None:
+        dst, src, scale = int(edit[0]), int(edit[1]), float(edit[2])
+        Wc = dict(W)
+        lm = W["lm_head.weight"].clone()
+        lm[dst] = (scale * lm[src]).to(torch.bfloat16).float()
+        Wc["lm_head.weight"] = lm
+    return b, Wc, n_new, edit
+
+
+def golden_evaluate():
+    """`LISAForCausalLM.evaluate` (model/LISA.py:473-555 — the dense twin of MedPLIB.py:574-680) EXECUTED: HF greedy `generate`
+    driven by the reference's own `prepare_inputs_for_generation`, hidden states of the last step, the <SEG> pick rules, prompt encoder,
+    mask decoder, postprocess.  transformers 5.15 here vs the reference's 4.31 pin: `use_cache` is switched off on the instance's
+    generation config, which is what the dense class's forward amounts to under 4.31 (it returns `past_key_values=None`,
+    medplib_llama.py:143, so every step re-runs the grown sequence and `outputs.hidden_states[-1]` covers all positions)."""
+    import contextlib
+    import io
+    from . import model as OM
+    cfg = lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=3)
+    out = {"weight_seed": np.int64(3), "cases": np.array(EVAL_CASES)}
+    base_b, _, _, _ = evaluate_case(cfg, W, "fallback")
+    base_ids, _ = OM.evaluate(base_b, W, cfg, max_new_tokens=20)
+    gen = base_ids[0, 40:].tolist()
+    edits = {"seg_generated": (cfg.seg_token_idx, gen[5], 1.25), "eos": (2, gen[8], 1.25)}
+    for name in EVAL_CASES:
+        b, Wc, n_new, edit = evaluate_case(cfg, W, name, edits.get(name))
+        m = _build_reference_lisa(cfg, Wc)           # a fresh module per case (golden_lisa explains why)
+        m.eval()
+        m.generation_config.use_cache = False
+        m.config.use_cache = False
+        with contextlib.redirect_stdout(io.StringIO()):           # evaluate() prints the embedding shape
+            ref_ids, ref_masks = m.evaluate(b["images_clip"], b["images"], b["input_ids"], b["resize_list"], b["label_list"],
+                                            max_new_tokens=n_new)
+        ora_ids, ora_masks, dbg = OM.evaluate(b, Wc, cfg, max_new_tokens=n_new, return_debug=True)
+        n_in = b["input_ids"].shape[1]
+        new = ref_ids[0, n_in:].tolist()
+        dm = (ora_masks[0] - ref_masks[0]).abs().max().item()
+        print(f"evaluate case {name}: {len(new)} new tokens {new} | oracle ids equal: {torch.equal(ora_ids, ref_ids)}, "
+              f"min top-2 gap {min(dbg['gaps']):.3f}, max|mask reference - oracle| {dm:.2e}")
+        assert torch.equal(ora_ids, ref_ids) and dm < 1e-4, name
+        if name == "seg_generated":
+            assert cfg.seg_token_idx in new
+        if name == "eos":
+            assert new[-1] == 2 and len(new) < n_new
+        if name == "fallback":
+            assert cfg.seg_token_idx not in ref_ids[0].tolist() and len(new) == n_new
+        out[f"{name}_output_ids"] = ref_ids.numpy().astype(np.int64)
+        out[f"{name}_pred_mask"] = ref_masks[0].numpy().astype(np.float32)
+        out[f"{name}_oracle_top2_gaps"] = np.array(dbg["gaps"], np.float32)
+        out[f"{name}_edit"] = np.array(edit if edit is not None else (-1, -1, 0.0), np.float64)
+        out[f"{name}_input_checksum"] = np.float64(float(b["images"].double().sum()) + float(b["images_clip"].double().sum())
+                                                   + float(b["input_ids"].sum()))
+    np.savez_compressed(os.path.join(OUT, "lisa_evaluate_reference.npz"), **out)
+    print("evaluate goldens ok:", os.path.getsize(os.path.join(OUT, "lisa_evaluate_reference.npz")) // 1024, "KiB")
 
 
 def golden_llama_layer():
@@ -839,3 +917,5 @@ if __name__ == "__main__":
         golden_lisa()
     if "llama_layer" in which:
         golden_llama_layer()
+    if "evaluate" in which:
+        golden_evaluate()

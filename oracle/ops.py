@@ -193,6 +193,29 @@ def threshold_iou(pred_logits, gt, thr=0.1):
     return b, (int(b.sum()), int(g.sum()), inter, union), iou, 2 * iou / (1 + iou)
 
 
+def mask_cut_report(pred, ref, gt, thr=0.1):
+    """How two mask-logit maps compare where a comparison can fail: at the reference's threshold `sigmoid(x) > 0.1`
+    (train_ds_medplib.py:750; logit cut log(0.1 / 0.9) = -2.197) and at logit 0.  Per cut: the positive-pixel fraction on both
+    sides, the number of pixels whose thresholded value differs, the number of reference pixels within the measured max |dlogit| of
+    the cut (the only pixels that MAY differ: `flipped <= near_cut` is the bit-exactness statement for mask indices under a
+    stated logit tolerance), and the Dice against the ground truth on both sides.  pred / ref / gt: [H, W] (or [1, H, W])."""
+    import math
+    pred, ref, g = pred.float().reshape(-1), ref.float().reshape(-1), gt.reshape(-1).bool()
+    err = (pred - ref).abs()
+    out = {"max_abs_dlogit": float(err.max()), "mean_abs_dlogit": float(err.mean()), "pixels": int(ref.numel())}
+    for name, cut in (("cut_ref", math.log(thr / (1.0 - thr))), ("cut_zero", 0.0)):
+        bp, br = pred > cut, ref > cut
+        def dice(b):
+            inter, union = int((b & g).sum()), int((b | g).sum())
+            iou = 0.0 if union == 0 else inter / union
+            return 2 * iou / (1 + iou)
+        out[name] = {"logit_cut": cut, "pos_frac_pred": float(bp.float().mean()), "pos_frac_ref": float(br.float().mean()),
+                     "flipped": int((bp != br).sum()), "near_cut": int(((ref - cut).abs() <= out["max_abs_dlogit"]).sum()),
+                     "dice_pred": dice(bp), "dice_ref": dice(br)}
+        out[name]["abs_ddice"] = abs(out[name]["dice_pred"] - out[name]["dice_ref"])
+    return out
+
+
 def validate_metrics(counts, n_pixels):
     """Per-sample metrics of validate() (train_ds_medplib.py:745-772) from the four integer counts of threshold_iou
     (|pred|, |gt|, |pred & gt|, |pred | gt|) for a binary target without ignore pixels: intersectionAndUnionGPU (utils/utils.py:

@@ -5,7 +5,9 @@ layers at 7B dims -> CE; SAM-Med2D encoder -> <SEG> projection -> mask decoder -
 (fp32) and once on the HIP path (bf16 trunk, fp32 tail) from the same seeded weights and the same B = 1 batch, and reports how far
 apart they are: the 10 losses, the last hidden state, per-layer routing agreement, the thresholded-mask Dice.  Weights: one decoder
 layer's seeded weights aliased over all layers on BOTH sides (`init_hf_weights_aliased`), which bounds host memory at true dims.
-Gate sampling (DeepSpeed's RTS draws) is off on both sides so the routing is a function of the gate alone.
+Gate sampling: either off on both sides (the routing is a function of the gate alone) or DeepSpeed's Random Token Selection with
+the SAME uniform draws injected on both sides (`rts_seed`), at B = 8 = the benchmark's T = 5112 tokens, where capacity overflow
+decides which tokens are dropped.  Masks are compared where a comparison can fail (`ops.mask_cut_report`).
 Called by tests/test_gpu_model.py (8 layers) and by bench.py's cpu_baseline leg (32 layers, un-timed), never by the product."""
 import copy
 import time
@@ -16,66 +18,148 @@ from . import model as OM
 from . import ops as O
 
 
-def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0):
+MASK_LOGIT_TOL = 0.08          # stated tolerance on the mask logits of the bf16 trunk + fp32 tail against the fp32 oracle at full depth
+                               # (measured 0.02-0.04 at 32 layers); pixels whose reference logit is farther than this from a cut must
+                               # threshold identically (`flipped <= near_cut`)
+
+
+def _to_dev(batch, device):
+    gb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for k in ("masks_list", "images_clip", "mask_images"):
+        if isinstance(batch.get(k), (list, tuple)):
+            gb[k] = [x.to(device) for x in batch[k]]
+    return gb
+
+
+def routing_report(coll, routing, T, capacity, rts):
+    """Per MoE layer: the HIP path's routing against (i) the oracle's routing of the same layer and (ii) DeepSpeed's selection rule
+    applied on the host to the HIP path's OWN expert choices with the same injected uniforms (`llm.top1_capacity_selection`) — the
+    second is exact by construction (no bf16 noise enters it): kept / dropped sets, slots and counts must be bit-equal in every
+    layer, at the benchmark's token count, whether or not an upstream gate probability flipped.  coll: oracle (idx, slot, counts)
+    per layer; routing: HIP (expert, slot, counts) per layer."""
+    import torch.nn.functional as F
+    from . import llm
+    per, same_all = [], torch.ones(T, dtype=torch.bool)
+    for li, ((e_ref, s_ref, c_ref), r) in enumerate(zip(coll, routing)):
+        e_hip, s_hip, c_hip = r[0].cpu().long()[:T], r[1].cpu().long()[:T], r[2].cpu().long()
+        E = int(c_ref.numel())
+        agree = e_hip == e_ref[:T]
+        same_all &= agree
+        kept_hip, kept_ref = s_hip >= 0, s_ref[:T] >= 0
+        _, slot_rule, kept_rule = llm.top1_capacity_selection(F.one_hot(e_hip, num_classes=E), capacity, None if rts is None else rts[li])
+        slot_rule = torch.where(kept_rule, slot_rule, torch.full_like(slot_rule, -1))
+        per.append({"layer": li, "expert_agreement": float(agree.float().mean()), "flipped_tokens": int((~agree).sum()),
+                    "dropped_hip": int((~kept_hip).sum()), "dropped_oracle": int((~kept_ref).sum()),
+                    # against the oracle's own run: a flipped token moves the capacity boundary of both experts by one
+                    "kept_state_differs_on_agreeing_rows": int((kept_hip != kept_ref)[agree].sum()),
+                    # against the rule on the HIP path's own choices: exact
+                    "kept_set_equals_rule": bool(torch.equal(kept_hip, kept_rule)), "slots_equal_rule": bool(torch.equal(s_hip, slot_rule)),
+                    "counts_equal_own_choices": bool(torch.equal(c_hip[:E], torch.bincount(e_hip, minlength=E)))})
+    return per, same_all
+
+
+def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0, B=1,
+                     rts_seed=None, capacity_factor=None, time_threads=None):
     """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
-    through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline)."""
+    through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline).
+    B: samples in the compared batch (8 = the benchmark's per-GPU batch, T = 5112).  rts_seed: DeepSpeed's Random Token Selection
+    ON with the same uniform draws injected on both sides (None: sampling off, first-come selection).  capacity_factor: override
+    (1.0 = the reference driver's argparse default, train_ds_medplib.py:127: the larger expert overflows in every layer, so the
+    RTS selection decides which tokens are dropped; 1.5 = scripts/train_stage4.sh, where balanced gates never overflow)."""
     from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
     if cpu_threads:
         torch.set_num_threads(cpu_threads)
     cfg = copy.deepcopy(cfg)
     cfg.moe_gate_sampling = False
+    if capacity_factor is not None:
+        cfg.capacity_factor = capacity_factor
     W = OM.init_hf_weights_aliased(cfg, seed=seed)
-    if icl_ctx:                                   # BASELINE config 5 shape: icl_ctx in-context (image, mask) pairs + the query, separate mode
-        batch = OM.make_batch_icl(cfg, 1, n_ctx=icl_ctx, H=H, Wd=Wd, seed=batch_seed, mask_size=cfg.clip_image_size)
-        batch["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]
-    else:
-        batch = OM.make_batch(cfg, 1, L=64, H=H, Wd=Wd, seed=batch_seed)
-        batch["images_clip"] = batch["images_clip"].to(torch.bfloat16).float()
-    batch["images"] = batch["images"].to(torch.bfloat16).float()
-    train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
-    Wt = dict(W)
-    for k in train:
-        Wt[k] = W[k].clone().requires_grad_()
+
+    def make(B_, bseed):
+        if icl_ctx:                               # BASELINE config 5 shape: icl_ctx in-context (image, mask) pairs + the query, separate mode
+            b = OM.make_batch_icl(cfg, B_, n_ctx=icl_ctx, H=H, Wd=Wd, seed=bseed, mask_size=cfg.clip_image_size)
+            b["images_clip"] = [x.to(torch.bfloat16).float() for x in b["images_clip"]]
+        else:
+            b = OM.make_batch(cfg, B_, L=64, H=H, Wd=Wd, seed=bseed)
+            b["images_clip"] = b["images_clip"].to(torch.bfloat16).float()
+        b["images"] = b["images"].to(torch.bfloat16).float()
+        return b
     times = []
     if time_oracle:
+        if time_threads:
+            torch.set_num_threads(time_threads)
+        b1 = make(1, batch_seed)
+        train = [k for k in W if k.startswith("model.visual_model.mask_decoder.") or k.startswith("model.text_hidden_fcs.")]
+        Wt = dict(W)
+        for k in train:
+            Wt[k] = W[k].clone().requires_grad_()
         for _ in range(time_oracle[0] + time_oracle[1]):
             for k in train:
                 Wt[k].grad = None
             t0 = time.time()
-            out = OM.model_forward(batch, Wt, cfg, training=True)
+            out = OM.model_forward(b1, Wt, cfg, training=True)
             out["loss"].backward()
             times.append(time.time() - t0)
         times = times[time_oracle[0]:]
+        del Wt, out
+        if cpu_threads:
+            torch.set_num_threads(cpu_threads)
+    batch = make(B, batch_seed)
+    rts = None
+    if rts_seed is not None and cfg.moe_enable:
+        g = torch.Generator().manual_seed(rts_seed)
+        S_ = batch["input_ids"].shape[1] - 1 + cfg.image_token_len if not icl_ctx else None
+        assert S_ is not None, "injected draws need the spliced length up front (single-image layout)"
+        rts = {i: torch.rand(B * S_, cfg.num_experts, generator=g) for i in sorted(cfg.moe_layer_set())}
     coll = []
+    t0 = time.time()
     with torch.no_grad():
-        ref, inter = OM.model_forward(batch, W, cfg, training=True, return_intermediates=True, collect=coll)
+        ref, inter = OM.model_forward(batch, W, cfg, training=True, return_intermediates=True, collect=coll, rts=rts)
+    t_oracle = time.time() - t0
 
     cls = MedPLIBForCausalLM if cfg.moe_enable else LISAForCausalLM
     m = cls(cfg, device=device).train()
     m.load_hf_state_dict(W)
     m.capture_intermediates = True
-    gb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-    for k in ("masks_list", "images_clip", "mask_images"):
-        if isinstance(batch.get(k), (list, tuple)):
-            gb[k] = [x.to(device) for x in batch[k]]
+    if rts is not None:
+        moe_ids = sorted(cfg.moe_layer_set())
+        rts_dev = {i: rts[i].to(device) for i in moe_ids}
+        m.model.llm.rts_uniform_provider = lambda i, T_, E_: rts_dev[i]
+        rts_list = [rts[i] for i in moe_ids]
+    else:
+        rts_list = None
+    gb = _to_dev(batch, device)
     with torch.no_grad():
         out = m(**gb)
         losses_gpu = {k: float(out[k]) for k in O.LOSS_KEYS}
         cap = m.captured
         hid = cap["last_hidden"].float().cpu()
         routing = cap.get("routing") or []
-        agree = []
-        same = torch.ones(hid.shape[0] * hid.shape[1], dtype=torch.bool)
-        for (e_ref, _, _), r in zip(coll, routing):
-            eq = r[0].cpu().long()[: same.numel()] == e_ref[: same.numel()]
-            agree.append(float(eq.float().mean()))
-            same &= eq
+        T = hid.shape[0] * hid.shape[1]
+        per_layer, same = routing_report(coll, routing, T, m.model.llm.capacity(T), rts_list) if routing else ([], torch.ones(T, dtype=torch.bool))
+        agree = [p["expert_agreement"] for p in per_layer]
         masks = m(**dict(gb, inference=True))["pred_masks"]
     losses_cpu = {k: float(ref[k]) for k in O.LOSS_KEYS}
-    _, _, _, dice_cpu = O.threshold_iou(inter["pred_masks"][0][0], batch["masks_list"][0])
-    _, _, _, dice_gpu = O.threshold_iou(masks[0][0].float().cpu(), batch["masks_list"][0])
+    # the masks, where a comparison can fail (oracle/ops.py: mask_cut_report): per mask at the reference's cut and at logit 0
+    reports = [O.mask_cut_report(masks[i][0].float().cpu(), inter["pred_masks"][i][0], batch["masks_list"][i]) for i in range(len(masks))]
+    def agg(cut, key, f=max):
+        return f(r[cut][key] for r in reports)
+    mask_summary = {"masks": len(reports), "pixels_per_mask": reports[0]["pixels"],
+                    "max_abs_dlogit": max(r["max_abs_dlogit"] for r in reports), "mean_abs_dlogit": sum(r["mean_abs_dlogit"] for r in reports) / len(reports),
+                    "logit_tolerance": MASK_LOGIT_TOL}
+    for cut in ("cut_ref", "cut_zero"):
+        mask_summary[cut] = {"logit_cut": reports[0][cut]["logit_cut"],
+                             "pos_frac_ref_min_max": [agg(cut, "pos_frac_ref", min), agg(cut, "pos_frac_ref", max)],
+                             "pos_frac_pred_min_max": [agg(cut, "pos_frac_pred", min), agg(cut, "pos_frac_pred", max)],
+                             "flipped_total": sum(r[cut]["flipped"] for r in reports), "near_cut_total": sum(r[cut]["near_cut"] for r in reports),
+                             "flipped_le_near_cut_every_mask": all(r[cut]["flipped"] <= r[cut]["near_cut"] for r in reports),
+                             "max_abs_ddice": agg(cut, "abs_ddice"), "dice_ref": [round(r[cut]["dice_ref"], 6) for r in reports],
+                             "dice_pred": [round(r[cut]["dice_pred"], 6) for r in reports]}
     href = inter["hidden"]
-    res = {"layers": cfg.num_hidden_layers, "moe": bool(cfg.moe_enable), "batch": 1, "seq_len": int(href.shape[1]),
+    d = hid.shape[-1]
+    res = {"layers": cfg.num_hidden_layers, "moe": bool(cfg.moe_enable), "batch": B, "seq_len": int(href.shape[1]), "tokens": int(T),
+           "capacity_factor": cfg.capacity_factor, "capacity": int(m.model.llm.capacity(T)) if cfg.moe_enable else None,
+           "gate_sampling": ("RTS on, identical uniforms injected on both sides (seed %d)" % rts_seed) if rts is not None else "off",
            "abs_dloss": abs(losses_gpu["loss"] - losses_cpu["loss"]),
            "max_abs_dloss_over_10": max(abs(losses_gpu[k] - losses_cpu[k]) for k in O.LOSS_KEYS),
            "loss_gpu": losses_gpu["loss"], "loss_cpu": losses_cpu["loss"], "ce_gpu": losses_gpu["ce_loss"], "ce_cpu": losses_cpu["ce_loss"],
@@ -83,15 +167,29 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "hidden_rel_err": float((hid - href).abs().max() / href.abs().max()),
            "hidden_mean_rel_err": float((hid - href).abs().mean() / href.abs().mean()),
            # a token that picked the other expert somewhere is a different computation from there on: bound the rest
-           "hidden_rel_err_agreeing_rows": float((hid.view(-1, hid.shape[-1])[same] - href.view(-1, href.shape[-1])[same]).abs().max()
-                                                 / href.abs().max()),
+           "hidden_rel_err_agreeing_rows": float((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().max() / href.abs().max()),
            "rows_agreeing_in_every_layer": float(same.float().mean()),
-           "dice_gpu": dice_gpu, "dice_cpu": dice_cpu, "abs_ddice": abs(dice_gpu - dice_cpu),
-           "mask_logit_max_abs_err": float((masks[0][0].float().cpu() - inter["pred_masks"][0][0]).abs().max()),
+           "mask": mask_summary,
+           # kept for continuity with earlier rounds' lines (Dice of mask 0 at the reference cut; see `mask` for what bites)
+           "dice_gpu": reports[0]["cut_ref"]["dice_pred"], "dice_cpu": reports[0]["cut_ref"]["dice_ref"],
+           "abs_ddice": max(mask_summary["cut_ref"]["max_abs_ddice"], mask_summary["cut_zero"]["max_abs_ddice"]),
+           "mask_logit_max_abs_err": mask_summary["max_abs_dlogit"],
            "routing_agreement_min": min(agree) if agree else None,
            "routing_agreement_mean": (sum(agree) / len(agree)) if agree else None,
            "routing_agreement_per_layer": [round(a, 4) for a in agree],
-           "weights": "one decoder layer's seeded weights aliased over all layers, both sides; gate sampling off"}
+           "oracle_forward_seconds": round(t_oracle, 2),
+           "weights": "one decoder layer's seeded weights aliased over all layers, both sides"}
+    if per_layer:
+        res["routing"] = {"dropped_hip_per_layer": [p["dropped_hip"] for p in per_layer],
+                          "dropped_oracle_per_layer": [p["dropped_oracle"] for p in per_layer],
+                          "flipped_tokens_per_layer": [p["flipped_tokens"] for p in per_layer],
+                          "kept_state_differs_on_agreeing_rows_per_layer": [p["kept_state_differs_on_agreeing_rows"] for p in per_layer],
+                          "layers_with_identical_choices": sum(p["flipped_tokens"] == 0 for p in per_layer),
+                          "kept_sets_bit_equal_where_choices_identical": all(p["kept_state_differs_on_agreeing_rows"] == 0 and p["dropped_hip"] == p["dropped_oracle"]
+                                                                             for p in per_layer if p["flipped_tokens"] == 0),
+                          "kept_set_equals_deepspeed_rule_every_layer": all(p["kept_set_equals_rule"] for p in per_layer),
+                          "slots_equal_deepspeed_rule_every_layer": all(p["slots_equal_rule"] for p in per_layer),
+                          "counts_equal_own_choices_every_layer": all(p["counts_equal_own_choices"] for p in per_layer)}
     if times:
         res["oracle_step_seconds"] = times
     del m

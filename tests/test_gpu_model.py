@@ -47,6 +47,27 @@ def _check_grads(params, ref_grads, rtol, tag):
     print(f"{tag} grads: worst relative error {worst:.3e} (largest gradient {gmax:.3e})")
 
 
+TINY_MASK_LOGIT_TOL = 5e-2     # mask logits (|x| up to ~3) of the bf16 trunk + bf16 SAM encoder + fp32 tail vs the fp32 reference; measured 0.027-0.037
+
+
+def _check_mask_cuts(tag, pred, ref, gt, tol):
+    """Masks compared where the comparison can fail (oracle/ops.py: mask_cut_report): the logits within `tol`; at the reference's
+    cut (sigmoid > 0.1, train_ds_medplib.py:750) AND at logit 0 (where the fixtures' masks are ~50 % positive) every pixel farther than
+    the measured error from the cut thresholds identically (mask indices bit-exact outside the error band).  Dice against the ground
+    truth: within 1e-3 at the reference's cut (the BASELINE target); at logit 0 within 1e-3 for full-size masks and 3e-3 for the tiny
+    fixtures' 96 x 80 masks (a pixel is 1.3e-4 of such a mask; measured 1.2e-3 with 23 of 7680 pixels inside the error band flipped)."""
+    r = O.mask_cut_report(pred.float().cpu(), ref.float().cpu(), gt.float().cpu())
+    print(f"{tag}: max|dlogit| {r['max_abs_dlogit']:.4f}; " + "; ".join(
+        f"{c}: pos {r[c]['pos_frac_ref']:.4f}/{r[c]['pos_frac_pred']:.4f} flipped {r[c]['flipped']} (near cut {r[c]['near_cut']}) "
+        f"dice {r[c]['dice_ref']:.5f}/{r[c]['dice_pred']:.5f}" for c in ("cut_ref", "cut_zero")))
+    assert r["max_abs_dlogit"] <= tol, (tag, r)
+    for c in ("cut_ref", "cut_zero"):
+        assert r[c]["flipped"] <= r[c]["near_cut"], (tag, c, r[c])
+    assert r["cut_ref"]["abs_ddice"] <= 1e-3, (tag, r["cut_ref"])
+    assert r["cut_zero"]["abs_ddice"] <= (1e-3 if r["pixels"] >= 100000 else 3e-3), (tag, r["cut_zero"])
+    return r
+
+
 def _model(cfg, dev, W, cls=None):
     from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
     cls = cls or (MedPLIBForCausalLM if cfg.moe_enable else LISAForCausalLM)
@@ -337,6 +358,37 @@ def test_evaluate_greedy_decode_and_mask(dev, moe):
         else:
             _stat("evaluate pred_mask", masks[0], masks_ref[0], atol=0.2)
             assert masks[0].shape == masks_ref[0].shape
+
+
+def test_evaluate_vs_executed_reference_golden(dev, golden_dir):
+    """evaluate() (KV-cache prefill + HIP-graph decode steps, <SEG> pick, mask head) vs the EXECUTED reference `LISAForCausalLM.evaluate`
+    (tests/golden/lisa_evaluate_reference.npz; the oracle equals it bit for bit on the CPU, tests/test_oracle_golden.py): token ids
+    bit-exact over 16-20 new tokens in all four cases (no <SEG> -> position -2; two <SEG> in the prompt -> the first; <SEG> generated by
+    the model; EOS stops the decode).  The widest escape hatch the bf16 trunk gets: a divergence is accepted only at a step whose fp32
+    top-2 logit gap is below 2e-2 — the stored gaps are all >= 3e-2, so none is.  Masks: logits within 3e-2, thresholded pixels equal
+    outside the error band at the reference cut and at logit 0, Dice within 1e-3."""
+    from oracle import make_golden as MG
+    g = np.load(os.path.join(golden_dir, "lisa_evaluate_reference.npz"))
+    cfg = MG.lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
+    for name in MG.EVAL_CASES:
+        edit = g[f"{name}_edit"]
+        b, Wc, n_new, _ = MG.evaluate_case(cfg, W, name, None if edit[0] < 0 else edit)
+        m = _model(cfg, dev, Wc).eval()
+        out_ids, masks = m.evaluate(b["images_clip"].to(dev), b["images"].to(dev), b["input_ids"], b["resize_list"], b["label_list"],
+                                    max_new_tokens=n_new)
+        want = g[f"{name}_output_ids"]
+        gaps = g[f"{name}_oracle_top2_gaps"]
+        got = out_ids.numpy() if torch.is_tensor(out_ids) else np.asarray(out_ids)
+        n_in = b["input_ids"].shape[1]
+        print(f"{name}: generated {got[0, n_in:].tolist()} | reference {want[0, n_in:].tolist()} | min fp32 top-2 gap {gaps.min():.3f}")
+        assert gaps.min() >= 2e-2, "fixture drifted: a near tie would make the id comparison vacuous"
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        gt = torch.zeros(tuple(b["label_list"][0].shape))          # Dice needs a target: a centred box (the fixture stores none)
+        H, Wd = gt.shape
+        gt[H // 4: 3 * H // 4, Wd // 4: 3 * Wd // 4] = 1
+        _check_mask_cuts(f"evaluate[{name}] mask", masks[0][0], torch.from_numpy(g[f"{name}_pred_mask"])[0], gt, tol=TINY_MASK_LOGIT_TOL)
+        del m
 
 
 def test_icl_token_compressor_and_mask_encoder(dev, golden_dir):
@@ -1422,10 +1474,7 @@ def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
         n = pmask.numel()
         rp = torch.from_numpy(ref_pm[off:off + n]).view(pmask.shape[-2:]); off += n
         assert tuple(pmask.shape[-2:]) == tuple(b["masks_list"][i].shape)
-        _, _, _, dice_ref = O.threshold_iou(rp, b["masks_list"][i])
-        _, _, _, dice_hip = O.threshold_iou(pmask[0].float().cpu(), b["masks_list"][i])
-        print(f"{case} dice[{i}] executed reference {dice_ref:.5f} hip {dice_hip:.5f}")
-        assert abs(dice_ref - dice_hip) <= 1e-3
+        _check_mask_cuts(f"{case} mask[{i}] vs executed reference", pmask[0], rp, b["masks_list"][i], tol=TINY_MASK_LOGIT_TOL)
     assert off == ref_pm.size
 
 
@@ -1442,11 +1491,42 @@ def test_full_depth_parity_at_true_dims(dev, moe):
     torch.set_num_threads(min(32, os.cpu_count()))
     r = full_size_parity(cfg, dev)
     print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
+    _assert_full_size(r, 8, moe)
+
+
+def _assert_full_size(r, layers, moe):
+    from oracle.parity import MASK_LOGIT_TOL
     assert r["max_abs_dloss_over_10"] < 5e-2, r
     assert r["hidden_rel_err_agreeing_rows"] < 0.1 and r["hidden_mean_rel_err"] < 2 ** -6, r
-    assert r["abs_ddice"] <= 1e-3, r
+    mk = r["mask"]
+    assert mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, mk
+    for c in ("cut_ref", "cut_zero"):
+        assert mk[c]["flipped_le_near_cut_every_mask"], mk[c]
+        assert mk[c]["max_abs_ddice"] <= 1e-3, mk[c]
     if moe:
-        assert len(r["routing_agreement_per_layer"]) == 8 and r["routing_agreement_min"] >= 0.97, r
+        assert len(r["routing_agreement_per_layer"]) == layers and r["routing_agreement_min"] >= 0.97, r
+        rt = r["routing"]
+        assert rt["kept_set_equals_deepspeed_rule_every_layer"] and rt["slots_equal_deepspeed_rule_every_layer"], rt
+        assert rt["counts_equal_own_choices_every_layer"] and rt["kept_sets_bit_equal_where_choices_identical"], rt
+        # against the oracle's own run: a token that flipped moves the capacity boundary of its old and its new expert by one each
+        assert all(d <= 2 * f for d, f in zip(rt["kept_state_differs_on_agreeing_rows_per_layer"], rt["flipped_tokens_per_layer"])), rt
+
+
+def test_full_depth_parity_batch8_rts_overflow(dev):
+    """The benchmark's own batch: B = 8 (T = 5112 tokens, capacity 3834 at the stage-IV factor 1.5), 8 MoE decoder layers at the 7B dims,
+    DeepSpeed's Random Token Selection ON with the same uniform draws injected on both sides.  The seeded gate is far from balanced
+    (one expert draws > 90 % of the tokens in the deeper layers), so the fuller expert overflows in EVERY layer and the draws decide
+    which tokens are dropped.  Per layer the HIP path's kept / dropped set, slots and counts must equal DeepSpeed's rule applied on
+    the host to the path's own expert choices (exact); against the oracle's own run they may differ by at most two tokens per flipped
+    gate decision; losses, hidden state and all 8 masks as in the B = 1 test."""
+    from oracle.parity import full_size_parity
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=8, vocab_size=4096, seg_token_idx=4000, moe_enable=True)
+    torch.set_num_threads(min(64, os.cpu_count()))
+    r = full_size_parity(cfg, dev, B=8, rts_seed=77)
+    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
+    assert r["tokens"] == 8 * 639 and r["capacity"] == 3834
+    assert min(r["routing"]["dropped_hip_per_layer"]) > 0, "capacity overflow was the point of this configuration"
+    _assert_full_size(r, 8, True)
 
 
 @pytest.mark.parametrize("layers,r_,targets", [(2, 8, "gate_proj,up_proj,down_proj"), (3, 16, "q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj")])
@@ -1504,9 +1584,7 @@ def test_icl_separate_mode_parity_at_true_dims(dev):
     r = full_size_parity(cfg, dev, icl_ctx=3)
     print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
     assert 1250 <= r["seq_len"] <= 1320, r["seq_len"]
-    assert r["max_abs_dloss_over_10"] < 5e-2, r
-    assert r["hidden_rel_err_agreeing_rows"] < 0.1 and r["hidden_mean_rel_err"] < 2 ** -6, r
-    assert r["abs_ddice"] <= 1e-3 and r["routing_agreement_min"] >= 0.97, r
+    _assert_full_size(r, 4, True)
 
 
 def test_capi_rccl_comm_single_rank(dev):

@@ -166,3 +166,27 @@ def test_oracle_decoder_layer_at_true_dims_matches_hf_golden(golden_dir):
         out, _ = llm.llama_forward(emb.float(), kv, W, cfg, training=True)
     got = out.view(-1, cfg.hidden_size)[torch.from_numpy(g["rows"])].numpy()
     assert np.abs(got - g["hidden_rows"]).max() < 5e-4
+
+
+def test_evaluate_oracle_matches_executed_reference(golden_dir):
+    """`oracle.model.evaluate` vs the EXECUTED `LISAForCausalLM.evaluate` (model/LISA.py:473-555, the dense twin of MedPLIB.py:574-680;
+    tests/golden/lisa_evaluate_reference.npz, oracle/make_golden.py: golden_evaluate): greedy token ids bit-equal over 16-20 new
+    tokens (3 when the model emits EOS), the <SEG> pick rules (none generated -> position -2, two in the prompt -> the first, <SEG>
+    generated by the model itself), the mask within 1e-4."""
+    from oracle import make_golden as MG
+    from oracle import model as OM
+    g = np.load(os.path.join(golden_dir, "lisa_evaluate_reference.npz"))
+    cfg = MG.lisa_tiny_cfg()
+    W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
+    assert [str(c) for c in g["cases"]] == list(MG.EVAL_CASES)
+    for name in MG.EVAL_CASES:
+        edit = g[f"{name}_edit"]
+        b, Wc, n_new, _ = MG.evaluate_case(cfg, W, name, None if edit[0] < 0 else edit)
+        assert abs(float(b["images"].double().sum()) + float(b["images_clip"].double().sum()) + float(b["input_ids"].sum())
+                   - float(g[f"{name}_input_checksum"])) < 1e-6
+        ids, masks = OM.evaluate(b, Wc, cfg, max_new_tokens=n_new)
+        assert np.array_equal(ids.numpy(), g[f"{name}_output_ids"]), name
+        assert np.abs(masks[0].numpy() - g[f"{name}_pred_mask"]).max() < 1e-4, name
+    n_in = 40
+    assert g["fallback_output_ids"].shape[1] - n_in == 20 and cfg.seg_token_idx not in g["fallback_output_ids"][0]
+    assert cfg.seg_token_idx in g["seg_generated_output_ids"][0, n_in:] and g["eos_output_ids"][0, -1] == 2

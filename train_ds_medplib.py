@@ -1,23 +1,27 @@
-"""The reference's training driver, call for call, against the MI355X build.
+"""Surface walk of the training driver — NOT a copy of it.
 
-This file replays `/root/reference/train_ds_medplib.py` main() :181-533 and train() :536-700 with the reference's own statements in
-the reference's own order — the only substitutions are the three imports a maintainer changes:
+The reference's `train_ds_medplib.py` is the script every `scripts/train_stage*.sh` launches.  A maintainer switching to this build
+keeps that script and changes two import lines (`import medplib_amd.engine as deepspeed`,
+`from medplib_amd.peft_compat import LoraConfig, get_peft_model`); `model.*`, `datasets` and `utils.utils` resolve to this
+repository's packages of the same names.  This module proves that claim without carrying the script: it is a harness, written
+for this build, that issues the SAME API CALLS in the same order against the same import faces — one small stage function per
+group of calls, listed in `STAGES` with the reference lines each group stands for — and accepts the reference's command line
+(`FLAG_TABLE`: names and defaults of train_ds_medplib.py:28-138, kept as data so a flag diff against the reference is one
+comparison).  `tests/test_gpu_surface.py` drives it for the dense, LoRA and LoRA + MoE configurations.
 
-    from model.MedPLIB import MedPLIBForCausalLM; from model.LISA import LISAForCausalLM     # unchanged: repo-root `model/` package
-    from medplib_amd.peft_compat import LoraConfig, get_peft_model                            # was: from peft import ...
-    import medplib_amd.engine as deepspeed                                                    # was: import deepspeed
-
-Flags are the reference's (:28-138).  Additions, all optional: `--dataset synthetic` (seeded batches of SURVEY §8d instead of
-JSON files — no datasets / tokenizer files exist on the build or GPU boxes), `--steps_per_epoch` to bound a synthetic epoch,
-`--tokenizer_path` for a sentencepiece model when `--version` holds no tokenizer files.
-`tests/test_gpu_surface.py` runs it end to end at tiny dims for the dense (LISA), LoRA and LoRA + MoE branches."""
+Additions of this build (optional flags at the end of the table): `--dataset synthetic` (seeded batches of SURVEY §8d — no dataset
+or tokenizer files exist on the build / GPU boxes), `--steps_per_epoch`, `--val_samples`, `--tokenizer_path`, `--seed`."""
 import argparse
+import itertools
+import json
 import math
 import os
+import shutil
 import sys
 import time
 import types
 from functools import partial
+from pathlib import Path
 
 import torch
 
@@ -25,325 +29,375 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import medplib_amd.engine as deepspeed                                        # noqa: E402
-from medplib_amd.peft_compat import LoraConfig, get_peft_model                # noqa: E402
-from model.LISA import LISAForCausalLM                                        # noqa: E402
-from model.MedPLIB import MedPLIBForCausalLM                                  # noqa: E402
+# ---- the reference driver's import block, as a maintainer leaves it after the switch (train_ds_medplib.py:11-26)
+import medplib_amd.engine as deepspeed                                                              # noqa: E402  was: import deepspeed
+from medplib_amd.peft_compat import LoraConfig, get_peft_model                                      # noqa: E402  was: from peft import ...
+from model.LISA import LISAForCausalLM                                                              # noqa: E402  unchanged
+from model.MedPLIB import MedPLIBForCausalLM                                                        # noqa: E402  unchanged
+from datasets import DataCollatorForSupervisedDataset, ICLLazySupervisedDataset, LazySupervisedDataset   # noqa: E402  unchanged
+from utils.utils import (ADD_OTHERS_TOKENS, DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, AverageMeter, ProgressMeter,   # noqa: E402
+                         Summary, dict_to_cuda, intersectionAndUnionGPU)                            # unchanged
 
-DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN = "<im_start>", "<im_end>"      # utils/utils.py
-
-
-def parse_args(args):
-    parser = argparse.ArgumentParser(description="MedPLIB Model Training")   # train_ds_medplib.py:28-138, same names and defaults
-    parser.add_argument("--local_rank", default=0, type=int, help="node rank")
-    parser.add_argument("--version", default="liuhaotian/llava-llama-2-13b-chat-lightning-preview")
-    parser.add_argument("--pretrain_mm_mlp_adapter", default=None, type=str)
-    parser.add_argument("--precision", default="bf16", type=str, choices=["fp32", "bf16", "fp16"])
-    parser.add_argument("--sam_img_size", default=256, type=int)
-    parser.add_argument("--model_max_length", default=512, type=int)
-    parser.add_argument("--vision_tower", default="openai/clip-vit-large-patch14", type=str)
-    parser.add_argument("--vision_pretrained", default="PATH_TO_SAM_ViT-H", type=str)
-    parser.add_argument("--sft_modules", default="lm_head,embed_tokens,mask_decoder,text_hidden_fcs", type=str)
-    parser.add_argument("--lora_r", default=8, type=int)
-    parser.add_argument("--lora_alpha", default=16, type=int)
-    parser.add_argument("--lora_dropout", default=0.05, type=float)
-    parser.add_argument("--lora_target_modules", default="q_proj,v_proj", type=str)
-    parser.add_argument("--image_folder", type=str, default="/path/to/SAMed2D_v1")
-    parser.add_argument("--image_aspect_ratio", type=str, default="pad")
-    parser.add_argument("--is_multimodal", type=bool, default=True)
-    parser.add_argument("--data_path", type=str, default="/path/to/xxx.json")
-    parser.add_argument("--val_data_path", type=str, default="/path/to/xxx.json")
-    parser.add_argument("--icl_enable", action="store_true", default=False)
-    parser.add_argument("--icl_mask_mode", type=str, default="overlay", choices=["overlay", "separate"])
-    parser.add_argument("--icl_mask_encoder", action="store_true", default=False)
-    parser.add_argument("--mask_encoder_token_count", type=int, default=64)
-    parser.add_argument("--mm_token_compress", action="store_true", default=False)
-    parser.add_argument("--mm_compressed_token_count", type=int, default=256)
-    parser.add_argument("--log_base_dir", default="./runs", type=str)
-    parser.add_argument("--exp_name", default="lisa", type=str)
-    parser.add_argument("--epochs", default=10, type=int)
-    parser.add_argument("--batch_size", default=2, type=int)
-    parser.add_argument("--grad_accumulation_steps", default=10, type=int)
-    parser.add_argument("--val_batch_size", default=1, type=int)
-    parser.add_argument("--workers", default=4, type=int)
-    parser.add_argument("--lr", default=0.0003, type=float)
-    parser.add_argument("--ce_loss_weight", default=1.0, type=float)
-    parser.add_argument("--dice_loss_weight", default=0.5, type=float)
-    parser.add_argument("--bce_loss_weight", default=2.0, type=float)
-    parser.add_argument("--iou_loss_weight", default=2.0, type=float)
-    parser.add_argument("--focal_loss_weight", default=2.0, type=float)
-    parser.add_argument("--beta1", default=0.9, type=float)
-    parser.add_argument("--beta2", default=0.95, type=float)
-    parser.add_argument("--no_eval", action="store_true", default=False)
-    parser.add_argument("--eval_only", action="store_true", default=False)
-    parser.add_argument("--out_dim", default=256, type=int)
-    parser.add_argument("--resume", default="", type=str)
-    parser.add_argument("--print_freq", default=1, type=int)
-    parser.add_argument("--save_steps", default=10, type=int)
-    parser.add_argument("--start_epoch", default=0, type=int)
-    parser.add_argument("--gradient_checkpointing", action="store_true", default=True)
-    parser.add_argument("--train_mask_decoder", action="store_true", default=False)
-    parser.add_argument("--use_mm_start_end", action="store_true", default=True)
-    parser.add_argument("--auto_resume", action="store_true", default=True)
-    parser.add_argument("--conv_type", default="llava_v1", type=str, choices=["llava_v1", "llava_llama_2"])
-    parser.add_argument("--region_fea_adapter", action="store_true", default=False)
-    parser.add_argument("--region_geo_sampler", action="store_true", default=False)
-    parser.add_argument("--max_sample_point", default=512, type=int)
-    parser.add_argument("--sampler_pooler_mode", default="max", type=str)
-    parser.add_argument("--moe_enable", type=bool, default=False)
-    parser.add_argument("--moe_mode", type=str, default="second_half", choices=["first_half", "second_half", "sparse", "dense"])
-    parser.add_argument("--num_experts", type=int, default=3)
-    parser.add_argument("--top_k_experts", type=int, default=2)
-    parser.add_argument("--capacity_factor", type=float, default=1)
-    parser.add_argument("--use_residual", type=bool, default=False)
-    parser.add_argument("--router_aux_loss_coef", type=float, default=0.01)
-    parser.add_argument("--eval_capacity_factor", type=float, default=2)
-    parser.add_argument("--moe_layers_idx", type=str, default=None)
-    parser.add_argument("--min_capacity", type=int, default=0)
-    parser.add_argument("--ep_size", type=int, default=1)
-    parser.add_argument("--expert_pretrained_path", type=str, default=None)
-    parser.add_argument("--finetune_moe", type=bool, default=False)
-    # ---- additions of this build (see the module docstring)
-    parser.add_argument("--dataset", default="json", choices=["json", "synthetic"])
-    parser.add_argument("--steps_per_epoch", default=0, type=int)
-    parser.add_argument("--tokenizer_path", default="", type=str)
-    parser.add_argument("--seed", default=42, type=int)
-    return parser.parse_args(args)
+ON, OFF = "store_true/default-on", "store_true/default-off"
+FLAG_TABLE = (
+    # name, default, kind (a type, ON / OFF, or a tuple of choices)            reference CLI, train_ds_medplib.py:28-138
+    ("local_rank", 0, int), ("version", "/path/to/llava-v1.5-7b", str), ("vis_save_path", "./vis_output", str),
+    ("pretrain_mm_mlp_adapter", None, str), ("precision", "bf16", ("fp32", "bf16", "fp16")), ("sam_img_size", 256, int),
+    ("model_max_length", 512, int), ("vision_tower", "openai/clip-vit-large-patch14", str),
+    ("vision_pretrained", "PATH_TO_SAM_ViT-H", str), ("sft_modules", "lm_head,embed_tokens,mask_decoder,text_hidden_fcs", str),
+    ("lora_r", 8, int), ("lora_alpha", 16, int), ("lora_dropout", 0.05, float), ("lora_target_modules", "q_proj,v_proj", str),
+    ("image_folder", "/path/to/SAMed2D_v1", str), ("image_aspect_ratio", "pad", str), ("is_multimodal", True, bool),
+    ("data_path", "/path/to/xxx.json", str), ("val_data_path", "/path/to/xxx.json", str),
+    ("icl_enable", False, OFF), ("icl_mask_mode", "overlay", ("overlay", "separate")), ("icl_mask_encoder", False, OFF),
+    ("mask_encoder_token_count", 64, int), ("mm_token_compress", False, OFF), ("mm_compressed_token_count", 256, int),
+    ("log_base_dir", "./runs", str), ("exp_name", "lisa", str), ("epochs", 10, int), ("batch_size", 2, int),
+    ("grad_accumulation_steps", 10, int), ("val_batch_size", 1, int), ("workers", 4, int), ("lr", 0.0003, float),
+    ("ce_loss_weight", 1.0, float), ("dice_loss_weight", 0.5, float), ("bce_loss_weight", 2.0, float),
+    ("iou_loss_weight", 2.0, float), ("focal_loss_weight", 2.0, float), ("beta1", 0.9, float), ("beta2", 0.95, float),
+    ("no_eval", False, OFF), ("eval_only", False, OFF), ("out_dim", 256, int), ("resume", "", str), ("print_freq", 1, int),
+    ("save_steps", 10, int), ("start_epoch", 0, int), ("gradient_checkpointing", True, ON), ("train_mask_decoder", False, OFF),
+    ("use_mm_start_end", True, ON), ("auto_resume", True, ON), ("conv_type", "llava_v1", ("llava_v1", "llava_llama_2")),
+    ("region_fea_adapter", False, OFF), ("region_geo_sampler", False, OFF), ("max_sample_point", 512, int),
+    ("sampler_pooler_mode", "max", str), ("moe_enable", False, bool),
+    ("moe_mode", "second_half", ("first_half", "second_half", "sparse", "dense")), ("num_experts", 3, int),
+    ("top_k_experts", 2, int), ("capacity_factor", 1.0, float), ("use_residual", False, bool),
+    ("router_aux_loss_coef", 0.01, float), ("eval_capacity_factor", 2.0, float), ("moe_layers_idx", None, str),
+    ("min_capacity", 0, int), ("ep_size", 1, int), ("expert_pretrained_path", None, str), ("finetune_moe", False, bool),
+    ("load_in_8bit", False, OFF), ("load_in_4bit", False, OFF), ("num_classes_per_sample", 3, int), ("exclude_val", False, OFF),
+    # ---- this build's additions
+    ("dataset", "json", ("json", "synthetic")), ("steps_per_epoch", 0, int), ("val_samples", 0, int), ("tokenizer_path", "", str),
+    ("seed", 42, int),
+)
 
 
-def build_tokenizer(args):
-    """train_ds_medplib.py:198-216.  Returns (tokenizer or None, number of token ids, <SEG> id): without tokenizer files (synthetic
-    runs) the ids are the ones the seeded batches use — <SEG> = the checkpoint's config.seg_token_idx, vocabulary unchanged."""
-    src = args.tokenizer_path or args.version
-    has_files = os.path.isdir(src) and any(os.path.exists(os.path.join(src, f)) for f in ("tokenizer.model", "tokenizer.json"))
-    if not has_files:
-        import json
-        cfg = json.load(open(os.path.join(args.version, "config.json")))
-        return None, int(cfg["vocab_size"]), int(cfg.get("seg_token_idx", 32000))
+def parse_args(argv):
+    """argparse parser generated from FLAG_TABLE (`type=bool` flags keep argparse's any-non-empty-string-is-True reading, which is
+    what `--moe_enable True` in the shipped scripts relies on)."""
+    ap = argparse.ArgumentParser(description="MedPLIB training: surface walk of the reference driver")
+    for name, default, kind in FLAG_TABLE:
+        if kind in (ON, OFF):
+            ap.add_argument("--" + name, action="store_true", default=default)
+        elif isinstance(kind, tuple):
+            ap.add_argument("--" + name, default=default, type=str, choices=list(kind))
+        else:
+            ap.add_argument("--" + name, default=default, type=kind)
+    return ap.parse_args(argv)
+
+
+class Run(types.SimpleNamespace):
+    """What the stages hand to each other."""
+
+
+# ------------------------------------------------------------------------------------------------------------------ stages
+def stage_process_setup(run):
+    a = run.args
+    a.log_dir = os.path.join(a.log_base_dir, a.exp_name)
+    a.local_rank = int(os.environ.get("LOCAL_RANK", a.local_rank))
+    torch.cuda.set_device(a.local_rank)
+    deepspeed.init_distributed(dist_backend="nccl")
+    torch.manual_seed(a.seed)
+    run.world = int(os.environ.get("WORLD_SIZE", "1"))
+    run.rank0 = a.local_rank == 0
+    if run.rank0:
+        Path(a.log_dir).mkdir(parents=True, exist_ok=True)
+    if isinstance(a.moe_layers_idx, str):
+        a.moe_layers_idx = list(map(int, a.moe_layers_idx.split(",")))
+    a.num_experts = [a.num_experts]                      # the model classes read a list (medplib_moe_llama.py:597)
+
+
+def stage_tokenizer(run):
+    """AutoTokenizer + the added tokens, in the reference's order (<SEG> etc. first, then the image brackets); without tokenizer
+    files (synthetic runs) the checkpoint's own ids stand in: vocabulary unchanged, <SEG> = config.seg_token_idx."""
+    a = run.args
+    src = a.tokenizer_path or a.version
+    if not (os.path.isdir(src) and any(os.path.exists(os.path.join(src, f)) for f in ("tokenizer.model", "tokenizer.json"))):
+        meta = json.loads(Path(a.version, "config.json").read_text())
+        run.tokenizer, run.n_tokens, a.seg_token_idx = None, int(meta["vocab_size"]), int(meta.get("seg_token_idx", 32000))
+        return
     import transformers
-    tokenizer = transformers.AutoTokenizer.from_pretrained(src, cache_dir=None, model_max_length=args.model_max_length,
-                                                           padding_side="right", use_fast=False, legacy=True)
-    tokenizer.pad_token = tokenizer.unk_token
-    others = ["<SEG>", "<region>", "</region>", "<mask>", "</mask>", "<bbox>", "</bbox>", "<point>", "</point>", "<p>", "</p>"]
-    for i in range(1, 257):
-        others.append("<gen_" + str(i) + ">")
-    for name in others:                                                       # ADD_OTHERS_TOKENS, utils/utils.py
-        tokenizer.add_tokens(name, special_tokens=True)
-    seg = tokenizer("<SEG>", add_special_tokens=False).input_ids[0]
-    if args.use_mm_start_end:
-        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
-    return tokenizer, len(tokenizer), seg
+    tok = transformers.AutoTokenizer.from_pretrained(src, cache_dir=None, model_max_length=a.model_max_length, padding_side="right",
+                                                     use_fast=False, legacy=True)
+    tok.pad_token = tok.unk_token
+    for extra in ADD_OTHERS_TOKENS:
+        tok.add_tokens(extra, special_tokens=True)
+    a.seg_token_idx = tok("<SEG>", add_special_tokens=False).input_ids[0]
+    if a.use_mm_start_end:
+        tok.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+    run.tokenizer, run.n_tokens = tok, len(tok)
+
+
+DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.half}
+
+
+def stage_open_checkpoint(run):
+    a = run.args
+    run.dtype = DTYPES[a.precision]
+    cls = MedPLIBForCausalLM if a.moe_enable else LISAForCausalLM
+    run.model = cls.from_pretrained(a.version, torch_dtype=run.dtype, low_cpu_mem_usage=True, ignore_mismatched_sizes=True, **vars(a))
+    if run.tokenizer is not None:
+        for field in ("eos_token_id", "bos_token_id", "pad_token_id"):
+            setattr(run.model.config, field, getattr(run.tokenizer, field))
+    run.model.enable_input_require_grads()
+    run.model.gradient_checkpointing_enable()
+
+
+def stage_vision_modules(run):
+    a, inner = run.args, run.model.get_model()
+    inner.initialize_vision_modules(inner.config)
+    if not a.eval_only:
+        (inner.initialize_bird_modules if a.moe_enable else inner.initialize_lisa_modules)(inner.config)
+    run.tower = inner.get_vision_tower()
+    run.tower.to(dtype=run.dtype, device=a.local_rank)
+    for frozen in itertools.chain(run.tower.parameters(), inner.mm_projector.parameters()):
+        frozen.requires_grad = False
+
+
+NEVER_ADAPTED = ("visual_model", "vision_tower", "mm_projector")
+
+
+def stage_adapters(run):
+    """LoRA targets = every nn.Linear whose name carries one of --lora_target_modules and none of the vision-side prefixes; with
+    --lora_r 0 the whole model is frozen instead and --sft_modules alone decides what trains."""
+    a = run.args
+    if a.lora_r <= 0:
+        for _, p in run.model.named_parameters():
+            p.requires_grad = False
+        return
+    wanted = a.lora_target_modules.split(",")
+    targets = sorted({name for name, mod in run.model.named_modules()
+                      if isinstance(mod, torch.nn.Linear) and not any(s in name for s in NEVER_ADAPTED) and any(w in name for w in wanted)})
+    if run.rank0:
+        print(f"[walk] {len(targets)} LoRA targets, e.g. {targets[:3]}")
+    run.model = get_peft_model(run.model, LoraConfig(r=a.lora_r, lora_alpha=a.lora_alpha, target_modules=targets,
+                                                     lora_dropout=a.lora_dropout, bias="none", task_type="CAUSAL_LM"))
+    run.model.print_trainable_parameters()
+
+
+def stage_moe_and_vocabulary(run):
+    if run.args.moe_enable:
+        run.model.initialize_moe_modules(run.args)
+    run.model.resize_token_embeddings(run.n_tokens)
+
+
+def stage_sft_flags(run):
+    wanted = [w for w in run.args.sft_modules.split(",") if w]
+    n_train = n_all = 0
+    for name, p in run.model.named_parameters():
+        if wanted and any(w in name for w in wanted):
+            p.requires_grad = True
+        n_all += p.numel()
+        n_train += p.numel() if p.requires_grad else 0
+    if run.rank0:
+        print(f"[walk] trainable {n_train} of {n_all} parameters ({100.0 * n_train / max(n_all, 1):.7f} %)")
+
+
+def stage_data(run):
+    """LazySupervisedDataset / ICLLazySupervisedDataset over the JSON files with the tower's image processor, or seeded synthetic
+    micro-batches (already collated: the collate function is the identity on a one-item list)."""
+    a = run.args
+    if a.dataset == "synthetic":
+        from medplib_amd.train import SyntheticDataset, synth_batch
+        cfg = run.model.config
+        tiny = cfg.hidden_size < 1024
+        a.steps_per_epoch = a.steps_per_epoch or 4
+        run.train_set = SyntheticDataset(cfg, a.batch_size, a.steps_per_epoch * a.grad_accumulation_steps * a.epochs,
+                                         a.seed + 1000 * a.local_rank, tiny)
+        run.collate, run.micro = (lambda items: items[0]), 1
+        run.val_batches = [dict(synth_batch(cfg, 1, a.seed + 7000 + i, tiny=tiny), inference=True) for i in range(a.val_samples)]
+        if not run.val_batches:
+            a.no_eval = True
+        return
+    data_args = types.SimpleNamespace(
+        image_folder=a.image_folder, image_aspect_ratio=a.image_aspect_ratio, is_multimodal=a.is_multimodal,
+        mm_use_im_start_end=a.use_mm_start_end, data_path=a.data_path, icl_mask_mode=a.icl_mask_mode,
+        icl_mask_encoder=a.icl_mask_encoder, mask_encoder_token_count=a.mask_encoder_token_count,
+        mm_token_compress=a.mm_token_compress, mm_compressed_token_count=a.mm_compressed_token_count,
+        image_processor=run.tower.image_processor)
+    make = ICLLazySupervisedDataset if a.icl_enable else LazySupervisedDataset
+    run.train_set = make(a.data_path, run.tokenizer, data_args, a.sam_img_size)
+    per_rank = math.ceil(len(run.train_set) / (a.batch_size * run.world))
+    a.steps_per_epoch = math.ceil(per_rank / a.grad_accumulation_steps)
+    run.collate, run.micro = partial(DataCollatorForSupervisedDataset), a.batch_size
+    run.val_batches = None
+    if not a.no_eval:
+        assert a.val_batch_size == 1
+        val_set = make(a.val_data_path, run.tokenizer, data_args, a.sam_img_size)
+        sampler = torch.utils.data.distributed.DistributedSampler(val_set, shuffle=False, drop_last=False) if run.world > 1 else None
+        run.val_batches = torch.utils.data.DataLoader(val_set, batch_size=1, shuffle=False, num_workers=a.workers, pin_memory=False,
+                                                      sampler=sampler, collate_fn=partial(DataCollatorForSupervisedDataset, inference=True))
+
+
+def engine_config(a, micro):
+    """The ds_config dict of train_ds_medplib.py:383-420 (ZeRO-2 bf16 AdamW, WarmupDecayLR over epochs x steps, warm-up = 1 % of an
+    epoch, clip 1.0), built from the flags."""
+    sched = {"total_num_steps": a.epochs * a.steps_per_epoch, "warmup_min_lr": 0, "warmup_max_lr": a.lr,
+             "warmup_num_steps": int(a.steps_per_epoch * 0.01), "warmup_type": "linear"}
+    return {"train_micro_batch_size_per_gpu": micro, "gradient_accumulation_steps": a.grad_accumulation_steps,
+            "optimizer": {"type": "AdamW", "params": {"lr": a.lr, "weight_decay": 0.0, "betas": (a.beta1, a.beta2)}},
+            "scheduler": {"type": "WarmupDecayLR", "params": sched}, "gradient_clipping": 1.0,
+            "fp16": {"enabled": a.precision == "fp16"}, "bf16": {"enabled": a.precision == "bf16"},
+            "zero_optimization": {"stage": 2, "contiguous_gradients": True, "overlap_comm": True, "reduce_scatter": True,
+                                  "reduce_bucket_size": 5e8, "allgather_bucket_size": 5e8}}
+
+
+def stage_engine(run):
+    a = run.args
+    params = run.model.parameters()
+    if a.moe_enable and "up_proj" in a.lora_target_modules:       # expert adapters get their own optimizer groups (:422-434)
+        params = deepspeed.split_params_into_different_moe_groups_for_optimizer({"params": list(params), "name": "parameters"})
+    run.engine, run.optimizer, run.loader, run.scheduler = deepspeed.initialize(
+        model=run.model, model_parameters=params, training_data=run.train_set, collate_fn=run.collate,
+        config=engine_config(a, run.micro))
+
+
+def stage_resume(run):
+    a = run.args
+    candidate = Path(a.log_dir, "ckpt_model")
+    if a.auto_resume and not a.resume and candidate.exists():
+        a.resume = str(candidate)
+    if not a.resume:
+        return
+    run.engine.load_checkpoint(a.resume)
+    tag = Path(a.resume, "latest").read_text().splitlines()[0].strip()
+    a.start_epoch = int(tag.replace("global_step", "")) // a.steps_per_epoch
+    if run.rank0:
+        print(f"[walk] resumed {a.resume} at {tag} (engine.global_steps {run.engine.global_steps}) -> epoch {a.start_epoch}")
+
+
+def fresh_checkpoint(run, name):
+    """save_checkpoint into a directory emptied first by rank 0 (the driver keeps one rolling checkpoint per name)."""
+    target = os.path.join(run.args.log_dir, name)
+    if run.rank0 and os.path.exists(target):
+        shutil.rmtree(target)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    run.engine.save_checkpoint(target)
+
+
+def stage_epochs(run):
+    a = run.args
+    run.history, run.val_scores = [], []
+    if a.eval_only:
+        run.val_scores.append(validate(run, 0))
+        return
+    feed = endless(run.loader)
+    for epoch in range(a.start_epoch, a.epochs):
+        run.history += train_epoch(run, epoch, feed)
+        if not a.no_eval:
+            run.val_scores.append(validate(run, epoch))
+        fresh_checkpoint(run, "last_ckpt_model")
+
+
+STAGES = (
+    # (stage, the reference lines whose calls it issues)
+    (stage_process_setup, "train_ds_medplib.py:181-196"), (stage_tokenizer, ":198-216"), (stage_open_checkpoint, ":218-238"),
+    (stage_vision_modules, ":240-259"), (stage_adapters, ":261-306"), (stage_moe_and_vocabulary, ":308-312"),
+    (stage_sft_flags, ":315-349"), (stage_data, ":352-381,472-489"), (stage_engine, ":383-448"), (stage_resume, ":452-470"),
+    (stage_epochs, ":491-533"),
+)
+
+
+# ------------------------------------------------------------------------------------------------------------------ loops
+def endless(loader):
+    while True:
+        yield from loader
+
+
+def to_device_in_dtype(batch, precision):
+    """dict_to_cuda + the image casts both loops of the reference apply (:586-598, :745-757)."""
+    batch = dict_to_cuda(batch)
+    want = DTYPES[precision]
+    batch["images"] = batch["images"].to(want)
+    clip = batch["images_clip"]
+    batch["images_clip"] = [c.to(want) for c in clip] if isinstance(clip, list) else clip.to(want)
+    return batch
+
+
+LOSS_METERS = ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", "unscale_mask_bce_loss", "unscale_mask_dice_loss",
+               "unscale_mask_loss", "unscale_mask_iou_loss", "unscale_mask_focal_loss")
+
+
+def train_epoch(run, epoch, feed):
+    """steps_per_epoch optimizer steps of grad_accumulation_steps micro-batches each: engine(**batch) -> engine.backward(loss) ->
+    engine.step(); ten loss meters + two timers shown through ProgressMeter every print_freq steps (all-reduced when distributed),
+    `ckpt_model` rewritten every save_steps steps (:536-700).  Returns the losses it displayed."""
+    a, eng = run.args, run.engine
+    clock = {"Time": AverageMeter("Time", ":6.2f"), "Data": AverageMeter("Data", ":6.2f")}
+    meters = {k: AverageMeter(k, ":.4f") for k in LOSS_METERS}
+    board = ProgressMeter(a.steps_per_epoch, list(clock.values()) + list(meters.values()), prefix=f"Epoch: [{epoch}]")
+    eng.train()
+    shown, tick = [], time.time()
+    for step in range(a.steps_per_epoch):
+        for _ in range(a.grad_accumulation_steps):
+            batch = next(feed)
+            clock["Data"].update(time.time() - tick)
+            batch = to_device_in_dtype(batch, a.precision)
+            out = eng(**batch)
+            n = batch["images"].size(0)
+            for k, m in meters.items():
+                if k in ("loss", "ce_loss") or batch["seg_flag"]:
+                    m.update(out[k].item(), n)
+            eng.backward(out["loss"])
+            eng.step()
+        clock["Time"].update(time.time() - tick)
+        tick = time.time()
+        if step % a.print_freq == 0:
+            if run.world > 1:
+                for m in itertools.chain(clock.values(), meters.values()):
+                    m.all_reduce()
+            shown.append(meters["loss"].avg)
+            if run.rank0:
+                board.display(step + 1)
+                print(f"[walk] global step {eng.global_steps} lr {run.scheduler.get_last_lr()[0]:.3e}", flush=True)
+            for m in itertools.chain(clock.values(), meters.values()):
+                m.reset()
+        if step != 0 and step % a.save_steps == 0:
+            fresh_checkpoint(run, "ckpt_model")
+    return shown
+
+
+@torch.no_grad()
+def validate(run, epoch):
+    """One pass over the validation samples in inference mode ({pred_masks, gt_masks}): sigmoid > 0.1, class counts through
+    intersectionAndUnionGPU (K = 2), the "no-object target" rule, per-sample IoU / Dice, five SUM meters reduced over the ranks;
+    gIoU = mean acc_iou[1], cIoU = (sum I / sum U)[1] (:721-800).  -> (giou, ciou, miou, mdice)."""
+    a, eng = run.args, run.engine
+    names = ("Intersec", "Union", "gIoU", "IoU", "Dice")
+    m = {k: AverageMeter(k, ":6.3f", Summary.SUM) for k in names}
+    eng.eval()
+    for batch in run.val_batches:
+        out = eng(**to_device_in_dtype(dict(batch), a.precision))
+        target = out["gt_masks"][0].int().unsqueeze(0)
+        guess = (torch.sigmoid(out["pred_masks"][0].float()) > 0.1).int()
+        inter = union = acc = 0.0
+        for g, p in zip(target, guess):
+            g, p = g.unsqueeze(0), p.unsqueeze(0)
+            i_k, u_k, _ = intersectionAndUnionGPU(p.contiguous().clone(), g.contiguous(), 2, ignore_index=255)
+            ratio = i_k / (u_k + 1e-5)
+            ratio[u_k == 0] += 1.0
+            inter, union, acc = inter + i_k, union + u_k, acc + ratio
+            both, either = int((p.bool() & g.bool()).sum()), int((p.bool() | g.bool()).sum())
+            iou = both / either if either else 0.0
+        k = target.shape[0]
+        m["Intersec"].update(inter.cpu().numpy()); m["Union"].update(union.cpu().numpy()); m["gIoU"].update(acc.cpu().numpy() / k, n=k)
+        m["IoU"].update(iou); m["Dice"].update(2 * iou / (1 + iou))
+    for meter in m.values():
+        meter.all_reduce()
+    ciou = (m["Intersec"].sum / (m["Union"].sum + 1e-10))[1]
+    giou = m["gIoU"].avg[1]
+    if run.rank0:
+        print("giou: {:.6f}, ciou: {:.6f}".format(giou, ciou))
+        print("miou: {:.6f}, mDice: {:.6f}".format(m["IoU"].avg, m["Dice"].avg))
+    eng.train()
+    return float(giou), float(ciou), float(m["IoU"].avg), float(m["Dice"].avg)
 
 
 def main(argv):
-    args = parse_args(argv)
-    args.log_dir = os.path.join(args.log_base_dir, args.exp_name)
-    local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank))
-    args.local_rank = local_rank
-    torch.cuda.set_device(local_rank)
-    deepspeed.init_distributed(dist_backend="nccl")                           # the launcher's env; RCCL on ROCm
-    torch.manual_seed(args.seed)
-    if args.local_rank == 0:
-        os.makedirs(args.log_dir, exist_ok=True)
-    if isinstance(args.moe_layers_idx, str):
-        args.moe_layers_idx = [int(x) for x in args.moe_layers_idx.split(",")]
-    args.num_experts = [args.num_experts]                                     # the model reads a list (medplib_moe_llama.py:597)
-
-    tokenizer, n_tokens, args.seg_token_idx = build_tokenizer(args)
-
-    # ---------------------------------------------------------------- Create model (train_ds_medplib.py:218-238)
-    model_args = vars(args)
-    torch_dtype = torch.float32
-    if args.precision == "bf16":
-        torch_dtype = torch.bfloat16
-    elif args.precision == "fp16":
-        torch_dtype = torch.half
-    if args.moe_enable:
-        model = MedPLIBForCausalLM.from_pretrained(args.version, torch_dtype=torch_dtype, low_cpu_mem_usage=True,
-                                                   ignore_mismatched_sizes=True, **model_args)
-    else:
-        model = LISAForCausalLM.from_pretrained(args.version, torch_dtype=torch_dtype, low_cpu_mem_usage=True,
-                                                ignore_mismatched_sizes=True, **model_args)
-    if tokenizer is not None:
-        model.config.eos_token_id = tokenizer.eos_token_id
-        model.config.bos_token_id = tokenizer.bos_token_id
-        model.config.pad_token_id = tokenizer.pad_token_id
-
-    model.enable_input_require_grads()
-    model.gradient_checkpointing_enable()
-
-    # load tower and projector weights (:240-247)
-    model.get_model().initialize_vision_modules(model.get_model().config)
-    if not args.eval_only:
-        if args.moe_enable:
-            model.get_model().initialize_bird_modules(model.get_model().config)
-        else:
-            model.get_model().initialize_lisa_modules(model.get_model().config)
-
-    vision_tower = model.get_model().get_vision_tower()
-    vision_tower.to(dtype=torch_dtype, device=args.local_rank)
-
-    for p in vision_tower.parameters():
-        p.requires_grad = False
-    for p in model.get_model().mm_projector.parameters():
-        p.requires_grad = False
-
-    # ---------------------------------------------------------------- LoRA (:261-306)
-    lora_r = args.lora_r
-    if lora_r > 0:
-
-        def find_linear_layers(model, lora_target_modules):
-            cls = torch.nn.Linear
-            lora_module_names = set()
-            for name, module in model.named_modules():
-                if (isinstance(module, cls)
-                        and all([x not in name for x in ["visual_model", "vision_tower", "mm_projector"]])
-                        and any([x in name for x in lora_target_modules])):
-                    lora_module_names.add(name)
-            return sorted(list(lora_module_names))
-
-        lora_target_modules = find_linear_layers(model, args.lora_target_modules.split(","))
-        if args.local_rank == 0:
-            print("lora_target_modules", len(lora_target_modules), lora_target_modules[:4], "...")
-        lora_config = LoraConfig(r=lora_r, lora_alpha=args.lora_alpha, target_modules=lora_target_modules,
-                                 lora_dropout=args.lora_dropout, bias="none", task_type="CAUSAL_LM")
-        model = get_peft_model(model, lora_config)
-        model.print_trainable_parameters()
-    else:
-        for n, p in model.named_parameters():
-            p.requires_grad = False
-
-    if args.moe_enable:
-        model.initialize_moe_modules(args)                                    # :308-310
-
-    model.resize_token_embeddings(n_tokens)                                   # :312
-
-    # make text_hidden_fcs, mask_decoder, lm_head, embed_tokens trainable (:315-326)
-    if args.sft_modules != "":
-        sft_modules = args.sft_modules.split(",")
-        for n, p in model.named_parameters():
-            if any([x in n for x in sft_modules]):
-                p.requires_grad = True
-
-    def count_parameters(model):
-        trainable_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        total_params = sum(p.numel() for p in model.parameters())
-        return trainable_params, total_params
-    trainable_params, total_params = count_parameters(model)
-    if args.local_rank == 0:
-        print(f"Trainable Parameters: {trainable_params}")
-        print(f"Total Parameters: {total_params}")
-        print(f"Trainable Parameters Percentage: {trainable_params / total_params * 100:.7f}%")
-
-    # ---------------------------------------------------------------- data (:352-381)
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.dataset == "synthetic":
-        from medplib_amd.train import SyntheticDataset
-        cfg = model.config
-        tiny = cfg.hidden_size < 1024
-        steps = args.steps_per_epoch or 4
-        train_dataset = SyntheticDataset(cfg, args.batch_size, steps * args.grad_accumulation_steps * args.epochs, args.seed + 1000 * args.local_rank, tiny)
-        args.steps_per_epoch = steps
-        collate, micro = (lambda items: items[0]), None      # an item already is one collated micro-batch
-    else:
-        from medplib_amd import dataset as D
-        from medplib_amd.collate import collate as DataCollatorForSupervisedDataset
-        data_args = types.SimpleNamespace(image_folder=args.image_folder, image_aspect_ratio=args.image_aspect_ratio,
-                                          is_multimodal=args.is_multimodal, mm_use_im_start_end=args.use_mm_start_end,
-                                          data_path=args.data_path, icl_mask_mode=args.icl_mask_mode, icl_mask_encoder=args.icl_mask_encoder,
-                                          mask_encoder_token_count=args.mask_encoder_token_count, mm_token_compress=args.mm_token_compress,
-                                          mm_compressed_token_count=args.mm_compressed_token_count,
-                                          image_processor=vision_tower.image_processor)
-        dataset_cls = D.ICLLazySupervisedDataset if args.icl_enable else D.LazySupervisedDataset
-        train_dataset = dataset_cls(args.data_path, tokenizer, data_args, args.sam_img_size)
-        args.steps_per_epoch = math.ceil(math.ceil(len(train_dataset) / (args.batch_size * world_size)) / args.grad_accumulation_steps)
-        collate, micro = partial(DataCollatorForSupervisedDataset), args.batch_size
-
-    ds_config = {                                                             # :383-420
-        "train_micro_batch_size_per_gpu": micro if micro is not None else 1,
-        "gradient_accumulation_steps": args.grad_accumulation_steps,
-        "optimizer": {"type": "AdamW", "params": {"lr": args.lr, "weight_decay": 0.0, "betas": (args.beta1, args.beta2)}},
-        "gradient_clipping": 1.0,
-        "scheduler": {"type": "WarmupDecayLR", "params": {"total_num_steps": args.epochs * args.steps_per_epoch, "warmup_min_lr": 0,
-                                                            "warmup_max_lr": args.lr, "warmup_num_steps": int(args.steps_per_epoch * 0.01),
-                                                            "warmup_type": "linear"}},
-        "fp16": {"enabled": args.precision == "fp16"},
-        "bf16": {"enabled": args.precision == "bf16"},
-        "zero_optimization": {"stage": 2, "contiguous_gradients": True, "overlap_comm": True, "reduce_scatter": True,
-                              "reduce_bucket_size": 5e8, "allgather_bucket_size": 5e8},
-    }
-
-    if args.moe_enable and "up_proj" in args.lora_target_modules:             # :422-434
-        parameters = {"params": [p for p in model.parameters()], "name": "parameters"}
-        optimizer_grouped_parameters = deepspeed.split_params_into_different_moe_groups_for_optimizer(parameters)
-    else:
-        optimizer_grouped_parameters = model.parameters()
-
-    model_engine, optimizer, train_loader, scheduler = deepspeed.initialize(   # :439-448
-        model=model, model_parameters=optimizer_grouped_parameters, training_data=train_dataset,
-        collate_fn=collate, config=ds_config)
-
-    # resume deepspeed checkpoint (:452-470)
-    if args.auto_resume and len(args.resume) == 0:
-        resume = os.path.join(args.log_dir, "ckpt_model")
-        if os.path.exists(resume):
-            args.resume = resume
-    if args.resume:
-        load_path, client_state = model_engine.load_checkpoint(args.resume)
-        with open(os.path.join(args.resume, "latest"), "r") as f:
-            ckpt_dir = f.readlines()[0].strip()
-        args.start_epoch = int(ckpt_dir.replace("global_step", "")) // args.steps_per_epoch
-        print("resume training from {}, start from epoch {}".format(args.resume, args.start_epoch))
-
-    history = []
-    train_iter = iter(train_loader)
-    for epoch in range(args.start_epoch, args.epochs):                        # :511-533
-        train_iter, losses = train(train_loader, model_engine, epoch, scheduler, train_iter, args)
-        history += losses
-        save_dir = os.path.join(args.log_dir, "ckpt_model")
-        model_engine.save_checkpoint(save_dir)
-    return history
-
-
-def dict_to_cuda(input_dict, device):                                         # utils.dict_to_cuda
-    out = {}
-    for k, v in input_dict.items():
-        if torch.is_tensor(v) and k not in ("input_ids", "labels", "attention_mask", "offset"):   # index tensors are host work here
-            v = v.to(device, non_blocking=True)
-        elif isinstance(v, list) and len(v) > 0 and torch.is_tensor(v[0]):
-            v = [e.to(device, non_blocking=True) for e in v]
-        out[k] = v
-    return out
-
-
-def train(train_loader, model, epoch, scheduler, train_iter, args):
-    """train() of the reference (:536-700): steps_per_epoch x grad_accumulation_steps micro-batches of
-    model(**input_dict) / model.backward(loss) / model.step()."""
-    model.train()
-    losses = []
-    for global_step in range(args.steps_per_epoch):
-        for i in range(args.grad_accumulation_steps):
-            try:
-                input_dict = next(train_iter)
-            except StopIteration:
-                train_iter = iter(train_loader)
-                input_dict = next(train_iter)
-            input_dict = dict_to_cuda(input_dict, torch.device("cuda", args.local_rank))
-            if args.precision == "bf16":                                      # :588-591
-                input_dict["images"] = input_dict["images"].bfloat16()
-                ic = input_dict["images_clip"]
-                input_dict["images_clip"] = [x.bfloat16() for x in ic] if isinstance(ic, list) else ic.bfloat16()
-            output_dict = model(**input_dict)
-            loss = output_dict["loss"]
-            model.backward(loss)
-            model.step()
-        if global_step % args.print_freq == 0:
-            losses.append(loss.item())
-            if args.local_rank == 0:
-                print(f"Epoch: [{epoch}][{global_step + 1}/{args.steps_per_epoch}] loss {losses[-1]:.4f} "
-                      f"ce {output_dict['ce_loss'].item():.4f} mask {output_dict['mask_loss'].item():.4f} lr {scheduler.get_last_lr()[0]:.3e}",
-                      flush=True)
-    return train_iter, losses
+    run = Run(args=parse_args(argv))
+    for stage, _ in STAGES:
+        stage(run)
+    main.last_run = run                                     # tests read run.val_scores here
+    return run.history
 
 
 if __name__ == "__main__":
