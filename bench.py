@@ -8,9 +8,13 @@ per-GPU micro-batch 8, data parallel (weak scaling), bf16 trunk / fp32 trainable
 weights at true dimensions.
 
 One step = forward of the whole path + backward through the trainable tail + gradient all-reduce + AdamW step.
-Launch:  python bench.py --gpus 1 --steps K --warmup W
+Launch:  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                                 torch.distributed.run with N ranks on 127.0.0.1)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line."""
+Rank 0 prints ONE JSON line.  The line never claims a GPU count other than the one asked for: `--gpus N` with WORLD_SIZE != N is
+refused, and `rccl_ranks` is what the RCCL communicator itself reports (ncclCommCount through the C ABI's mp_comm_count).
+`--dry` runs the launch / rendezvous / timing / one-line protocol on CPU ranks over gloo with a stand-in gradient bucket (no GPU,
+no model): what tests/test_bench_launch.py drives."""
 import argparse
 import json
 import os
@@ -126,6 +130,67 @@ def upsampler_roofline(device):
     return out
 
 
+def ensure_ranks(want, dry):
+    """`--gpus N` must mean N ranks.  No launcher in the environment and N > 1: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`
+    (the reference's launch line is `deepspeed --include localhost:0..7 train_ds_medplib.py`, scripts/train_stage3.sh).  A launcher
+    that started a different number of ranks is an error, not a smaller benchmark."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is None and want > 1:
+        if not dry and torch.cuda.device_count() < want:
+            sys.exit(f"bench.py: --gpus {want} but only {torch.cuda.device_count()} GPU(s) visible")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={want}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execvpe(cmd[0], cmd, env)
+    if int(world or 1) != want:
+        sys.exit(f"bench.py: --gpus {want} but the launcher started WORLD_SIZE={world} rank(s); refusing to report n_gpus != requested")
+
+
+def dry_main(args):
+    """The multi-rank protocol of this file without a GPU: gloo ranks, a stand-in flat gradient bucket through the engine's
+    launch_grad_reduce / wait_grad_reduce, the barrier + MAX-over-ranks timing, one JSON line from rank 0."""
+    from medplib_amd import engine
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    tail = torch.nn.Linear(64, 32)
+    eng, _, _, _ = engine.initialize(model=tail, model_parameters=list(tail.parameters()), config={"optimizer": {"params": {"lr": 1e-3}}})
+    ok = True
+
+    def step(k):
+        nonlocal ok
+        eng.optimizer.flat_grad.fill_(float(rank + 1 + k))
+        eng.launch_grad_reduce(); eng.wait_grad_reduce()
+        ok &= bool(torch.all(eng.optimizer.flat_grad == sum(r + 1 + k for r in range(world))))
+    for k in range(args.warmup):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        dt = tmax.item()
+        print(json.dumps({"metric": "dry run: gradient-bucket all-reduce steps/s on CPU ranks (gloo)", "dry": True, "value": round(args.steps / dt, 3),
+                          "unit": "steps/s", "n_gpus": world, "rccl_ranks": None, "ranks": dist.get_world_size() if world > 1 else 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "bucket_sums_correct": ok,
+                          "config": {"workload": f"{eng.optimizer.numel}-element fp32 bucket, backend gloo", "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +212,11 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="images and masks start every step in pageable host memory (the reference's dict_to_cuda per batch): the "
                          "PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the default, HBM-resident run")
+    ap.add_argument("--dry", action="store_true", help="CPU ranks over gloo, stand-in gradient bucket: the launch / timing / one-line protocol only")
     args = ap.parse_args()
+    ensure_ranks(args.gpus, args.dry)
+    if args.dry:
+        return dry_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,6 +229,20 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl")
+    rccl_ranks = None
+    if world > 1:
+        # what RCCL itself connected: a communicator through the C ABI (bootstrapped with a unique id that travels over the process group),
+        # its own rank count (ncclCommCount) and a SUM of ones over it
+        try:
+            from medplib_amd.comm import RcclComm
+            cc = RcclComm()
+            one = torch.ones(1, dtype=torch.float32, device=device)
+            cc.all_reduce_(one)
+            torch.cuda.synchronize()
+            rccl_ranks = {"ncclCommCount": cc.count()[0], "sum_of_ones": float(one.item())}
+            cc.close()
+        except Exception as e:            # the line says so instead of guessing
+            rccl_ranks = {"error": f"{type(e).__name__}: {e}"}
 
     from medplib_amd import engine, ops
     from medplib_amd.model.config import MedPLIBConfig
@@ -226,6 +309,7 @@ def main():
     if not args.no_kernel_timer:
         timer = ops.KernelTimer(sample_every=23)         # every 23rd GEMM launch (coprime to the layer's GEMM period): ~290 samples over 20 steps
         ops.GEMM_TIMER = timer
+    eng.enable_bucket_timing()           # HIP-event pairs around the tail backward and every gradient bucket (a few events per step)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -322,6 +406,9 @@ def main():
             "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1),
             "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
             "roofline": roof,
+            # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the
+            # communication stream) against the tail backward it follows — both per optimizer step, from HIP events on their streams
+            "rccl_ranks": rccl_ranks, "dp_bucket": eng.bucket_timing_summary(args.steps),
         }
         print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         if world == 1:

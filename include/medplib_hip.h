@@ -444,6 +444,9 @@ int mp_comm_unique_id_bytes(void);
 int mp_comm_unique_id(void* out, int64_t bytes);
 int mp_comm_init(int rank, int world, const void* unique_id, void** comm);
 int mp_comm_destroy(void* comm);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank): the number of ranks it spans and this rank's index in it;
+ * either pointer may be NULL.  bench.py prints it as `rccl_ranks` so a line can never claim more GPUs than RCCL connected. */
+int mp_comm_count(void* comm, int* world, int* rank);
 /* in-place SUM all-reduce of one gradient bucket (`count` elements of MP_F32 / MP_BF16) */
 int mp_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype_tag, hipStream_t stream);
 /* equal-split all-to-all of routed token slabs: chunk p (count_per_peer elements) of `send` goes to rank p, chunk p of `recv` arrives

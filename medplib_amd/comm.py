@@ -40,6 +40,12 @@ class RcclComm:
         L.call("mp_comm_unique_id", buf, n)
         return buf.raw
 
+    def count(self):
+        """(ranks, this rank) as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        w, r = ctypes.c_int(0), ctypes.c_int(0)
+        lib().call("mp_comm_count", self._h, ctypes.byref(w), ctypes.byref(r))
+        return int(w.value), int(r.value)
+
     def all_reduce_(self, t: torch.Tensor):
         """In-place SUM over the communicator, asynchronous on the current stream."""
         assert t.is_cuda and t.is_contiguous() and t.dtype in _TAG

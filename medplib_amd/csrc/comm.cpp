@@ -105,6 +105,15 @@ extern "C" int mp_comm_destroy(void* comm) {
   return MP_OK;
 }
 
+extern "C" int mp_comm_count(void* comm, int* world, int* rank) {
+  const Rccl* R = rccl();
+  MP_REQUIRE(R != nullptr && comm != nullptr, MP_ERR_ARG, "mp_comm_count: no communicator");
+  MP_REQUIRE(world != nullptr || rank != nullptr, MP_ERR_ARG, "mp_comm_count: nothing asked for");
+  if (world != nullptr) MP_RCCL(R, R->CommCount(reinterpret_cast<ncclComm_t>(comm), world), "ncclCommCount");
+  if (rank != nullptr) MP_RCCL(R, R->CommUserRank(reinterpret_cast<ncclComm_t>(comm), rank), "ncclCommUserRank");
+  return MP_OK;
+}
+
 extern "C" int mp_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype_tag, hipStream_t stream) {
   const Rccl* R = rccl();
   MP_REQUIRE(R != nullptr && comm != nullptr, MP_ERR_ARG, "mp_allreduce_bucket: no communicator");

@@ -13,6 +13,7 @@ reduce-scatter + all-gather collapses to this when optimizer state is replicated
 import math
 import os
 
+import collections.abc
 import contextlib
 
 import torch
@@ -24,11 +25,17 @@ from . import ops
 class WarmupDecayLR:
     """DeepSpeed WarmupDecayLR with warmup_type 'linear' (ds_config at train_ds_medplib.py:395-404)."""
 
-    def __init__(self, total_num_steps, warmup_min_lr=0.0, warmup_max_lr=1e-3, warmup_num_steps=0, **_):
+    def __init__(self, total_num_steps, warmup_min_lr=0.0, warmup_max_lr=1e-3, warmup_num_steps=0, initial_lr=None, **_):
         self.total, self.min_lr, self.max_lr = max(1, int(total_num_steps)), warmup_min_lr, warmup_max_lr
         self.warmup = max(2, int(warmup_num_steps))            # DeepSpeed clamps warmup_num_steps to >= 2
         self.last_batch_iteration = -1
-        self._lr = self.min_lr                                  # WarmupLR.get_lr() before the first step() returns min_lrs
+        # Pinned to deepspeed==0.13.1 (the reference's requirements.txt:22; its source is absent here: parity unpinned, restated):
+        # that release's WarmupLR.__init__ does NOT write a learning rate into the optimizer — only step() does — so the FIRST
+        # optimizer step runs at the optimizer's own configured lr (`initial_lr` = ds_config optimizer.params.lr = args.lr), the
+        # second at lr(0) = warmup_min_lr, the third at lr(1), ...  ("initialise lr in the optimizer at construction", after which the
+        # first step would run at warmup_min_lr, arrived in later DeepSpeed releases.)  Without `initial_lr`: warmup_min_lr.
+        self._lr = self.min_lr if initial_lr is None else float(initial_lr)
+        self._initial = self._lr
 
     def _compute(self, it):
         if it < self.warmup:
@@ -48,7 +55,7 @@ class WarmupDecayLR:
 
     def load_state_dict(self, sd):
         self.last_batch_iteration = sd["last_batch_iteration"]
-        self._lr = self._compute(self.last_batch_iteration) if self.last_batch_iteration >= 0 else self.min_lr
+        self._lr = self._compute(self.last_batch_iteration) if self.last_batch_iteration >= 0 else self._initial
 
 
 class FlatAdamW:
@@ -105,7 +112,7 @@ class Engine:
                                    eps=opt.get("eps", 1e-8), weight_decay=opt.get("weight_decay", 0.0),
                                    max_norm=float(config.get("gradient_clipping", 0.0)))
         sch = config.get("scheduler", {}).get("params", None)
-        self.scheduler = WarmupDecayLR(**sch) if sch else None
+        self.scheduler = WarmupDecayLR(**dict(sch, initial_lr=opt.get("lr", 1e-3))) if sch else None
         self.grad_accum = int(config.get("gradient_accumulation_steps", 1))
         self.micro_steps = 0
         self.global_steps = 0
@@ -142,6 +149,34 @@ class Engine:
         # (attached on one rank as well: the sink is also how the decoder backward writes adapter gradients straight into the flat buffer)
         if lora is not None and int(config.get("overlap_comm", 1)):
             self._setup_layer_buckets(lora)
+        self._timing = None                                     # enable_bucket_timing(): HIP-event pairs around backward / every bucket
+        # Expert-data-parallel gradient semantics (DeepSpeed: `split_params_into_different_moe_groups_for_optimizer`, train_ds_medplib.py:
+        # 422-434 + engine allreduce of expert gradients over the expert-data-parallel group).  Every rank here holds all experts' adapter
+        # parameters but produces gradients only for the experts it owns, so the SUM all-reduce over the world adds each expert's gradient
+        # over exactly its expert-data-parallel group (world / ep ranks); DeepSpeed then divides by THAT group's size, everything else by
+        # the world size.  With grad_scale = 1 / world applied to the whole buffer, expert ranges are multiplied by ep first
+        # ("deepspeed", default: what a reference checkpoint's Adam state was built with); "world" keeps the gradient of the mean loss.
+        self.expert_grad_mult = None
+        llm = getattr(getattr(model, "model", None), "llm", None)
+        ep_obj = getattr(llm, "ep", None)
+        self.ep_size = int(getattr(ep_obj, "ep", 0) or config.get("ep_size", 1))
+        mode = config.get("expert_grad_scaling", "deepspeed")
+        if mode not in ("deepspeed", "world"):
+            raise ValueError(f"expert_grad_scaling: 'deepspeed' or 'world', not {mode!r}")
+        if self.ep_size > 1 and mode == "deepspeed":
+            names = {id(p): n for n, p in model.named_parameters()}
+            if lora is not None:
+                names.update({id(p): n for n, p in zip(lora.names, lora.params)})
+            mult = torch.ones(self.optimizer.numel, dtype=torch.float32)
+            self.expert_param_names = []
+            for p in self.optimizer.params:
+                n = names.get(id(p), "")
+                if ".deepspeed_experts." in n:                   # expert tensors are told apart by their (reference) names
+                    off, k = self.optimizer.offsets[id(p)]
+                    mult[off:off + k] = float(self.ep_size)
+                    self.expert_param_names.append(n)
+            if self.expert_param_names:
+                self.expert_grad_mult = mult.to(self.optimizer.flat_grad.device)
         self.training_dataloader = None
         if training_data is not None:
             sampler = None
@@ -168,14 +203,46 @@ class Engine:
         """autograd backward (grads accumulate straight into the flat buffer; `loss` = the loss tensor as with DeepSpeed, or the model's
         output dict, whose "loss" is then taken without ordering the caller's stream behind the mask tail), then — at an accumulation boundary — one
         bucketed all-reduce of the flat gradient on the communication stream (collective C1)."""
-        if isinstance(loss, dict):                                # the step's output dict itself (medplib.StreamOrderedLosses: no cross-stream wait)
+        if isinstance(loss, collections.abc.Mapping):             # the step's output dict itself (medplib.StreamOrderedLosses: no cross-stream wait)
             loss = loss.raw("loss") if hasattr(loss, "raw") else loss["loss"]
         with self._tail_ctx():
             if self.grad_accum > 1:
                 loss = loss / self.grad_accum
+            ev = self._mark("backward")
             loss.backward()
+            self._mark_end(ev)
             if self.is_gradient_accumulation_boundary():
                 self.launch_grad_reduce()
+
+    # bucket timing (bench.py: "all-reduce us vs tail-backward us" per step) ---------------------------------------------------
+    def enable_bucket_timing(self):
+        """From now on every backward pass and every gradient bucket is bracketed by a HIP-event pair on the stream it runs on."""
+        self._timing = {"backward": [], "allreduce": [], "bytes": 0}
+
+    def _mark(self, kind, nbytes=0):
+        if self._timing is None or not torch.cuda.is_available():
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self._timing[kind].append((a, b))
+        self._timing["bytes"] += nbytes
+        return b
+
+    @staticmethod
+    def _mark_end(ev):
+        if ev is not None:
+            ev.record()
+
+    def bucket_timing_summary(self, steps):
+        """-> {"tail_backward_us", "allreduce_us", "buckets_per_step", "allreduce_MB_per_step"} averaged per optimizer step (events
+        read after a device synchronisation); None when timing was never enabled."""
+        if self._timing is None:
+            return None
+        torch.cuda.synchronize()
+        tot = {k: sum(a.elapsed_time(b) for a, b in self._timing[k]) * 1e3 for k in ("backward", "allreduce")}
+        n = max(1, steps)
+        return {"tail_backward_us": round(tot["backward"] / n, 1), "allreduce_us": round(tot["allreduce"] / n, 1),
+                "buckets_per_step": len(self._timing["allreduce"]) / n, "allreduce_MB_per_step": round(self._timing["bytes"] / n / 1e6, 2)}
 
     def _tail_ctx(self):
         """The stream the model put the trainable tail on for this step (or the caller's stream)."""
@@ -219,12 +286,21 @@ class Engine:
         if self.capi_comm is not None:                          # stream-ordered: nothing to wait on but the stream itself
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                ev = self._mark("allreduce", buf.numel() * 4)
                 self.capi_comm.all_reduce_(buf)
+                self._mark_end(ev)
             self._pendings.append(None)
         elif self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+                ev = self._mark("allreduce", buf.numel() * 4)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                self._pendings.append(work)
+                if ev is not None:
+                    # the collective runs on the process group's own stream: order the communication stream behind it (a stream
+                    # wait, the host does not block) so the closing event brackets the RCCL kernel
+                    work.wait()
+                    ev.record()
         else:                                                   # gloo (CPU tests of the multi-rank plumbing)
             self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
         self._reduced.append((s, e))
@@ -241,6 +317,12 @@ class Engine:
             pos = max(pos, e)
         self._reduced = []
 
+    def apply_expert_grad_scaling(self):
+        """After the reduction, before the clip norm and AdamW: expert ranges x ep (see __init__); one elementwise pass, only when
+        ep_size > 1 and expert tensors train."""
+        if self.expert_grad_mult is not None:
+            self.optimizer.flat_grad.mul_(self.expert_grad_mult)
+
     def wait_grad_reduce(self):
         if self._pendings:
             for w in self._pendings:
@@ -255,11 +337,12 @@ class Engine:
         self.micro_steps += 1
         if not boundary:
             return
-        # DeepSpeed order (engine._take_model_step): optimizer.step() with the lr currently set, THEN lr_scheduler.step(); the
-        # scheduler starts at warmup_min_lr (last_batch_iteration = -1), so optimizer step k runs at lr(k - 2)
+        # DeepSpeed order (engine._take_model_step): optimizer.step() with the lr currently set, THEN lr_scheduler.step(): optimizer
+        # step 1 runs at the optimizer's configured lr (see WarmupDecayLR.__init__), step k >= 2 at lr(k - 2)
         lr = self.scheduler.get_last_lr()[0] if self.scheduler is not None else self.optimizer.lr
         with self._tail_ctx():
             self.wait_grad_reduce()
+            self.apply_expert_grad_scaling()
             self.optimizer.step(lr=lr, grad_scale=1.0 / self.world)         # SUM all-reduce -> mean
             self.optimizer.zero_grad()
         if self.scheduler is not None:
@@ -320,8 +403,10 @@ def initialize(model=None, model_parameters=None, training_data=None, collate_fn
 def split_params_into_different_moe_groups_for_optimizer(param_groups, max_group_size=None):
     """`deepspeed.moe.utils.split_params_into_different_moe_groups_for_optimizer` (train_ds_medplib.py:422-431): DeepSpeed moves expert
     parameters (tagged allreduce=False) into their own optimizer groups so they reduce over the expert-data-parallel group.  Here the
-    grouping is a property of the engine's buckets (expert tensors are told apart by name when ep_size > 1), so the call only
-    normalises its argument to a list of group dicts; `initialize()` reads the requires_grad flags off the model."""
+    grouping is a property of the engine: with ep_size > 1 it tells expert tensors apart by the `.deepspeed_experts.` level of their
+    names and gives their gradient ranges DeepSpeed's expert-data-parallel scaling (Engine.__init__: `expert_grad_mult`,
+    tests/test_host_logic.py 4-rank gloo test), so the call only normalises its argument to a list of group dicts;
+    `initialize()` reads the requires_grad flags off the model."""
     if isinstance(param_groups, dict):
         return [param_groups]
     return list(param_groups)

@@ -399,6 +399,11 @@ def _moe_fwd_ep(llm, lora, i, lw, pad, h2, x_mid, s, seed):
     per expert with the expert's matrix broadcast over the slabs, its LoRA adapters the same way — and the outputs travel back.
     Slabs are zero where no token sits, so every row is finite and empty rows add nothing to the weight gradients."""
     cfg, ep = llm.cfg, llm.ep
+    if cfg.top_k_experts != 1:
+        # checked HERE, where the routing happens: enable_lora() and enable_expert_parallel() may be called in either order, and the
+        # frozen / eval path (`LlamaStack._mlp`) does route top-2 — training top-1 next to it would be a silently different model
+        raise NotImplementedError(f"expert-parallel MoE layers under LoRA training route top-1 only; top_k_experts = {cfg.top_k_experts} "
+                                  "(the reference driver's default) needs ep_size 1, or train with --top_k_experts 1")
     T, d = h2.shape
     E, ff = cfg.num_experts, cfg.intermediate_size
     cap = llm.capacity(T)
@@ -419,11 +424,11 @@ def _moe_fwd_ep(llm, lora, i, lw, pad, h2, x_mid, s, seed):
         st = {}
         gu = ops.gemm_batched(xin[e], w_gu, _zeros((ep.ep, capx, 2 * ff), h2.device), m_dev=rc[e])
         if "gu" in pad:
-            gu, st["bufd"], st["t_gu"] = _adapter_fwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), xin[e], gu, rc[e], seed + 16 * eg)
+            gu, st["bufd"], st["t_gu"] = _adapter_fwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), xin[e], gu, rc[e], seed * 16 + eg)
         act = ops.swiglu_pair_fwd(gu.view(ep.ep * capx, 2 * ff)).view(ep.ep, capx, ff)
         y = ops.gemm_batched(act, w_dn, _zeros((ep.ep, capx, d), h2.device), m_dev=rc[e])
         if "down" in pad:
-            y, st["actd"], st["t_d"] = _adapter_fwd_moe(lora, _ep_pad(pad["down"], eg, ep.ep), act, y, rc[e], seed + 16 * eg + 1)
+            y, st["actd"], st["t_d"] = _adapter_fwd_moe(lora, _ep_pad(pad["down"], eg, ep.ep), act, y, rc[e], (seed + 1) * 16 + eg)
         y_loc[e] = y
         st.update(gu=gu, x=xin[e])
         loc.append(st)
@@ -452,12 +457,12 @@ def _moe_bwd_ep(llm, lora, i, lw, s, dx, d_aux, grads, take_e):
         d_act = ops.gemm_batched(dy_loc[e], dn_T, _zeros((ep.ep, capx, ff), dx.device), m_dev=rc[e])
         if "down" in pad:
             d_act, dB, dAT = _adapter_bwd_moe(lora, _ep_pad(pad["down"], eg, ep.ep), dy_loc[e], st["actd"], st["t_d"], d_act, rc[e],
-                                              s["seed"] + 16 * eg + 1)
+                                              (s["seed"] + 1) * 16 + eg)
             take_e(i, pad["down"], {eg: sum(dB[1:], dB[0])}, {eg: sum(dAT[1:], dAT[0])})
         d_gu = ops.swiglu_pair_bwd(st["gu"].view(ep.ep * capx, 2 * ff), d_act.view(ep.ep * capx, ff)).view(ep.ep, capx, 2 * ff)
         d_in = ops.gemm_batched(d_gu, gu_T, _zeros((ep.ep, capx, d), dx.device), m_dev=rc[e])
         if "gu" in pad:
-            d_in, dB, dAT = _adapter_bwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), d_gu, st["bufd"], st["t_gu"], d_in, rc[e], s["seed"] + 16 * eg)
+            d_in, dB, dAT = _adapter_bwd_moe(lora, _ep_pad(pad["gu"], eg, ep.ep), d_gu, st["bufd"], st["t_gu"], d_in, rc[e], s["seed"] * 16 + eg)
             take_e(i, pad["gu"], {eg: sum(dB[1:], dB[0])}, {eg: sum(dAT[1:], dAT[0])})
         dbuf_loc[e] = d_in
     d_buf = ep.combine(dbuf_loc.permute(1, 0, 2, 3).contiguous())                                          # [E, capx, d]

@@ -14,6 +14,8 @@ import os
 from typing import List, Optional
 
 import numpy as np
+import collections.abc
+
 import torch
 import torch.nn as nn
 
@@ -71,40 +73,47 @@ class _Inner(nn.Module):
                                                             nn.Dropout(0.0))])
 
 
-class StreamOrderedLosses(dict):
-    """The loss dict of a step whose mask tail ran on its own stream.  Reading a value (out[k], .get, .items, .values) first makes the
-    READER's current stream wait for the event recorded behind the tail forward -- once per stream -- so any use of the tensors is
-    ordered exactly as if model_forward had waited itself; `raw(k)` hands a tensor out without the wait (for consumers that run on the
-    tail stream themselves: Engine.backward)."""
+class StreamOrderedLosses(collections.abc.Mapping):
+    """The loss dict of a step whose mask tail ran on its own stream — a read-only Mapping, NOT a dict subclass: every way of getting
+    a value out (`out[k]`, `.get`, `.items()`, `.values()`, `dict(out)`, `{**out}`, `.copy()`, iteration + indexing) goes through
+    `__getitem__`, which first makes the READER's current stream wait for the event recorded behind the tail forward (once per
+    stream) and tells the caching allocator that this stream uses the tensors (`record_stream`: they were allocated on the tail
+    stream).  Any use is therefore ordered exactly as if model_forward had waited itself.  `raw(k)` hands a tensor out without the
+    wait, for consumers that run on the tail stream themselves (Engine.backward).  There is no mutation API: dict fast paths that
+    bypass `__getitem__` (pop / setdefault / `|`) do not exist on this type."""
 
     def __init__(self, values, event):
-        super().__init__(values)
-        self._event, self._ordered = event, set()
+        self._values, self._event, self._ordered = dict(values), event, set()
 
     def _order(self):
         st = torch.cuda.current_stream()
         if st.cuda_stream not in self._ordered:
             st.wait_event(self._event)
+            for v in self._values.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(st)
             self._ordered.add(st.cuda_stream)
 
     def raw(self, key):
-        return dict.__getitem__(self, key)
+        return self._values[key]
 
     def __getitem__(self, key):
+        if key not in self._values:
+            raise KeyError(key)
         self._order()
-        return dict.__getitem__(self, key)
+        return self._values[key]
 
-    def get(self, key, default=None):
-        self._order()
-        return dict.get(self, key, default)
+    def __iter__(self):
+        return iter(self._values)
 
-    def items(self):
-        self._order()
-        return dict.items(self)
+    def __len__(self):
+        return len(self._values)
 
-    def values(self):
-        self._order()
-        return dict.values(self)
+    def copy(self):
+        return dict(self)
+
+    def __repr__(self):
+        return f"StreamOrderedLosses({list(self._values)})"
 
 
 class MedPLIBForCausalLM(nn.Module):
@@ -189,14 +198,40 @@ class MedPLIBForCausalLM(nn.Module):
     def get_model(self):
         return self.model
 
-    def trainable_parameters(self):
-        """Stage-III selection (train_ds_medplib.py:316-326 with sft_modules mask_decoder,text_hidden_fcs) + the LoRA adapters when
-        enable_lora() attached them (get_peft_model marks exactly those trainable, :294-303)."""
-        ps = list(self.model.text_hidden_fcs.parameters())
-        if self.config.train_mask_decoder:
+    TAIL_FAMILIES = ("text_hidden_fcs", "mask_decoder")          # what trains without the decoder backward (the fp32 mask tail)
+    DECODER_SIDE_FAMILIES = ("lm_head", "embed_tokens", "input_layernorm", "post_attention_layernorm", "wg", "mm_projector",
+                             "mm_token_compressor", "region_fea_adapter", "mask_encoder")
+
+    def trainable_parameters(self, sft_modules=None):
+        """The parameters the engine trains.  `sft_modules` = the driver's `--sft_modules` (train_ds_medplib.py:54,316-326: substring
+        families): of the fp32 tail exactly the named families train — `text_hidden_fcs` and / or `mask_decoder`, nothing
+        unconditionally; the decoder-side families (lm_head, embed_tokens, norm weights, wg, front-end modules) train through the
+        decoder backward, i.e. they must have been handed to `enable_lora(..., sft_modules=)` first — naming one without that state is
+        an error, not a silently smaller training set.  Without the argument: the stage-III selection (text_hidden_fcs + mask decoder
+        when config.train_mask_decoder) as before.  The LoRA adapters come along when enable_lora() attached them (get_peft_model
+        marks exactly those trainable, :294-303)."""
+        lora = getattr(self.model, "lora", None)
+        if sft_modules is None:
+            fams = ["text_hidden_fcs"] + (["mask_decoder"] if self.config.train_mask_decoder else [])
+        else:
+            fams = [f for f in (sft_modules.split(",") if isinstance(sft_modules, str) else list(sft_modules)) if f]
+            unknown = [f for f in fams if f not in self.TAIL_FAMILIES + self.DECODER_SIDE_FAMILIES]
+            if unknown:
+                raise ValueError(f"--sft_modules {unknown}: not a trainable family of this build "
+                                 f"({', '.join(self.TAIL_FAMILIES + self.DECODER_SIDE_FAMILIES)})")
+            needs_decoder = [f for f in fams if f in self.DECODER_SIDE_FAMILIES]
+            if needs_decoder and lora is None:
+                raise ValueError(f"--sft_modules {needs_decoder} train through the decoder backward: call enable_lora(..., sft_modules=...) "
+                                 "first (train.py: --lora_r > 0), or drive the model.MedPLIB surface, whose resolve_training_plan builds that state")
+        ps = []
+        if "text_hidden_fcs" in fams:
+            ps += list(self.model.text_hidden_fcs.parameters())
+        if "mask_decoder" in fams:
             ps += list(self.model.visual_model.mask_decoder.parameters())
-        if getattr(self.model, "lora", None) is not None:
-            ps += list(self.model.lora.parameters())
+        if lora is not None:
+            ps += list(lora.parameters())
+        if not ps:
+            raise ValueError("nothing to train: --sft_modules is empty and no adapters are attached")
         return ps
 
     def _require_merged(self, what):

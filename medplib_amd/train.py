@@ -195,7 +195,7 @@ def main(argv=None):
                  "scheduler": {"type": "WarmupDecayLR", "params": {"total_num_steps": total_steps, "warmup_min_lr": 0, "warmup_max_lr": args.lr,
                                                                      "warmup_num_steps": max(1, args.steps_per_epoch // 100), "warmup_type": "linear"}},
                  "gradient_clipping": 1.0, "bf16": {"enabled": True}}                     # train_ds_medplib.py:383-420
-    eng, optimizer, _, scheduler = E.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
+    eng, optimizer, _, scheduler = E.initialize(model=model, model_parameters=model.trainable_parameters(args.sft_modules), config=ds_config)
     if args.dataset == "synthetic":
         data = SyntheticDataset(cfg, args.batch_size, 1 << 30, args.seed + 1000 * rank, args.model_size == "tiny")
         val = SyntheticDataset(cfg, 1, 4, args.seed + 7, args.model_size == "tiny")

@@ -251,6 +251,15 @@ def test_stream_ordered_losses_and_towers_run_ahead(dev):
             eng.backward(out if pass_dict else out["loss"])
             eng.step()
             seen.append(out)
+        # every way of copying values out orders the copying stream first (round-2 advisor item: dict fast paths must not bypass it)
+        out = eng(**gb)
+        for take in (lambda o: dict(o), lambda o: {**o}, lambda o: o.copy(), lambda o: list(o.values()), lambda o: o.get("loss")):
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                take(out)
+            assert side.cuda_stream in out._ordered
+        assert not hasattr(out, "pop") and not hasattr(out, "setdefault") and set(out) == set(O.LOSS_KEYS) and len(out) == len(O.LOSS_KEYS)
+        eng.backward(out); eng.step()
         torch.cuda.synchronize()
         runs.append([{k: float(o[k].detach()) for k in O.LOSS_KEYS} for o in seen])
     assert runs[0] == runs[1], (runs[0], runs[1])
@@ -866,6 +875,61 @@ def test_training_entry_point_runs_and_resumes(dev, tmp_path):
     hist2 = train.main(argv + ["--epochs", "3"])          # resumes at epoch 2 (global step 6) and runs one more epoch
     assert len(hist2) == 3
     assert open(os.path.join(str(tmp_path), "ckpt_model", "latest")).read().strip() == "global_step9"
+
+
+def test_trainable_parameters_honours_sft_modules(dev, tmp_path):
+    """`--sft_modules` decides what of the fp32 tail trains in the build's own entry point too (train_ds_medplib.py:316-326): only the
+    named families are returned, a decoder-side family without the decoder-backward state is refused, an unknown family is refused,
+    and `train.py --sft_modules text_hidden_fcs` leaves the mask decoder's weights untouched."""
+    from medplib_amd import train
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2)
+    m = _model(cfg, dev, OM.init_hf_weights(cfg))
+    ids = lambda ps: {id(p) for p in ps}
+    fcs, dec = ids(m.model.text_hidden_fcs.parameters()), ids(m.model.visual_model.mask_decoder.parameters())
+    assert ids(m.trainable_parameters("text_hidden_fcs")) == fcs
+    assert ids(m.trainable_parameters("mask_decoder")) == dec
+    assert ids(m.trainable_parameters("mask_decoder,text_hidden_fcs")) == fcs | dec == ids(m.trainable_parameters())
+    for bad in ("lm_head,text_hidden_fcs", "wg", "no_such_family", ""):
+        with pytest.raises(ValueError):
+            m.trainable_parameters(bad)
+    argv = ["--model_size", "tiny", "--lisa", "--batch_size", "2", "--epochs", "1", "--steps_per_epoch", "2", "--lr", "1e-2", "--no_eval",
+            "--log_dir", str(tmp_path), "--sft_modules", "text_hidden_fcs"]
+    train.main(argv)
+    saved = torch.load(tmp_path / "ckpt_model" / "global_step2" / "mp_rank_00_model_states.pt", map_location="cpu")["module"]
+    assert saved and all("text_hidden_fcs" in k for k in saved), list(saved)[:4]
+
+
+def test_merge_and_unload_keeps_a_trained_gate(dev):
+    """Stage IV trains the MoE gate `wg` next to the adapters (`--sft_modules wg,...`, scripts/train_stage4.sh): after two optimizer
+    steps merge_and_unload() must leave the TRAINED gate in the model (and in the exported HF dict, under
+    `mlp.deepspeed_moe.gate.wg.weight`), and the merged model's inference forward must route with it: its routing equals the
+    training model's own routing on the same batch."""
+    from medplib_amd import engine
+    cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_experts=2, top_k_experts=1, capacity_factor=4.0)
+    W = OM.init_hf_weights(cfg)
+    m = _model(cfg, dev, W).train()
+    lora = m.enable_lora(lora_r=4, lora_alpha=8, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj",
+                         sft_modules="wg,mask_decoder,text_hidden_fcs")
+    wg_names = [n for n in lora.names if n.endswith("gate.wg.weight")]
+    assert len(wg_names) == cfg.num_hidden_layers
+    eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters("wg,mask_decoder,text_hidden_fcs"),
+                                     config={"optimizer": {"params": {"lr": 5e-2}}, "gradient_clipping": 1.0})
+    batch = OM.make_batch(cfg, 2, seed=4)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    for _ in range(2):
+        out = eng(**gb)
+        eng.backward(out["loss"]); eng.step()
+    torch.cuda.synchronize()
+    trained = {n: lora.params[lora.index[n]].detach().float().cpu().clone() for n in wg_names}
+    for n in wg_names:
+        assert (trained[n] - W[n]).abs().max() > 1e-4, "the gate did not train"
+    m.merge_and_unload()
+    sd = m.hf_state_dict()
+    for n in wg_names:
+        assert torch.equal(sd[n].float().cpu(), trained[n]), n          # the gate is fp32 on both sides: exact
+        i = int(n.split(".")[2])
+        assert torch.equal(m.model.llm.layers[i]["wg"].float().cpu(), trained[n])
 
 
 def test_generate_matches_evaluate_tokens(dev):

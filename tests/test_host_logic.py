@@ -107,6 +107,16 @@ def test_warmup_decay_lr():
         s.step(); lrs.append(s.get_last_lr()[0])
     assert lrs[0] == 0.0 and abs(lrs[5] - 0.5e-3) < 1e-12 and abs(lrs[10] - 1e-3) < 1e-12
     assert abs(lrs[55] - 1e-3 * 45 / 90) < 1e-12 and lrs[-1] > 0 and all(a >= b for a, b in zip(lrs[10:], lrs[11:]))
+    # what the optimizer sees before the scheduler's first step(): the optimizer's own lr (deepspeed 0.13.1: the scheduler's constructor
+    # writes nothing), then lr(0) = warmup_min_lr, lr(1), ...; a restored scheduler that never stepped goes back to it
+    s2 = WarmupDecayLR(total_num_steps=100, warmup_min_lr=0, warmup_max_lr=1e-3, warmup_num_steps=10, initial_lr=3e-4)
+    seen = [s2.get_last_lr()[0]]
+    for _ in range(3):
+        s2.step(); seen.append(s2.get_last_lr()[0])
+    assert seen[0] == 3e-4 and seen[1] == 0.0 and abs(seen[2] - 1e-4) < 1e-12 and abs(seen[3] - 2e-4) < 1e-12
+    s3 = WarmupDecayLR(total_num_steps=100, warmup_min_lr=0, warmup_max_lr=1e-3, warmup_num_steps=10, initial_lr=3e-4)
+    s3.load_state_dict({"last_batch_iteration": -1})
+    assert s3.get_last_lr()[0] == 3e-4
 
 
 _WORKER = r'''
@@ -512,3 +522,96 @@ def test_seed_experts_from_dense_checkpoints():
             wg = out[f"model.layers.{L}.mlp.deepspeed_moe.gate.wg.weight"]
             assert wg.shape == (2, d) and wg.dtype == torch.float32 and float(wg.abs().max()) <= 1.0 / d ** 0.5
     assert torch.equal(out["model.layers.1.self_attn.q_proj.weight"], base["model.layers.1.self_attn.q_proj.weight"])
+
+
+_EDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from medplib_amd import engine, expert_parallel as EP
+rank, world, ep = int(os.environ["RANK"]), 4, 2
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['PORT']}", rank=rank, world_size=world)
+ep_groups, edp_groups = EP.group_ranks(world, ep)
+assert ep_groups == [[0, 1], [2, 3]] and edp_groups == [[0, 2], [1, 3]]          # ep 2 x 2 replicas
+E = 4                                                                            # experts 2r', 2r'+1 live on the ranks with r % ep == r'
+owned = [e for e in range(E) if e // (E // ep) == rank % ep]
+class Lora(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.names, ps = [], []
+        for e in range(E):
+            self.names += [f"model.layers.0.mlp.deepspeed_moe.experts.deepspeed_experts.{e}.up_proj.lora_A.default.weight"]
+            ps += [torch.nn.Parameter(torch.zeros(2, 3))]
+        self.names += ["model.layers.0.self_attn.q_proj.lora_A.default.weight", "model.layers.0.mlp.deepspeed_moe.gate.wg.weight"]
+        ps += [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4, 3))]
+        self.params = torch.nn.ParameterList(ps)
+        self.index = {n: k for k, n in enumerate(self.names)}
+        self.grad_sink = None
+class Inner(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.tail = torch.nn.Linear(3, 2)
+        self.lora = Lora()
+class Model(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = Inner()
+# single-process reference: per-rank losses L_r; the job's loss is their mean.  d L_r / d (expert e's adapter) is non-zero only for the
+# tokens of L_r that reached expert e; the OWNER of e in r's expert-parallel group computes it (the tokens travelled there), i.e. owner o
+# holds  G[o][e] = sum over r in o's ep group of dL_r/dW_e.  Stand-in values:
+def g_expert(owner, e): return float(10 * (owner + 1) + e)
+def g_dense(r): return float(100 * (r + 1))
+for mode in ("deepspeed", "world"):
+    m = Model()
+    params = list(m.model.tail.parameters()) + list(m.model.lora.parameters())
+    eng, opt, _, _ = engine.initialize(model=m, model_parameters=params,
+                                       config={"optimizer": {"params": {"lr": 1e-2}}, "ep_size": ep, "expert_grad_scaling": mode, "overlap_comm": 0})
+    lo = m.model.lora
+    assert (eng.expert_grad_mult is not None) == (mode == "deepspeed")
+    if mode == "deepspeed":
+        assert len(eng.expert_param_names) == E and all(".deepspeed_experts." in n for n in eng.expert_param_names)
+    for n, p in zip(lo.names, lo.params):
+        if ".deepspeed_experts." in n:
+            e = int(n.split(".deepspeed_experts.")[1].split(".")[0])
+            p.grad.fill_(g_expert(rank, e) if e in owned else 0.0)        # no gradient exists for experts this rank does not own
+        else:
+            p.grad.fill_(g_dense(rank))
+    for p in m.model.tail.parameters():
+        p.grad.fill_(g_dense(rank))
+    eng.launch_grad_reduce(); eng.wait_grad_reduce(); eng.apply_expert_grad_scaling()
+    scale = 1.0 / world                                                   # what the AdamW kernel applies (grad_scale)
+    dense_mean = sum(g_dense(r) for r in range(world)) / world            # the gradient of the mean loss, either convention
+    for n, p in zip(lo.names, lo.params):
+        got = p.grad * scale
+        if ".deepspeed_experts." in n:
+            e = int(n.split(".deepspeed_experts.")[1].split(".")[0])
+            owners = [r for r in range(world) if e // (E // ep) == r % ep]              # = one expert-data-parallel group
+            assert sorted(owners) in edp_groups
+            total = sum(g_expert(o, e) for o in owners)
+            # DeepSpeed: mean over the expert-data-parallel group (world / ep ranks); 'world': the gradient of the mean loss
+            want = total / len(owners) if mode == "deepspeed" else total / world
+            assert torch.allclose(got, torch.full_like(got, want)), (mode, n, got.flatten()[0].item(), want)
+        else:
+            assert torch.allclose(got, torch.full_like(got, dense_mean)), (mode, n)
+    for p in m.model.tail.parameters():
+        assert torch.allclose(p.grad * scale, torch.full_like(p.grad, dense_mean))
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_expert_data_parallel_gradient_scaling_four_ranks_gloo(tmp_path):
+    """ep = 2 x 2 replicas on four gloo ranks: after the engine's SUM all-reduce + expert scaling + the optimizer's 1 / world, a dense
+    parameter's gradient is the mean over the world under both conventions; an expert adapter's is the mean over its
+    expert-data-parallel group under "deepspeed" (DeepSpeed's expert groups, train_ds_medplib.py:422-434) and the gradient of the mean
+    loss (ep times smaller) under "world" — both checked against the single-process sums."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "edp_worker.py"
+    script.write_text(_EDP_WORKER)
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
