@@ -204,9 +204,12 @@ def main():
                          "contract's default line is BASELINE configs[3] (LoRA off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--towers-ahead", action="store_true",
-                    help="the frozen CLIP tower / SAM encoder of a step start on their own streams when the step is issued (model.towers_run_ahead): "
-                         "+2 % samples/s, but the overlapped GEMM launches read slower in `roofline`")
+    ap.add_argument("--towers-in-order", action="store_true",
+                    help="debug / A-B: the frozen CLIP tower of a step queues behind the previous step's decoder instead of starting on its own "
+                         "stream when the step is issued (model.towers_run_ahead, the default since round 3: +2.6 % samples/s)")
+    ap.add_argument("--roofline-steps", type=int, default=6,
+                    help="extra un-timed steps AFTER the timed region in which the dominant GEMM is measured unshared (towers in order, SAM "
+                         "encoder and mask tail on the decoder's stream): `roofline`; the timed region's own figure is `roofline_timed_region`")
     ap.add_argument("--no-side-streams", action="store_true",
                     help="debug only: SAM encoder and mask tail on the decoder's stream (what the side streams buy; what they cost the GEMM launches they run beside)")
     ap.add_argument("--host-inputs", action="store_true",
@@ -268,10 +271,10 @@ def main():
                  "scheduler": {"type": "WarmupDecayLR", "params": {"total_num_steps": 10000, "warmup_min_lr": 0,
                                                                      "warmup_max_lr": 3e-4, "warmup_num_steps": 100,
                                                                      "warmup_type": "linear"}}}
-    # optional: the synthetic images are resident before the loop starts, so the frozen towers of a step may start as soon as the step is issued
-    # (beside the previous step's last decoder layers).  Off by default: the GEMM launches that share the chip with the towers stretch, which the
-    # roofline object would report as a slower kernel although the step gets faster.
-    model.towers_run_ahead = bool(args.towers_ahead) and not args.host_inputs and not args.no_side_streams
+    # the synthetic images are resident before the loop starts, so the frozen towers of a step start as soon as the step is issued (beside the
+    # previous step's last decoder layers) instead of queueing behind them.  The decoder GEMM launches that share the chip with the towers
+    # stretch, so the kernel's own roofline figure is taken from an unshared sample after the timed region (below).
+    model.towers_run_ahead = not args.towers_in_order and not args.host_inputs and not args.no_side_streams
     if args.no_side_streams:
         model.sam_side_stream = False
         ds_config["overlap_mask_tail"] = 0
@@ -326,9 +329,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
-    if rank == 0:
-        samples = world * args.batch * args.steps
-        value = samples / dt
+    # ---- the dominant kernel measured UNSHARED: a few more steps (not part of `value`) with the towers in order and the SAM encoder / mask
+    # tail on the decoder's own stream, so nothing else is resident on the CUs while a sampled GEMM launch runs
+    timer_u = None
+    if timer is not None and args.roofline_steps > 0 and not args.lora:
+        model.sync_side_streams(); torch.cuda.synchronize()
+        keep = (model.towers_run_ahead, model.sam_side_stream, model.tail_side_stream)
+        model.towers_run_ahead, model.sam_side_stream, model.tail_side_stream = False, False, False
+        step(); torch.cuda.synchronize()                       # one step for the stream change to settle
+        timer_u = ops.KernelTimer(sample_every=7)
+        ops.GEMM_TIMER = timer_u
+        for _ in range(args.roofline_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.GEMM_TIMER = None
+        model.towers_run_ahead, model.sam_side_stream, model.tail_side_stream = keep
+
+    def roofline_of(timer, n_steps):
+        """The `roofline` object from one KernelTimer: the dominant bf16 GEMM tile kernel (most GPU time among the sampled launches),
+        the other tile kernel and all bf16 GEMM launches beside it."""
         roof = None
         if timer is not None:
             # every 23rd GEMM launch of the timed steps is bracketed by HIP events on the launch stream (ops.KernelTimer)
@@ -356,14 +375,14 @@ def main():
             roof = {"bound": "mfma", "kernel": fams[dom],
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": launches // args.steps, "sampled_launches": sampled,
+                    "launches_per_step": launches // n_steps, "sampled_launches": sampled,
                     "avg_launch_us": round(ms * 1e3 / max(sampled, 1), 2),
-                    "gemm_tflop_per_step": round(all_flops / args.steps / 1e12, 2),
-                    "gemm_ms_per_step": round(all_flops / args.steps / (achieved * 1e12) * 1e3, 2),
+                    "gemm_tflop_per_step": round(all_flops / n_steps / 1e12, 2),
+                    "gemm_ms_per_step": round(all_flops / n_steps / (achieved * 1e12) * 1e3, 2),
                     "all_bf16_gemms": {"kernels": "gemm256v3_bf16_nt_kernel + gemm320_bf16_nt_kernel + gemm_bf16_nt_kernel", "achieved": round(a_ach, 1),
-                                       "frac": round(a_ach / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": a_launches // args.steps,
+                                       "frac": round(a_ach / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": a_launches // n_steps,
                                        "sampled_launches": a_sampled, "avg_launch_us": round(a_ms * 1e3 / max(a_sampled, 1), 2),
-                                       "tflop_per_step": round(a_all / args.steps / 1e12, 2)}}
+                                       "tflop_per_step": round(a_all / n_steps / 1e12, 2)}}
             for k in fams:             # the other tile kernel beside the dominant one (320-row tiles: the dense projections and the experts'
                 if k == dom:           # gate|up; 256x256 tiles: the experts' down projection with the combine epilogue, CLIP's qkv / fc2)
                     continue
@@ -371,8 +390,8 @@ def main():
                 if t_sampled:
                     t_ach = t_flops / (max(t_ms, 1e-9) * 1e-3) / 1e12
                     roof[fams[k]] = {"achieved": round(t_ach, 1), "frac": round(t_ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                                     "launches_per_step": t_launches // args.steps, "sampled_launches": t_sampled,
-                                     "avg_launch_us": round(t_ms * 1e3 / t_sampled, 2), "tflop_per_step": round(t_all / args.steps / 1e12, 2)}
+                                     "launches_per_step": t_launches // n_steps, "sampled_launches": t_sampled,
+                                     "avg_launch_us": round(t_ms * 1e3 / t_sampled, 2), "tflop_per_step": round(t_all / n_steps / 1e12, 2)}
             # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
@@ -388,6 +407,17 @@ def main():
                                               "write_bytes_per_launch": tj["write_bytes_per_launch"],
                                               "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE over this same command, "
                                                         "read = 2 x FETCH_SIZE per the gfx950 correction)"}
+        return roof
+
+    if rank == 0:
+        samples = world * args.batch * args.steps
+        value = samples / dt
+        roof_timed = roofline_of(timer, args.steps)
+        roof = roofline_of(timer_u, args.roofline_steps) if timer_u is not None else roof_timed
+        if timer_u is not None and roof is not None:
+            roof["sample"] = (f"{args.roofline_steps} extra steps after the timed region with nothing else resident on the CUs (frozen towers in order, SAM "
+                              "encoder and mask tail on the decoder's stream), every 7th GEMM launch bracketed by HIP events; the timed region, where "
+                              "the next step's towers and the previous step's tail share the chip with the decoder, is `roofline_timed_region`")
         res = {
             "metric": "train samples/sec (img+64tok)", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
@@ -405,7 +435,7 @@ def main():
             # projections' input gradients + the attention backward; no wgrad for frozen weights)
             "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1),
             "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
-            "roofline": roof,
+            "roofline": roof, "roofline_timed_region": (roof_timed if timer_u is not None else None),
             # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the
             # communication stream) against the tail backward it follows — both per optimizer step, from HIP events on their streams
             "rccl_ranks": rccl_ranks, "dp_bucket": eng.bucket_timing_summary(args.steps),

@@ -224,10 +224,13 @@ class MedPLIBForCausalLM(nn.Module):
                 raise ValueError(f"--sft_modules {needs_decoder} train through the decoder backward: call enable_lora(..., sft_modules=...) "
                                  "first (train.py: --lora_r > 0), or drive the model.MedPLIB surface, whose resolve_training_plan builds that state")
         ps = []
-        if "text_hidden_fcs" in fams:
-            ps += list(self.model.text_hidden_fcs.parameters())
-        if "mask_decoder" in fams:
-            ps += list(self.model.visual_model.mask_decoder.parameters())
+        for fam, mod in (("text_hidden_fcs", self.model.text_hidden_fcs), ("mask_decoder", self.model.visual_model.mask_decoder)):
+            chosen = fam in fams
+            for p in mod.parameters():
+                if sft_modules is not None:
+                    p.requires_grad_(chosen)         # an unnamed tail family is FROZEN (no gradient work, not in checkpoints), as in the reference
+            if chosen:
+                ps += list(mod.parameters())
         if lora is not None:
             ps += list(lora.parameters())
         if not ps:

@@ -887,8 +887,10 @@ def test_trainable_parameters_honours_sft_modules(dev, tmp_path):
     ids = lambda ps: {id(p) for p in ps}
     fcs, dec = ids(m.model.text_hidden_fcs.parameters()), ids(m.model.visual_model.mask_decoder.parameters())
     assert ids(m.trainable_parameters("text_hidden_fcs")) == fcs
+    assert not any(p.requires_grad for p in m.model.visual_model.mask_decoder.parameters())      # the unnamed family is frozen
     assert ids(m.trainable_parameters("mask_decoder")) == dec
     assert ids(m.trainable_parameters("mask_decoder,text_hidden_fcs")) == fcs | dec == ids(m.trainable_parameters())
+    assert all(p.requires_grad for p in m.model.visual_model.mask_decoder.parameters())
     for bad in ("lm_head,text_hidden_fcs", "wg", "no_such_family", ""):
         with pytest.raises(ValueError):
             m.trainable_parameters(bad)
@@ -908,7 +910,7 @@ def test_merge_and_unload_keeps_a_trained_gate(dev):
     cfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_experts=2, top_k_experts=1, capacity_factor=4.0)
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
-    lora = m.enable_lora(lora_r=4, lora_alpha=8, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj",
+    lora = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj",
                          sft_modules="wg,mask_decoder,text_hidden_fcs")
     wg_names = [n for n in lora.names if n.endswith("gate.wg.weight")]
     assert len(wg_names) == cfg.num_hidden_layers
