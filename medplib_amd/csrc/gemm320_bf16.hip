@@ -62,9 +62,11 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
 // fixed cost per launch, 28 of them the epilogue).
 // EPI: 0 = alpha / bias / QuickGELU / residual, 1 = RoPE pairing (fused qkv), 2 = SwiGLU pairing (gate|up), 3 = MoE combine (row scatter)
 constexpr int EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_COMBINE = 3;
+// `items`: which of the wave tile's 10 (fragment row i, column half) items this call finishes — bit i * 2 + half; all ten for an unsplit
+// tile, a unit's share of them in the cooperative fix-up of a split tail tile (the kernel's tail: every unit reduces and stores a share).
 template <int EPI>
 __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int batch, int M, int N, int m0, int n0, int wr, int wc,
-                                                 int fr, int fq) {
+                                                 int fr, int fq, unsigned items = 0x3ffu) {
   bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
   const int cw = n0 + wc * 128;
   const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
@@ -76,6 +78,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
       const int row = m0 + wr * 80 + i * 16 + fr;
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
+        if (!((items >> (i * 2 + jb)) & 1u)) continue;
         bf16x4 o[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -122,7 +125,8 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int jp = 0; jp < 2; ++jp) {
           const int col = cw + (h * 2 + jp) * 32 + c8;
           rv[i][jp] = bf16x8{};
-          if (g.residual && orow[i] >= 0) rv[i][jp] = *reinterpret_cast<const bf16x8*>(g.residual + (int64_t)orow[i] * g.ldr + col);
+          if (g.residual && orow[i] >= 0 && ((items >> (i * 2 + h)) & 1u))
+            rv[i][jp] = *reinterpret_cast<const bf16x8*>(g.residual + (int64_t)orow[i] * g.ldr + col);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -138,7 +142,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
             if (g.residual) v += (float)rv[i][jp][e];
             o[e] = (bf16_t)v;
           }
-          if (orow[i] >= 0) *reinterpret_cast<bf16x8*>(Cs + (int64_t)orow[i] * g.ldc + col) = o;
+          if (orow[i] >= 0 && ((items >> (i * 2 + h)) & 1u)) *reinterpret_cast<bf16x8*>(Cs + (int64_t)orow[i] * g.ldc + col) = o;
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -234,7 +238,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int jp = 0; jp < 2; ++jp) {
           const int col = cw + (h * 2 + jp) * 32 + c8;
           rv[i][jp] = bf16x8{};
-          if (row < M && col < N) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
+          if (row < M && col < N && ((items >> (i * 2 + h)) & 1u)) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -250,7 +254,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
           for (int e = 0; e < 8; ++e) p[e] = (bf16_t)((float)p[e] + (float)rv[i][jp][e]);
         }
-        if (row < M && col < N) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+        if (row < M && col < N && ((items >> (i * 2 + h)) & 1u)) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   const int full = (T / C) * C, rem = T - full;
   const int nt_all = g.K / BK3;
   int S = 1;
-  if (g.ws && rem > 0 && rem * 2 <= C) S = max(1, min(min(C / rem, g.max_split), nt_all / 4));
+  if (g.ws && rem > 0 && rem * 2 <= C) S = max(1, min(min(min(C / rem, g.max_split), nt_all / 4), 10));     // <= the 10 fix-up items of a tile
   const int bid = blockIdx.x;
   if (bid >= full + rem * S) return;
   int flat, split = 0;
@@ -442,9 +446,16 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     MP3_MFMA_40(1);
   }
   if (wc == 0) MP3_BAR();
+  unsigned items = 0x3ffu;
   if (is_split) {
-    // (see gemm256_bf16.hip: partials travel write-through to the memory-side coherence point, so no L2 flush is needed for the other
-    // XCDs to see them; the sum runs in ascending split order whichever unit arrives last, so the rounding does not depend on the order)
+    // COOPERATIVE FIX-UP of a split tail tile (round 3; before: the last arriver summed all S partials alone — S x 320 KiB through one
+    // CU, 15-20 us in which the other S - 1 CUs of the tile had nothing left to do).  Every unit stores its fp32 partial in register
+    // order (write-through 16-byte stores: they reach the memory-side coherence point, no L2 flush is needed for the other XCDs to see
+    // them), announces itself on the tile's arrival counter and waits for the other S - 1 (they are all resident or about to be: the
+    // units of a tile are consecutive workgroups of the launch's last wave, and nothing they could wait for depends on them).  Then
+    // unit `split` sums, in ascending split order whoever arrived when (so the rounding does not depend on the order), the wave-tile
+    // items it % S == split of ALL partials — an item = one fragment row x one column half = 4 of the 40 accumulator fragments — and
+    // runs the epilogue on exactly those.  The departure counter lets the last unit out re-arm both counters for the next launch.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int SLAB = BM3 * BN3 * 4;                  // one unit's partial tile, bytes
     const int tail = flat - full;
@@ -458,13 +469,17 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, my_off + (i * 8 + j) * (NT3 * 16), 0, 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
     __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) *flag = __hip_atomic_fetch_add(g.tickets + tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* arrive = g.tickets + tail;
+    int* depart = g.tickets + 128 + tail;                // rem <= 128 (the split rule), the registered ticket array holds 256
+    if (tid == 0) {
+      __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
-    const int ticket = *flag;
-    __syncthreads();
-    if (ticket != S - 1) return;
-    if (tid == 0) __hip_atomic_store(g.tickets + tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting
+    items = 0;
+#pragma unroll
+    for (int it = 0; it < 10; ++it)
+      if (it % S == split) items |= 1u << it;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -472,12 +487,22 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     for (int sp = 0; sp < S; ++sp) {
       const int base = sp * SLAB + tid * 16;
 #pragma unroll
-      for (int ip = 0; ip < 5; ++ip) {                 // 8 x 16-byte loads in flight, then their adds
-        u32x4 t[8];
+      for (int it = 0; it < 10; ++it) {
+        if (!((items >> it) & 1u)) continue;             // wave-uniform
+        const int i = it >> 1, j0 = (it & 1) * 4;
+        u32x4 t[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (ip * 8 + q) * (NT3 * 16), 0, 16);
+        for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (i * 8 + j0 + q) * (NT3 * 16), 0, 16);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[ip][q] += __builtin_bit_cast(f32x4, t[q]);
+        for (int q = 0; q < 4; ++q) acc[i][j0 + q] += __builtin_bit_cast(f32x4, t[q]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // every wave of this unit has read what it needs of the partials
+    if (tid == 0) {
+      if (__hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {     // last one out: re-arm (self-resetting)
+        __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -485,7 +510,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   // arithmetic is kept in registers across the K loop
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
-  gemm320_epilogue<EPI>(g, acc, batch, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3);
+  gemm320_epilogue<EPI>(g, acc, batch, M, N, m0, n0, (tid2 >> 6) & 3, tid2 >> 8, tid2 & 15, (tid2 >> 4) & 3, items);
 }
 
 }  // namespace
@@ -523,7 +548,7 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   g.nbatch = batch;
   g.n_cu = std::min(mp_device_cus(), 256);
   static int max_split = -1;
-  if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 8; }     // 1 = no tail split (A/B)
+  if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 10; }    // 1 = no tail split (A/B)
   // dense calls keep whole waves and one accumulation order per shape (the selection model counts whole waves; a gemm() must not differ
   // from the kept-gate|up form of the same product by a split's extra fp32 rounding); the tail split serves the batched expert calls
   g.max_split = (batch > 1 || g.m_dev) ? max_split : 1;

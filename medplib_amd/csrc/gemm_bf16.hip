@@ -390,7 +390,14 @@ static bool use_320_batched(const GemmArgs& g, int batch) {
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
   if (mode == 2) return true;
-  return env_b && g.K >= 2048 && g.N >= 8192;
+  if (!env_b) return false;
+  if (g.K >= 2048 && g.N >= 8192) return true;
+  // round 3: the experts' down projection (N = 4096, K = 11008, combine epilogue) too.  8 + 9 row tiles of 320 are 272 tiles = one wave
+  // + 16 tail tiles; the tail is now cut 10 ways with a COOPERATIVE fix-up (every unit reduces and stores a share of the tile instead
+  // of the last arriver summing S x 320 KiB alone, gemm320_bf16.hip), which is what the rule above was waiting for.  MP_GEMM320_DOWN=0: A/B.
+  static int env_d = -1;
+  if (env_d < 0) { const char* e = getenv("MP_GEMM320_DOWN"); env_d = (e && atoi(e) == 0) ? 0 : 1; }
+  return env_d && g.c_rows && g.K >= 8192 && g.N >= 2048;
 }
 
 // which kernel the last bf16 GEMM entry of this thread dispatched to (bench.py attributes its HIP-event samples per kernel)

@@ -590,6 +590,48 @@ def test_gemm_swiglu_keep_equals_gemm_plus_swiglu_kernel(dev):
         assert torch.equal(act, act_ref) and float(buf[:, N // 2:].float().abs().max()) == 0.0
 
 
+def test_gemm320_cooperative_tail_fixup(dev):
+    """The 320-row kernel's split tail with the cooperative fix-up (round 3): 8 + 9 row tiles x 2 column tiles = 34 tail tiles cut 7
+    ways (K = 2048) — every unit stores its partial, waits for the tile's other units on the arrival counter, then reduces and stores
+    its share of the tile's ten items.  Five launches back to back (the counters re-arm themselves) must be bit-identical with each
+    other (the partials are summed in split order, not arrival order), agree with the 256-row tiling to two bf16 ulps, and leave rows
+    outside the routed set untouched."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(77)
+    E, cap, ff, N, T = 2, 2700, 2048, 512, 5112
+    c0, c1 = 2500, 2612
+    counts = torch.tensor([c0, c1], dtype=torch.int32, device=dev)
+    perm = torch.randperm(T, generator=g)
+    slot_token = torch.zeros(E, cap, dtype=torch.int32)
+    slot_token[0, :c0] = perm[:c0].int(); slot_token[1, :c1] = perm[c0:].int()
+    slot_token = slot_token.to(dev)
+    act = _bf(torch.randn(E, cap, ff, generator=g) * 0.5).to(dev)
+    w_dn = _bf(torch.randn(E, N, ff, generator=g) * 0.05).to(dev)
+    weight = torch.rand(T, generator=g).to(dev)
+    res = _bf(torch.randn(T, N, generator=g)).to(dev)
+    outs = {}
+    try:
+        for pol in (0, 2):
+            ops.gemm_tile_policy(pol)
+            runs = []
+            for _ in range(5 if pol == 2 else 1):
+                out = torch.full((T, N), 3.0, dtype=torch.bfloat16, device=dev)
+                ops.gemm_batched_rows(act, w_dn, out, counts, c_rows=slot_token, c_scale=weight, residual=res, rows_stride=cap)
+                assert (ops.gemm_last_kernel() == 320) == (pol == 2)
+                runs.append(out)
+            torch.cuda.synchronize()
+            for r in runs[1:]:
+                assert torch.equal(r, runs[0]), "the split tail's result depends on the arrival order (or a counter did not re-arm)"
+            outs[pol] = runs[0]
+    finally:
+        ops.gemm_tile_policy(-1)
+    _report("gemm320 cooperative tail vs 256-row tiling", outs[2], outs[0].float(), rtol=2 * BF16_EPS, atol=2e-2)
+    e = 1
+    rows = slot_token[e, :c1].long()
+    ref = (act[e, :c1].float() @ w_dn[e].float().T).to(torch.bfloat16).float() * weight[rows, None] + res[rows].float()
+    _report("gemm320 cooperative tail vs fp32 (expert 1: 9 row tiles, the last one 52 rows)", outs[2][rows], ref, rtol=2 * BF16_EPS, atol=2e-2)
+
+
 def test_gemm_320_row_tile_kernel(dev):
     """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
     no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
