@@ -130,6 +130,18 @@ def upsampler_roofline(device):
     return out
 
 
+def claim_stdout():
+    """stdout carries ONE JSON line and nothing else: fd 1 is pointed at stderr for the life of the process (RCCL prints a version banner
+    to the C stdout of every rank, flushed at exit — i.e. after the line) and the returned function writes to the original stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(text):
+        os.write(real, (text + "\n").encode())
+    return emit
+
+
 def ensure_ranks(want, dry):
     """`--gpus N` must mean N ranks.  No launcher in the environment and N > 1: replace this process by
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`
@@ -152,7 +164,7 @@ def ensure_ranks(want, dry):
         sys.exit(f"bench.py: --gpus {want} but the launcher started WORLD_SIZE={world} rank(s); refusing to report n_gpus != requested")
 
 
-def dry_main(args):
+def dry_main(args, emit):
     """The multi-rank protocol of this file without a GPU: gloo ranks, a stand-in flat gradient bucket through the engine's
     launch_grad_reduce / wait_grad_reduce, the barrier + MAX-over-ranks timing, one JSON line from rank 0."""
     from medplib_amd import engine
@@ -182,11 +194,11 @@ def dry_main(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
         dt = tmax.item()
-        print(json.dumps({"metric": "dry run: gradient-bucket all-reduce steps/s on CPU ranks (gloo)", "dry": True, "value": round(args.steps / dt, 3),
+        emit(json.dumps({"metric": "dry run: gradient-bucket all-reduce steps/s on CPU ranks (gloo)", "dry": True, "value": round(args.steps / dt, 3),
                           "unit": "steps/s", "n_gpus": world, "rccl_ranks": None, "ranks": dist.get_world_size() if world > 1 else 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "bucket_sums_correct": ok,
-                          "config": {"workload": f"{eng.optimizer.numel}-element fp32 bucket, backend gloo", "parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"workload": f"{eng.optimizer.numel}-element fp32 bucket, backend gloo", "parallelism": f"dp{world}"}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -218,8 +230,9 @@ def main():
     ap.add_argument("--dry", action="store_true", help="CPU ranks over gloo, stand-in gradient bucket: the launch / timing / one-line protocol only")
     args = ap.parse_args()
     ensure_ranks(args.gpus, args.dry)
+    emit = claim_stdout()
     if args.dry:
-        return dry_main(args)
+        return dry_main(args, emit)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,11 +242,17 @@ def main():
     # the GPU leg's host work is index planning on 8 x 64 ids: a handful of threads per rank (N ranks x every core would
     # oversubscribe the host with spinning OpenMP pools); the cpu_baseline leg sets its own thread count
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
-    if world > 1:
+    # MP_BENCH_FORCE_DIST=1 (debug, one-GPU boxes): take the multi-rank code path on a ONE-rank RCCL group — process group, the C-ABI
+    # communicator, the gradient bucket on the communication stream with its event timing, barriers, the MAX over ranks
+    force_dist = os.environ.get("MP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl")
     rccl_ranks = None
-    if world > 1:
+    if world > 1 or force_dist:
         # what RCCL itself connected: a communicator through the C ABI (bootstrapped with a unique id that travels over the process group),
         # its own rank count (ncclCommCount) and a SUM of ones over it
         try:
@@ -278,6 +297,10 @@ def main():
     if args.no_side_streams:
         model.sam_side_stream = False
         ds_config["overlap_mask_tail"] = 0
+    if force_dist and os.environ.get("MP_BENCH_NO_REDUCE") != "1":
+        ds_config["reduce_single_rank"] = 1
+    if os.environ.get("MP_BENCH_COMM"):                  # "rccl_capi": the gradient bucket through the library's own mp_allreduce_bucket
+        ds_config["comm_backend"] = os.environ["MP_BENCH_COMM"]
     eng, _, _, _ = engine.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
     batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
 
@@ -313,19 +336,19 @@ def main():
         timer = ops.KernelTimer(sample_every=23)         # every 23rd GEMM launch (coprime to the layer's GEMM period): ~290 samples over 20 steps
         ops.GEMM_TIMER = timer
     eng.enable_bucket_timing()           # HIP-event pairs around the tail backward and every gradient bucket (a few events per step)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.GEMM_TIMER = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
@@ -455,8 +478,8 @@ def main():
             except Exception as e:   # the GPU number stands on its own; say why the host leg is missing
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        emit(json.dumps(res))
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -282,27 +282,38 @@ class Engine:
                 self._reduce_range(s, e)
 
     def _reduce_range(self, s, e):
+        """SUM all-reduce of flat_grad[s:e].  With layer buckets (decoder adapters training) the collective goes to the communication
+        stream so it overlaps the backward of the layers below; WITHOUT them (stage III: everything trainable sits in the mask tail) the
+        bucket follows the tail backward and precedes AdamW on the stream they run on — there is nothing to overlap it with, and a
+        further stream is not free: measured on one GPU (one-rank RCCL group, `MP_BENCH_FORCE_DIST=1`), hopping to a fifth stream and back
+        cost the DECODER 4.5 ms per step (61 -> 65.5 ms) although the collective itself took 35 us — the runtime multiplexes streams onto a
+        few hardware queues, and a queue entry that waits for the (late-running) tail backward holds back whatever shares its queue."""
         buf = self.optimizer.flat_grad[s:e]
-        if self.capi_comm is not None:                          # stream-ordered: nothing to wait on but the stream itself
+        # torch.distributed's RCCL backend runs every collective on the process group's OWN stream (ordered behind the calling stream at
+        # the call, asynchronous to it afterwards): that is already the overlap the layer buckets want, and measured free (61.6 vs 61.7 ms).
+        # Only the C-ABI communicator, which runs on the stream it is given, needs the hop — and only when there is something to overlap.
+        own_stream = self.comm_stream is not None and self.capi_comm is not None and bool(self._layer_ranges)
+        if os.environ.get("MP_ENGINE_COMM_STREAM") == "1":       # A/B: always hop to the communication stream (the pre-round-3 behaviour)
+            own_stream = self.comm_stream is not None
+        ctx = torch.cuda.stream(self.comm_stream) if own_stream else contextlib.nullcontext()
+        if own_stream:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                ev = self._mark("allreduce", buf.numel() * 4)
+        with ctx:
+            ev = self._mark("allreduce", buf.numel() * 4)
+            if os.environ.get("MP_ENGINE_FAKE_REDUCE") == "1":   # debug: the stream choreography without the collective
+                buf.mul_(1.0)
+                work = None
+            elif self.capi_comm is not None:                     # stream-ordered: nothing to wait on but the stream itself
                 self.capi_comm.all_reduce_(buf)
-                self._mark_end(ev)
-            self._pendings.append(None)
-        elif self.comm_stream is not None:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                ev = self._mark("allreduce", buf.numel() * 4)
+                work = None
+            else:                                                # torch.distributed ("nccl" = RCCL; gloo in the CPU tests)
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-                self._pendings.append(work)
-                if ev is not None:
-                    # the collective runs on the process group's own stream: order the communication stream behind it (a stream
-                    # wait, the host does not block) so the closing event brackets the RCCL kernel
+                if ev is not None and torch.cuda.is_available():
+                    # the collective runs on the process group's own stream: order this stream behind it (a stream wait, the host does
+                    # not block) so the closing event brackets the RCCL kernel
                     work.wait()
-                    ev.record()
-        else:                                                   # gloo (CPU tests of the multi-rank plumbing)
-            self._pendings.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+            self._mark_end(ev)
+        self._pendings.append((work, own_stream))
         self._reduced.append((s, e))
 
     def launch_grad_reduce(self):
@@ -325,10 +336,12 @@ class Engine:
 
     def wait_grad_reduce(self):
         if self._pendings:
-            for w in self._pendings:
+            hop = False
+            for w, own_stream in self._pendings:
                 if w is not None:
                     w.wait()
-            if self.comm_stream is not None:
+                hop |= own_stream
+            if hop:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             self._pendings = []
 
