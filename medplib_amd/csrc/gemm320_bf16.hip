@@ -62,11 +62,12 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
 // fixed cost per launch, 28 of them the epilogue).
 // EPI: 0 = alpha / bias / QuickGELU / residual, 1 = RoPE pairing (fused qkv), 2 = SwiGLU pairing (gate|up), 3 = MoE combine (row scatter)
 constexpr int EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_COMBINE = 3;
-// `items`: which of the wave tile's 10 (fragment row i, column half) items this call finishes — bit i * 2 + half; all ten for an unsplit
-// tile, a unit's share of them in the cooperative fix-up of a split tail tile (the kernel's tail: every unit reduces and stores a share).
+// `items`: which of the wave tile's 20 (fragment row i, fragment pair) items this call finishes — bit i * 4 + pair, pair = 2 consecutive
+// fragments = 32 columns; all twenty for an unsplit tile, a unit's share of them in the cooperative fix-up of a split tail tile (every
+// unit reduces and stores a share).  The SwiGLU family pairs fragments j and j + 2, so its items come as the two pairs of a column half.
 template <int EPI>
 __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)[5][8], int batch, int M, int N, int m0, int n0, int wr, int wc,
-                                                 int fr, int fq, unsigned items = 0x3ffu) {
+                                                 int fr, int fq, unsigned items = 0xfffffu) {
   bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C) + batch * g.sC;
   const int cw = n0 + wc * 128;
   const int c8 = pair_col8(fq);                             // the lane's eight columns inside a fragment pair's 32 (gemm_common.h)
@@ -78,7 +79,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
       const int row = m0 + wr * 80 + i * 16 + fr;
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
-        if (!((items >> (i * 2 + jb)) & 1u)) continue;
+        if (!((items >> (i * 4 + jb * 2)) & 1u)) continue;
         bf16x4 o[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -125,7 +126,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int jp = 0; jp < 2; ++jp) {
           const int col = cw + (h * 2 + jp) * 32 + c8;
           rv[i][jp] = bf16x8{};
-          if (g.residual && orow[i] >= 0 && ((items >> (i * 2 + h)) & 1u))
+          if (g.residual && orow[i] >= 0 && ((items >> (i * 4 + h * 2 + jp)) & 1u))
             rv[i][jp] = *reinterpret_cast<const bf16x8*>(g.residual + (int64_t)orow[i] * g.ldr + col);
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -142,7 +143,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
             if (g.residual) v += (float)rv[i][jp][e];
             o[e] = (bf16_t)v;
           }
-          if (orow[i] >= 0 && ((items >> (i * 2 + h)) & 1u)) *reinterpret_cast<bf16x8*>(Cs + (int64_t)orow[i] * g.ldc + col) = o;
+          if (orow[i] >= 0 && ((items >> (i * 4 + h * 2 + jp)) & 1u)) *reinterpret_cast<bf16x8*>(Cs + (int64_t)orow[i] * g.ldc + col) = o;
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -238,7 +239,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int jp = 0; jp < 2; ++jp) {
           const int col = cw + (h * 2 + jp) * 32 + c8;
           rv[i][jp] = bf16x8{};
-          if (row < M && col < N && ((items >> (i * 2 + h)) & 1u)) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
+          if (row < M && col < N && ((items >> (i * 4 + h * 2 + jp)) & 1u)) rv[i][jp] = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * g.ldr + col);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +255,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
           for (int e = 0; e < 8; ++e) p[e] = (bf16_t)((float)p[e] + (float)rv[i][jp][e]);
         }
-        if (row < M && col < N && ((items >> (i * 2 + h)) & 1u)) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
+        if (row < M && col < N && ((items >> (i * 4 + h * 2 + jp)) & 1u)) *reinterpret_cast<bf16x8*>(Cb + (int64_t)row * g.ldc + col) = p;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   const int full = (T / C) * C, rem = T - full;
   const int nt_all = g.K / BK3;
   int S = 1;
-  if (g.ws && rem > 0 && rem * 2 <= C) S = max(1, min(min(min(C / rem, g.max_split), nt_all / 4), 10));     // <= the 10 fix-up items of a tile
+  if (g.ws && rem > 0 && rem * 2 <= C) S = max(1, min(min(min(C / rem, g.max_split), nt_all / 4), EPI == EPI_SWIGLU ? 10 : 20));   // <= the fix-up items of a tile
   const int bid = blockIdx.x;
   if (bid >= full + rem * S) return;
   int flat, split = 0;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     MP3_MFMA_40(1);
   }
   if (wc == 0) MP3_BAR();
-  unsigned items = 0x3ffu;
+  unsigned items = 0xfffffu;
   if (is_split) {
     // COOPERATIVE FIX-UP of a split tail tile (round 3; before: the last arriver summed all S partials alone — S x 320 KiB through one
     // CU, 15-20 us in which the other S - 1 CUs of the tile had nothing left to do).  Every unit stores its fp32 partial in register
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     // them), announces itself on the tile's arrival counter and waits for the other S - 1 (they are all resident or about to be: the
     // units of a tile are consecutive workgroups of the launch's last wave, and nothing they could wait for depends on them).  Then
     // unit `split` sums, in ascending split order whoever arrived when (so the rounding does not depend on the order), the wave-tile
-    // items it % S == split of ALL partials — an item = one fragment row x one column half = 4 of the 40 accumulator fragments — and
+    // items it % S == split of ALL partials — an item = one fragment row x one fragment pair = 2 of the 40 accumulator fragments (a column half = 4 for the SwiGLU family) — and
     // runs the epilogue on exactly those.  The departure counter lets the last unit out re-arm both counters for the next launch.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int SLAB = BM3 * BN3 * 4;                  // one unit's partial tile, bytes
@@ -476,10 +477,12 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
       while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
+    // the share: work items it % S == split; an item = a fragment pair (20 per tile), or for the SwiGLU family a column half (10)
+    constexpr int N_ITEMS = (EPI == EPI_SWIGLU) ? 10 : 20;
     items = 0;
 #pragma unroll
-    for (int it = 0; it < 10; ++it)
-      if (it % S == split) items |= 1u << it;
+    for (int it = 0; it < N_ITEMS; ++it)
+      if (it % S == split) items |= (EPI == EPI_SWIGLU) ? (3u << (2 * it)) : (1u << it);
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -487,14 +490,14 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     for (int sp = 0; sp < S; ++sp) {
       const int base = sp * SLAB + tid * 16;
 #pragma unroll
-      for (int it = 0; it < 10; ++it) {
+      for (int it = 0; it < 20; ++it) {
         if (!((items >> it) & 1u)) continue;             // wave-uniform
-        const int i = it >> 1, j0 = (it & 1) * 4;
-        u32x4 t[4];
+        const int i = it >> 2, j0 = (it & 3) * 2;
+        u32x4 t[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (i * 8 + j0 + q) * (NT3 * 16), 0, 16);
+        for (int q = 0; q < 2; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (i * 8 + j0 + q) * (NT3 * 16), 0, 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[i][j0 + q] += __builtin_bit_cast(f32x4, t[q]);
+        for (int q = 0; q < 2; ++q) acc[i][j0 + q] += __builtin_bit_cast(f32x4, t[q]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -548,7 +551,7 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   g.nbatch = batch;
   g.n_cu = std::min(mp_device_cus(), 256);
   static int max_split = -1;
-  if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 10; }    // 1 = no tail split (A/B)
+  if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 10; }    // 1 = no tail split (A/B); 16 measured 357 us against 349 at 10 (down projection, 2500 + 2612 rows): more units, more partial traffic
   // dense calls keep whole waves and one accumulation order per shape (the selection model counts whole waves; a gemm() must not differ
   // from the kept-gate|up form of the same product by a split's extra fp32 rounding); the tail split serves the batched expert calls
   g.max_split = (batch > 1 || g.m_dev) ? max_split : 1;
