@@ -130,6 +130,43 @@ def upsampler_roofline(device):
     return out
 
 
+def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warmup=3):
+    """Secondary object of the default line: scripts/train_stage3.sh's configuration (the one every shipped script trains: dense Llama-7B,
+    LoRA r = 8 / alpha 16 / dropout 0.05 on gate / up / down_proj, mask decoder + text_hidden_fcs trainable) = the whole decoder backward in
+    the step, measured in the same process after the headline leg (8 steps after 3) so the driver's run carries it."""
+    from medplib_amd import engine
+    from medplib_amd.model.config import MedPLIBConfig
+    from medplib_amd.model.medplib import LISAForCausalLM
+    torch.manual_seed(1234)
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, moe_enable=False)
+    model = LISAForCausalLM(cfg, device=device).train()
+    lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules="gate_proj,up_proj,down_proj",
+                             sft_modules="mask_decoder,text_hidden_fcs")
+    for n, p in zip(lora.names, lora.params):                # B = 0 at initialisation would make half the gradients trivially zero
+        if "lora_B" in n:
+            p.data.normal_(0, 0.01)
+    model.towers_run_ahead = not args.towers_in_order
+    eng, _, _, _ = engine.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
+    batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
+    for _ in range(warmup):
+        out = eng(**batch); eng.backward(out); eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng(**batch); eng.backward(out); eng.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": "MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh), "
+                       f"whole decoder backward, per-GPU batch {args.batch}", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 2), "samples_per_s": round(args.batch * steps / dt, 2),
+           "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + 8.66) * args.batch * steps / dt, 1),
+           "trainable_params": eng.optimizer.numel, "loss_last": float(out["loss"].detach())}
+    model.sync_side_streams(); torch.cuda.synchronize()
+    del eng, model, lora, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def claim_stdout():
     """stdout carries ONE JSON line and nothing else: fd 1 is pointed at stderr for the life of the process (RCCL prints a version banner
     to the C stdout of every rank, flushed at exit — i.e. after the line) and the returned function writes to the original stdout."""
@@ -215,6 +252,7 @@ def main():
                          "gate/up/down_proj, mask decoder + text_hidden_fcs trainable) = the whole decoder backward in the step; the "
                          "contract's default line is BASELINE configs[3] (LoRA off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lora-line", action="store_true", help="skip the secondary LoRA measurement (`lora_stage3`) of the default line")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--towers-in-order", action="store_true",
                     help="debug / A-B: the frozen CLIP tower of a step queues behind the previous step's decoder instead of starting on its own "
@@ -471,6 +509,12 @@ def main():
                 res["roofline_upsampler"] = upsampler_roofline(device)
             except Exception as e:
                 res["roofline_upsampler"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.lora and not args.no_lora_line:
+            try:
+                model.sync_side_streams(); torch.cuda.synchronize()
+                res["lora_stage3"] = lora_secondary(args, device, ds_config, synthetic_batch, rank)
+            except Exception as e:
+                res["lora_stage3"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # (the parity model is a second set of weights in HBM beside the benchmarked one: 2 x 23 GB of 288)
