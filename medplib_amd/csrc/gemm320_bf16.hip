@@ -554,7 +554,14 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   if (max_split < 0) { const char* e = getenv("MP_GEMM320_MAX_SPLIT"); max_split = (e && atoi(e) >= 1) ? atoi(e) : 10; }    // 1 = no tail split (A/B); 16 measured 357 us against 349 at 10 (down projection, 2500 + 2612 rows): more units, more partial traffic
   // dense calls keep whole waves and one accumulation order per shape (the selection model counts whole waves; a gemm() must not differ
   // from the kept-gate|up form of the same product by a split's extra fp32 rounding); the tail split serves the batched expert calls
-  g.max_split = (batch > 1 || g.m_dev) ? max_split : 1;
+  // round 3: with the cooperative fix-up a dense call's tail may split too — only behind at least one whole wave (small calls keep the
+  // single accumulation order the bit-equality tests of fused against unfused paths rely on): the dense gate|up of the LoRA step is 16 x 86
+  // = 1376 tiles = 5.375 waves, whose 96 tail tiles are cut in two instead of holding 96 CUs for a whole tile-time.  MP_GEMM320_DENSE_SPLIT=0: A/B.
+  static int dense_split = -1;
+  if (dense_split < 0) { const char* e = getenv("MP_GEMM320_DENSE_SPLIT"); dense_split = (e && atoi(e) == 0) ? 0 : 1; }
+  const int64_t dense_tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3);
+  g.max_split = (batch > 1 || g.m_dev) ? max_split : ((dense_split && dense_tiles > g.n_cu) ? max_split : 1);
+  if (g.act == ACT_ROPE_QK) g.max_split = 1;            // the RoPE family's epilogue has no item mask (its calls are dense qkv projections)
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &g.ws, &g.tickets, &ws_bytes);
   if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }

@@ -632,6 +632,35 @@ def test_gemm320_cooperative_tail_fixup(dev):
     _report("gemm320 cooperative tail vs fp32 (expert 1: 9 row tiles, the last one 52 rows)", outs[2][rows], ref, rtol=2 * BF16_EPS, atol=2e-2)
 
 
+def test_gemm320_dense_tail_split(dev):
+    """A DENSE call whose tiles exceed one wave with a short tail (16 row tiles x 22 column tiles = 352 = 256 + 96): the 96 tail tiles are
+    cut in two with the cooperative fix-up (the LoRA step's dense gate|up is 1376 tiles = 5 waves + 96).  SwiGLU and plain + residual
+    families against the 256-row tiling (two bf16 ulps: one more fp32 rounding), bit-identical run to run; a call within one wave keeps the
+    single accumulation order (bit-equal with the 256-row kernel, as test_gemm_320_row_tile_kernel requires)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(78)
+    M, N, K = 5112, 5632, 512
+    x = _bf(torch.randn(M, K, generator=g) * 0.5).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    res = _bf(torch.randn(M, N, generator=g)).to(dev)
+    outs = {}
+    try:
+        for pol in (0, 2):
+            ops.gemm_tile_policy(pol)
+            a = [ops.gemm(x, w, act=ops.ACT_SWIGLU_PAIR) for _ in range(3)]
+            assert (ops.gemm_last_kernel() == 320) == (pol == 2)
+            b = [ops.gemm(x, w, residual=res) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(t, a[0]) for t in a[1:]) and all(torch.equal(t, b[0]) for t in b[1:])
+            outs[pol] = (a[0], b[0])
+    finally:
+        ops.gemm_tile_policy(-1)
+    _report("gemm320 dense tail split (swiglu) vs 256-row tiling", outs[2][0], outs[0][0].float(), rtol=2 * BF16_EPS, atol=2e-2)
+    _report("gemm320 dense tail split (+ residual) vs 256-row tiling", outs[2][1], outs[0][1].float(), rtol=2 * BF16_EPS, atol=2e-2)
+    ref = x.float() @ w.float().T + res.float()
+    _report("gemm320 dense tail split (+ residual) vs fp32", outs[2][1], ref, rtol=2 * BF16_EPS, atol=2e-2)
+
+
 def test_gemm_320_row_tile_kernel(dev):
     """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
     no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
