@@ -167,6 +167,29 @@ def gemm_tile_policy(mode):
     lib().call("mp_gemm_tile_policy", int(mode))
 
 
+class throughput_tiles:
+    """Context for work issued on a SIDE stream beside the decoder (frozen towers started ahead, the SAM encoder): its GEMMs take the
+    320-row tiles whenever they are eligible, however few workgroups that leaves.  Alone, a 60-workgroup launch idles three quarters of the
+    chip and the selection model rightly prefers 296 small tiles; beside the decoder's GEMMs (one 147 KB workgroup per CU: nothing
+    co-resides) every side workgroup displaces decoder work for exactly its own duration, so what counts is CU x time, not latency —
+    CLIP's out_proj is 60 x 39.5 us on 320-row tiles against 296 x 30 us on 128 x 128 ones, fc2 60 x 120 us against 228 split units x
+    64 us.  MP_TOWER_THROUGHPUT_TILES=0 switches it off (A/B)."""
+    _on = None
+
+    def __enter__(self):
+        if throughput_tiles._on is None:
+            import os
+            throughput_tiles._on = os.environ.get("MP_TOWER_THROUGHPUT_TILES", "1") != "0"
+        if throughput_tiles._on:
+            gemm_tile_policy(2)
+        return self
+
+    def __exit__(self, *exc):
+        if throughput_tiles._on:
+            gemm_tile_policy(-1)
+        return False
+
+
 def gemm_last_kernel():
     """320 / 256 / 128: the tile of the kernel the last GEMM call of this thread went to."""
     return int(lib().raw("mp_gemm_last_kernel")())
