@@ -50,6 +50,44 @@ def test_sgemm_forms(dev):
     _close("batched heads NT", s, ref, rtol=1e-4, atol=1e-4)
 
 
+_SGEMM_AB = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO"])
+from medplib_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(9)
+out = {}
+for i, (M, N, K, nb) in enumerate([(2048, 256, 256, 0), (70, 33, 19, 0), (2048, 2048, 256, 0), (8, 256, 4096, 0), (300, 130, 66, 3), (64, 64, 16, 0)]):
+    bs = (nb,) if nb else ()
+    a = torch.randn(*bs, M, K, generator=g).to(dev); b = torch.randn(*bs, K, N, generator=g).to(dev); bias = torch.randn(N, generator=g).to(dev)
+    out[f"nn{i}"] = ops.sgemm(a, b).cpu()
+    out[f"nt{i}"] = ops.sgemm(a, b.transpose(-1, -2).contiguous(), trans_b=True, bias=bias, act=ops.SACT_GELU).cpu()
+    out[f"tn{i}"] = ops.sgemm(a.transpose(-1, -2).contiguous(), b, trans_a=True, alpha=0.37).cpu()
+torch.save(out, os.environ["OUT"])
+"""
+
+
+def test_sgemm_mfma_form_is_bitwise_the_fma_chain(dev, tmp_path):
+    """The tail's fp32 GEMM runs its inner product on v_mfma_f32_32x32x2_f32 (round 3): same staging, same ascending-k accumulation —
+    the hardware's f32 MFMA is an fmaf chain — so every output must equal the register-tile FMA loop (MP_SGEMM_MFMA=0) BIT FOR BIT:
+    NN / NT (+ bias + GELU) / TN (alpha), ragged edges, a long-K skinny product (the deterministic split), a batched call."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sgemm_ab.py"
+    script.write_text(_SGEMM_AB)
+    res = {}
+    for mode in ("1", "0"):
+        outp = tmp_path / f"out{mode}.pt"
+        env = dict(os.environ, REPO=repo, OUT=str(outp), MP_SGEMM_MFMA=mode)
+        p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = torch.load(outp)
+    assert set(res["1"]) == set(res["0"]) and len(res["1"]) == 18
+    for k in res["1"]:
+        assert torch.equal(res["1"][k], res["0"][k]), (k, (res["1"][k] - res["0"][k]).abs().max().item())
+
+
 def test_layernorm_softmax_act_fwd_bwd(dev):
     from medplib_amd import ops
     g = torch.Generator().manual_seed(2)
