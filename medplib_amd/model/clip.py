@@ -99,6 +99,7 @@ class ClipTower:
         return sd
 
     # ------------------------------------------------------------------ forward
+    @ops.with_throughput_tiles
     def encode_images(self, images, return_raw=False):
         """images [n,3,336,336] (bf16 or f32) -> projected features [n*576, hidden] bf16 (encode_images,
         medplib_arch.py:198-212, without compressor); with return_raw also the tower features [n*576, C] the region adapter

@@ -526,12 +526,12 @@ class MedPLIBForCausalLM(nn.Module):
                 side.wait_stream(main)
             else:
                 images.record_stream(side)
-            with torch.cuda.stream(side), torch.no_grad(), ops.throughput_tiles():
+            with torch.cuda.stream(side), torch.no_grad():
                 image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
         if ahead:
             main, vis = torch.cuda.current_stream(), self._vision_stream()
             images_clip.record_stream(vis)
-            with torch.cuda.stream(vis), torch.no_grad(), ops.throughput_tiles():
+            with torch.cuda.stream(vis), torch.no_grad():
                 plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, None, kwargs.get("image_token_types"),
                                                     kwargs.get("image_token_lengths"))
             main.wait_stream(vis)

@@ -137,6 +137,7 @@ class SamImageEncoder:
             ops.scatter_parity(y, xn, tmp, B, half, half, C, 2, py, px, G, G)
         return ops.layernorm(tmp.view(B * T, C), blk["ad_norm"][0], blk["ad_norm"][1], 1e-5)
 
+    @ops.with_throughput_tiles
     def forward(self, images):
         """images [B,3,256,256] (f32 or bf16, SAM-normalised) -> image embedding tokens [B, 256, 256] bf16 = the
         reference's [B,256,16,16] in NHWC order (flatten(2).permute(0,2,1), transformer.py:82)."""

@@ -54,6 +54,8 @@ class KernelTimer:
     def end(self, work, start):
         self.total_work += work
         kern = int(lib().raw("mp_gemm_last_kernel")())
+        if _TOWER_DEPTH:                 # a frozen tower's launch (throughput tiles: few, fat workgroups by design): its own family (+1000), so
+            kern += 1000                 # the dominant decoder kernel's figure is not averaged with launches that idle most of the chip alone
         acc = self.per_kernel.setdefault(kern, [0, 0.0])
         acc[0] += 1; acc[1] += work
         if start is None:
@@ -164,12 +166,31 @@ def gemm_swiglu_keep(a, w, act_out=None):
 def gemm_tile_policy(mode):
     """Tile choice of this thread's dense bf16 GEMM calls (mp_gemm_tile_policy): 1 = 320x256 tiles where the wave model prefers them
     (default), 0 = 256-row tiles only, 2 = 320-row tiles whenever eligible, -1 = process default."""
+    global _TILE_POLICY
     lib().call("mp_gemm_tile_policy", int(mode))
+    _TILE_POLICY = int(mode)
+
+
+_TOWER_DEPTH = 0             # > 0 while a frozen tower's forward is being issued (throughput_tiles)
+_TILE_POLICY = -1            # what this thread last asked for (the library keeps it thread-local; contexts restore it)
+
+
+def with_throughput_tiles(fn):
+    """Decorator form of `throughput_tiles` for a frozen tower's forward: the tile choice is a property of the MODULE, not of the stream
+    arrangement of a particular step, so a step's results do not depend on which streams were switched on (the bit-reproducibility tests
+    compare exactly that)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        with throughput_tiles():
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 class throughput_tiles:
-    """Context for work issued on a SIDE stream beside the decoder (frozen towers started ahead, the SAM encoder): its GEMMs take the
-    320-row tiles whenever they are eligible, however few workgroups that leaves.  Alone, a 60-workgroup launch idles three quarters of the
+    """Context for the frozen towers (CLIP tower + projector, SAM-Med2D encoder), which in a training step run on side streams beside the
+    decoder (started ahead): their GEMMs take the 320-row tiles whenever they are eligible, however few workgroups that leaves.  Alone, a 60-workgroup launch idles three quarters of the
     chip and the selection model rightly prefers 296 small tiles; beside the decoder's GEMMs (one 147 KB workgroup per CU: nothing
     co-resides) every side workgroup displaces decoder work for exactly its own duration, so what counts is CU x time, not latency —
     CLIP's out_proj is 60 x 39.5 us on 320-row tiles against 296 x 30 us on 128 x 128 ones, fc2 60 x 120 us against 228 split units x
@@ -180,13 +201,18 @@ class throughput_tiles:
         if throughput_tiles._on is None:
             import os
             throughput_tiles._on = os.environ.get("MP_TOWER_THROUGHPUT_TILES", "1") != "0"
-        if throughput_tiles._on:
+        global _TOWER_DEPTH
+        _TOWER_DEPTH += 1
+        self._prev = _TILE_POLICY
+        if throughput_tiles._on and self._prev == -1:          # an explicit policy of the caller (tests, A/B scripts) wins
             gemm_tile_policy(2)
         return self
 
     def __exit__(self, *exc):
-        if throughput_tiles._on:
-            gemm_tile_policy(-1)
+        global _TOWER_DEPTH
+        _TOWER_DEPTH -= 1
+        if _TILE_POLICY != self._prev:
+            gemm_tile_policy(self._prev)
         return False
 
 
