@@ -270,10 +270,19 @@ __device__ __forceinline__ int v_key(int row) {
 
 // GENERAL = false: no key-padding mask and no rel-pos bias (the un-padded Llama batch, CLIP) -- the masked tiles (causal diagonal, last
 // partial key tile) then need no per-element index arithmetic: both tests compare a per-lane constant with a wave-uniform threshold.
-template <int D, bool GENERAL>
+// KT = keys per LDS stage.  64 (default): two stages, one tile in flight while one is computed.  32 (round 3 experiment, MP_ATTN_KT=32):
+// the same LDS as FOUR half-size stages, so three tiles are in flight — 96 keys of prefetch instead of 64 — behind a counted vmcnt; the
+// per-tile bookkeeping (two row-max shuffles, one rescale exp per query fragment, a barrier) runs twice as often.  MEASURED SLOWER on every
+// shape (scripts/attn_bench.py, same box, twice): Llama causal S = 639 76.6 vs 63.1 us, CLIP 37.1 vs 32.5, S = 1316 130 vs 109 — the
+// "DMA wait" of the round-2 ablation is not a prefetch-depth problem: what a deeper ring buys is less than what twice the barriers and
+// online-softmax bookkeeping cost.  Kept as the A/B switch that produced the numbers; all results are identical to KT = 64's up to the
+// online softmax's rescale points (tests/test_gpu_trunk_kernels.py passes with either).
+template <int D, bool GENERAL, int KT>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
-  constexpr int KT = 64, CH = D / 8, NF = D / 16, KS = D / 32;
+  constexpr int CH = D / 8, NF = D / 16, KS = D / 32;
+  constexpr int NST = 128 / KT;                   // stages of the K / V ring (2 x 64 keys or 4 x 32 keys: the same bytes)
+  constexpr int NKF = KT / 16, NKP = KT / 32;     // key fragments / key-fragment pairs per tile
   constexpr int TILE_BYTES = KT * D * 2;          // one operand, one stage
   constexpr int RPI = 1024 / (D * 2);             // rows per 1-KiB DMA instruction
   constexpr int IPW = (TILE_BYTES / 1024) / 4;    // DMA instructions per wave per operand per tile
@@ -331,9 +340,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
                                        (__attribute__((address_space(3))) void*)(sV + j * 1024), 16, 0, 0);
     }
   };
-  issue(0, 0);
-
-  // Q fragments (B operand): query = qw0 + j*16 + fr, k = kk*32 + fq*8 .. +8
+  // Q fragments (B operand): query = qw0 + j*16 + fr, k = kk*32 + fq*8 .. +8 — requested BEFORE the ring's first tiles, so every counted
+  // wait on the tile DMAs below also covers them (vmcnt retires in order)
   bf16x8 qf[2][KS];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -341,6 +349,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) qf[j][kk] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * a.q_ss + kk * 32 + fq * 8);
   }
+#pragma unroll
+  for (int p_ = 0; p_ < NST - 1; ++p_)
+    if (p_ < n_tiles) issue(p_, p_);
 
   f32x4 o[NF][2];
 #pragma unroll
@@ -362,23 +373,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 
   for (int t = 0; t < n_tiles; ++t) {
     const int k0 = t * KT;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // tile t has landed for every wave; nobody still reads the other stage
-    if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
+    // tile t has landed when at most the DMAs of the tiles issued after it are outstanding (2 * IPW instructions per tile and wave)
+    {
+      const int later = min(NST - 2, n_tiles - 1 - t);      // wave-uniform
+      if (NST > 2 && later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * IPW) : "memory");
+      else if (NST > 2 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                       // tile t is visible to every wave; nobody still reads the stage tile t + NST - 1 goes to
+    if (t + NST - 1 < n_tiles) issue(t + NST - 1, (t + NST - 1) % NST);
     if (a.causal && k0 > qw0 + 31) continue;            // wave-uniform: every key of this tile is in the future of this wave's queries
-    const char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* sK = smem + (t % NST) * 2 * TILE_BYTES;
     const char* sV = sK + TILE_BYTES;
 
-    // ---- S^T = K Q^T: 4 key fragments x 2 query fragments ----
-    f32x4 s[4][2];
+    // ---- S^T = K Q^T: NKF key fragments x 2 query fragments ----
+    f32x4 s[NKF][2];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+    for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
       for (int j = 0; j < 2; ++j) s[kf][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf) {
+      for (int kf = 0; kf < NKF; ++kf) {
         const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + k_off<D>(kf * 16 + fr, kk * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 2; ++j) s[kf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[j][kk], s[kf][j], 0, 0, 0);
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 
     // ---- online softmax; s[kf][j][r]: key = k0 + kf*16 + fq*4 + r, query = qw0 + j*16 + fr ----
     const bool masked = (kv != nullptr) || (relh != nullptr) || (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > qw0);
-    bf16x8 pb[2][2];                         // [key-fragment pair][query fragment]: B operands of the PV MFMAs
+    bf16x8 pb[NKP][2];                       // [key-fragment pair][query fragment]: B operands of the PV MFMAs
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int qi = qw0 + j * 16 + fr;
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       if (!masked) {
         // interior tile: the max is taken on the raw scores (c2 > 0 commutes with max) and the scaling rides in the exp's fma
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
+        for (int kf = 0; kf < NKF; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
         mx *= c2;
       } else if (!GENERAL) {
         // key kj = k0 + kf*16 + fq*4 + r, query qi = qw0 + j*16 + fr:
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
         const int fb = fq * 4, bb = a.Sk - 1 - k0;
         const int dl = a.causal ? fq * 4 - fr : 0, cb = a.causal ? qw0 - k0 + j * 16 : 1 << 20;
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
+        for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = (fb <= bb - kf * 16 - r) && (dl <= cb - kf * 16 - r);
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       } else {
         const int qc = min(qi, a.Sq - 1);
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
+        for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kj = k0 + kf * 16 + fq * 4 + r;
@@ -441,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       m_run[j] = m_new;
       f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
           // p = 2^(s*c2 - m): packed fma, one v_exp_f32 per value; a masked score is -inf -> p = 0
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     // The d-blocks are walked in Gray-code order so that the swizzled address of block n, vrow_base + ((n ^ key) << 5), follows from
     // the previous one by ONE add of a per-lane delta (the bit that flips): one running address register instead of NF of them.
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
       int va = v_a0 + kp * 32 * (D * 2);
 #pragma unroll
       for (int g = 0; g < NF; ++g) {
@@ -510,10 +527,13 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
+  static int kt32 = -1;
+  if (kt32 < 0) { const char* e = getenv("MP_ATTN_KT"); kt32 = (e && atoi(e) == 32) ? 1 : 0; }      // 32: four half-size stages (A/B)
   static int chunk = -1;
   if (chunk < 0) { const char* e = getenv("MP_ATTN_CHUNK"); chunk = e ? atoi(e) : 64; }
   AttnArgs ac = a;
@@ -521,8 +541,10 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   dim3 grid(a.B * a.H, (a.Sq + 127) / 128);
   static int plain = -1;
   if (plain < 0) { const char* e = getenv("MP_ATTN_PLAIN"); plain = (e && atoi(e) == 0) ? 0 : 1; }      // 0: always the general kernel (A/B)
-  if (plain && !a.key_valid && !a.rel_h) hipLaunchKernelGGL((attn_fwd2_kernel<D, false>), grid, dim3(256), LDS, stream, ac);
-  else hipLaunchKernelGGL((attn_fwd2_kernel<D, true>), grid, dim3(256), LDS, stream, ac);
+  if (plain && !a.key_valid && !a.rel_h) {
+    if (kt32) hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 32>), grid, dim3(256), LDS, stream, ac);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 64>), grid, dim3(256), LDS, stream, ac);
+  } else hipLaunchKernelGGL((attn_fwd2_kernel<D, true, 64>), grid, dim3(256), LDS, stream, ac);
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }
 
