@@ -145,6 +145,38 @@ def upsampler_roofline(device):
         out[key] = {"geometry": f"{grid}x{grid} tokens ({grid * 16}-px SAM)", "us_per_launch": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
                     "achieved": round(nbytes / us / 1e3, 1), "frac": round(nbytes / (us * 1e-6) / 8.0e12, 4)}
     out["achieved"], out["frac"] = out["sam1024"]["achieved"], out["sam1024"]["frac"]
+    # what a TRIVIAL kernel gets for the same byte volume on this GPU, measured the same way: a plain bf16 copy of 25.2 MB (25.2 read + 25.2
+    # written = the 50.3 MB of the sam1024 launch), rotating buffers, graph replay — the practical ceiling for a 50 MB launch, which the
+    # 8 TB/s figure is not (launch ramp + drain are a fifth of a ~10 us kernel)
+    try:
+        nb = 12
+        ca = [torch.randn(8 * 4096 * 256 * 3 // 2, device=device, generator=g).to(torch.bfloat16) for _ in range(nb)]
+        cb = [torch.empty_like(x) for x in ca]
+        for i in range(5):
+            cb[i % nb].copy_(ca[i % nb])
+        torch.cuda.synchronize()
+        cs = torch.cuda.Stream(device=device)
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cs):
+                for i in range(24):
+                    cb[i % nb].copy_(ca[i % nb])
+        torch.cuda.current_stream().wait_stream(cs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        cus = e0.elapsed_time(e1) * 1e3 / (40 * 24)
+        cbytes = 2 * ca[0].numel() * 2
+        out["copy_floor"] = {"what": "torch bf16 copy, 25.2 MB -> 25.2 MB (the sam1024 launch's 50.3 MB), same timing method",
+                             "us_per_launch": round(cus, 2), "achieved": round(cbytes / cus / 1e3, 1), "frac_of_8TBps": round(cbytes / (cus * 1e-6) / 8.0e12, 4),
+                             "upsampler_vs_copy": round(cus / out["sam1024"]["us_per_launch"], 4)}
+    except Exception as e:
+        out["copy_floor"] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("24 launches per captured HIP graph, 40 replays bracketed by HIP events (rotating inputs beyond the Infinity Cache at the large "
                    "geometry); the model runs the sam256 geometry, which is latency-bound at 3.29 MB; the kernel is VALU-issue bound, not HBM bound "
                    "(DESIGN.md section 3.2: 8.2 us of pure VALU issue + launch ~ 62 % of 8 TB/s at 100 % VALU utilisation)")

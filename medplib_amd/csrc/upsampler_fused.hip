@@ -49,6 +49,7 @@ struct UpArgs {
   float* mask;            // [B, 4h, 4w] or null
   int B, h, w;
   float eps;
+  int skew;               // MP_UPS_SKEW: waves sharing a SIMD start (wave >> 2) * skew * 64 clocks apart (0 = together)
 };
 
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
@@ -129,6 +130,15 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
   for (int p = 0; p < 2; ++p) b2v[p] = a.b2[p * 16 + fr];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // At the benchmark geometry every wave makes exactly ONE pass, so without this all sixteen waves of a CU walk the phases (token read,
+  // GEMM1, LayerNorm + GELU, transposition, GEMM2, GELU + stores) in lockstep and the four waves of a SIMD want the same unit at the same
+  // time.  Starting the k-th wave of each SIMD k * skew * 64 clocks late puts them in different phases: the matrix pipe of one runs under
+  // the VALU phase of another.
+  if (a.skew > 0) {
+    const int k = wave >> 2;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(1);
+    for (int i = 0; i < k * (a.skew - 1); ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   const int OW = 4 * a.w, OH = 4 * a.h;
   for (; grp < n_groups; grp += stride) {
@@ -291,8 +301,10 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
   MP_REQUIRE(B > 0 && h > 0 && w > 0 && w % 16 == 0, MP_ERR_SHAPE, "mp_mask_upsample_fused_bf16: token-grid width must be a multiple of 16");
   MP_REQUIRE(up != nullptr || mask != nullptr, MP_ERR_ARG, "mp_mask_upsample_fused_bf16: nothing to produce");
   MP_REQUIRE(mask == nullptr || hyper != nullptr, MP_ERR_ARG, "mp_mask_upsample_fused_bf16: mask output needs hyper");
+  static int skew = -1;
+  if (skew < 0) { const char* e = getenv("MP_UPS_SKEW"); skew = e ? atoi(e) : 0; }
   UpArgs a{(const bf16_t*)src, (const bf16_t*)w1_packed, b1, ln_w, ln_b, (const bf16_t*)w2_packed, b2, hyper, (bf16_t*)up, mask,
-           B, h, w, ln_eps};
+           B, h, w, ln_eps, skew};
   const int64_t groups = mp_cdiv((int64_t)B * h * w, 16);
   // one group per wave and pass; two workgroups (kh = 0, 1) per group set; up to 128 group sets (256 CUs), then more waves
   const int nw = (int)std::min<int64_t>(UP_WAVES, mp_cdiv(groups, 128));
