@@ -111,8 +111,6 @@ class Engine:
         self.optimizer = FlatAdamW(params, lr=opt.get("lr", 1e-3), betas=tuple(opt.get("betas", (0.9, 0.95))),
                                    eps=opt.get("eps", 1e-8), weight_decay=opt.get("weight_decay", 0.0),
                                    max_norm=float(config.get("gradient_clipping", 0.0)))
-        if hasattr(model, "_tail_graphs"):
-            model._tail_graphs = {}          # FlatAdamW re-homed the parameters into its flat buffers: captured graphs hold the old addresses
         sch = config.get("scheduler", {}).get("params", None)
         self.scheduler = WarmupDecayLR(**dict(sch, initial_lr=opt.get("lr", 1e-3))) if sch else None
         self.grad_accum = int(config.get("gradient_accumulation_steps", 1))

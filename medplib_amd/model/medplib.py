@@ -116,32 +116,6 @@ class StreamOrderedLosses(collections.abc.Mapping):
         return f"StreamOrderedLosses({list(self._values)})"
 
 
-class _MaskTail(nn.Module):
-    """The trainable mask tail of one batch geometry as ONE callable — <SEG> rows -> text_hidden_fcs -> prompt encoder + mask decoder ->
-    postprocess -> the fused mask losses (MedPLIB.py:456-572) — so that torch.cuda.make_graphed_callables can capture its forward and its
-    backward (about 600 launches of 5-20 us each: two-way transformer, hypernetworks, upscaling, resize, losses) into two HIP graphs.  The
-    submodules are the model's own (registered here a second time so `parameters()` finds them; this module is never a child of the model)."""
-
-    def __init__(self, owner, n, resize, shapes):
-        super().__init__()
-        m = owner.model
-        self.text_hidden_fcs, self.mask_decoder, self.prompt_encoder = m.text_hidden_fcs, m.visual_model.mask_decoder, m.visual_model.prompt_encoder
-        self._owner = (owner,)                                 # a tuple: not registered as a submodule
-        self.n, self.resize, self.shapes = n, [tuple(r) for r in resize], [tuple(s_) for s_ in shapes]
-        cfg = owner.config
-        self.weights = (cfg.ce_loss_weight, cfg.bce_loss_weight, cfg.dice_loss_weight, cfg.iou_loss_weight, cfg.focal_loss_weight)
-
-    def forward(self, hidden_rows, image_tokens, gt, ce):
-        owner, n = self._owner[0], self.n
-        fc = self.text_hidden_fcs[0]
-        pred_emb = A.linear(A.linear(hidden_rows, fc[0].weight, fc[0].bias, ops.SACT_RELU), fc[2].weight, fc[2].bias)
-        pe = self.prompt_encoder
-        low_res, iou_pred = self.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight, pred_emb.view(n, 1, -1))
-        full, _ = owner._postprocess(low_res, self.resize, self.shapes)
-        H, W = full.shape[-2:]
-        return A.MaskLossFn.apply(full.view(n, H * W), gt, iou_pred, ce, self.weights)
-
-
 class MedPLIBForCausalLM(nn.Module):
     moe_default = True
 
@@ -191,11 +165,6 @@ class MedPLIBForCausalLM(nn.Module):
         self.active_tail_stream = None
         self.capture_intermediates = False      # tests: keep the trunk outputs that feed the trainable tail
         self.captured = {}
-        # Training steps of a batch geometry seen before replay the mask tail (forward and backward) as two captured HIP graphs instead of
-        # about 600 launches (round 3; the reference's K13: "60 tiny kernels per mask, pure launch latency").  Same kernels, same order, same
-        # bits as the eager tail; masks of one size per step only (a ragged step takes the eager path).  `graph_mask_tail = False`: eager.
-        self.graph_mask_tail = os.environ.get("MP_TAIL_GRAPH", "1") != "0"
-        self._tail_graphs = {}                  # geometry key -> graphed callable (None while the key has been seen once, False = capture failed)
 
     # ------------------------------------------------------------------ plumbing
     def _side_stream(self):
@@ -242,7 +211,6 @@ class MedPLIBForCausalLM(nn.Module):
         when config.train_mask_decoder) as before.  The LoRA adapters come along when enable_lora() attached them (get_peft_model
         marks exactly those trainable, :294-303)."""
         lora = getattr(self.model, "lora", None)
-        self._tail_graphs = {}                                   # the trainable set may change: captured tail graphs are rebuilt
         if sft_modules is None:
             fams = ["text_hidden_fcs"] + (["mask_decoder"] if self.config.train_mask_decoder else [])
         else:
@@ -646,37 +614,6 @@ class MedPLIBForCausalLM(nn.Module):
             res._order()
         return res
 
-    def _graphed_tail(self, n, hidden_rows, image_tokens, ce, masks_list, resize_list, shapes, inference):
-        """The captured tail of this step's geometry, or None (eager): training steps only, all masks of one size, a geometry seen at
-        least once before (the first sighting runs eagerly: one-off shapes are not worth a capture), at most four geometries kept."""
-        if (not self.graph_mask_tail or inference or not self.training or not torch.is_grad_enabled() or self.capture_intermediates
-                or n == 0 or masks_list is None or len(set(shapes)) != 1
-                or len(set(tuple(int(v) for v in r) for r in resize_list[:n])) != 1):
-            return None
-        if any(tuple(g.shape[-2:]) != shapes[0] for g in masks_list[:n]):
-            return None
-        cfg = self.config
-        key = (n, shapes[0], tuple(int(v) for v in resize_list[0]), bool(hidden_rows.requires_grad), bool(ce.requires_grad),
-               cfg.ce_loss_weight, cfg.bce_loss_weight, cfg.dice_loss_weight, cfg.iou_loss_weight, cfg.focal_loss_weight)
-        if key not in self._tail_graphs:
-            if len(self._tail_graphs) >= 4:
-                self._tail_graphs.pop(next(iter(self._tail_graphs)))
-            self._tail_graphs[key] = None
-            return None
-        if self._tail_graphs[key] is None:
-            H, W = shapes[0]
-            tail = _MaskTail(self, n, resize_list[:n], shapes).train()
-            sample = (torch.zeros_like(hidden_rows).requires_grad_(hidden_rows.requires_grad), torch.zeros_like(image_tokens.contiguous()),
-                      torch.zeros((n, H * W), dtype=torch.float32, device=self.device_),
-                      torch.zeros_like(ce).requires_grad_(ce.requires_grad))
-            try:
-                self._tail_graphs[key] = torch.cuda.make_graphed_callables(tail, sample, allow_unused_input=True)
-            except Exception as e:                                 # capture is an optimisation: say why it is off and stay eager
-                import warnings
-                warnings.warn(f"mask tail: graph capture failed ({type(e).__name__}: {e}); running the eager tail")
-                self._tail_graphs[key] = False
-        return self._tail_graphs[key] or None
-
     def _mask_tail(self, plan, last_hidden, ce, image_tokens, seg_rows_d, exp_d, masks_list, label_list, resize_list, inference, B):
         cfg, dev, m = self.config, self.device_, self.model
         with torch.no_grad():
@@ -694,18 +631,12 @@ class MedPLIBForCausalLM(nn.Module):
         assert n <= image_tokens.shape[0], "more <SEG> rows than expanded image embeddings"   # pairing by position, :473-487
         if n < image_tokens.shape[0]:
             image_tokens = image_tokens[:n].contiguous()
-        shapes = [tuple(l.shape[-2:]) for l in label_list[:n]]
-        graphed = self._graphed_tail(n, hidden_rows, image_tokens, ce, masks_list, resize_list, shapes, inference)
-        if graphed is not None:
-            H, W = shapes[0]
-            gt = torch.stack([g.reshape(H, W) for g in masks_list[:n]]).to(device=dev, dtype=torch.float32).view(n, H * W)
-            out10 = graphed(hidden_rows, image_tokens.contiguous(), gt, ce).clone()      # the graph's output buffer is overwritten by the next replay
-            return {k: out10[i] for i, k in enumerate(LOSS_KEYS)}
         fc = m.text_hidden_fcs[0]
         pred_emb = A.linear(A.linear(hidden_rows, fc[0].weight, fc[0].bias, ops.SACT_RELU), fc[2].weight, fc[2].bias)
         pe = m.visual_model.prompt_encoder
         low_res, iou_pred = m.visual_model.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight,
                                                          pred_emb.view(n, 1, -1))
+        shapes = [tuple(l.shape[-2:]) for l in label_list[:n]]
         full, pred_masks = self._postprocess(low_res, resize_list[:n], shapes)
         if inference:
             return {"pred_masks": pred_masks, "gt_masks": masks_list}
