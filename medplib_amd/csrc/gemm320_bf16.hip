@@ -457,6 +457,8 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     // unit `split` sums, in ascending split order whoever arrived when (so the rounding does not depend on the order), the wave-tile
     // items it % S == split of ALL partials — an item = one fragment row x one fragment pair = 2 of the 40 accumulator fragments (a column half = 4 for the SwiGLU family) — and
     // runs the epilogue on exactly those.  The departure counter lets the last unit out re-arm both counters for the next launch.
+    // Progress: a tile's units are never more than the CUs (S * rem <= CUs) and wait only for each other, so a resident kernel of another
+    // stream can delay them (until it ends) but not block them; the wait itself is bounded.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int SLAB = BM3 * BN3 * 4;                  // one unit's partial tile, bytes
     const int tail = flat - full;
@@ -474,7 +476,9 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     int* depart = g.tickets + 128 + tail;                // rem <= 128 (the split rule), the registered ticket array holds 256
     if (tid == 0) {
       __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(8);
+      // bounded (~1 s): a sibling that never arrives (a launch torn down under us) must cost a wrong tile, not a hung GPU
+      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ++spin)
+        __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
     // the share: work items it % S == split; an item = a fragment pair (20 per tile), or for the SwiGLU family a column half (10)

@@ -135,6 +135,17 @@ def test_reference_inference_driver_call_shapes(dev, tmp_path):
         p = (torch.sigmoid(pm[0].float()) > 0.1).reshape(-1)
         ious.append(int((p & g).sum()) / max(int((p | g).sum()), 1))
     assert abs(sum(ious) / 2 - out["miou"]) < 1e-9
+    # the MoE class from an MoE checkpoint directory (what scripts/eval on a stage-IV model load): E = 2 top-1 experts in every layer
+    from medplib_amd.model.medplib import MedPLIBForCausalLM as CoreMoE
+    mcfg = MedPLIBConfig.tiny(moe_enable=True, sam_depth=2, num_experts=2, top_k_experts=1)
+    moe = CoreMoE(mcfg, device=dev)
+    moe.load_hf_state_dict(OM.init_hf_weights(mcfg, seed=12))
+    moe_dir = str(tmp_path / "moe_base")
+    moe.save_pretrained(moe_dir)
+    out_m = V.main(["--version", moe_dir, "--dataset", "synthetic", "--n_samples", "1", "--max_new_tokens", "4", "--colon_token_id", "7",
+                    "--eval_seg", "--eval_vqa", "--moe_enable", "--moe_mode", "dense", "--num_experts", "2", "--top_k_experts", "1",
+                    "--precision", "bf16"])
+    assert 0.0 <= out_m["miou"] <= 1.0 and len(out_m["answers"]) == 1 and len(out_m["answers"][0]) >= 1
     # what the walk refuses loudly
     m2 = V.LISAForCausalLM.from_pretrained(base, torch_dtype=torch.bfloat16, test_only=True)
     with pytest.raises(ValueError):

@@ -278,6 +278,8 @@ def stage_epochs(run):
     a = run.args
     run.history, run.val_scores = [], []
     if a.eval_only:
+        if not run.val_batches:
+            raise ValueError("--eval_only needs validation samples (--val_data_path, or --val_samples N with --dataset synthetic)")
         run.val_scores.append(validate(run, 0))
         return
     feed = endless(run.loader)
