@@ -517,11 +517,13 @@ def main():
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            tname = next((n for n in ("r03c_hbm_traffic.json", "r03a_hbm_traffic.json", "r02s_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+            tname = next((n for n in ("r03d_hbm_traffic.json", "r03c_hbm_traffic.json", "r03a_hbm_traffic.json", "r02s_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
                           if os.path.exists(os.path.join(pdir, n))), None)
             tpath = os.path.join(pdir, tname or "")
             if tname:
-                tj = json.load(open(tpath)).get({256: "gemm256v3", 320: "gemm320"}[dom])
+                tjs = json.load(open(tpath))
+                # (since the towers' GEMMs share the 320-row kernel's plain family, the decoder's launches are the epilogue families 1-3)
+                tj = (tjs.get("gemm320_decoder") if dom == 320 else None) or tjs.get({256: "gemm256v3", 320: "gemm320"}[dom])
                 if tj and not args.lora:
                     roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
                     roof["traffic_detail"] = {"kernel": fams[dom], "read_bytes_per_launch": tj["read_bytes_per_launch"],

@@ -22,6 +22,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                    "rmsnorm" if "rmsnorm" in n else "moe_combine" if "moe_combine" in n else "rope" if "rope_qk" in n else None)
             if fam:
                 res[fam][c].append(float(r["Counter_Value"]))
+            if "gemm320" in n and "kernel<0>" not in n:      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
+                res["gemm320_decoder"][c].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --kernel-trace --pmc <counter> over bench.py (3 steps); per-launch averages; read_bytes = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM section), write_bytes = WRITE_SIZE KiB raw (uncalibrated)"}
 for fam, cs in res.items():
     f, w = cs.get("FETCH_SIZE", []), cs.get("WRITE_SIZE", [])
