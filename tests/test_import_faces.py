@@ -74,3 +74,29 @@ def test_surface_walk_flag_tables():
         table = next(n.value for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "FLAG_TABLE")
         names = [e.elts[0].value for e in table.elts]
         assert len(names) == len(set(names)) and must <= set(names), (rel, must - set(names))
+
+
+def test_surface_walk_command_lines_parse_like_the_reference():
+    """The walks accept the reference's command lines: scripts/train_stage4.sh's flag set (argparse `type=bool` reads any non-empty string
+    as True, which `--moe_enable True` relies on), store_true switches, choices; engine_config builds the ds_config of :383-420 from them."""
+    import train_ds_medplib as T
+    a = T.parse_args(["--version", "/ckpt", "--moe_enable", "True", "--moe_mode", "dense", "--num_experts", "2", "--top_k_experts", "1",
+                      "--capacity_factor", "1.5", "--lora_r", "8", "--lora_target_modules", "gate_proj,up_proj,down_proj,q_proj,v_proj",
+                      "--sft_modules", "wg,lm_head,embed_tokens,mask_decoder,text_hidden_fcs", "--train_mask_decoder", "--epochs", "3",
+                      "--batch_size", "8", "--grad_accumulation_steps", "2", "--lr", "2e-4", "--no_eval", "--icl_mask_mode", "separate"])
+    assert a.moe_enable is True and a.num_experts == 2 and a.top_k_experts == 1 and a.capacity_factor == 1.5 and a.train_mask_decoder
+    assert a.gradient_checkpointing and a.use_mm_start_end and a.auto_resume and a.no_eval and not a.eval_only      # defaults kept
+    assert a.router_aux_loss_coef == 0.01 and a.eval_capacity_factor == 2.0 and a.ep_size == 1 and a.precision == "bf16"
+    a.steps_per_epoch = 500
+    c = T.engine_config(a, a.batch_size)
+    assert c["train_micro_batch_size_per_gpu"] == 8 and c["gradient_accumulation_steps"] == 2 and c["gradient_clipping"] == 1.0
+    assert c["optimizer"]["params"] == {"lr": 2e-4, "weight_decay": 0.0, "betas": (0.9, 0.95)} and c["bf16"]["enabled"] and not c["fp16"]["enabled"]
+    assert c["scheduler"]["params"] == {"total_num_steps": 1500, "warmup_min_lr": 0, "warmup_max_lr": 2e-4, "warmup_num_steps": 5,
+                                        "warmup_type": "linear"}
+    assert c["zero_optimization"]["stage"] == 2 and c["zero_optimization"]["overlap_comm"]
+    assert [s.__name__ for s, _ in T.STAGES][:3] == ["stage_process_setup", "stage_tokenizer", "stage_open_checkpoint"] and len(T.STAGES) == 11
+    from model.eval import vqa_infer as V
+    v = V.parse_args(["--version", "/ckpt", "--eval_seg", "--moe_enable", "--num-chunks", "4", "--chunk-idx", "1", "--answers-file", "/tmp/a.jsonl",
+                      "--temperature", "0", "--num_beams", "1"])
+    assert v.eval_seg and not v.eval_vqa and v.moe_enable and v.num_chunks == 4 and v.chunk_idx == 1 and v.answers_file == "/tmp/a.jsonl"
+    assert v.model_max_length == 2048 and v.is_multimodal and v.use_mm_start_end and v.val_batch_size == 1
