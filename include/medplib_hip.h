@@ -70,8 +70,9 @@ int mp_gemm_swiglu_keep_bf16(const void* A, int64_t lda, const void* W, int64_t 
 int mp_gemm_last_kernel(void);
 /* Tile choice of the calling thread's dense mp_gemm_bf16_nt / mp_gemm_qkv_rope_bf16 calls: 1 (default) = 320x256 tiles where the wave model
  * says they beat 256x256 tiles (M = 5112: one whole wave instead of 1.25 for every N = 4096 projection), 0 = never, 2 = whenever the call
- * is eligible (dense, bf16 out, N % 256 == 0, act NONE / QUICK_GELU / RoPE), -1 = back to the process default (MP_GEMM320).  A/B runs and
- * tests; mp_gemm_last_kernel() then reports 320. */
+ * is eligible (dense, bf16 out, N % 256 == 0, act NONE / QUICK_GELU / RoPE), 3 = as 2 and the 320-row kernel never splits a tail (the
+ * frozen towers, which run on streams beside the decoder: a split tail's units wait for each other, and only one kernel per device may
+ * do that at a time), -1 = back to the process default (MP_GEMM320).  mp_gemm_last_kernel() then reports 320. */
 int mp_gemm_tile_policy(int mode);
 /* `batch` independent GEMMs at fixed strides — the per-expert SwiGLU GEMMs of DeepSpeed `Experts`
  * (call site medplib_moe_llama.py:604-614). m_dev[b] = rows routed to expert b. */

@@ -684,6 +684,15 @@ void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int6
   *ws = it->second.ws; *tickets = it->second.tickets; *bytes = it->second.bytes;
 }
 
+// Whether `stream` has its own registered workspace, i.e. the host declared that it runs GEMMs CONCURRENTLY with the device's primary
+// stream.  The 320-row kernel's cooperative tail (units that WAIT for their siblings) is only deadlock-free while a single kernel on
+// the device waits at a time: two such kernels on two streams can each hold CUs the other's missing units need.
+bool mp_gemm_stream_registered(hipStream_t stream) {
+  if (!stream) return false;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  return g_split.find(std::make_pair(current_device(), stream)) != g_split.end();
+}
+
 // CU count of the CURRENT device (immutable per device; cached per device id, not in a process-wide static)
 int mp_device_cus() {
   static std::mutex mu;

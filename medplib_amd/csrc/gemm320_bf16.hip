@@ -37,6 +37,8 @@
 
 int mp_device_cus();
 void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
+bool mp_gemm_stream_registered(hipStream_t stream);
+bool mp_gemm_policy_whole_tiles();
 
 namespace {
 
@@ -476,9 +478,14 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     int* depart = g.tickets + 128 + tail;                // rem <= 128 (the split rule), the registered ticket array holds 256
     if (tid == 0) {
       __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // bounded (~1 s): a sibling that never arrives (a launch torn down under us) must cost a wrong tile, not a hung GPU
-      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ++spin)
+      // bounded (~1 s): a sibling that never arrives must end the process with a launch failure — neither a hung GPU nor a silently
+      // wrong tile with the tickets left mis-counted for every later launch.  The host side keeps the wait deadlock-free (one waiting
+      // kernel per device at a time: mp_launch_gemm320), so the trap is a tripwire, not a code path.
+      int spin = 0;
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
+        if (++spin > (1 << 22)) __builtin_trap();
         __builtin_amdgcn_s_sleep(8);
+      }
     }
     __syncthreads();
     // the share: work items it % S == split; an item = a fragment pair (20 per tile), or for the SwiGLU family a column half (10)
@@ -566,6 +573,12 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   const int64_t dense_tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3);
   g.max_split = (batch > 1 || g.m_dev) ? max_split : ((dense_split && dense_tiles > g.n_cu) ? max_split : 1);
   if (g.act == ACT_ROPE_QK) g.max_split = 1;            // the RoPE family's epilogue has no item mask (its calls are dense qkv projections)
+  // Units of a split tail WAIT for their siblings, so only one such kernel may be in flight on the device: a second one on a concurrent
+  // stream can hold the CUs the first one's unscheduled units need while waiting for CUs the first one holds (B = 16 with the towers
+  // started ahead: the CLIP qkv projection, 348 tiles cut into 92 x 2 units, beside the experts' down projection -> ~1 s stalls per
+  // step).  Streams the host registered as concurrent (mp_gemm_set_stream_workspace) therefore never split; the primary stream does.
+  // The frozen towers ask for whole tiles outright (tile policy 3), so that their results do not depend on which stream a step ran them on.
+  if (mp_gemm_stream_registered(stream) || mp_gemm_policy_whole_tiles()) g.max_split = 1;
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &g.ws, &g.tickets, &ws_bytes);
   if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }

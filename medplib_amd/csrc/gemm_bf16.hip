@@ -351,7 +351,7 @@ static bool use_320(const GemmArgs& g, int batch) {
   if (env_mode < 0) { const char* e = getenv("MP_GEMM320"); env_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
-  if (mode == 2) return true;
+  if (mode >= 2) return true;
   const int C = std::min(mp_device_cus(), 256);
   const int64_t t256 = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256), t320 = mp_cdiv(g.M, 320) * (g.N / 256);
   if (t320 * 2 < C) return false;                     // fewer workgroups than half the CUs: the smaller tiles (or a K split) fill the machine better
@@ -389,7 +389,7 @@ static bool use_320_batched(const GemmArgs& g, int batch) {
   if (env_mode < 0) { const char* e = getenv("MP_GEMM320"); env_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
   if (mode == 0 || gemm_variant() != 2 || !mp_gemm320_eligible(g, batch)) return false;
-  if (mode == 2) return true;
+  if (mode >= 2) return true;
   if (!env_b) return false;
   if (g.K >= 2048 && g.N >= 8192) return true;
   // round 3: the experts' down projection (N = 4096, K = 11008, combine epilogue) too.  8 + 9 row tiles of 320 are 272 tiles = one wave
@@ -408,8 +408,10 @@ static bool use_256(const GemmArgs& g, int batch) {
   return big;
 }
 extern "C" int mp_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+// policy 3 (the frozen towers): the 320-row kernel's tails never split, whichever stream the call is on (gemm320_bf16.hip: mp_launch_gemm320)
+bool mp_gemm_policy_whole_tiles() { return g_tile_policy == 3; }
 extern "C" int mp_gemm_tile_policy(int mode) {
-  MP_REQUIRE(mode >= -1 && mode <= 2, MP_ERR_ARG, "mp_gemm_tile_policy: mode must be -1 (default), 0 (256-row tiles only), 1 (by the wave model) or 2 (320-row tiles whenever eligible)");
+  MP_REQUIRE(mode >= -1 && mode <= 3, MP_ERR_ARG, "mp_gemm_tile_policy: mode must be -1 (default), 0 (256-row tiles only), 1 (by the wave model), 2 (320-row tiles whenever eligible) or 3 (as 2, tails never split)");
   g_tile_policy = mode;
   return MP_OK;
 }

@@ -165,7 +165,8 @@ def gemm_swiglu_keep(a, w, act_out=None):
 
 def gemm_tile_policy(mode):
     """Tile choice of this thread's dense bf16 GEMM calls (mp_gemm_tile_policy): 1 = 320x256 tiles where the wave model prefers them
-    (default), 0 = 256-row tiles only, 2 = 320-row tiles whenever eligible, -1 = process default."""
+    (default), 0 = 256-row tiles only, 2 = 320-row tiles whenever eligible, 3 = as 2 with tails never split (the frozen towers),
+    -1 = process default."""
     global _TILE_POLICY
     lib().call("mp_gemm_tile_policy", int(mode))
     _TILE_POLICY = int(mode)
@@ -205,7 +206,7 @@ class throughput_tiles:
         _TOWER_DEPTH += 1
         self._prev = _TILE_POLICY
         if throughput_tiles._on and self._prev == -1:          # an explicit policy of the caller (tests, A/B scripts) wins
-            gemm_tile_policy(2)
+            gemm_tile_policy(3)                                # whole tiles: a split tail's units wait, and the decoder's stream owns that
         return self
 
     def __exit__(self, *exc):

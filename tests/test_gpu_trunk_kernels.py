@@ -661,6 +661,57 @@ def test_gemm320_dense_tail_split(dev):
     _report("gemm320 dense tail split (+ residual) vs fp32", outs[2][1], ref, rtol=2 * BF16_EPS, atol=2e-2)
 
 
+def test_gemm320_split_tails_never_wait_on_two_streams_at_once(dev):
+    """Units of a split tail wait for their siblings, so two such kernels on two concurrent streams could each hold the CUs the other's
+    unscheduled units need (bench.py --batch 16 with the towers started ahead stalled ~1 s per step before the rule).  A stream the
+    host registered as concurrent (ops.side_stream(..., with_gemm_workspace=True)) therefore never splits: the same dense call that splits
+    on the primary stream (two more fp32 roundings) is, on the side stream, BIT-EQUAL to the unsplit 256-row result, and 40 rounds of the
+    two streams side by side finish in kernel time, not in wait time, with every output identical to the serial one."""
+    import time
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(79)
+    M, N, K = 5112, 5632, 512                                  # 16 x 22 tiles = 256 + 96: the tail splits on the primary stream
+    x = _bf(torch.randn(M, K, generator=g) * 0.5).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    M2, N2, K2 = 9232, 3072, 1024                              # the CLIP qkv projection at B = 16: 29 x 12 = 348 tiles = 256 + 92
+    x2 = _bf(torch.randn(M2, K2, generator=g) * 0.5).to(dev)
+    w2 = _bf(torch.randn(N2, K2, generator=g) * 0.05).to(dev)
+    side = ops.side_stream(dev, "test_concurrent_gemm", with_gemm_workspace=True)
+    try:
+        ops.gemm_tile_policy(0)
+        unsplit = ops.gemm(x2, w2)
+        ops.gemm_tile_policy(2)
+        main_ref = ops.gemm(x, w)
+        primary = ops.gemm(x2, w2)
+        assert ops.gemm_last_kernel() == 320
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            on_side = ops.gemm(x2, w2)
+            assert ops.gemm_last_kernel() == 320
+        side.synchronize()
+        # the 320- and 256-row kernels add K-tiles in the same order when neither splits: the side-stream call did not split
+        assert torch.equal(on_side, unsplit)
+        assert not torch.equal(primary, unsplit)               # the primary stream's call did (this is what the rule withholds from `side`)
+        ops.gemm_tile_policy(3)                                # the towers' policy: whole tiles on whichever stream
+        whole = ops.gemm(x2, w2)
+        assert ops.gemm_last_kernel() == 320 and torch.equal(whole, unsplit)
+        ops.gemm_tile_policy(2)
+        t0 = time.perf_counter()
+        outs_main, outs_side = [], []
+        for _ in range(40):
+            outs_main.append(ops.gemm(x, w))
+            with torch.cuda.stream(side):
+                outs_side.append(ops.gemm(x2, w2))
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        ops.gemm_tile_policy(-1)
+    assert all(torch.equal(t, main_ref) for t in outs_main) and all(torch.equal(t, on_side) for t in outs_side)
+    print(f"[concurrent split tails] 40 rounds on two streams: {wall * 1e3:.1f} ms")
+    assert wall < 0.25, wall                                   # ~40 x (0.1 + 0.15) ms of kernels; one stalled wait alone is ~1 s
+
+
 def test_gemm_320_row_tile_kernel(dev):
     """The 320x256 tile kernel (gemm320_bf16.hip) against the fp32 reference and against the 256x256 kernel: where the 256 tiling has
     no split-K tail both kernels add the K-tiles in the same order, so the outputs must be EQUAL; ragged last row tile (rows beyond M
