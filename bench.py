@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--towers-in-order", action="store_true",
                     help="debug / A-B: the frozen CLIP tower of a step queues behind the previous step's decoder instead of starting on its own "
-                         "stream when the step is issued (model.towers_run_ahead, the default since round 3: +2.6 % samples/s)")
+                         "stream when the step is issued (model.towers_run_ahead, the default since round 3: +2.6 %% samples/s)")
     ap.add_argument("--roofline-steps", type=int, default=6,
                     help="extra un-timed steps AFTER the timed region in which the dominant GEMM is measured unshared (towers in order, SAM "
                          "encoder and mask tail on the decoder's stream): `roofline`; the timed region's own figure is `roofline_timed_region`")
