@@ -553,7 +553,9 @@ def main():
                                    "336x336 CLIP image + 256x256 SAM image + 64-token prompt (S=639 after splice), "
                                    f"per-GPU batch {args.batch}, DP={world}",
                        "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
-                       "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel},
+                       "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel,
+                       "mask_upsampler": ("fused bf16 kernel, forward + recomputing backward (in the step)" if cfg.fused_bf16_upsampler
+                                          else "fp32 tail (6 launches forward, 14 backward)")},
             # algorithmic work per sample: the forward (9.15 TFLOP); with --lora also the decoder's dgrad (8.66: the frozen
             # projections' input gradients + the attention backward; no wgrad for frozen weights)
             "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1),

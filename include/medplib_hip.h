@@ -181,6 +181,16 @@ int mp_scale_f32(float* x, int64_t n, float s, hipStream_t stream);
 int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packed, const float* b1, const float* ln_w, const float* ln_b,
                                 const void* w2_packed, const float* b2, const float* hyper, void* up, float* mask, int B, int h,
                                 int w, float ln_eps, hipStream_t stream);
+/* Backward of the fused upsampler + hypernetwork product (training form): recomputes the forward of every 16-token group and returns
+ * dx2 [2][B*h*w][256] (the two row-parity shares of d src; the caller adds them), the operands of the two weight-gradient `tn` products
+ * — dy1 [B*h*w][256] (column (kh*2+kw)*64 + c), a1 [B*h*w*4][64] and dy2 [B*h*w*4][128] (rows in (group, kh, kw, token) order, column
+ * (kh2*2+kw2)*32 + c2):  dW1_packed = dy1^T @ src,  dW2_packed = dy2^T @ a1 — and part [B*h*w/8][256], one row per (group, kh) task:
+ * db1[64] | dln_w[64] | dln_b[64] | db2[32] | dhyper[32] (column sums over all tasks give the first four; dhyper sums over the tasks of
+ * one image).  w1_t / w2_t are the packed weights transposed ([256][256], [64][128]).  No atomics: deterministic. */
+int mp_mask_upsample_fused_bwd_bf16(const void* src, const void* w1_packed, const float* b1, const float* ln_w, const float* ln_b,
+                                    const void* w2_packed, const float* b2, const float* hyper, const void* w1_t, const void* w2_t,
+                                    const float* dmask, float* dx2, float* dy1, float* a1, float* dy2, float* part,
+                                    int B, int h, int w, float ln_eps, hipStream_t stream);
 /* postprocess_masks (MedPLIB.py:682-701): crop window (already resolved with Python slice semantics by the caller)
  * then F.interpolate(bilinear, align_corners=False) to (out_h, out_w). */
 int mp_bilinear_resize_fwd(const void* in, int in_dtype, float* out, int n, int in_h, int in_w, int crop_y0, int crop_x0,

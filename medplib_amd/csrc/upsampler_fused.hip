@@ -293,6 +293,335 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
   }
 }
 
+// ------------------------------------------------------------------ backward ---------------------------------------------------
+// Training form (round 3): the forward above with the hypernetwork product is differentiated by ONE kernel that recomputes the
+// forward of its 16-token group (same instruction sequence, same bf16 rounding points: no intermediate was kept) and walks the chain
+//   dmask -> d gelu2 -> [dW2, db2 operands] -> da1 = dy2 . W2 -> d gelu1 -> d LayerNorm2d -> [dW1, db1 operands] -> dx = dy1 . W1
+// with the two data-gradient products on MFMA (bf16 operands, fp32 accumulation) and GELU' / LayerNorm' in registers.  The weight
+// gradients are `tn` products over ALL tokens; the kernel writes their operands (dy1, a1, dy2: 8 MB at the model's 16 x 16 geometry,
+// batch 8) and the host runs them as two deterministic GEMMs; bias / LayerNorm / hypernetwork gradients leave as one partial row per
+// (group, kh) task that a fixed-order column sum finishes.  Nothing is accumulated with atomics: the step stays bit-reproducible.
+// One wave per (group, kh) task as in the forward, at most four waves per workgroup (one per SIMD: ~300 live VGPRs).
+constexpr int UPB_WAVES = 4;
+constexpr int TB_WAVE_BYTES = T_WAVE_BYTES;        // per-wave LDS, 4 KiB, used in turn for a1 [32][64], dy2 [32][64] per output line and dy1 [16][128] (bf16)
+constexpr int UPB_LDS = W1H_BYTES + W2_BYTES + UPB_WAVES * TB_WAVE_BYTES;
+
+struct UpBwdArgs {
+  UpArgs f;               // the forward's operands (up / mask unused)
+  const bf16_t* w1t;      // [256 cin][256 n1]  = w1p transposed
+  const bf16_t* w2t;      // [64 ch][128 n2]    = w2p transposed
+  const float* dmask;     // [B, 4h, 4w]
+  float* dx;              // [2 kh][B*h*w][256]
+  float* dy1;             // [B*h*w][256]            column n1 = (kh*2 + kw)*64 + ch
+  float* a1;              // [tasks*32][64]          task = group*2 + kh, row = kw*16 + token
+  float* dy2;             // [tasks*32][128]         column n2 = (kh2*2 + kw2)*32 + c2
+  float* part;            // [tasks][256]            db1[64] | dlnw[64] | dlnb[64] | db2[32] | dhyper[32]
+};
+
+// d/dx of x Phi(x) = Phi(x) + x phi(x), with Phi(-a) = 2^q5(a) from the forward's own fit (|error of Phi| < 2e-5: far below the bf16
+// rounding of the operands the gradient is multiplied into) and phi by one v_exp_f32
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float a = fabsf(x);
+  float q = fmaf(-0.0004733088717330247f, a, 0.007084553129971027f);
+  q = fmaf(q, a, -0.05182736739516258f);
+  q = fmaf(q, a, -0.4599924683570862f);
+  q = fmaf(q, a, -1.1507878303527832f);
+  q = fmaf(q, a, -1.000037670135498f);
+  const float tail = __builtin_amdgcn_exp2f(q);                       // Phi(-|x|)
+  const float cdf = x >= 0.f ? 1.f - tail : tail;
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+
+__device__ __forceinline__ float sum_over_fq(float v) {        // the four 16-lane rows of the wave hold partial sums of the same channel
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__global__ __launch_bounds__(64 * UPB_WAVES, 1) void upsample_fused_bwd_kernel(UpBwdArgs g) {
+  const UpArgs& a = g.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW1 = smem;
+  char* sW2 = smem + W1H_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16_t* tw = reinterpret_cast<bf16_t*>(smem + W1H_BYTES + W2_BYTES + wave * TB_WAVE_BYTES);
+
+  int kh, gset;
+  const int n_gsets = gridDim.x >> 1;
+  if ((gridDim.x & 15) == 0) { const int loc = blockIdx.x >> 3; kh = loc & 1; gset = (loc >> 1) * 8 + (blockIdx.x & 7); }
+  else { kh = blockIdx.x & 1; gset = blockIdx.x >> 1; }
+  const int tokens_per_img = a.h * a.w;
+  const int64_t n_tokens = (int64_t)a.B * tokens_per_img;
+  const int64_t n_groups = n_tokens / 16;
+  const int nw = blockDim.x >> 6;
+  const int64_t stride = (int64_t)n_gsets * nw;
+  int64_t grp = (int64_t)gset * nw + wave;
+
+  for (int j = wave; j < 64; j += nw) {
+    const int n = 2 * j + (lane >> 5), pc = lane & 31;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w1p + (int64_t)(kh * 128 + n) * 256 + ((pc ^ (n & 7)) << 3)),
+                                     (__attribute__((address_space(3))) void*)(sW1 + j * 1024), 16, 0, 0);
+  }
+  for (int j = wave; j < 16; j += nw) {
+    const int n = 8 * j + (lane >> 3), pc = lane & 7;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w2p + (int64_t)n * 64 + ((pc ^ (n & 7)) << 3)),
+                                     (__attribute__((address_space(3))) void*)(sW2 + j * 1024), 16, 0, 0);
+  }
+  float b1v[4], lwv[4], lbv[4], b2v[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { b1v[j] = a.b1[j * 16 + fr]; lwv[j] = a.lnw[j * 16 + fr]; lbv[j] = a.lnb[j * 16 + fr]; }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) b2v[p] = a.b2[p * 16 + fr];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int OW = 4 * a.w, OH = 4 * a.h;
+  for (; grp < n_groups; grp += stride) {
+    const int64_t t0 = grp * 16;
+    const int64_t task = grp * 2 + kh;
+    const int b = (int)(t0 / tokens_per_img);
+    const int ti = (int)(t0 % tokens_per_img);
+    const int irow = ti / a.w, j0 = ti % a.w;
+    bf16x8 xa[8];
+    {
+      const bf16_t* xrow = a.src + (t0 + fr) * 256;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(xrow + (kk * 4 + fq) * 8);
+    }
+    const float hv[2] = {a.hyper[(int64_t)b * 32 + fr], a.hyper[(int64_t)b * 32 + 16 + fr]};
+    // ---------------- recompute: GEMM1 -> + bias, LayerNorm2d, GELU (the forward's own sequence) ----------------
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[kw][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sW1 + w1_off(kw * 64 + j * 16 + fr, kk * 4 + fq));
+          acc1[kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb, acc1[kw][j], 0, 0, 0);
+        }
+    }
+    f32x2 zh[2][2][4], g1[2][2][4], rs[2][2];           // normalised value, gelu'(z), 1 / sigma   per [kw][token pair][j]
+    float* a1row = g.a1 + task * (32 * 64);
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw) {
+      f32x2 v[2][4];
+      f32x2 s[2] = {splat2(0.f), splat2(0.f)};
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[rp][j] = f32x2{acc1[kw][j][2 * rp], acc1[kw][j][2 * rp + 1]} + splat2(b1v[j]);
+          s[rp] += v[rp][j];
+        }
+      {
+        float s0 = s[0].x, s1 = s[0].y, s2 = s[1].x, s3 = s[1].y;
+        row16_sum4(s0, s1, s2, s3);
+        s[0] = f32x2{s0, s1}; s[1] = f32x2{s2, s3};
+      }
+      f32x2 q[2] = {splat2(0.f), splat2(0.f)};
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        const f32x2 mean = s[rp] * splat2(1.f / 64.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[rp][j] -= mean; q[rp] = __builtin_elementwise_fma(v[rp][j], v[rp][j], q[rp]); }
+      }
+      {
+        float q0 = q[0].x, q1 = q[0].y, q2 = q[1].x, q3 = q[1].y;
+        row16_sum4(q0, q1, q2, q3);
+        q[0] = f32x2{q0, q1}; q[1] = f32x2{q2, q3};
+      }
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        const f32x2 var = __builtin_elementwise_fma(q[rp], splat2(1.f / 64.f), splat2(a.eps));
+        const f32x2 rstd = {__builtin_amdgcn_rsqf(var.x), __builtin_amdgcn_rsqf(var.y)};
+        rs[kw][rp] = rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          zh[kw][rp][j] = v[rp][j] * rstd;
+          const f32x2 z = __builtin_elementwise_fma(zh[kw][rp][j], splat2(lwv[j]), splat2(lbv[j]));
+          const f32x2 y = gelu2<0>(z);
+          g1[kw][rp][j] = f32x2{gelu_grad(z.x), gelu_grad(z.y)};
+          const int ch = j * 16 + fr;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int tk = fq * 4 + 2 * rp + e;
+            const bf16_t yb = (bf16_t)y[e];
+            tw[(kw * 16 + tk) * 64 + ((((ch >> 3) ^ (tk & 7)) << 3) | (ch & 7))] = yb;
+            a1row[(kw * 16 + tk) * 64 + ch] = (float)yb;       // dW2's operand: what GEMM2 multiplied
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 ya[2][2];
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        ya[kw][kk] = *reinterpret_cast<const bf16x8*>(tw + (kw * 16 + fr) * 64 + (((kk * 4 + fq) ^ (fr & 7)) << 3));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- per output line: recompute GEMM2, d gelu2, and da1 += dy2 . W2 ----------------
+    f32x4 da1[2][4];
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) da1[kw][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dhp[2] = {0.f, 0.f}, db2p[2] = {0.f, 0.f};
+    float* dy2row = g.dy2 + task * (32 * 128);
+#pragma unroll 1
+    for (int kh2 = 0; kh2 < 2; ++kh2) {
+      f32x4 acc2[2][4];
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) acc2[kw][qn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+          const int n2 = (kh2 * 4 + qn) * 16 + fr;
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(sW2 + n2 * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 4));
+#pragma unroll
+          for (int kw = 0; kw < 2; ++kw) acc2[kw][qn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[kw][kk], wb, acc2[kw][qn], 0, 0, 0);
+        }
+      float dm[16];                          // the 16 pixels of this line the lane row fq owns: pixel = r*4 + kw*2 + kw2
+      {
+        const float* dmp = g.dmask + ((int64_t)b * OH + 4 * irow + 2 * kh + kh2) * OW + 4 * j0 + 16 * fq;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(dmp + i);
+          dm[i] = t.x; dm[i + 1] = t.y; dm[i + 2] = t.z; dm[i + 3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+          const int kw2 = qn >> 1, half = qn & 1;
+          const f32x4 c = acc2[kw][qn];
+          const f32x2 g01 = gelu2<0>(f32x2{c[0], c[1]} + splat2(b2v[half]));
+          const f32x2 g23 = gelu2<0>(f32x2{c[2], c[3]} + splat2(b2v[half]));
+          const float a2[4] = {(float)(bf16_t)g01.x, (float)(bf16_t)g01.y, (float)(bf16_t)g23.x, (float)(bf16_t)g23.y};
+          const int n2l = qn * 16 + fr;       // column within this line's 64
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dmv = dm[r * 4 + kw * 2 + kw2];
+            dhp[half] = fmaf(dmv, a2[r], dhp[half]);
+            const float d = dmv * hv[half] * gelu_grad(c[r] + b2v[half]);
+            db2p[half] += d;
+            const int tk = fq * 4 + r;
+            dy2row[(kw * 16 + tk) * 128 + kh2 * 64 + n2l] = d;
+            tw[(kw * 16 + tk) * 64 + ((((n2l >> 3) ^ (tk & 7)) << 3) | (n2l & 7))] = (bf16_t)d;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      bf16x8 dya[2][2];
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          dya[kw][kk] = *reinterpret_cast<const bf16x8*>(tw + (kw * 16 + fr) * 64 + (((kk * 4 + fq) ^ (fr & 7)) << 3));
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // da1[(kw, token)][ch] += sum_n2 dy2[(kw, token)][n2] * W2p[n2][ch]: B operand = W2^T rows (16 KiB, L1 / L2 resident)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(g.w2t + (j * 16 + fr) * 128 + kh2 * 64 + kk * 32 + fq * 8);
+#pragma unroll
+          for (int kw = 0; kw < 2; ++kw) da1[kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dya[kw][kk], wb, da1[kw][j], 0, 0, 0);
+        }
+    }
+    // ---------------- d gelu1, d LayerNorm2d -> dy1 ----------------
+    float db1p[4] = {0.f, 0.f, 0.f, 0.f}, dlwp[4] = {0.f, 0.f, 0.f, 0.f}, dlbp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw) {
+      f32x2 dzh[2][4];
+      f32x2 s1[2] = {splat2(0.f), splat2(0.f)}, s2[2] = {splat2(0.f), splat2(0.f)};
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 dz = f32x2{da1[kw][j][2 * rp], da1[kw][j][2 * rp + 1]} * g1[kw][rp][j];
+          const f32x2 t = dz * zh[kw][rp][j];
+          dlwp[j] += t.x + t.y;
+          dlbp[j] += dz.x + dz.y;
+          dzh[rp][j] = dz * splat2(lwv[j]);
+          s1[rp] += dzh[rp][j];
+          s2[rp] = __builtin_elementwise_fma(dzh[rp][j], zh[kw][rp][j], s2[rp]);
+        }
+      {
+        float s0 = s1[0].x, sa = s1[0].y, sb = s1[1].x, sc = s1[1].y;
+        row16_sum4(s0, sa, sb, sc);
+        s1[0] = f32x2{s0, sa}; s1[1] = f32x2{sb, sc};
+        float u0 = s2[0].x, ua = s2[0].y, ub = s2[1].x, uc = s2[1].y;
+        row16_sum4(u0, ua, ub, uc);
+        s2[0] = f32x2{u0, ua}; s2[1] = f32x2{ub, uc};
+      }
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        const f32x2 m1 = s1[rp] * splat2(1.f / 64.f), m2 = s2[rp] * splat2(1.f / 64.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 d = rs[kw][rp] * (dzh[rp][j] - m1 - zh[kw][rp][j] * m2);
+          db1p[j] += d.x + d.y;
+          const int ch = j * 16 + fr, n1l = kw * 64 + ch;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int tk = fq * 4 + 2 * rp + e;
+            g.dy1[(t0 + tk) * 256 + kh * 128 + n1l] = d[e];
+            tw[tk * 128 + ((((n1l >> 3) ^ (tk & 7)) << 3) | (n1l & 7))] = (bf16_t)d[e];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 d1a[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) d1a[kk] = *reinterpret_cast<const bf16x8*>(tw + fr * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 3));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- dx[token][cin] (this kh's share) = sum_n1 dy1[token][n1] * W1p[n1][cin]: B operand = W1^T rows (L2) ----------------
+    float* dxrow = g.dx + ((int64_t)kh * n_tokens + t0) * 256;
+#pragma unroll 2
+    for (int nf = 0; nf < 16; ++nf) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 wb = *reinterpret_cast<const bf16x8*>(g.w1t + (int64_t)(nf * 16 + fr) * 256 + kh * 128 + kk * 32 + fq * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1a[kk], wb, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dxrow[(fq * 4 + r) * 256 + nf * 16 + fr] = acc[r];
+    }
+    // ---------------- this task's partial row: db1 | dlnw | dlnb | db2 | dhyper ----------------
+    float* prow = g.part + task * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x1 = sum_over_fq(db1p[j]), x2 = sum_over_fq(dlwp[j]), x3 = sum_over_fq(dlbp[j]);
+      if (fq == 0) { prow[j * 16 + fr] = x1; prow[64 + j * 16 + fr] = x2; prow[128 + j * 16 + fr] = x3; }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float x1 = sum_over_fq(db2p[half]), x2 = sum_over_fq(dhp[half]);
+      if (fq == 0) { prow[192 + half * 16 + fr] = x1; prow[224 + half * 16 + fr] = x2; }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packed, const float* b1, const float* ln_w,
@@ -329,4 +658,23 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
   else if (up) launch(upsample_fused_kernel<true, false>);
   else launch(upsample_fused_kernel<false, true>);
   return mp_check_launch("mp_mask_upsample_fused_bf16");
+}
+
+extern "C" int mp_mask_upsample_fused_bwd_bf16(const void* src, const void* w1_packed, const float* b1, const float* ln_w, const float* ln_b,
+                                               const void* w2_packed, const float* b2, const float* hyper, const void* w1_t, const void* w2_t,
+                                               const float* dmask, float* dx2, float* dy1, float* a1, float* dy2, float* part,
+                                               int B, int h, int w, float ln_eps, hipStream_t stream) {
+  MP_REQUIRE(B > 0 && h > 0 && w > 0 && w % 16 == 0, MP_ERR_SHAPE, "mp_mask_upsample_fused_bwd_bf16: token-grid width must be a multiple of 16");
+  MP_REQUIRE(src && w1_packed && w2_packed && w1_t && w2_t && hyper && dmask && dx2 && dy1 && a1 && dy2 && part, MP_ERR_ARG,
+             "mp_mask_upsample_fused_bwd_bf16: null operand");
+  UpBwdArgs g{UpArgs{(const bf16_t*)src, (const bf16_t*)w1_packed, b1, ln_w, ln_b, (const bf16_t*)w2_packed, b2, hyper, nullptr, nullptr,
+                     B, h, w, ln_eps, 0},
+              (const bf16_t*)w1_t, (const bf16_t*)w2_t, dmask, dx2, dy1, a1, dy2, part};
+  const int64_t groups = (int64_t)B * h * w / 16;
+  const int nw = (int)std::min<int64_t>(UPB_WAVES, std::max<int64_t>(2, mp_cdiv(groups, 128)));
+  const int64_t gsets = mp_cdiv(groups, nw);
+  const int grid = 2 * (int)(gsets < 128 ? gsets : 128);
+  (void)hipFuncSetAttribute((const void*)upsample_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UPB_LDS);
+  hipLaunchKernelGGL(upsample_fused_bwd_kernel, dim3(grid), dim3(64 * nw), UPB_LDS, stream, g);
+  return mp_check_launch("mp_mask_upsample_fused_bwd_bf16");
 }

@@ -167,6 +167,40 @@ class HyperDotFn(torch.autograd.Function):
         return dhyper, dup
 
 
+class FusedUpsampleMaskFn(torch.autograd.Function):
+    """output_upscaling + hyper_in @ upscaled_embedding (mask_decoder.py:53-59,141-148) as the single fused bf16 kernel, differentiable:
+    ConvT(256->64) -> LayerNorm2d -> GELU -> ConvT(64->32) -> GELU -> . hyper, in the arithmetic the reference itself trains in under
+    `--precision bf16` (bf16 operands, fp32 accumulation).  src [n, g*g, 256] fp32 tokens (NHWC order), weights in the reference layout
+    [Cin, Cout, 2, 2], hyper [n, 32]  ->  mask logits [n, 4g, 4g] fp32.  The backward is one recomputing kernel
+    (mp_mask_upsample_fused_bwd_bf16) + the two weight-gradient `tn` GEMMs + fixed-order column sums: deterministic."""
+
+    @staticmethod
+    def forward(ctx, src, w1, b1, lnw, lnb, w2, b2, hyper, g, eps):
+        n = src.shape[0]
+        src = src.contiguous()
+        src_bf = ops.cast_to_bf16(src).view(n, g * g, 256)
+        w1p, w2p = ops.pack_upsampler_weights(w1.detach(), w2.detach())
+        b1, lnw, lnb, b2 = (t.detach().float().contiguous() for t in (b1, lnw, lnb, b2))
+        hyper = hyper.detach().contiguous()
+        _, masks = ops.mask_upsample_fused(src_bf, w1p, b1, lnw, lnb, w2p, b2, g, g, hyper=hyper, want_up=False, eps=eps)
+        ctx.save_for_backward(src, src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper)
+        ctx.dims = (n, g, eps)
+        return masks
+
+    @staticmethod
+    def backward(ctx, dm):
+        src, src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper = ctx.saved_tensors
+        n, g, eps = ctx.dims
+        dx2, dy1, a1, dy2, part = ops.mask_upsample_fused_bwd(src_bf, w1p, b1, lnw, lnb, w2p, b2, hyper, dm.contiguous().float(), g, g, eps=eps)
+        dx = ops.add_f32(dx2[0], dx2[1]).view_as(src)
+        # packed rows are (kh, kw, cout): back to the reference layout [Cin, Cout, 2, 2]
+        dw1 = ops.sgemm(dy1, src.view(-1, 256), trans_a=True).view(2, 2, 64, 256).permute(3, 2, 0, 1).contiguous()
+        dw2 = ops.sgemm(dy2, a1, trans_a=True).view(2, 2, 32, 64).permute(3, 2, 0, 1).contiguous()
+        cs = ops.colsum_f32(part)
+        dhyper = part[:, 224:].reshape(n, -1, 32).sum(1)
+        return dx, dw1, cs[:64], cs[64:128], cs[128:192], dw2, cs[192:224], dhyper, None, None
+
+
 class BilinearResizeFn(torch.autograd.Function):
     """postprocess_masks (MedPLIB.py:682-701) for n masks sharing one (input_size, original_size)."""
 

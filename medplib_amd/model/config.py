@@ -62,9 +62,11 @@ class MedPLIBConfig:
     focal_loss_weight: float = 1.0
     seg_token_idx: int = 32000
     train_mask_decoder: bool = True
-    # inference only: run the mask decoder's upsampler + hypernetwork product as the single fused bf16 kernel (what the reference
-    # computes under --precision bf16) instead of the fp32 tail that training differentiates through
-    fused_bf16_upsampler: bool = False
+    # the mask decoder's upsampler + hypernetwork product as the single fused bf16 kernel (what the reference computes under
+    # --precision bf16), training and inference; training differentiates through it with one recomputing backward kernel
+    # (autograd_ops.FusedUpsampleMaskFn).  False = six fp32 launches forward, fourteen backward (the strict-parity tail: 2e-4 / 2e-3
+    # against the oracle on the same trunk outputs, where the fused form holds 2e-3 / 3e-2).  Needs a 16-multiple token grid.
+    fused_bf16_upsampler: bool = True
 
     @property
     def head_dim(self):

@@ -343,6 +343,12 @@ class MaskDecoder(nn.Module):
             _, masks = ops.mask_upsample_fused(ops.cast_to_bf16(src.contiguous()).view(n, g * g, C), w1p, b1, lw, lb, w2p, b2, g, g,
                                                hyper=hyper0.contiguous(), want_up=False, eps=eps)
             return masks, self.iou_prediction_head(iou_tok)[:, 0]
+        if self.fused_bf16_upsampler and g % 16 == 0:
+            # training: the same kernel, differentiated by one recomputing backward kernel (A.FusedUpsampleMaskFn)
+            ct1, ln, ct2 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
+            hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)
+            masks = A.FusedUpsampleMaskFn.apply(src, ct1.weight, ct1.bias, ln.weight, ln.bias, ct2.weight, ct2.bias, hyper0, g, float(ln.eps))
+            return masks, self.iou_prediction_head(iou_tok)[:, 0]
         up = A.ConvT2x2Fn.apply(src.view(n, g, g, C), self.output_upscaling[0].weight, self.output_upscaling[0].bias)
         ln = self.output_upscaling[1]
         up = A.GeluFn.apply(A.layernorm(up, ln.weight, ln.bias, ln.eps))

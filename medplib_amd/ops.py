@@ -869,6 +869,24 @@ def mask_upsample_fused(src, w1p, b1, ln_w, ln_b, w2p, b2, h, w, hyper=None, wan
     return up, mask
 
 
+def mask_upsample_fused_bwd(src, w1p, b1, ln_w, ln_b, w2p, b2, hyper, dmask, h, w, eps=1e-6):
+    """Backward of mask_upsample_fused(..., hyper=...) -> (dx2 [2,B,h*w,256], dy1 [B*h*w,256], a1 [B*h*w*4,64], dy2 [B*h*w*4,128],
+    part [B*h*w/8,256]); see mp_mask_upsample_fused_bwd_bf16 for what the caller finishes (two `tn` GEMMs + column sums)."""
+    _chk(src, torch.bfloat16, "upsample_bwd.src"); _chk(dmask, torch.float32, "upsample_bwd.dmask")
+    assert src.is_contiguous() and dmask.is_contiguous() and hyper.is_contiguous() and w % 16 == 0
+    B, T = src.shape[0], h * w
+    dev = src.device
+    w1t, w2t = w1p.t().contiguous(), w2p.t().contiguous()
+    dx2 = torch.empty((2, B, T, 256), dtype=torch.float32, device=dev)
+    dy1 = torch.empty((B * T, 256), dtype=torch.float32, device=dev)
+    a1 = torch.empty((B * T * 4, 64), dtype=torch.float32, device=dev)
+    dy2 = torch.empty((B * T * 4, 128), dtype=torch.float32, device=dev)
+    part = torch.empty((B * T // 8, 256), dtype=torch.float32, device=dev)
+    lib().call("mp_mask_upsample_fused_bwd_bf16", _p(src), _p(w1p), _p(b1), _p(ln_w), _p(ln_b), _p(w2p), _p(b2), _p(hyper), _p(w1t), _p(w2t),
+               _p(dmask), _p(dx2), _p(dy1), _p(a1), _p(dy2), _p(part), B, h, w, float(eps), _stream())
+    return dx2, dy1, a1, dy2, part
+
+
 def py_slice_window(full, start, length):
     """Resolve masks[..., start:start+length] exactly like Python slicing does (negative starts wrap, ends clamp) —
     this is the 'crop' of postprocess_masks (model/MedPLIB.py:689-699)."""

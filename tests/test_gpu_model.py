@@ -268,7 +268,9 @@ def test_stream_ordered_losses_and_towers_run_ahead(dev):
 
 @pytest.mark.parametrize("moe,ragged", [(True, True), (False, False)])
 def test_model_forward_losses_and_grads(dev, moe, ragged):
-    cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2, iou_loss_weight=0.7)
+    # the strict-parity tail (fp32 upsampler): gradients at 2e-3 against the oracle; the default fused bf16 upsampler has its own golden
+    # test at bf16 bounds (test_lisa_golden_training_through_the_fused_bf16_upsampler)
+    cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2, iou_loss_weight=0.7, fused_bf16_upsampler=False)
     W = OM.init_hf_weights(cfg)
     m = _model(cfg, dev, W).train()
     m.capture_intermediates = True
@@ -776,11 +778,10 @@ def test_validate_batch_metrics(dev):
 
 
 def test_inference_with_fused_bf16_upsampler(dev):
-    """config.fused_bf16_upsampler: inference masks through the single fused bf16 upsampler kernel vs the fp32 tail on the same
-    model: logits agree to bf16 noise, the thresholded masks' Dice agrees within 1e-3 (the BASELINE target), training is untouched
-    (the fp32 autograd path is used whenever gradients are enabled)."""
+    """config.fused_bf16_upsampler (the default) against the fp32 tail (False) on the same model: inference logits agree to bf16 noise,
+    the thresholded masks' Dice agrees within 1e-3 (the BASELINE target); a training step through the fused form has finite gradients."""
     from medplib_amd import ops
-    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2)
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, fused_bf16_upsampler=False)
     W = OM.init_hf_weights(cfg)
     batch = OM.make_batch(cfg, 3)
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -800,7 +801,7 @@ def test_inference_with_fused_bf16_upsampler(dev):
         da, db = dice(ca[0].tolist()), dice(cb[0].tolist())
         print(f"dice fp32 {da:.5f} fused-bf16 {db:.5f}")
         assert abs(da - db) < 1e-3
-    # training path of the bf16-flagged model still differentiates through the fp32 tail
+    # training of the bf16-flagged model differentiates through the same kernel (test_lisa_golden_training_through_the_fused_bf16_upsampler)
     out = mbf.train()(**gb)
     out["loss"].backward()
     assert all(torch.isfinite(p.grad).all() for p in mbf.trainable_parameters() if p.grad is not None)
@@ -1481,8 +1482,9 @@ def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
     directly at 5 % (a ReLU unit of text_hidden_fcs within bf16 noise of zero toggles rows of dW) and at 2e-3 against the oracle
     fed this path's own trunk outputs — the oracle itself equals the golden to 1e-5 (tests/test_oracle_golden.py)."""
     from oracle import make_golden as MG
+    import dataclasses
     g = np.load(os.path.join(golden_dir, "lisa_forward_reference.npz"))
-    cfg = MG.lisa_tiny_cfg()
+    cfg = dataclasses.replace(MG.lisa_tiny_cfg(), fused_bf16_upsampler=False)     # the strict fp32 tail; the fused default: next test
     W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
     b = MG.lisa_cases(cfg)[case]
     m = _model(cfg, dev, W).train()
@@ -1542,6 +1544,52 @@ def test_model_forward_vs_executed_reference_lisa_golden(dev, golden_dir, case):
         assert tuple(pmask.shape[-2:]) == tuple(b["masks_list"][i].shape)
         _check_mask_cuts(f"{case} mask[{i}] vs executed reference", pmask[0], rp, b["masks_list"][i], tol=TINY_MASK_LOGIT_TOL)
     assert off == ref_pm.size
+
+
+@pytest.mark.parametrize("case", ["std", "ragged", "multimask"])
+def test_lisa_golden_training_through_the_fused_bf16_upsampler(dev, golden_dir, case):
+    """config.fused_bf16_upsampler in TRAINING: the mask decoder's upsampler + hypernetwork product run as the single fused bf16 kernel
+    and its recomputing backward (A.FusedUpsampleMaskFn) instead of six fp32 launches forward and fourteen backward.  Against the
+    EXECUTED REFERENCE (tests/golden/lisa_forward_reference.npz): the ten losses hold the same 2e-3 as the fp32 tail; the trainable
+    tail's gradient norms within 5 %; and against the oracle fed this path's own trunk outputs the gradients agree to bf16 operand
+    rounding (3e-2 of each tensor's scale; the fp32 tail holds 2e-3 there) — the arithmetic the reference itself trains in under
+    `--precision bf16`."""
+    from oracle import make_golden as MG
+    import dataclasses
+    g = np.load(os.path.join(golden_dir, "lisa_forward_reference.npz"))
+    cfg = dataclasses.replace(MG.lisa_tiny_cfg(), fused_bf16_upsampler=True)
+    W = OM.init_hf_weights(cfg, seed=int(g["weight_seed"]))
+    b = MG.lisa_cases(cfg)[case]
+    m = _model(cfg, dev, W).train()
+    m.capture_intermediates = True
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    gb["masks_list"] = [x.to(dev) for x in b["masks_list"]]
+    out = m(**gb)
+    ref_losses = dict(zip(O.LOSS_KEYS, g[f"{case}_losses"]))
+    for k in O.LOSS_KEYS:
+        _stat(f"{case} fused-upsampler loss[{k}] vs executed reference", out[k], torch.tensor(ref_losses[k]), atol=2e-3)
+    out["loss"].backward()
+    named = dict(m.named_parameters())
+    train_keys = [str(k) for k in g["tail_keys"]]
+    ref_stats = dict(zip([str(k) for k in g["grad_stat_keys"]], g[f"{case}_grad_stats"]))
+    worst = 0.0
+    for k in train_keys:
+        gr = named[k].grad
+        if gr is None or ref_stats[k][1] < 1e-3:
+            continue
+        rel = abs(float(gr.double().norm()) - ref_stats[k][1]) / ref_stats[k][1]
+        worst = max(worst, rel)
+        assert rel < 5e-2, (k, float(gr.double().norm()), ref_stats[k][1])
+    print(f"{case}: fused-upsampler training, worst tail gradient-norm deviation from the executed reference {worst:.3e}")
+    Wr2 = {k: (v.detach().clone().requires_grad_() if k in train_keys else v) for k, v in W.items()}
+    cap = m.captured
+    ov = {"hidden": cap["last_hidden"].float().cpu(), "ce": cap["ce"].cpu()[0],
+          "image_emb": cap["image_tokens"].cpu().view(-1, 16, 16, 256).permute(0, 3, 1, 2).contiguous()}
+    ref2 = OM.model_forward(b, Wr2, cfg, training=True, override=ov)
+    ref2["loss"].backward()
+    for k in O.LOSS_KEYS:
+        _stat(f"{case} fused-upsampler tail-injected loss[{k}]", out[k], ref2[k], atol=2e-3)
+    _check_grads({k: named[k] for k in train_keys}, {k: Wr2[k].grad for k in train_keys}, rtol=3e-2, tag=f"{case} fused upsampler (same trunk outputs)")
 
 
 @pytest.mark.parametrize("moe", [True, False])
