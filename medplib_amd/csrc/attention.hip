@@ -277,7 +277,34 @@ __device__ __forceinline__ int v_key(int row) {
 // "DMA wait" of the round-2 ablation is not a prefetch-depth problem: what a deeper ring buys is less than what twice the barriers and
 // online-softmax bookkeeping cost.  Kept as the A/B switch that produced the numbers; all results are identical to KT = 64's up to the
 // online softmax's rescale points (tests/test_gpu_trunk_kernels.py passes with either).
-template <int D, bool GENERAL, int KT>
+// Round 3 (TUNED): the kernel is VALU-issue bound (~800 non-MFMA instructions per 64-key tile and wave against 64 MFMAs; ISA census in
+// DESIGN section 10), so the tuned form removes instructions, not latency:
+//   * row max by v_max3_f32 directly (fmaxf canonicalises both operands first on this target: 3 instructions per value instead of 1/2);
+//   * the cross-row (fq) max by v_permlane16_swap / v_permlane32_swap + v_max instead of two ds_bpermute round trips through the LDS pipe;
+//   * the accumulator rescale unconditional (the wave-uniform skip made the compiler copy all 64 accumulator registers around the branch:
+//     32 v_mov_b64 per tile whether or not the branch was taken — as many issue slots as the 32 v_pk_mul it saved);
+//   * causal self-attention (Sq == Sk): the key bound kj < Sk is implied by kj <= qi, one compare per value on the diagonal tiles.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+typedef __attribute__((ext_vector_type(2))) unsigned int attn_u32x2;
+__device__ __forceinline__ float max_over_rows(float v) {           // all-reduce over the four 16-lane rows (same fr); all 64 lanes must execute
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const attn_u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = vmax2(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  const unsigned w = __builtin_bit_cast(unsigned, m);
+  const attn_u32x2 q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return vmax2(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+}
+
+template <int D, bool GENERAL, int KT, bool TUNED = true>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   if (a.sk_dev) a.Sk = min(a.Sk, a.sk_dev[0]);
   constexpr int CH = D / 8, NF = D / 16, KS = D / 32;
@@ -325,10 +352,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 
   // ---- DMA: instruction j of an operand fills LDS bytes [j*1024, +1024) = rows j*RPI .. +RPI-1; wave w issues j = w*IPW + i
   const int dma_row = lane / CH, dma_c = lane % CH;
+  // TUNED: the per-lane source addresses of a WHOLE tile differ from tile 0's by a wave-uniform offset, so they are kept as pointers and
+  // advanced by one scalar product per tile (2 VALU per DMA instruction instead of ~6: a 64-bit multiply-add per lane); only the last,
+  // partial tile clamps rows and takes the general form
+  const bf16_t* kbase[IPW];
+  const bf16_t* vbase[IPW];
+  if constexpr (TUNED) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int row = (wave * IPW + i) * RPI + dma_row;
+      kbase[i] = Kb + (int64_t)row * a.k_ss + ((dma_c ^ (row & (CH - 1))) << 3);
+      vbase[i] = Vb + (int64_t)row * a.v_ss + ((dma_c ^ (v_key<D>(row) << 1)) << 3);
+    }
+  }
   auto issue = [&](int t, int stage) {
     const int k0 = t * KT;
     char* sK = smem + stage * 2 * TILE_BYTES;
     char* sV = sK + TILE_BYTES;
+    if (TUNED && k0 + KT <= a.Sk) {
+      const int64_t ko = (int64_t)k0 * a.k_ss, vo = (int64_t)k0 * a.v_ss;          // wave-uniform
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int j = wave * IPW + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase[i] + ko),
+                                         (__attribute__((address_space(3))) void*)(sK + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase[i] + vo),
+                                         (__attribute__((address_space(3))) void*)(sV + j * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int j = wave * IPW + i;
@@ -371,9 +423,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   const float c2 = a.scale * 1.44269504088896340736f;          // exponent of 2 per unit of raw score (softmax in the log2 domain)
   const float inv_scale = 1.f / a.scale;                       // the rel-pos bias is added to the UNSCALED score, so it is pre-divided
 
-  for (int t = 0; t < n_tiles; ++t) {
-    const int k0 = t * KT;
-    // tile t has landed when at most the DMAs of the tiles issued after it are outstanding (2 * IPW instructions per tile and wave)
+  // tile t has landed when at most the DMAs of the tiles issued after it are outstanding (2 * IPW instructions per tile and wave)
+  auto land_and_refill = [&](int t) {
     {
       const int later = min(NST - 2, n_tiles - 1 - t);      // wave-uniform
       if (NST > 2 && later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * IPW) : "memory");
@@ -382,7 +433,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     }
     __syncthreads();                       // tile t is visible to every wave; nobody still reads the stage tile t + NST - 1 goes to
     if (t + NST - 1 < n_tiles) issue(t + NST - 1, (t + NST - 1) % NST);
-    if (a.causal && k0 > qw0 + 31) continue;            // wave-uniform: every key of this tile is in the future of this wave's queries
+  };
+  // Causal: the tiles whose every key is in the future of this wave's 32 queries (k0 > qw0 + 31) need only this wave's share of the
+  // workgroup's DMA / barrier protocol.  They are the LAST tiles, so they get their own trailing loop: a `continue` inside the main loop
+  // made the 64 accumulator registers a two-way merge at the loop header, which the register allocator resolved with 69 v_mov per tile
+  // on the back edge (ISA census, round 3).
+  const int my_tiles = (TUNED && a.causal) ? min(n_tiles, (qw0 + 31) / KT + 1) : n_tiles;
+  for (int t = 0; t < my_tiles; ++t) {
+    const int k0 = t * KT;
+    land_and_refill(t);
+    if (!TUNED && a.causal && k0 > qw0 + 31) continue;            // wave-uniform: every key of this tile is in the future of this wave's queries
     const char* sK = smem + (t % NST) * 2 * TILE_BYTES;
     const char* sV = sK + TILE_BYTES;
 
@@ -410,8 +470,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       float mx = -INFINITY;
       if (!masked) {
         // interior tile: the max is taken on the raw scores (c2 > 0 commutes with max) and the scaling rides in the exp's fma
+        if constexpr (TUNED) {
 #pragma unroll
-        for (int kf = 0; kf < NKF; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
+          for (int kf = 0; kf < NKF; ++kf) mx = vmax3(vmax3(mx, s[kf][j][0], s[kf][j][1]), s[kf][j][2], s[kf][j][3]);
+        } else {
+#pragma unroll
+          for (int kf = 0; kf < NKF; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
+        }
+        mx *= c2;
+      } else if (TUNED && !GENERAL && a.causal && a.Sq <= a.Sk) {
+        // causal self-attention: kj <= qi < Sq <= Sk, so the key bound is implied (rows qi >= Sq are never stored)
+        const int dl = fq * 4 - fr, cb = qw0 - k0 + j * 16;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = (dl <= cb - kf * 16 - r) ? s[kf][j][r] : -INFINITY;
+            s[kf][j][r] = v;
+          }
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) mx = vmax3(vmax3(mx, s[kf][j][0], s[kf][j][1]), s[kf][j][2], s[kf][j][3]);
         mx *= c2;
       } else if (!GENERAL) {
         // key kj = k0 + kf*16 + fq*4 + r, query qi = qw0 + j*16 + fr:
@@ -450,8 +528,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
           }
         mx *= c2;                                      // -inf stays -inf
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if constexpr (TUNED) mx = max_over_rows(mx);
+      else {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      }
       const float m_new = fmaxf(m_run[j], mx);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_safe);
@@ -470,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
         }
       l_part[j] = l_part[j] * alpha + (rs2.x + rs2.y);
       // rescale the accumulators only when some lane's running max moved (wave-uniform test)
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+      if (TUNED || __builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) o[n][j] *= alpha;
       }
@@ -500,6 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       }
     }
   }
+  for (int t = my_tiles; t < n_tiles; ++t) land_and_refill(t);
 
   // ---- normalise and store: o[n][j][r] = O[query qw0 + j*16 + fr][d = n*16 + fq*4 + r] ----
   bf16_t* Ob = a.O + b * a.o_sb + (int64_t)h * D;
@@ -527,8 +609,10 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, true, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<D, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
@@ -541,10 +625,14 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   dim3 grid(a.B * a.H, (a.Sq + 127) / 128);
   static int plain = -1;
   if (plain < 0) { const char* e = getenv("MP_ATTN_PLAIN"); plain = (e && atoi(e) == 0) ? 0 : 1; }      // 0: always the general kernel (A/B)
+  static int tuned = -1;
+  if (tuned < 0) { const char* e = getenv("MP_ATTN_TUNED"); tuned = (e && atoi(e) == 0) ? 0 : 1; }       // 0: the round-2 instruction stream (A/B)
   if (plain && !a.key_valid && !a.rel_h) {
     if (kt32) hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 32>), grid, dim3(256), LDS, stream, ac);
-    else hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 64>), grid, dim3(256), LDS, stream, ac);
-  } else hipLaunchKernelGGL((attn_fwd2_kernel<D, true, 64>), grid, dim3(256), LDS, stream, ac);
+    else if (tuned) hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 64, true>), grid, dim3(256), LDS, stream, ac);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 64, false>), grid, dim3(256), LDS, stream, ac);
+  } else if (tuned) hipLaunchKernelGGL((attn_fwd2_kernel<D, true, 64, true>), grid, dim3(256), LDS, stream, ac);
+  else hipLaunchKernelGGL((attn_fwd2_kernel<D, true, 64, false>), grid, dim3(256), LDS, stream, ac);
   return mp_check_launch("mp_attention_fwd_bf16(v2)");
 }
 
