@@ -283,7 +283,15 @@ __device__ __forceinline__ int v_key(int row) {
 //   * the cross-row (fq) max by v_permlane16_swap / v_permlane32_swap + v_max instead of two ds_bpermute round trips through the LDS pipe;
 //   * the accumulator rescale unconditional (the wave-uniform skip made the compiler copy all 64 accumulator registers around the branch:
 //     32 v_mov_b64 per tile whether or not the branch was taken — as many issue slots as the 32 v_pk_mul it saved);
-//   * causal self-attention (Sq == Sk): the key bound kj < Sk is implied by kj <= qi, one compare per value on the diagonal tiles.
+//   * causal self-attention (Sq == Sk): the key bound kj < Sk is implied by kj <= qi, one compare per value on the diagonal tiles;
+//   * the tiles a wave skips (all keys in its queries' future) run in a trailing loop instead of a `continue`: the accumulators stopped
+//     being a two-way merge at the loop header, which had cost 69 v_mov per tile on the back edge;
+//   * DMA source pointers advanced by a scalar offset per whole tile; at D = 128 one V^T address register per d-block.
+// Llama causal S = 639: 62.6 -> 53.4 us (501 TF/s of the causal half's flops), S = 1316 110 -> 91 us; CLIP 33.4 -> 29.1 us.
+// What did NOT help (measured, removed; commit 44be988 holds the code): pipelining the loop INSIDE a wave — QK^T of tile t+1 in one basic
+// block with the exponentials of tile t, interleaved by sched_group_barrier (69.0 us, and 37.0 on CLIP where no register pressure
+// confounds it), and the in-tile variant (second half of the exponentials behind the first PV MFMAs: 55.2 vs 54.5).  Per 64-key tile
+// the time matches MFMA + VALU issue of the two resident waves added, however they are arranged: fewer instructions is what pays.
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -560,6 +568,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     // ---- O^T += V^T P^T: A = V^T fragment (d rows) by the hardware transpose read, B = P^T from registers ----
     // The d-blocks are walked in Gray-code order so that the swizzled address of block n, vrow_base + ((n ^ key) << 5), follows from
     // the previous one by ONE add of a per-lane delta (the bit that flips): one running address register instead of NF of them.
+    if constexpr (TUNED && D == 128) {
+      // one address register per d-block (block n of this lane's key row: (n ^ key) << 5), advanced to this stage by ONE add each; the
+      // key pair and the +16-row half ride in the instructions' offset fields — 8 VALU per tile instead of the ~36 of the running
+      // Gray-code address below (which saved 7 registers when the kernel sat at the 256-register limit; it no longer does).  D = 128 only:
+      // at D = 64 (CLIP, SAM) the block-major order measured 3 us SLOWER (32.1 vs 29.1 us, CLIP shape)
+      const int stage_off = (t % NST) * 2 * TILE_BYTES + TILE_BYTES;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const char* p0 = smem + stage_off + (v_a0 ^ (n << 5));
+#pragma unroll
+        for (int kp = 0; kp < NKP; ++kp) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + kp * 32 * (D * 2)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + kp * 32 * (D * 2) + 16 * (D * 2)));
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) o[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[kp][j], o[n][j], 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll
     for (int kp = 0; kp < NKP; ++kp) {
       int va = v_a0 + kp * 32 * (D * 2);
@@ -604,251 +632,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
   }
 }
 
-// =====================================================================================================================
-// v3 (round 3): v2's transposed formulation with the loop SOFTWARE-PIPELINED inside each wave — the QK^T MFMAs of tile t+1 are issued
-// in the same basic block as the exponentials of tile t, interleaved by sched_group_barrier (one K-fragment read, two MFMAs, a handful
-// of VALU / transcendental instructions, sixteen times), so the matrix pipe works under the VALU phase of the SAME wave instead of only
-// under the other resident wave's.  K and V rings are skewed by one tile: iteration t holds K(t+1) and V(t), and refills K(t+2), V(t+1);
-// still one barrier per tile and the same 64 KiB of LDS (two workgroups per CU).  Plain form only (no key padding, no rel-pos bias: the
-// Llama and CLIP attentions); the general form stays on v2.  MP_ATTN_PIPE=0 selects v2 (A/B).
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs a) {
-  constexpr int KT = 64;
-  constexpr int PIPE_VALU = 6;          // VALU instructions per MFMA pair in the fused block (~100 in the block / 16 pairs)
-  constexpr int CH = D / 8, NF = D / 16, KS = D / 32;
-  constexpr int NKF = KT / 16, NKP = KT / 32;
-  constexpr int TILE_BYTES = KT * D * 2;
-  constexpr int RPI = 1024 / (D * 2);
-  constexpr int IPW = (TILE_BYTES / 1024) / 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];        // K ring: stages 0, 1; V ring: stages 0, 1
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fq = lane >> 4;
-  int bh, qrank;
-  {
-    const int BH = gridDim.x, nqb = gridDim.y;
-    const int L = blockIdx.y * BH + blockIdx.x;
-    const int CHK = a.bh_chunk > 0 ? a.bh_chunk : BH;
-    const int nch = (BH + CHK - 1) / CHK;
-    const int chunk = min(L / (CHK * nqb), nch - 1);
-    const int cs = min(CHK, BH - chunk * CHK);
-    const int rem = L - chunk * CHK * nqb;
-    qrank = rem / cs;
-    bh = chunk * CHK + rem % cs;
-  }
-  const int b = bh / a.H, h = bh % a.H;
-  const int q0 = (a.causal ? (int)(gridDim.y - 1 - qrank) : qrank) * 128;
-  const int qw0 = q0 + wave * 32;
-  const bf16_t* Qb = a.Q + b * a.q_sb + (int64_t)h * D;
-  const bf16_t* Kb = a.K + b * a.k_sb + (int64_t)h * D;
-  const bf16_t* Vb = a.V + b * a.v_sb + (int64_t)h * D;
-
-  int n_tiles = (a.Sk + KT - 1) / KT;
-  if (a.causal) n_tiles = min(n_tiles, (min(q0 + 128, a.Sq) + KT - 1) / KT);
-  const int my_tiles = a.causal ? min(n_tiles, (qw0 + 31) / KT + 1) : n_tiles;
-
-  const int dma_row = lane / CH, dma_c = lane % CH;
-  auto issue_k = [&](int t) {
-    const int k0 = t * KT;
-    char* sK = smem + (t & 1) * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-      const int j = wave * IPW + i;
-      const int row = j * RPI + dma_row;
-      const int kr = min(k0 + row, a.Sk - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)kr * a.k_ss + ((dma_c ^ (row & (CH - 1))) << 3)),
-                                       (__attribute__((address_space(3))) void*)(sK + j * 1024), 16, 0, 0);
-    }
-  };
-  auto issue_v = [&](int t) {
-    const int k0 = t * KT;
-    char* sV = smem + (2 + (t & 1)) * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-      const int j = wave * IPW + i;
-      const int row = j * RPI + dma_row;
-      const int kr = min(k0 + row, a.Sk - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)kr * a.v_ss + ((dma_c ^ (v_key<D>(row) << 1)) << 3)),
-                                       (__attribute__((address_space(3))) void*)(sV + j * 1024), 16, 0, 0);
-    }
-  };
-  bf16x8 qf[2][KS];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int qr = min(qw0 + j * 16 + fr, a.Sq - 1);
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) qf[j][kk] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * a.q_ss + kk * 32 + fq * 8);
-  }
-  issue_k(0);
-  if (n_tiles > 1) issue_k(1);
-  issue_v(0);
-
-  f32x4 o[NF][2];
-#pragma unroll
-  for (int n = 0; n < NF; ++n)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) o[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int VBITS = (D == 128) ? 3 : 2;
-  const int v_row = fq * 4 + (fr >> 2);
-  const int v_k = v_key<D>(v_row);
-  const int v_a0 = v_row * (D * 2) + (v_k << 5) + (fr & 3) * 8;
-  int v_dlt[VBITS];
-#pragma unroll
-  for (int bit = 0; bit < VBITS; ++bit) v_dlt[bit] = ((v_k >> bit) & 1) ? -(32 << bit) : (32 << bit);
-  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
-  const float c2 = a.scale * 1.44269504088896340736f;
-
-  // S^T of tile t into sc: NKF key fragments x 2 query fragments
-  auto qk = [&](int t, f32x4 (&sc)[NKF][2]) {
-    const char* sK = smem + (t & 1) * TILE_BYTES;
-#pragma unroll
-    for (int kf = 0; kf < NKF; ++kf)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) sc[kf][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) {
-        const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + k_off<D>(kf * 16 + fr, kk * 4 + fq));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) sc[kf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[j][kk], sc[kf][j], 0, 0, 0);
-      }
-  };
-  // masks (diagonal / last partial tile) + running max of tile t: returns, per query fragment, the rescale factor and the safe max
-  auto mask_max = [&](int t, f32x4 (&sc)[NKF][2], float (&alpha)[2], float (&m_safe)[2]) {
-    const int k0 = t * KT;
-    const bool masked = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > qw0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float mx = -INFINITY;
-      if (masked) {
-        const int fb = fq * 4, bb = a.Sk - 1 - k0;
-        const int dl = a.causal ? fq * 4 - fr : 0, cb = a.causal ? qw0 - k0 + j * 16 : 1 << 20;
-        if (a.causal && a.Sq <= a.Sk) {
-#pragma unroll
-          for (int kf = 0; kf < NKF; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kf][j][r] = (dl <= cb - kf * 16 - r) ? sc[kf][j][r] : -INFINITY;
-        } else {
-#pragma unroll
-          for (int kf = 0; kf < NKF; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kf][j][r] = ((fb <= bb - kf * 16 - r) && (dl <= cb - kf * 16 - r)) ? sc[kf][j][r] : -INFINITY;
-        }
-      }
-#pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) mx = vmax3(vmax3(mx, sc[kf][j][0], sc[kf][j][1]), sc[kf][j][2], sc[kf][j][3]);
-      mx = max_over_rows(mx * c2);
-      const float m_new = vmax2(m_run[j], mx);
-      m_safe[j] = (m_new == -INFINITY) ? 0.f : m_new;
-      alpha[j] = __builtin_amdgcn_exp2f(m_run[j] - m_safe[j]);
-      m_run[j] = m_new;
-    }
-  };
-  // p = 2^(s c2 - m) -> bf16 B operands of the PV product; row-sum partials; accumulator rescale
-  auto exps = [&](f32x4 (&sc)[NKF][2], const float (&alpha)[2], const float (&m_safe)[2], bf16x8 (&pb)[NKP][2]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x2 rs2 = {0.f, 0.f};
-#pragma unroll
-      for (int kf = 0; kf < NKF; ++kf)
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-          const f32x2 e = __builtin_elementwise_fma(f32x2{sc[kf][j][2 * hp], sc[kf][j][2 * hp + 1]}, f32x2{c2, c2}, f32x2{-m_safe[j], -m_safe[j]});
-          const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-          rs2 += p;
-          pb[kf >> 1][j][(kf & 1) * 4 + 2 * hp] = (bf16_t)p.x;
-          pb[kf >> 1][j][(kf & 1) * 4 + 2 * hp + 1] = (bf16_t)p.y;
-        }
-      l_part[j] = l_part[j] * alpha[j] + (rs2.x + rs2.y);
-#pragma unroll
-      for (int n = 0; n < NF; ++n) o[n][j] *= alpha[j];
-    }
-  };
-  auto pv = [&](int t, const bf16x8 (&pb)[NKP][2]) {
-    const char* sV = smem + (2 + (t & 1)) * TILE_BYTES;
-#pragma unroll
-    for (int kp = 0; kp < NKP; ++kp) {
-      int va = v_a0 + kp * 32 * (D * 2);
-#pragma unroll
-      for (int g = 0; g < NF; ++g) {
-        const int n = g ^ (g >> 1);
-        if (g > 0) {
-          const int bit = __builtin_ctz(g);
-          va += ((n >> bit) & 1) ? v_dlt[bit] : -v_dlt[bit];
-          asm volatile("" : "+v"(va));
-        }
-        const char* p0 = sV + va;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * (D * 2)));
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) o[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[kp][j], o[n][j], 0, 0, 0);
-      }
-    }
-  };
-  // iteration t of the workgroup's protocol: K(t+1) and V(t) have landed and are visible; every wave is done with K(t) and V(t-1)
-  auto land_and_refill = [&](int t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 2 < n_tiles) issue_k(t + 2);
-    if (t + 1 < n_tiles) issue_v(t + 1);
-  };
-
-  f32x4 sA[NKF][2], sB[NKF][2];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                   // K(0) (and K(1), V(0)) visible
-  qk(0, sA);
-  auto step = [&](int t, f32x4 (&cur)[NKF][2], f32x4 (&nxt)[NKF][2]) {
-    land_and_refill(t);
-    float alpha[2], m_safe[2];
-    bf16x8 pb[NKP][2];
-    mask_max(t, cur, alpha, m_safe);
-    if (t + 1 < my_tiles) {
-      // ONE basic block: the next tile's QK^T on the matrix pipe under this tile's exponentials on the VALU
-      qk(t + 1, nxt);
-      exps(cur, alpha, m_safe, pb);
-      // two K-fragment reads ahead, then sixteen times: the two MFMAs of the oldest fragment, the next read, a slice of the softmax's VALU
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int i = 0; i < NKF * KS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        if (i + 2 < NKF * KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, PIPE_VALU, 0);
-      }
-    } else {
-      exps(cur, alpha, m_safe, pb);
-    }
-    pv(t, pb);
-  };
-  for (int t = 0; t < my_tiles; t += 2) {
-    step(t, sA, sB);
-    if (t + 1 < my_tiles) step(t + 1, sB, sA);
-  }
-  for (int t = my_tiles; t < n_tiles; ++t) land_and_refill(t);
-
-  bf16_t* Ob = a.O + b * a.o_sb + (int64_t)h * D;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float l = l_part[j];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const int qi = qw0 + j * 16 + fr;
-    if (qi >= a.Sq) continue;
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    if (a.lse2 && fq == 0) a.lse2[(int64_t)bh * a.Sq + qi] = l > 0.f ? m_run[j] + __builtin_amdgcn_logf(l) : INFINITY;
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-      bf16x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[n][j][r] * inv);
-      *reinterpret_cast<bf16x4*>(Ob + (int64_t)qi * a.o_ss + n * 16 + fq * 4) = v;
-    }
-  }
-}
-
 template <int D>
 int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int LDS = 4 * 64 * D * 2;
@@ -872,14 +655,6 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   if (plain < 0) { const char* e = getenv("MP_ATTN_PLAIN"); plain = (e && atoi(e) == 0) ? 0 : 1; }      // 0: always the general kernel (A/B)
   static int tuned = -1;
   if (tuned < 0) { const char* e = getenv("MP_ATTN_TUNED"); tuned = (e && atoi(e) == 0) ? 0 : 1; }       // 0: the round-2 instruction stream (A/B)
-  static int pipe = -1;
-  if (pipe < 0) { const char* e = getenv("MP_ATTN_PIPE"); pipe = (e && atoi(e) == 0) ? 0 : 1; }          // 0: the v2 loop (A/B)
-  if (plain && pipe && !kt32 && !a.key_valid && !a.rel_h && !a.sk_dev) {
-    static bool attr3 = false;
-    if (!attr3) { (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr3 = true; }
-    hipLaunchKernelGGL((attn_fwd3_kernel<D>), grid, dim3(256), LDS, stream, ac);
-    return mp_check_launch("mp_attention_fwd_bf16(v3)");
-  }
   if (plain && !a.key_valid && !a.rel_h) {
     if (kt32) hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 32>), grid, dim3(256), LDS, stream, ac);
     else if (tuned) hipLaunchKernelGGL((attn_fwd2_kernel<D, false, 64, true>), grid, dim3(256), LDS, stream, ac);
