@@ -279,8 +279,11 @@ __device__ __forceinline__ int v_key(int row) {
 // online softmax's rescale points (tests/test_gpu_trunk_kernels.py passes with either).
 // Round 3 (TUNED): the kernel is VALU-issue bound (~800 non-MFMA instructions per 64-key tile and wave against 64 MFMAs; ISA census in
 // DESIGN section 10), so the tuned form removes instructions, not latency:
-//   * row max by v_max3_f32 directly (fmaxf canonicalises both operands first on this target: 3 instructions per value instead of 1/2);
-//   * the cross-row (fq) max by v_permlane16_swap / v_permlane32_swap + v_max instead of two ds_bpermute round trips through the LDS pipe;
+//   * the scores are multiplied by scale*log2(e) once, right after QK^T: fmaxf on the result of a multiply needs no canonicalisation
+//     (on raw MFMA outputs it costs a v_max x,x,x per operand: 3 instructions per value instead of 1/2), the compiler folds the chain
+//     into v_max3_f32, and the exponent is a subtraction.  (An inline-asm v_max3 did the same with 16 instructions fewer, but asm reads
+//     of MFMA results and asm writes feeding v_permlane swaps are outside the compiler's hazard bookkeeping — see max_over_rows);
+//   * the cross-row (fq) max by v_permlane16_swap / v_permlane32_swap + v_max (max_over_rows) instead of two ds_bpermute round trips through LDS;
 //   * the accumulator rescale unconditional (the wave-uniform skip made the compiler copy all 64 accumulator registers around the branch:
 //     32 v_mov_b64 per tile whether or not the branch was taken — as many issue slots as the 32 v_pk_mul it saved);
 //   * causal self-attention (Sq == Sk): the key bound kj < Sk is implied by kj <= qi, one compare per value on the diagonal tiles;
@@ -292,24 +295,29 @@ __device__ __forceinline__ int v_key(int row) {
 // block with the exponentials of tile t, interleaved by sched_group_barrier (69.0 us, and 37.0 on CLIP where no register pressure
 // confounds it), and the in-tile variant (second half of the exponentials behind the first PV MFMAs: 55.2 vs 54.5).  Per 64-key tile
 // the time matches MFMA + VALU issue of the two resident waves added, however they are arranged: fewer instructions is what pays.
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float vmax2(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-typedef __attribute__((ext_vector_type(2))) unsigned int attn_u32x2;
-__device__ __forceinline__ float max_over_rows(float v) {           // all-reduce over the four 16-lane rows (same fr); all 64 lanes must execute
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const attn_u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float m = vmax2(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-  const unsigned w = __builtin_bit_cast(unsigned, m);
-  const attn_u32x2 q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-  return vmax2(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+// All-reduce (max) over the wave's four 16-lane rows (same fr), every lane gets the result; all 64 lanes must execute.  One asm block
+// with its own wait states, for two reasons found the hard way (tests/test_gpu_trunk_kernels.py::test_attention_row_max_spans_all_lane_rows):
+//   * with the builtins, `max(swap(x, x)[0], swap(x, x)[1])` was compiled to swap, copy, swap — the compiler folded the max away (also
+//     with an opaque copy as second operand), leaving a permutation: every lane used ANOTHER row's max.  A smaller-than-true max is
+//     still a valid softmax shift as long as all four rows agree, which two swaps in a row happen to preserve, so every tolerance test
+//     passed; a dominant key in the wrong row overflowed 2^(s - m);
+//   * a VALU write of a swap operand needs two wait states before v_permlane*_swap reads it; the compiler inserts them only for
+//     instructions it emitted itself.
+// v_permlane16_swap: odd rows of vdst <-> even rows of src; v_permlane32_swap: rows 2,3 of vdst <-> rows 0,1 of src.
+__device__ __forceinline__ float max_over_rows(float v) {
+  float t;
+  asm("v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32 %0, %0, %1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32 %0, %0, %1"
+      : "+v"(v), "=&v"(t));
+  return v;
 }
 
 template <int D, bool GENERAL, int KT, bool TUNED = true>
@@ -472,20 +480,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
     // ---- online softmax; s[kf][j][r]: key = k0 + kf*16 + fq*4 + r, query = qw0 + j*16 + fr ----
     const bool masked = (kv != nullptr) || (relh != nullptr) || (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > qw0);
     bf16x8 pb[NKP][2];                       // [key-fragment pair][query fragment]: B operands of the PV MFMAs
+    // TUNED: log2-domain scores from here on.  The multiply sits in the SAME basic block as the fmaxf that reads it (each branch below
+    // starts with it): only then does the compiler know the operand is canonical and drop the v_max x,x,x in front of every max.
+    const float pre = TUNED ? c2 : 1.f;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    const float mx_scale = TUNED ? 1.f : c2;                   // what the row max still has to be multiplied by
+    const float rel_scale = TUNED ? LOG2E : inv_scale;         // the rel-pos bias joins the score in the score's current units
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int qi = qw0 + j * 16 + fr;
       float mx = -INFINITY;
       if (!masked) {
-        // interior tile: the max is taken on the raw scores (c2 > 0 commutes with max) and the scaling rides in the exp's fma
-        if constexpr (TUNED) {
+        // interior tile (non-TUNED: the max is taken on the raw scores — c2 > 0 commutes with max — and the scaling rides in the exp's fma)
 #pragma unroll
-          for (int kf = 0; kf < NKF; ++kf) mx = vmax3(vmax3(mx, s[kf][j][0], s[kf][j][1]), s[kf][j][2], s[kf][j][3]);
-        } else {
-#pragma unroll
-          for (int kf = 0; kf < NKF; ++kf) mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
+        for (int kf = 0; kf < NKF; ++kf) {
+          if constexpr (TUNED) s[kf][j] *= pre;
+          mx = fmaxf(fmaxf(mx, fmaxf(s[kf][j][0], s[kf][j][1])), fmaxf(s[kf][j][2], s[kf][j][3]));
         }
-        mx *= c2;
       } else if (TUNED && !GENERAL && a.causal && a.Sq <= a.Sk) {
         // causal self-attention: kj <= qi < Sq <= Sk, so the key bound is implied (rows qi >= Sq are never stored)
         const int dl = fq * 4 - fr, cb = qw0 - k0 + j * 16;
@@ -493,12 +504,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
         for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = (dl <= cb - kf * 16 - r) ? s[kf][j][r] : -INFINITY;
+            const float v = (dl <= cb - kf * 16 - r) ? s[kf][j][r] * pre : -INFINITY;
             s[kf][j][r] = v;
+            mx = fmaxf(mx, v);
           }
-#pragma unroll
-        for (int kf = 0; kf < NKF; ++kf) mx = vmax3(vmax3(mx, s[kf][j][0], s[kf][j][1]), s[kf][j][2], s[kf][j][3]);
-        mx *= c2;
       } else if (!GENERAL) {
         // key kj = k0 + kf*16 + fq*4 + r, query qi = qw0 + j*16 + fr:
         //   kj < Sk    <=>  fq*4      <= (Sk - 1 - k0) - kf*16 - r
@@ -510,11 +519,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = (fb <= bb - kf * 16 - r) && (dl <= cb - kf * 16 - r);
-            const float v = ok ? s[kf][j][r] : -INFINITY;
+            const float v = ok ? s[kf][j][r] * pre : -INFINITY;
             s[kf][j][r] = v;
             mx = fmaxf(mx, v);
           }
-        mx *= c2;
       } else {
         const int qc = min(qi, a.Sq - 1);
 #pragma unroll
@@ -522,10 +530,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kj = k0 + kf * 16 + fq * 4 + r;
-            float v = s[kf][j][r];
+            float v = s[kf][j][r] * pre;
             if (relh) {
               const int kc = min(kj, a.Sk - 1);
-              v += (relh[(int64_t)qc * a.kh + kc / a.kw] + relw[(int64_t)qc * a.kw + kc % a.kw]) * inv_scale;
+              v += (relh[(int64_t)qc * a.kh + kc / a.kw] + relw[(int64_t)qc * a.kw + kc % a.kw]) * rel_scale;
             }
             bool ok = kj < a.Sk;
             if (a.causal) ok = ok && (kj <= qi);
@@ -534,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
             s[kf][j][r] = v;
             mx = fmaxf(mx, v);
           }
-        mx *= c2;                                      // -inf stays -inf
       }
+      mx *= mx_scale;                                    // -inf stays -inf
       if constexpr (TUNED) mx = max_over_rows(mx);
       else {
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -550,14 +558,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
       for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
-          // p = 2^(s*c2 - m): packed fma, one v_exp_f32 per value; a masked score is -inf -> p = 0
-          const f32x2 e = __builtin_elementwise_fma(f32x2{s[kf][j][2 * hp], s[kf][j][2 * hp + 1]}, f32x2{c2, c2}, f32x2{-m_safe, -m_safe});
+          // p = 2^(s*c2 - m): one v_exp_f32 per value; a masked score is -inf -> p = 0
+          const f32x2 sv = {s[kf][j][2 * hp], s[kf][j][2 * hp + 1]};
+          const f32x2 e = TUNED ? sv - f32x2{m_safe, m_safe} : __builtin_elementwise_fma(sv, f32x2{c2, c2}, f32x2{-m_safe, -m_safe});
           const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
           rs2 += p;
           pb[kf >> 1][j][(kf & 1) * 4 + 2 * hp] = (bf16_t)p.x;
           pb[kf >> 1][j][(kf & 1) * 4 + 2 * hp + 1] = (bf16_t)p.y;
         }
-      l_part[j] = l_part[j] * alpha + (rs2.x + rs2.y);
+      l_part[j] = fmaf(l_part[j], alpha, rs2.x + rs2.y);      // explicit: the contraction must not depend on the instantiation
       // rescale the accumulators only when some lane's running max moved (wave-uniform test)
       if (TUNED || __builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll

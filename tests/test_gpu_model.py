@@ -441,16 +441,23 @@ def test_model_forward_icl_separate_mode(dev):
     batch = OM.make_batch_icl(cfg, 2, n_ctx=2)
     bq = dict(batch)
     bq["images_clip"] = [x.to(torch.bfloat16).float() for x in batch["images_clip"]]; bq["images"] = batch["images"].to(torch.bfloat16).float()
+    coll = []
     with torch.no_grad():
-        ref, inter = OM.model_forward(bq, W, cfg, training=True, return_intermediates=True)
+        ref, inter = OM.model_forward(bq, W, cfg, training=True, return_intermediates=True, collect=coll)
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
     gb["images_clip"] = [x.to(dev) for x in batch["images_clip"]]; gb["mask_images"] = [x.to(dev) for x in batch["mask_images"]]
     out = m(**gb)
     S = inter["embeds"].shape[1]
     assert m.captured["last_hidden"].shape[1] == S == batch["input_ids"].shape[1] + 3 * 7 + 2 * 3
+    # A token whose two gate probabilities tie within bf16 noise may pick the other expert than the fp32 oracle: the loss then moves by
+    # a discrete step (5.7e-3 measured with one flipped token; 2e-4 with none) whichever side of the tie the kernels' last bits fall on.
+    # The tight bound therefore holds when every token agreed in every layer; a flipped token is reported and gets 2e-2.
+    T = S * batch["input_ids"].shape[0]
+    flips = sum(int((r[0].cpu().long()[:T] != e_ref[:T]).sum()) for (e_ref, _, _), r in zip(coll, m.captured["routing"]))
+    print(f"icl: {flips} token-layer expert choices differ from the oracle's (of {T * len(coll)})")
     for k in O.LOSS_KEYS:
-        _stat(f"icl loss[{k}]", out[k], ref[k], atol=5e-3)
+        _stat(f"icl loss[{k}]", out[k], ref[k], atol=5e-3 if flips == 0 else 2e-2)
 
 
 def test_moe_routing_small_token_counts(dev):

@@ -183,6 +183,32 @@ def test_attention(dev, variant, B, S, H, D, causal, ragged):
     _report(f"attention v{variant} S={S} D={D}", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
 
 
+@pytest.mark.parametrize("D,causal,ragged", [(128, True, False), (128, False, False), (64, False, False), (128, True, True)])
+def test_attention_row_max_spans_all_lane_rows(dev, D, causal, ragged):
+    """The running row max of the transposed formulation is an all-reduce over the wave's four 16-lane rows (keys fq*4 .. fq*4+3 of every
+    16-key fragment).  A version that fed an inline-asm v_max into v_permlane32_swap without the two wait states the swap needs read a
+    STALE register: the reference became the max over two of the four rows — still a valid softmax shift, so every tolerance test
+    passed, until a dominant key sits in an excluded row and 2^(s - m) overflows.  Here one key per case dominates by ~100 (log2
+    domain ~147 > 128) in each of the four row positions: the output must be that key's value row, finite."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(D + causal)
+    B, S, H = 1, 200, 2
+    for pos in (1, 6, 9, 14, 64 + 5, 128 + 11):                 # key index mod 16 in rows fq = 0, 1, 2, 3 (and later tiles)
+        qkv = _bf(torch.randn(B, S, 3, H, D, generator=g) * 0.3)
+        big = 3.0 if D == 128 else 4.3                          # q.k * D^-0.5 = 9 * 128 / 11.3 = 102 (D = 64: 18.5 * 64 / 8 = 148)
+        qkv[:, :, 0] = big
+        qkv[:, pos, 1] = big
+        kv = None
+        if ragged:
+            kv = torch.ones(B, S, dtype=torch.bool); kv[:, S - 20:] = False
+        ref = O.attention(qkv[:, :, 0].float(), qkv[:, :, 1].float(), qkv[:, :, 2].float(), causal=causal, key_valid=kv)
+        dq = qkv.to(dev)
+        out = ops.attention(dq[:, :, 0], dq[:, :, 1], dq[:, :, 2], causal=causal, key_valid=None if kv is None else kv.to(torch.uint8).to(dev))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all(), (D, causal, pos)
+        _report(f"attention dominant key at {pos} (D={D}, causal={causal})", out, ref, rtol=3 * BF16_EPS, atol=2e-2)
+
+
 def test_attention_relpos_sam_window(dev):
     """SAM-Med2D windowed attention: 196 tokens (14x14), D=64, decomposed rel-pos bias added unscaled."""
     from medplib_amd import ops
