@@ -438,6 +438,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.GEMM_TIMER = None
+    dp_bucket = eng.bucket_timing_summary(args.steps)        # the timed steps only: the roofline / LoRA steps below must not count
+    eng.disable_bucket_timing()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -563,7 +565,7 @@ def main():
             "roofline": roof, "roofline_timed_region": (roof_timed if timer_u is not None else None),
             # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the
             # communication stream) against the tail backward it follows — both per optimizer step, from HIP events on their streams
-            "rccl_ranks": rccl_ranks, "dp_bucket": eng.bucket_timing_summary(args.steps),
+            "rccl_ranks": rccl_ranks, "dp_bucket": dp_bucket,
         }
         print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         if world == 1:

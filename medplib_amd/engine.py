@@ -219,6 +219,9 @@ class Engine:
         """From now on every backward pass and every gradient bucket is bracketed by a HIP-event pair on the stream it runs on."""
         self._timing = {"backward": [], "allreduce": [], "bytes": 0}
 
+    def disable_bucket_timing(self):
+        self._timing = None
+
     def _mark(self, kind, nbytes=0):
         if self._timing is None or not torch.cuda.is_available():
             return None
