@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU micro-batch (BASELINE config: 8)")
     ap.add_argument("--layers", type=int, default=32, help="debug only; the reported config is 32")
+    ap.add_argument("--experts", type=int, default=2, help="debug only: experts per MoE layer (the reported config: 2)")
+    ap.add_argument("--top-k", type=int, default=1, choices=(1, 2), help="debug only: DeepSpeed top-k gating (the reported config: top-1)")
+    ap.add_argument("--use-residual", action="store_true", help="debug only: DeepSpeed MoE(use_residual=True)")
     ap.add_argument("--lora", action="store_true",
                     help="secondary line: scripts/train_stage3.sh's configuration (dense Llama-7B, LoRA r = 8 / alpha 16 / dropout 0.05 on "
                          "gate/up/down_proj, mask decoder + text_hidden_fcs trainable) = the whole decoder backward in the step; the "
@@ -373,7 +376,10 @@ def main():
                 p.data.normal_(0, 0.01)
         args.no_cpu_baseline = True                          # the host leg and the parity object belong to the default configuration
     else:
-        cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers)
+        cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, num_experts=args.experts, top_k_experts=args.top_k,
+                                       use_residual=args.use_residual)
+        if (args.experts, args.top_k, args.use_residual) != (2, 1, False):
+            args.no_cpu_baseline = True                      # the host leg and the parity object belong to the reported configuration
         model = MedPLIBForCausalLM(cfg, device=device).train()
     ds_config = {"train_micro_batch_size_per_gpu": args.batch, "gradient_accumulation_steps": 1,
                  "optimizer": {"type": "AdamW", "params": {"lr": 3e-4, "weight_decay": 0.0, "betas": (0.9, 0.95)}},
@@ -551,7 +557,8 @@ def main():
                     + (" (frozen towers started ahead on their own streams)" if model.towers_run_ahead else ""),
             "config": {"workload": ("MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh; "
                                     "whole decoder backward), " if args.lora else
-                                    "MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E=2 top-1 experts x32 layers), ") +
+                                    f"MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E={args.experts} top-{args.top_k} experts x{args.layers} layers"
+                                    f"{', use_residual' if args.use_residual else ''}), ") +
                                    "336x336 CLIP image + 256x256 SAM image + 64-token prompt (S=639 after splice), "
                                    f"per-GPU batch {args.batch}, DP={world}",
                        "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
