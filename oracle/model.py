@@ -117,14 +117,20 @@ def init_hf_weights_aliased(cfg, seed=0):
     layers (the same tensor objects: 1.6 GB of fp32 instead of 52 GB for 32 layers; arithmetic and memory traffic per layer are what
     distinct weights would cost).  Used by bench.py's cpu_baseline leg and the full-depth parity check (oracle/parity.py)."""
     import copy
+    moe_set = cfg.moe_layer_set()
+    mixed = 0 < len(moe_set) < cfg.num_hidden_layers          # dense AND MoE layers (moe_mode second_half / sparse: the reference's default)
     cfg1 = copy.deepcopy(cfg)
-    cfg1.num_hidden_layers = 1
-    if cfg1.moe_layers_idx is not None:
+    cfg1.num_hidden_layers = 2 if mixed else 1
+    if mixed:
+        cfg1.moe_layers_idx = [1]                               # prototype layer 0 = dense, 1 = MoE
+    elif cfg1.moe_layers_idx is not None:
         cfg1.moe_layers_idx = [0] if 0 in cfg.moe_layers_idx else []
-    W = init_hf_weights(cfg1, seed=seed)
-    for i in range(1, cfg.num_hidden_layers):
-        for k in [k for k in W if k.startswith("model.layers.0.")]:
-            W[k.replace("model.layers.0.", f"model.layers.{i}.")] = W[k]
+    W1 = init_hf_weights(cfg1, seed=seed)
+    W = {k: v for k, v in W1.items() if not k.startswith("model.layers.")}
+    for i in range(cfg.num_hidden_layers):
+        src = f"model.layers.{1 if (mixed and i in moe_set) else 0}."
+        for k in [k for k in W1 if k.startswith(src)]:
+            W[f"model.layers.{i}." + k[len(src):]] = W1[k]
     return W
 
 

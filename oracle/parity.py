@@ -49,7 +49,14 @@ def routing_report(coll, routing, T, capacity, rts):
             e_hip2 = torch.stack([eh[:T], eh[eh.numel() // 2:eh.numel() // 2 + T]], 1)
             agree = (e_hip2 == e_ref).all(1)
             same_all &= agree
+            sh = r[1].cpu().long()
+            kept_hip2 = torch.stack([sh[:T], sh[sh.numel() // 2:sh.numel() // 2 + T]], 1) >= 0
+            kept_ref2 = torch.stack([s_ref[0][:T], s_ref[1][:T]], 1) >= 0
             per.append({"layer": li, "expert_agreement": float(agree.float().mean()), "flipped_tokens": int((~agree).sum()),
+                        # entries (token, choice) dropped for capacity on either side; on agreeing tokens the kept state may differ only
+                        # where a flipped token moved an expert's capacity boundary (each flip touches up to four queues)
+                        "dropped_entries_hip": int((~kept_hip2).sum()), "dropped_entries_oracle": int((~kept_ref2).sum()),
+                        "kept_state_differs_on_agreeing_rows": int(((kept_hip2 != kept_ref2).any(1) & agree).sum()),
                         "first_choice_agreement": float((e_hip2[:, 0] == e_ref[:T, 0]).float().mean()),
                         "counts_equal_oracle": bool(torch.equal(r[2].cpu().long().view(-1)[:c_ref.numel()], c_ref.view(-1).long()))})
             continue
@@ -194,6 +201,9 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "weights": "one decoder layer's seeded weights aliased over all layers, both sides"}
     if per_layer and "first_choice_agreement" in per_layer[0]:        # top-2 layers
         res["routing"] = {"top_k": 2, "flipped_tokens_per_layer": [p["flipped_tokens"] for p in per_layer],
+                          "dropped_entries_hip_per_layer": [p["dropped_entries_hip"] for p in per_layer],
+                          "dropped_entries_oracle_per_layer": [p["dropped_entries_oracle"] for p in per_layer],
+                          "kept_state_differs_on_agreeing_rows_per_layer": [p["kept_state_differs_on_agreeing_rows"] for p in per_layer],
                           "first_choice_agreement_per_layer": [round(p["first_choice_agreement"], 4) for p in per_layer],
                           "counts_equal_oracle_where_choices_identical": all(p["counts_equal_oracle"] for p in per_layer if p["flipped_tokens"] == 0)}
     elif per_layer:
