@@ -371,6 +371,36 @@ def test_evaluate_greedy_decode_and_mask(dev, moe):
             assert masks[0].shape == masks_ref[0].shape
 
 
+@pytest.mark.parametrize("moe", [True, False])
+def test_evaluate_at_true_dims(dev, moe):
+    """evaluate() at the 7B layer dimensions (2 decoder layers, 336-px CLIP, S = 639 after the splice, vocabulary 4096): the prefill, then
+    the decode steps on the kernels only this path uses at this size — the M = 1 GEMVs (shared and expert-indexed), the flash-decoding
+    attention over a 640-key cache, the fused norm + gate + routing launch, the HIP-graph replay — against the oracle's cache-free greedy
+    decode from the same weights.  Token ids equal (a divergence only at a step whose top-2 logit gap in the oracle is below bf16
+    noise); the mask of the picked <SEG> row within the full-size logit tolerance and Dice bounds."""
+    from oracle.parity import MASK_LOGIT_TOL
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=2, vocab_size=4096, seg_token_idx=4000, moe_enable=moe, moe_gate_sampling=False)
+    W = OM.init_hf_weights_aliased(cfg, seed=5)
+    m = _model(cfg, dev, W).eval()
+    torch.set_num_threads(min(32, os.cpu_count()))
+    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=11)
+    bq = dict(batch, images_clip=batch["images_clip"].to(torch.bfloat16).float(), images=batch["images"].to(torch.bfloat16).float())
+    ids_ref, masks_ref, dbg = OM.evaluate(bq, W, cfg, max_new_tokens=5, return_debug=True)
+    out_ids, masks = m.evaluate(bq["images_clip"].to(dev), bq["images"].to(dev), bq["input_ids"], batch["resize_list"], batch["label_list"],
+                                max_new_tokens=5)
+    a, b = out_ids[0].tolist(), ids_ref[0].tolist()
+    n_in = bq["input_ids"].shape[1]
+    agree = 0
+    while agree < min(len(a), len(b)) and a[agree] == b[agree]:
+        agree += 1
+    print(f"moe={moe}: generated {a[n_in:]} vs oracle {b[n_in:]}, oracle top-2 gaps {['%.3f' % g for g in dbg['gaps']]}")
+    if agree < max(len(a), len(b)):
+        step = agree - n_in
+        assert 0 <= step < len(dbg["gaps"]) and dbg["gaps"][step] < 5e-2, "token ids diverge at a step that is not a near tie"
+    else:
+        _check_mask_cuts(f"evaluate at true dims (moe={moe})", masks[0][0], masks_ref[0][0], batch["masks_list"][0], tol=MASK_LOGIT_TOL)
+
+
 def test_evaluate_vs_executed_reference_golden(dev, golden_dir):
     """evaluate() (KV-cache prefill + HIP-graph decode steps, <SEG> pick, mask head) vs the EXECUTED reference `LISAForCausalLM.evaluate`
     (tests/golden/lisa_evaluate_reference.npz; the oracle equals it bit for bit on the CPU, tests/test_oracle_golden.py): token ids
