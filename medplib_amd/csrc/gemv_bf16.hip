@@ -172,6 +172,82 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
   }
 }
 
+// RMSNorm folded into the GEMV (decode steps: input_layernorm -> qkv projection, final norm -> lm_head).  Every wave normalises the
+// row itself — K bf16 (8 KB at 7B) from L2 and two wave reductions, nothing beside the 4 x K weight stream it is about to read — and
+// keeps the normalised row in registers; the stand-alone norm kernel's launch (5 us of a 130 us decode layer) disappears.  BIT-IDENTICAL
+// with mp_rmsnorm_bf16 followed by mp_gemv_bf16: lane l holds the 16-byte chunks q = k*64 + l, the chunk thread (c = q >> 8, t = q & 255)
+// of rmsnorm_bf16_kernel owns, so the sum of squares is accumulated per "virtual wave" (q >> 6) & 3 in that kernel's order (the same
+// construction as rmsnorm_gate_kernel, ce_moe.hip), the HF rounding points are the same, and chunk q is also what the GEMV's lane l
+// multiplies in its k-th step.
+template <int M, int NCH>
+__global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const float* __restrict__ nw, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int rows[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+  if (rows[0] >= g.N) return;
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)min(rows[r], g.N - 1) * g.ldw;
+  bf16x8 hx[M][NCH];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      hx[m][k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)hx[m][k][j]; part[k & 3] += f * f; }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) ss += wave_sum(part[wv]);
+    const float rs = rsqrtf(ss / (float)g.K + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = (k * 64 + lane) * 8;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16_t t = (bf16_t)((float)hx[m][k][j] * rs);          // HF: the normalised value is cast to the input dtype first
+        hx[m][k][j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
+      }
+    }
+  }
+  float acc[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    bf16x8 w0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + (k * 64 + lane) * 8);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(hx[m][k], w0[r], acc[m][r]);
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+  if (lane != 0) return;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = rows[r];
+      if (n >= g.N) continue;
+      const float v = acc[m][r] * g.alpha;
+      if (g.out_f32) reinterpret_cast<float*>(g.y)[(int64_t)m * g.ldy + n] = v;
+      else reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+    }
+}
+
 template <int M>
 void launch_shared(const GemvArgs& g, dim3 grid, hipStream_t s) {
   if (g.act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL((gemv_shared_kernel<M, true>), grid, dim3(256), 0, s, g);
@@ -215,4 +291,28 @@ extern "C" int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t l
     }
   }
   return mp_check_launch("mp_gemv_bf16");
+}
+
+extern "C" int mp_gemv_rmsnorm_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W, int64_t ldw, void* y,
+                                    int64_t ldy, int M, int N, int K, int out_dtype, hipStream_t stream) {
+  MP_REQUIRE(M >= 1 && M <= 2 && N > 0 && K >= 512 && K % 512 == 0 && K <= 8192 && ldx % 8 == 0 && ldw % 8 == 0, MP_ERR_SHAPE,
+             "mp_gemv_rmsnorm_bf16: 1 <= M <= 2, K a multiple of 512 up to 8192 (M=%d N=%d K=%d)", M, N, K);
+  MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemv_rmsnorm_bf16: bad out dtype");
+  MP_REQUIRE(norm_w != nullptr, MP_ERR_ARG, "mp_gemv_rmsnorm_bf16: norm weight missing");
+  GemvArgs g{(const bf16_t*)x, ldx, (const bf16_t*)W, ldw, 0, y, ldy, nullptr, nullptr, 0, nullptr, nullptr, nullptr, M, N, K, ACT_NONE,
+             out_dtype == MP_F32, 1.f};
+  const dim3 grid((unsigned)mp_cdiv(mp_cdiv(N, 4), 4));
+#define MP_GVN(MM, NC) hipLaunchKernelGGL((gemv_rmsnorm_kernel<MM, NC>), grid, dim3(256), 0, stream, g, norm_w, eps)
+#define MP_GVN_M(NC) do { if (M == 1) MP_GVN(1, NC); else MP_GVN(2, NC); } while (0)
+  switch (K / 512) {
+    case 1: MP_GVN_M(1); break;
+    case 2: MP_GVN_M(2); break;
+    case 4: MP_GVN_M(4); break;
+    case 8: MP_GVN_M(8); break;
+    case 16: MP_GVN_M(16); break;
+    default: MP_REQUIRE(false, MP_ERR_SHAPE, "mp_gemv_rmsnorm_bf16: K / 512 must be 1, 2, 4, 8 or 16 (K=%d)", K);
+  }
+#undef MP_GVN_M
+#undef MP_GVN
+  return mp_check_launch("mp_gemv_rmsnorm_bf16");
 }

@@ -374,6 +374,24 @@ def test_gemv_decode_projections(dev):
     assert torch.equal(out[2].cpu(), res[2]), "a capacity-dropped row keeps the residual stream exactly"
 
 
+def test_gemv_with_folded_rmsnorm_is_bit_identical(dev):
+    """mp_gemv_rmsnorm_bf16 (the decode steps' input_layernorm inside the qkv GEMV) against mp_rmsnorm_bf16 followed by mp_gemv_bf16: EQUAL
+    bits, bf16 and fp32 outputs, one and two rows, K = 512 ... 8192 (every wave reproduces the norm kernel's summation order)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for (M, N, K) in [(1, 12288, 4096), (2, 4096, 4096), (1, 515, 512), (2, 1030, 2048), (1, 4099, 8192), (1, 64, 1024)]:
+        x = _bf(torch.randn(M, K, generator=g) * 1.7).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+        nw = (1.0 + 0.3 * torch.randn(K, generator=g)).to(dev)
+        assert ops.gemv_rmsnorm_ok(M, K)
+        for od in (torch.bfloat16, torch.float32):
+            ref = ops.gemv(ops.rmsnorm(x, nw, 1e-5), w, out_dtype=od)
+            got = ops.gemv_rmsnorm(x, nw, 1e-5, w, out_dtype=od)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (M, N, K, od, float((got.float() - ref.float()).abs().max()))
+    assert not ops.gemv_rmsnorm_ok(3, 4096) and not ops.gemv_rmsnorm_ok(1, 256)
+
+
 @pytest.mark.parametrize("D,H", [(128, 4), (64, 3)])
 def test_attention_decode_single_query(dev, D, H):
     """One query per sequence against a KV cache whose valid length lives in device memory (the decode steps of evaluate()):
