@@ -298,9 +298,9 @@ __device__ __forceinline__ int v_key(int row) {
 // All-reduce (max) over the wave's four 16-lane rows (same fr), every lane gets the result; all 64 lanes must execute.  One asm block
 // with its own wait states, for two reasons found the hard way (tests/test_gpu_trunk_kernels.py::test_attention_row_max_spans_all_lane_rows):
 //   * with the builtins, `max(swap(x, x)[0], swap(x, x)[1])` was compiled to swap, copy, swap — the compiler folded the max away (also
-//     with an opaque copy as second operand), leaving a permutation: every lane used ANOTHER row's max.  A smaller-than-true max is
-//     still a valid softmax shift as long as all four rows agree, which two swaps in a row happen to preserve, so every tolerance test
-//     passed; a dominant key in the wrong row overflowed 2^(s - m);
+//     with an opaque copy as second operand), which leaves ROW 0's max broadcast to all four rows.  A smaller-than-true max is still a
+//     valid softmax shift as long as the four rows agree on it, which they did, so every tolerance test passed; a dominant key in
+//     rows 1-3 overflowed 2^(s - m);
 //   * a VALU write of a swap operand needs two wait states before v_permlane*_swap reads it; the compiler inserts them only for
 //     instructions it emitted itself.
 // v_permlane16_swap: odd rows of vdst <-> even rows of src; v_permlane32_swap: rows 2,3 of vdst <-> rows 0,1 of src.
