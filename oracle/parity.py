@@ -78,7 +78,7 @@ def routing_report(coll, routing, T, capacity, rts):
 
 
 def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0, B=1,
-                     rts_seed=None, capacity_factor=None, time_threads=None):
+                     rts_seed=None, capacity_factor=None, time_threads=None, prompt_len=64, ragged=False):
     """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
     through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline).
     B: samples in the compared batch (8 = the benchmark's per-GPU batch, T = 5112).  rts_seed: DeepSpeed's Random Token Selection
@@ -99,7 +99,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
             b = OM.make_batch_icl(cfg, B_, n_ctx=icl_ctx, H=H, Wd=Wd, seed=bseed, mask_size=cfg.clip_image_size)
             b["images_clip"] = [x.to(torch.bfloat16).float() for x in b["images_clip"]]
         else:
-            b = OM.make_batch(cfg, B_, L=64, H=H, Wd=Wd, seed=bseed)
+            b = OM.make_batch(cfg, B_, L=prompt_len, H=H, Wd=Wd, seed=bseed, ragged=ragged)
             b["images_clip"] = b["images_clip"].to(torch.bfloat16).float()
         b["images"] = b["images"].to(torch.bfloat16).float()
         return b
@@ -127,7 +127,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     rts = None
     if rts_seed is not None and cfg.moe_enable:
         g = torch.Generator().manual_seed(rts_seed)
-        S_ = batch["input_ids"].shape[1] - 1 + cfg.image_token_len if not icl_ctx else None
+        S_ = batch["input_ids"].shape[1] - 1 + cfg.image_token_len if not icl_ctx else None     # the padded length (ragged rows are padded to it)
         assert S_ is not None, "injected draws need the spliced length up front (single-image layout)"
         rts = {i: torch.rand(B * S_, cfg.num_experts, generator=g) for i in sorted(cfg.moe_layer_set())}
     coll = []

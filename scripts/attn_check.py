@@ -6,7 +6,7 @@ from medplib_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 worst = 0.0
-for (B, S, H, D) in [(1, 639, 4, 128), (1, 1257, 4, 128), (2, 1316, 4, 128), (1, 1257, 4, 64), (1, 2000, 2, 128), (3, 1087, 2, 128)]:
+for (B, S, H, D) in [(1, 639, 4, 128), (1, 1257, 4, 128), (2, 1316, 4, 128), (1, 1257, 4, 64), (1, 2000, 2, 128), (3, 1087, 2, 128), (2, 775, 4, 128), (2, 769, 2, 128), (2, 129, 2, 64), (1, 65, 2, 128)]:
     qkv = torch.randn(B, S, 3, H, D, device=dev).to(torch.bfloat16)
     q, k, v = (qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3))
     for causal in (True, False):
