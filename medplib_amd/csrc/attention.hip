@@ -711,8 +711,39 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, float* __r
   float q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) q[j] = (float)qv[j];
-  // ---- scores of this split's keys (two key rows in flight per lane)
+  // ---- short splits (<= 8 key rows per lane group = 128 keys at D = 128: every decode step of evaluate()): ALL K rows and ALL V rows of
+  //      the split are requested up front — the V rows travel while the scores, the block max and the exponentials are computed — instead
+  //      of one dependent round trip to memory per pair of rows (3 + 3 of them at 80-112 keys per split).  Same arithmetic in the same
+  //      order as the general loops below (scores per key, the pairs (key, key + KPB) of the PV accumulation ascending).
+  constexpr int NR = 8;
+  const bool short_split = (k_hi - k_lo) <= NR * KPB;
+  bf16x8 vv[NR];
   float mx = -INFINITY;
+  if (short_split) {
+    bf16x8 kr[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int key = k_lo + i * KPB + kg;
+      kr[i] = bf16x8{};
+      if (key < k_hi) kr[i] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)key * a.k_ss + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int key = k_lo + i * KPB + kg;
+      vv[i] = bf16x8{};
+      if (key < k_hi) vv[i] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)key * a.v_ss + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int key = k_lo + i * KPB + kg;
+      float d0 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d0 = fmaf(q[j], (float)kr[i][j], d0);
+#pragma unroll
+      for (int off = 1; off < CH; off <<= 1) d0 += __shfl_xor(d0, off, 64);
+      if (key < k_hi) { d0 *= a.scale; if (c == 0) sc[key - k_lo] = d0; mx = fmaxf(mx, d0); }
+    }
+  } else
   for (int k0 = k_lo; k0 < k_hi; k0 += 2 * KPB) {
     const int key0 = k0 + kg, key1 = k0 + KPB + kg;
     bf16x8 kv0 = {}, kv1 = {};
@@ -742,6 +773,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, float* __r
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  if (short_split) {
+#pragma unroll
+    for (int i = 0; i < NR; i += 2) {
+      const int key = k_lo + i * KPB + kg, key1 = key + KPB;
+      if (key < k_hi) {
+        const float p0 = sc[key - k_lo], p1 = key1 < k_hi ? sc[key1 - k_lo] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(p1, (float)vv[i + 1][j], fmaf(p0, (float)vv[i][j], o[j]));
+      }
+    }
+  } else
   for (int key = k_lo + kg; key < k_hi; key += 2 * KPB) {
     const int key1 = key + KPB;
     const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)key * a.v_ss + c * 8);
