@@ -29,3 +29,11 @@ print(f"wall {wall:.2f} ms/step")
 print("main stream, start -> end of a step's own work (ms):", [round(a.elapsed_time(b), 2) for a, b in ev])
 print("main stream, end of step i -> start of step i+1 (ms):", [round(ev[i][1].elapsed_time(ev[i + 1][0]), 3) for i in range(N - 1)])
 print("main stream, start i -> start i+1 (ms):", [round(ev[i][0].elapsed_time(ev[i + 1][0]), 2) for i in range(N - 1)])
+# host side: how long the host takes to ISSUE a step (the step() call returns when everything is enqueued), against the wall time
+torch.cuda.synchronize()
+host = []
+t_all = time.perf_counter()
+for i in range(N):
+    t1 = time.perf_counter(); step(); host.append((time.perf_counter() - t1) * 1e3)
+torch.cuda.synchronize()
+print(f"host issue time per step (ms): {[round(h, 1) for h in host]}; wall {(time.perf_counter() - t_all) * 1e3 / N:.2f} ms/step; towers_run_ahead={getattr(model, 'towers_run_ahead', None)}")

@@ -34,4 +34,20 @@ for x, y in zip(d, d[1:]):
 print(f"step span {(seg[-1][1] - seg[0][0]) / 1e6:.2f} ms; decoder queue {mainq}: {len(d)} kernels over {span / 1e6:.2f} ms, kernel time {busy / 1e6:.2f} ms, gaps {(span - busy) / 1e6:.2f} ms")
 for k, (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
     print(f"  {t / 1e3:6.2f} ms  x{n:3d}  avg {t / n:5.1f} us   {k}")
+# what the decoder's queue does outside the decoder: from the previous step's last decoder GEMM to this step's first one
+prev = [r for r in byq[mainq] if r[1] <= d[0][0]]
+allq = rows[:a + 0]
+pm = [r for r in rows if r[3] == mainq and r[0] < d[0][0]]
+pdec = [i for i, r in enumerate(pm) if "gemm320_bf16_nt_kernel<3>" in r[2]]
+if pdec:
+    w = pm[pdec[-1] + 1:]
+    t_a, t_b = pm[pdec[-1]][1], d[0][0]
+    busy = sum(e - s for s, e, _, _ in w)
+    print(f"between two decoders on queue {mainq}: {(t_b - t_a) / 1e6:.2f} ms, {len(w)} kernels, kernel time {busy / 1e6:.2f} ms, idle {(t_b - t_a - busy) / 1e6:.2f} ms")
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for s_, e_, n_, _ in w: agg[short(n_)][0] += 1; agg[short(n_)][1] += (e_ - s_) / 1e3
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
+        print(f"  {t / 1e3:6.2f} ms  x{n:3d}   {k}")
+    big = sorted(((y[0] - x[1], short(x[2]), short(y[2])) for x, y in zip([pm[pdec[-1]]] + w, w + [d[0]]) if y[0] - x[1] > 20000), reverse=True)[:8]
+    for g, x, y in big: print(f"  gap {g / 1e3:7.1f} us after {x} before {y}")
 PY
