@@ -42,22 +42,8 @@ __global__ __launch_bounds__(256) void mean_plus_kernel(const float* __restrict_
 
 // ---------------- MoE gate: logits = x.float() @ wg.float()^T ; gates = softmax(logits) ----------------
 // one token's gate by one wave: fp32 logits and their softmax (lane 0 writes them)
-__device__ __forceinline__ void moe_gate_token(const bf16_t* __restrict__ xr, const float* __restrict__ wg, int d, int E, int lane,
-                                               float* __restrict__ logits_out, float* __restrict__ gates_out) {
-  float acc[MAXE];
-#pragma unroll
-  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
-  for (int i = lane * 8; i < d; i += 64 * 8) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + i);
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      if (e < E) {
-        const float* w = wg + (int64_t)e * d + i;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[e] = fmaf((float)v[j], w[j], acc[e]);
-      }
-    }
-  }
+// the end of a token's gate: wave-reduce the E partial logits, softmax on lane 0 (shared by every form of the gate so they agree to the bit)
+__device__ __forceinline__ void moe_gate_finish(float (&acc)[MAXE], int E, int lane, float* __restrict__ logits_out, float* __restrict__ gates_out) {
   float mx = -INFINITY;
 #pragma unroll
   for (int e = 0; e < MAXE; ++e)
@@ -74,6 +60,25 @@ __device__ __forceinline__ void moe_gate_token(const bf16_t* __restrict__ xr, co
         gates_out[e] = p[e] / s;
       }
   }
+}
+
+__device__ __forceinline__ void moe_gate_token(const bf16_t* __restrict__ xr, const float* __restrict__ wg, int d, int E, int lane,
+                                               float* __restrict__ logits_out, float* __restrict__ gates_out) {
+  float acc[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
+  for (int i = lane * 8; i < d; i += 64 * 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + i);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      if (e < E) {
+        const float* w = wg + (int64_t)e * d + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e] = fmaf((float)v[j], w[j], acc[e]);
+      }
+    }
+  }
+  moe_gate_finish(acc, E, lane, logits_out, gates_out);
 }
 
 __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wg,
@@ -477,6 +482,24 @@ __global__ __launch_bounds__(256) void decode_norm_gate_route_kernel(const bf16_
   __shared__ float red[16];
   __shared__ float gates_sh[8 * MAXE];
   constexpr int NC = 4;                                // dim <= 256 * 8 * 4
+  // The decode steps' shape (d = 4096, E <= 2, T <= 4 rows): a row's gate is ONE wave's serial chain of 8 dependent trips to memory in
+  // moe_gate_token (a runtime loop: x chunk, then the experts' weight chunks).  Here the wave requests its 8 x E weight chunks when the
+  // kernel starts — they travel under the RMSNorm — and takes the normalised row from LDS instead of reading it back from global
+  // memory; the fma chain per expert is the same (chunks ascending, elements ascending), so the bits are moe_gate_token's.
+  constexpr int FK = 8;                                // 16-byte x chunks per lane at d = 4096
+  __shared__ __attribute__((aligned(16))) bf16_t h_sh[4 * 4096];
+  const bool fast = (d == FK * 512) && E <= 2 && T <= 4;
+  const int lane_f = threadIdx.x & 63, wave_f = threadIdx.x >> 6;
+  f32x4 gw[2][FK][2];
+  if (fast && wave_f < T) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        const float* wp_ = wg + (int64_t)(e < E ? e : 0) * d + (k * 64 + lane_f) * 8;
+        gw[e][k][0] = *reinterpret_cast<const f32x4*>(wp_); gw[e][k][1] = *reinterpret_cast<const f32x4*>(wp_ + 4);
+      }
+  }
   for (int row = 0; row < T; ++row) {
     const bf16_t* xr = x + row * ldx;
     bf16_t* hr = h + row * ldh;
@@ -504,11 +527,30 @@ __global__ __launch_bounds__(256) void decode_norm_gate_route_kernel(const bf16_
           o[j] = (bf16_t)(ln_w[i + j] * (float)t);
         }
         *reinterpret_cast<bf16x8*>(hr + i) = o;
+        if (fast) *reinterpret_cast<bf16x8*>(h_sh + row * 4096 + i) = o;
       }
     }
   }
-  __syncthreads();                                     // the normed rows (global) are visible to the whole workgroup
+  __syncthreads();                                     // the normed rows (global / LDS) are visible to the whole workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (fast) {
+    if (wave < T) {
+      float acc[MAXE];
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(h_sh + wave * 4096 + (k * 64 + lane) * 8);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if (e < E) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[e] = fmaf((float)v[j], j < 4 ? gw[e][k][0][j & 3] : gw[e][k][1][j & 3], acc[e]);
+          }
+      }
+      moe_gate_finish(acc, E, lane, nullptr, gates_sh + wave * E);
+    }
+  } else
   for (int row = wave; row < T; row += 4) moe_gate_token(h + row * ldh, wg, d, E, lane, nullptr, gates_sh + row * E);
   __syncthreads();
   if (gates_out)

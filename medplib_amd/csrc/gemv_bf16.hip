@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
     for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
   const int iters = g.K / 512;                              // 64 lanes x 8 elements per step
   int k = lane * 8;
-  for (int it = 0; it + 1 < iters; it += 2, k += 1024) {    // two steps per trip: 8 weight loads in flight per lane
+  // (four steps per trip for the one-row case, 16 loads in flight, was measured too: o_proj 11.0 -> 11.2 us — no change)
+  int it = 0;
+  for (; it + 1 < iters; it += 2, k += 1024) {              // two steps per trip: 8 weight loads in flight per lane
     bf16x8 w0[4], w1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k + 512); }
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
       for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
     }
   }
-  if (iters & 1) {
+  if (it < iters) {
     bf16x8 w0[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k);
@@ -143,7 +145,23 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) wp[r] = Wm + (int64_t)min(rows[r], g.N - 1) * g.ldw;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 8; k < g.K; k += 512) {
+    int k = lane * 8;
+    // four steps per trip: 16 weight loads in flight per lane (one step per trip left every trip waiting on its own 4 loads: the down
+    // projection's 21.5 trips per row were 21.5 dependent round trips); same accumulation order
+    for (; k + 3 * 512 < g.K; k += 4 * 512) {
+      bf16x8 xs[4], ws[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xs[u] = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k + u * 512);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[u][r] = *reinterpret_cast<const bf16x8*>(wp[r] + k + u * 512);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(xs[u], ws[u][r], acc[r]);
+    }
+    for (; k < g.K; k += 512) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + k), acc[r]);

@@ -414,7 +414,8 @@ def test_decode_norm_gate_route_equals_separate_kernels(dev):
     over-capacity case with RTS draws."""
     from medplib_amd import ops
     g = torch.Generator().manual_seed(21)
-    for T, E, d, cap, with_draws in [(1, 2, 4096, 4, False), (5, 3, 4096, 8, False), (8, 2, 1024, 2, True), (3, 4, 512, 1, True)]:
+    for T, E, d, cap, with_draws in [(1, 2, 4096, 4, False), (5, 3, 4096, 8, False), (8, 2, 1024, 2, True), (3, 4, 512, 1, True),
+                                     (4, 2, 4096, 1, True), (3, 1, 4096, 2, False), (2, 2, 4096, 2, True)]:   # + the prefetching form (d 4096, E <= 2, T <= 4)
         x = (torch.randn(T, d, generator=g) * 2).to(torch.bfloat16).to(dev)
         ln_w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
         wg = (torch.randn(E, d, generator=g) * 0.05).to(dev)
