@@ -102,10 +102,11 @@ int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, int64_t
                  const void* residual, int64_t ldr, const int* w_index, const float* row_scale, const int* row_keep, int M, int N, int K,
                  int act, int out_dtype, float alpha, hipStream_t stream);
 /* mp_rmsnorm_bf16 (HF LlamaRMSNorm, medplib_moe_llama.py:121 / :286) folded into the GEMV that consumes it: y[m, :] = rmsnorm(x[m, :]) @ W^T,
- * bit-identical with the two separate calls.  Decode steps: input_layernorm -> the fused q|k|v projection, and the final norm -> lm_head.
- * 1 <= M <= 2; K a multiple of 512 (1, 2, 4, 8 or 16 x 512). */
+ * bit-identical with the two separate calls.  Decode steps: input_layernorm -> the fused q|k|v projection, and (dense layers)
+ * post_attention_layernorm -> the interleaved gate|up projection with act = SWIGLU_PAIR (y [M, N/2]).  1 <= M <= 2; K a multiple of 512
+ * (1, 2, 4, 8 or 16 x 512). */
 int mp_gemv_rmsnorm_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W, int64_t ldw, void* y, int64_t ldy,
-                         int M, int N, int K, int out_dtype, hipStream_t stream);
+                         int M, int N, int K, int act, int out_dtype, hipStream_t stream);
 
 /* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never

@@ -197,13 +197,19 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
 // of rmsnorm_bf16_kernel owns, so the sum of squares is accumulated per "virtual wave" (q >> 6) & 3 in that kernel's order (the same
 // construction as rmsnorm_gate_kernel, ce_moe.hip), the HF rounding points are the same, and chunk q is also what the GEMV's lane l
 // multiplies in its k-th step.
-template <int M, int NCH>
+template <int M, int NCH, bool SWIGLU = false>
 __global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const float* __restrict__ nw, float eps) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   int rows[4];
+  if (SWIGLU) {                                             // as gemv_shared_kernel: gate rows {g0, g0+1} and their up rows {g0+32, g0+33}
+    const int pair = wid * 2;
+    const int blk = pair >> 5, j = pair & 31;
+    rows[0] = blk * 64 + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + 32; rows[3] = rows[0] + 33;
+  } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+    for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+  }
   if (rows[0] >= g.N) return;
   const bf16_t* wp[4];
 #pragma unroll
@@ -255,15 +261,26 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const flo
     for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
   if (lane != 0) return;
 #pragma unroll
-  for (int m = 0; m < M; ++m)
+  for (int m = 0; m < M; ++m) {
+    if (SWIGLU) {                                           // the shared kernel's SwiGLU epilogue, rounding points included
+      bf16_t* yo = reinterpret_cast<bf16_t*>(g.y) + (int64_t)m * g.ldy;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = rows[r];
-      if (n >= g.N) continue;
-      const float v = acc[m][r] * g.alpha;
-      if (g.out_f32) reinterpret_cast<float*>(g.y)[(int64_t)m * g.ldy + n] = v;
-      else reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+      for (int p = 0; p < 2; ++p) {
+        const float gf = (float)(bf16_t)(acc[m][p] * g.alpha), uf = (float)(bf16_t)(acc[m][2 + p] * g.alpha);
+        const int col = (rows[p] >> 6) * 32 + (rows[p] & 31);
+        if (rows[p] < g.N) yo[col] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = rows[r];
+        if (n >= g.N) continue;
+        const float v = acc[m][r] * g.alpha;
+        if (g.out_f32) reinterpret_cast<float*>(g.y)[(int64_t)m * g.ldy + n] = v;
+        else reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+      }
     }
+  }
 }
 
 template <int M>
@@ -312,15 +329,19 @@ extern "C" int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t l
 }
 
 extern "C" int mp_gemv_rmsnorm_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W, int64_t ldw, void* y,
-                                    int64_t ldy, int M, int N, int K, int out_dtype, hipStream_t stream) {
+                                    int64_t ldy, int M, int N, int K, int act, int out_dtype, hipStream_t stream) {
   MP_REQUIRE(M >= 1 && M <= 2 && N > 0 && K >= 512 && K % 512 == 0 && K <= 8192 && ldx % 8 == 0 && ldw % 8 == 0, MP_ERR_SHAPE,
              "mp_gemv_rmsnorm_bf16: 1 <= M <= 2, K a multiple of 512 up to 8192 (M=%d N=%d K=%d)", M, N, K);
   MP_REQUIRE(out_dtype == MP_BF16 || out_dtype == MP_F32, MP_ERR_DTYPE, "mp_gemv_rmsnorm_bf16: bad out dtype");
   MP_REQUIRE(norm_w != nullptr, MP_ERR_ARG, "mp_gemv_rmsnorm_bf16: norm weight missing");
-  GemvArgs g{(const bf16_t*)x, ldx, (const bf16_t*)W, ldw, 0, y, ldy, nullptr, nullptr, 0, nullptr, nullptr, nullptr, M, N, K, ACT_NONE,
+  MP_REQUIRE(act == ACT_NONE || (act == ACT_SWIGLU_PAIR && N % 64 == 0 && out_dtype == MP_BF16), MP_ERR_ARG,
+             "mp_gemv_rmsnorm_bf16: activation NONE, or SWIGLU_PAIR with N %% 64 == 0 and bf16 output");
+  GemvArgs g{(const bf16_t*)x, ldx, (const bf16_t*)W, ldw, 0, y, ldy, nullptr, nullptr, 0, nullptr, nullptr, nullptr, M, N, K, act,
              out_dtype == MP_F32, 1.f};
-  const dim3 grid((unsigned)mp_cdiv(mp_cdiv(N, 4), 4));
-#define MP_GVN(MM, NC) hipLaunchKernelGGL((gemv_rmsnorm_kernel<MM, NC>), grid, dim3(256), 0, stream, g, norm_w, eps)
+  const bool sw = act == ACT_SWIGLU_PAIR;
+  const dim3 grid((unsigned)mp_cdiv(sw ? N / 4 : mp_cdiv(N, 4), 4));
+#define MP_GVN(MM, NC) do { if (sw) hipLaunchKernelGGL((gemv_rmsnorm_kernel<MM, NC, true>), grid, dim3(256), 0, stream, g, norm_w, eps); \
+                            else hipLaunchKernelGGL((gemv_rmsnorm_kernel<MM, NC, false>), grid, dim3(256), 0, stream, g, norm_w, eps); } while (0)
 #define MP_GVN_M(NC) do { if (M == 1) MP_GVN(1, NC); else MP_GVN(2, NC); } while (0)
   switch (K / 512) {
     case 1: MP_GVN_M(1); break;

@@ -338,6 +338,10 @@ class LlamaStack:
                 h, expert, slot, weight, _, _, _ = ops.decode_norm_gate_route(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"], cap, draws)
                 act = ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR, w_index=expert)
                 x = ops.gemv(act, lw["down"], residual=x, w_index=expert, row_scale=weight, row_keep=slot)
+            elif fold and i not in self.moe_layers:
+                # dense layer: post_attention_layernorm inside the gate|up GEMV (same bits as rmsnorm + gemv), then the down projection
+                act = ops.gemv_rmsnorm(x, lw["ln2"], cfg.rms_norm_eps, lw["gu"], act=ops.ACT_SWIGLU_PAIR)
+                x = ops.gemv(act, lw["down"], residual=x)
             else:
                 h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
                 x, _, _ = self._mlp(i, lw, h, x)

@@ -222,15 +222,16 @@ def gemm_last_kernel():
     return int(lib().raw("mp_gemm_last_kernel")())
 
 
-def gemv_rmsnorm(x, norm_w, eps, w, out_dtype=torch.bfloat16):
-    """rmsnorm(x) @ w^T for M <= 2 rows with the norm folded into the GEMV (bit-identical with rmsnorm + gemv); x [M, K] bf16, K % 512 == 0."""
+def gemv_rmsnorm(x, norm_w, eps, w, out_dtype=torch.bfloat16, act=ACT_NONE):
+    """act(rmsnorm(x) @ w^T) for M <= 2 rows with the norm folded into the GEMV (bit-identical with rmsnorm + gemv); x [M, K] bf16,
+    K % 512 == 0; act NONE or SWIGLU_PAIR (w = the interleaved gate|up matrix, result [M, N / 2])."""
     _chk(x, torch.bfloat16, "gemv_rmsnorm.x"); _chk(w, torch.bfloat16, "gemv_rmsnorm.w"); _chk(norm_w, torch.float32, "gemv_rmsnorm.norm_w")
     M, K = x.shape
     N = w.shape[0]
     assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and norm_w.is_contiguous() and norm_w.numel() == K
-    out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
     lib().call("mp_gemv_rmsnorm_bf16", _p(x), x.stride(0), _p(norm_w), float(eps), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
-               _dt(out_dtype), _stream())
+               int(act), _dt(out_dtype), _stream())
     return out
 
 

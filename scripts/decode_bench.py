@@ -33,9 +33,12 @@ res = {}
 # one untimed call first: code-object loading and other first-use costs belong to neither of the two lengths the slope is taken between
 model.evaluate(images_clip, images, ids.numpy(), [(256, 256)], [(336, 336)], max_new_tokens=8, eos_token_id=-1)
 for n_new in (args.new, 4 * args.new):      # slope between two lengths: prefill and the one-off graph capture cancel out
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out_ids, masks = model.evaluate(images_clip, images, ids.numpy(), [(256, 256)], [(336, 336)], max_new_tokens=n_new, eos_token_id=-1)
-    torch.cuda.synchronize(); res[n_new] = time.perf_counter() - t0
+    best = float("inf")
+    for _ in range(3):                      # the fastest of three calls per length: a one-off hiccup in either length tilts the slope
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out_ids, masks = model.evaluate(images_clip, images, ids.numpy(), [(256, 256)], [(336, 336)], max_new_tokens=n_new, eos_token_id=-1)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    res[n_new] = best
 steps = 3 * args.new
 ms = (res[4 * args.new] - res[args.new]) / steps * 1e3
 d, ff = cfg.hidden_size, cfg.intermediate_size

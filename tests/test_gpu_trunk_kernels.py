@@ -379,7 +379,7 @@ def test_gemv_with_folded_rmsnorm_is_bit_identical(dev):
     bits, bf16 and fp32 outputs, one and two rows, K = 512 ... 8192 (every wave reproduces the norm kernel's summation order)."""
     from medplib_amd import ops
     g = torch.Generator().manual_seed(23)
-    for (M, N, K) in [(1, 12288, 4096), (2, 4096, 4096), (1, 515, 512), (2, 1030, 2048), (1, 4099, 8192), (1, 64, 1024)]:
+    for (M, N, K) in [(1, 12288, 4096), (2, 4096, 4096), (1, 515, 512), (2, 1030, 2048), (1, 4099, 8192), (1, 64, 1024), (1, 22016, 4096)]:
         x = _bf(torch.randn(M, K, generator=g) * 1.7).to(dev)
         w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
         nw = (1.0 + 0.3 * torch.randn(K, generator=g)).to(dev)
@@ -389,6 +389,11 @@ def test_gemv_with_folded_rmsnorm_is_bit_identical(dev):
             got = ops.gemv_rmsnorm(x, nw, 1e-5, w, out_dtype=od)
             torch.cuda.synchronize()
             assert torch.equal(got, ref), (M, N, K, od, float((got.float() - ref.float()).abs().max()))
+        if N % 64 == 0:                                          # the SwiGLU form (dense layers' gate|up): [M, N / 2]
+            ref = ops.gemv(ops.rmsnorm(x, nw, 1e-5), w, act=ops.ACT_SWIGLU_PAIR)
+            got = ops.gemv_rmsnorm(x, nw, 1e-5, w, act=ops.ACT_SWIGLU_PAIR)
+            torch.cuda.synchronize()
+            assert got.shape == (M, N // 2) and torch.equal(got, ref), (M, N, K, "swiglu")
     assert not ops.gemv_rmsnorm_ok(3, 4096) and not ops.gemv_rmsnorm_ok(1, 256)
 
 
