@@ -277,6 +277,8 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
   }
   if (rts && over) {
     __shared__ unsigned hist[256];
+    __shared__ unsigned bin_suf[256], bin_tot[4];
+    __shared__ int bin_hi[4];
     __shared__ unsigned sel_bin, sel_need;
     __shared__ int eq_scan[16];
     for (int e = 0; e < E; ++e) {
@@ -298,10 +300,32 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
           if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
+        // the bin that holds the need-th largest key: the LARGEST b with suffix(b) = hist[b] + ... + hist[255] >= need (bin 0 if none), and
+        // what is still needed inside it, need - suffix(b + 1).  Four waves scan the 256 bins (thread t <-> bin t) instead of one thread
+        // walking them: the serial walk was 256 dependent LDS reads per pass, four passes per over-capacity expert.
+        unsigned suf = 0;
+        if (tid < 256) {
+          suf = hist[tid];                                    // inclusive suffix sum within the wave (this lane and the lanes above it)
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned n = __shfl_down(suf, off, 64);
+            if (lane + off < 64) suf += n;
+          }
+          if (lane == 0) bin_tot[wv] = suf;                   // the wave's total
+        }
+        __syncthreads();
+        if (tid < 256) {
+          for (int w = wv + 1; w < 4; ++w) suf += bin_tot[w];
+          const unsigned long long m = __ballot(suf >= need);
+          if (lane == 0) bin_hi[wv] = m ? 63 - __builtin_clzll(m) + 64 * wv : -1;
+          bin_suf[tid] = suf;
+        }
+        __syncthreads();
         if (tid == 0) {
-          unsigned cum = 0; int b = 255;
-          for (; b > 0; --b) { if (cum + hist[b] >= need) break; cum += hist[b]; }
-          sel_bin = (unsigned)b; sel_need = need - cum;
+          int b = 0;
+          for (int w = 3; w >= 0; --w) if (bin_hi[w] >= 0) { b = bin_hi[w]; break; }
+          const unsigned above = b < 255 ? bin_suf[b + 1] : 0u;
+          sel_bin = (unsigned)b; sel_need = need - above;
         }
         __syncthreads();
         prefix |= sel_bin << shift; pmask |= 0xffu << shift; need = sel_need;
