@@ -276,8 +276,20 @@ def test_fused_upsampler_backward_vs_fp32_autograd(dev):
     norm (measured ~5e-3); two runs are bit-identical (no atomics)."""
     import torch.nn.functional as F
     from medplib_amd.model import autograd_ops as A
-    g = torch.Generator().manual_seed(41)
-    n, G = 3, 16
+    _fused_upsampler_training_case(dev, n=3, G=16, seed=41)
+
+
+def test_fused_upsampler_backward_many_groups_per_wave(dev):
+    """The same check at the 1024-px geometry (64 x 64 tokens, 3 prompts = 768 sixteen-token groups): more groups than the launch has
+    waves, so every wave of the forward and of the backward walks several groups (the persistent loops' stride) and a workgroup's partial
+    rows cover more than one image."""
+    _fused_upsampler_training_case(dev, n=3, G=64, seed=43)
+
+
+def _fused_upsampler_training_case(dev, n, G, seed):
+    import torch.nn.functional as F
+    from medplib_amd.model import autograd_ops as A
+    g = torch.Generator().manual_seed(seed)
     src = torch.randn(n, G * G, 256, generator=g)
     w1 = torch.randn(256, 64, 2, 2, generator=g) * 0.06; b1 = torch.randn(64, generator=g) * 0.1
     lnw = 1.0 + 0.2 * torch.randn(64, generator=g); lnb = 0.1 * torch.randn(64, generator=g)
