@@ -253,7 +253,11 @@ __global__ __launch_bounds__(1024) void moe_route_top1_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) if (k == e) { m = me[k]; c = cnt[k]; }
     const float msum = block_sum(m, red);
-    if (c) atomicAdd(&cnt_sh[e], c);
+    // one LDS atomic per WAVE (16 of them), not per thread: up to 1024 atomics on a single LDS word serialise
+    int cw = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) cw += __shfl_xor(cw, off, 64);
+    if ((tid & 63) == 0 && cw) atomicAdd(&cnt_sh[e], cw);
     __syncthreads();
     aux += (msum / (float)T) * ((float)cnt_sh[e] / (float)T);
   }
@@ -756,8 +760,11 @@ __global__ __launch_bounds__(1024) void moe_route_top2_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) if (k == e) { m = me[k]; a = c1[k]; b = c2[k]; }
     const float msum = block_sum(m, red);
-    if (a) atomicAdd(&tot1[e], a);
-    if (b) atomicAdd(&tot2[e], b);
+    // one LDS atomic per wave and total (see moe_route_top1_kernel): per-thread atomics on one word serialise
+    int aw = a, bw = b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { aw += __shfl_xor(aw, off, 64); bw += __shfl_xor(bw, off, 64); }
+    if ((tid & 63) == 0) { if (aw) atomicAdd(&tot1[e], aw); if (bw) atomicAdd(&tot2[e], bw); }
     __syncthreads();
     aux += (msum / (float)T) * ((float)tot1[e] / (float)T);
   }
