@@ -997,14 +997,16 @@ def patch_im2col(img, patch, k_padded):
     return out
 
 
-def im2col_nhwc(x, OH, OW, stride, taps):
+def im2col_nhwc(x, OH, OW, stride, taps, out=None):
     """x [B,H,W,C] bf16 -> [B*OH*OW, len(taps)*C]; taps = [(dy, dx), ...]."""
     import ctypes
     _chk(x, torch.bfloat16, "im2col.x"); assert x.is_contiguous()
     B, H, W, C = x.shape
     n = len(taps)
     dy = (ctypes.c_int * n)(*[t[0] for t in taps]); dx = (ctypes.c_int * n)(*[t[1] for t in taps])
-    out = torch.empty((B * OH * OW, n * C), dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty((B * OH * OW, n * C), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (B * OH * OW, n * C) and out.is_contiguous() and out.dtype == torch.bfloat16
     lib().call("mp_im2col_nhwc_bf16", _p(x), _p(out), B, H, W, C, OH, OW, stride, stride, n, ctypes.cast(dy, ctypes.c_void_p),
                ctypes.cast(dx, ctypes.c_void_p), _stream())
     return out
