@@ -615,3 +615,41 @@ def test_expert_data_parallel_gradient_scaling_four_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_aliased_weights_for_mixed_dense_and_moe_stacks():
+    """oracle.model.init_hf_weights_aliased with MoE on SOME layers (the reference's `second_half` / sparse moe_mode): dense layers alias
+    one dense prototype, MoE layers one MoE prototype; every layer gets exactly the keys its kind needs."""
+    from medplib_amd.model.config import MedPLIBConfig
+    from oracle import model as OM
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=4, moe_layers_idx=[2, 3], num_experts=3, top_k_experts=2)
+    W = OM.init_hf_weights_aliased(cfg, seed=1)
+    for i in range(4):
+        moe = i in (2, 3)
+        assert (f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight" in W) == moe
+        assert (f"model.layers.{i}.mlp.gate_proj.weight" in W) == (not moe)
+        assert f"model.layers.{i}.self_attn.q_proj.weight" in W
+    assert W["model.layers.0.mlp.gate_proj.weight"] is W["model.layers.1.mlp.gate_proj.weight"]
+    assert W["model.layers.2.mlp.deepspeed_moe.gate.wg.weight"] is W["model.layers.3.mlp.deepspeed_moe.gate.wg.weight"]
+    assert sum(k.startswith("model.layers.2.mlp.deepspeed_moe.experts.deepspeed_experts.") for k in W) == 3 * 3
+    # all-MoE and all-dense stacks keep the one-prototype form
+    W2 = OM.init_hf_weights_aliased(MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=3), seed=1)
+    assert all(f"model.layers.{i}.mlp.deepspeed_moe.gate.wg.weight" in W2 for i in range(3))
+
+
+def test_routing_report_top2_entries():
+    """oracle.parity.routing_report on top-2 layers: the oracle's (idx1, idx2) against the HIP path's entry arrays of length 2T (first
+    choices, then second choices): a token agrees when BOTH choices agree in order; dropped entries and the kept state on agreeing tokens."""
+    import torch
+    from oracle.parity import routing_report
+    T, E = 6, 3
+    idx1 = torch.tensor([0, 1, 2, 0, 1, 2]); idx2 = torch.tensor([1, 2, 0, 2, 0, 1])
+    s1 = torch.tensor([0, 0, 0, 1, 1, 1]); s2 = torch.tensor([2, 2, 2, -1, 3, -1])
+    counts = torch.tensor([4, 4, 4])
+    e_hip = torch.cat([idx1, idx2]).int().clone(); e_hip[T + 4] = 2            # token 4's SECOND choice differs
+    s_hip = torch.cat([s1, s2]).int().clone(); s_hip[T + 1] = -1                 # token 1 (agreeing) dropped on the HIP side only
+    per, same = routing_report([((idx1, idx2), (s1, s2), counts)], [(e_hip, s_hip, counts.int())], T, 4, None)
+    p = per[0]
+    assert p["flipped_tokens"] == 1 and abs(p["expert_agreement"] - 5 / 6) < 1e-6 and p["first_choice_agreement"] == 1.0
+    assert p["dropped_entries_oracle"] == 2 and p["dropped_entries_hip"] == 3 and p["kept_state_differs_on_agreeing_rows"] == 1
+    assert same.tolist() == [True, True, True, True, False, True]
