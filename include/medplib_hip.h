@@ -107,6 +107,13 @@ int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, int64_t
  * (1, 2, 4, 8 or 16 x 512). */
 int mp_gemv_rmsnorm_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W, int64_t ldw, void* y, int64_t ldy,
                          int M, int N, int K, int act, int out_dtype, hipStream_t stream);
+/* The decode step's q|k|v projection with both neighbours folded in: input_layernorm (as mp_gemv_rmsnorm_bf16) in front, RoPE at position
+ * *pos_dev and the KV-cache append (as mp_decode_rope_append_bf16) behind.  Writes the rotated q into the q third of qkv [M, 3*H*D] (the k and v
+ * thirds are not written), the rotated k and v into the caches [B, max_len, H, D] at that position.  Bit-identical with the three launches. */
+int mp_gemv_rmsnorm_rope_append_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W_qkv, int64_t ldw, void* qkv,
+                                     int64_t ldy, const float* cos_t, const float* sin_t, void* cache_k, void* cache_v, const int* pos_dev,
+                                     int M, int heads, int head_dim, int K, int64_t cache_batch_stride, int64_t cache_seq_stride,
+                                     hipStream_t stream);
 
 /* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
  * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never

@@ -283,6 +283,125 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const flo
   }
 }
 
+// The decode step's q|k|v projection with BOTH neighbours folded in: input_layernorm in front (gemv_rmsnorm_kernel's prologue) and RoPE at
+// the device-side position + the KV-cache append behind it (mp_decode_rope_append_bf16's arithmetic: the projection rounded to bf16, then
+// lo' = fma(lo, cos, -(hi * sin)), hi' = fma(lo, sin, hi * cos) in fp32, rounded to bf16 — the forms that kernel compiles to).  A wave of the
+// q and k thirds owns the rotary pairs (c, c + 1) and (c + D/2, c + D/2 + 1) of one head instead of four consecutive columns, so both
+// partners of a rotation sit in the same lane-0 registers; a wave of the v third keeps four consecutive columns.  Outputs: the rotated q in
+// the q third of `y` (the k and v thirds of y are NOT written), rotated k and v at cache position pos_dev[0].  Same bits as the three launches.
+struct RopeArgs {
+  const float* cos_t; const float* sin_t;    // [positions, D/2]
+  bf16_t* ck; bf16_t* cv;                    // caches [B, max_len, H, D]
+  const int* pos_dev;
+  int H, D;
+  int64_t c_sb, c_ss;
+};
+
+template <int M, int NCH>
+__global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, const float* __restrict__ nw, float eps, RopeArgs ra) {
+  // the normalised row goes through a per-wave LDS region and the weight stream runs as a RUNTIME loop, two steps per trip (8 loads in
+  // flight) like gemv_shared_kernel: with the row in registers and the loop unrolled the compiler kept ~320 values live (256 VGPRs + 63
+  // AGPRs, one wave per SIMD) and the launch took 42 us against the 26.5 of the three launches it replaces
+  __shared__ __attribute__((aligned(16))) bf16_t hsh[4][M][NCH * 512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 4 + wv;
+  const int d = ra.H * ra.D, half = ra.D / 2;
+  const int per_region = d / 4;                            // waves per third
+  if (wid >= 3 * per_region) return;
+  const int region = wid / per_region, idx = wid % per_region;
+  const int per_head = ra.D / 4;
+  const int head = idx / per_head, c = (idx % per_head) * 2;
+  const int row0 = region < 2 ? region * d + head * ra.D + c : 2 * d + idx * 4;          // wave-uniform
+  const int step2 = region < 2 ? half : 2;                                               // rows: row0, +1, +step2, +step2 + 1
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)(row0 + (r & 1) + (r >> 1) * step2) * g.ldw;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
+    bf16x8 hx[NCH];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      hx[k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)hx[k][j]; part[k & 3] += f * f; }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) ss += wave_sum(part[w4]);
+    const float rs = rsqrtf(ss / (float)g.K + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = (k * 64 + lane) * 8;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16_t t = (bf16_t)((float)hx[k][j] * rs);
+        o[j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
+      }
+      *reinterpret_cast<bf16x8*>(&hsh[wv][m][i]) = o;        // lane l reads back exactly the chunks it wrote: no barrier needed
+    }
+  }
+  float acc[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+  int kk = lane * 8;
+#pragma unroll 1
+  for (int it = 0; it + 1 < NCH; it += 2, kk += 1024) {
+    bf16x8 w0[4], w1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk + 512); }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk + 512]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+    }
+  }
+  if (NCH & 1) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + kk), acc[m][r]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+  if (lane != 0) return;
+  const int pos = ra.pos_dev[0];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)(acc[m][r] * g.alpha);        // the projection's own bf16 rounding
+    if (region == 2) {
+      bf16_t* vd = ra.cv + m * ra.c_sb + (int64_t)pos * ra.c_ss + idx * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vd[r] = (bf16_t)v[r];
+      continue;
+    }
+    const float* cs = ra.cos_t + (int64_t)pos * half + c;
+    const float* sn = ra.sin_t + (int64_t)pos * half + c;
+    bf16_t o[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float lo = v[p], hi = v[2 + p];
+      o[p] = (bf16_t)fmaf(lo, cs[p], -(hi * sn[p]));
+      o[2 + p] = (bf16_t)fmaf(lo, sn[p], hi * cs[p]);
+    }
+    bf16_t* dst = region == 0 ? reinterpret_cast<bf16_t*>(g.y) + (int64_t)m * g.ldy + head * ra.D
+                              : ra.ck + m * ra.c_sb + (int64_t)pos * ra.c_ss + head * ra.D;
+    dst[c] = o[0]; dst[c + 1] = o[1]; dst[half + c] = o[2]; dst[half + c + 1] = o[3];
+  }
+}
+
 template <int M>
 void launch_shared(const GemvArgs& g, dim3 grid, hipStream_t s) {
   if (g.act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL((gemv_shared_kernel<M, true>), grid, dim3(256), 0, s, g);
@@ -354,4 +473,31 @@ extern "C" int mp_gemv_rmsnorm_bf16(const void* x, int64_t ldx, const float* nor
 #undef MP_GVN_M
 #undef MP_GVN
   return mp_check_launch("mp_gemv_rmsnorm_bf16");
+}
+
+extern "C" int mp_gemv_rmsnorm_rope_append_bf16(const void* x, int64_t ldx, const float* norm_w, float eps, const void* W_qkv, int64_t ldw,
+                                                void* qkv, int64_t ldy, const float* cos_t, const float* sin_t, void* cache_k, void* cache_v,
+                                                const int* pos_dev, int M, int heads, int head_dim, int K, int64_t cache_batch_stride,
+                                                int64_t cache_seq_stride, hipStream_t stream) {
+  MP_REQUIRE(M >= 1 && M <= 2 && heads > 0 && head_dim % 16 == 0 && K >= 512 && K % 512 == 0 && K <= 8192 && ldx % 8 == 0 && ldw % 8 == 0,
+             MP_ERR_SHAPE, "mp_gemv_rmsnorm_rope_append_bf16: 1 <= M <= 2, head_dim %% 16 == 0, K a multiple of 512 up to 8192");
+  MP_REQUIRE(norm_w && cos_t && sin_t && cache_k && cache_v && pos_dev, MP_ERR_ARG, "mp_gemv_rmsnorm_rope_append_bf16: null operand");
+  const int N = 3 * heads * head_dim;
+  GemvArgs g{(const bf16_t*)x, ldx, (const bf16_t*)W_qkv, ldw, 0, qkv, ldy, nullptr, nullptr, 0, nullptr, nullptr, nullptr, M, N, K, ACT_NONE,
+             0, 1.f};
+  RopeArgs ra{cos_t, sin_t, (bf16_t*)cache_k, (bf16_t*)cache_v, pos_dev, heads, head_dim, cache_batch_stride, cache_seq_stride};
+  const dim3 grid((unsigned)mp_cdiv(N / 4, 4));
+#define MP_GVR(MM, NC) hipLaunchKernelGGL((gemv_rmsnorm_rope_kernel<MM, NC>), grid, dim3(256), 0, stream, g, norm_w, eps, ra)
+#define MP_GVR_M(NC) do { if (M == 1) MP_GVR(1, NC); else MP_GVR(2, NC); } while (0)
+  switch (K / 512) {
+    case 1: MP_GVR_M(1); break;
+    case 2: MP_GVR_M(2); break;
+    case 4: MP_GVR_M(4); break;
+    case 8: MP_GVR_M(8); break;
+    case 16: MP_GVR_M(16); break;
+    default: MP_REQUIRE(false, MP_ERR_SHAPE, "mp_gemv_rmsnorm_rope_append_bf16: K / 512 must be 1, 2, 4, 8 or 16 (K=%d)", K);
+  }
+#undef MP_GVR_M
+#undef MP_GVR
+  return mp_check_launch("mp_gemv_rmsnorm_rope_append_bf16");
 }

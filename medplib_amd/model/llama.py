@@ -322,11 +322,12 @@ class LlamaStack:
         self.gate_pass += 1
         fold = ops.gemv_rmsnorm_ok(B, d)                      # input_layernorm inside the qkv GEMV (same bits, one launch less per layer)
         for i, lw in enumerate(self.layers):
-            if fold:
-                qkv = ops.gemv_rmsnorm(x, lw["ln1"], cfg.rms_norm_eps, lw["qkv"])
+            if fold:                                            # norm + projection + RoPE + cache append: one launch, the three launches' bits
+                qkv = ops.gemv_rmsnorm_rope_append(x, lw["ln1"], cfg.rms_norm_eps, lw["qkv"], self.cos, self.sin, kv_cache["k"][i],
+                                                   kv_cache["v"][i], counters[0:1], H, D)
             else:
                 qkv = ops.gemv(ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps), lw["qkv"])
-            ops.decode_rope_append(qkv, self.cos, self.sin, kv_cache["k"][i], kv_cache["v"][i], counters[0:1], H, D)
+                ops.decode_rope_append(qkv, self.cos, self.sin, kv_cache["k"][i], kv_cache["v"][i], counters[0:1], H, D)
             q4 = qkv.view(B, 1, 3, H, D)[:, :, 0]
             attn = ops.attention(q4, kv_cache["k"][i], kv_cache["v"][i], causal=False, sk_dev=counters[1:2])
             x = ops.gemv(attn.view(B, d), lw["o"], residual=x)

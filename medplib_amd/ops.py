@@ -235,6 +235,19 @@ def gemv_rmsnorm(x, norm_w, eps, w, out_dtype=torch.bfloat16, act=ACT_NONE):
     return out
 
 
+def gemv_rmsnorm_rope_append(x, norm_w, eps, w_qkv, cos_t, sin_t, cache_k, cache_v, pos_dev, heads, head_dim):
+    """One decode-step launch for input_layernorm -> q|k|v projection -> RoPE at pos_dev[0] -> KV-cache append (bit-identical with
+    rmsnorm + gemv + decode_rope_append).  Returns qkv [M, 3*H*D] of which only the q third is written (the rotated q)."""
+    _chk(x, torch.bfloat16, "gemv_rmsnorm_rope.x"); _chk(w_qkv, torch.bfloat16, "gemv_rmsnorm_rope.w"); _chk(pos_dev, torch.int32, "gemv_rmsnorm_rope.pos")
+    M, K = x.shape
+    assert w_qkv.shape == (3 * heads * head_dim, K) and x.stride(1) == 1 and w_qkv.stride(1) == 1
+    assert cache_k.stride(3) == 1 and cache_k.stride(2) == head_dim and cache_v.stride() == cache_k.stride()
+    qkv = torch.empty((M, 3 * heads * head_dim), dtype=torch.bfloat16, device=x.device)
+    lib().call("mp_gemv_rmsnorm_rope_append_bf16", _p(x), x.stride(0), _p(norm_w), float(eps), _p(w_qkv), w_qkv.stride(0), _p(qkv), qkv.stride(0),
+               _p(cos_t), _p(sin_t), _p(cache_k), _p(cache_v), _p(pos_dev), M, heads, head_dim, K, cache_k.stride(0), cache_k.stride(1), _stream())
+    return qkv
+
+
 def gemv_rmsnorm_ok(M, K):
     return M <= 2 and K % 512 == 0 and (K // 512) in (1, 2, 4, 8, 16)
 

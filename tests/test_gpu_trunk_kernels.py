@@ -374,6 +374,31 @@ def test_gemv_decode_projections(dev):
     assert torch.equal(out[2].cpu(), res[2]), "a capacity-dropped row keeps the residual stream exactly"
 
 
+def test_decode_qkv_launch_equals_norm_gemv_rope_append(dev):
+    """mp_gemv_rmsnorm_rope_append_bf16 (a decode step's input_layernorm -> q|k|v projection -> RoPE at the device-side position -> KV-cache
+    append in ONE launch) against mp_rmsnorm_bf16 + mp_gemv_bf16 + mp_decode_rope_append_bf16: the rotated q and the appended cache rows
+    carry EQUAL bits, other cache rows are untouched; head dims 128 and 64, one and two sequences, several positions."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(29)
+    for (B, H, D, K, pos) in [(1, 32, 128, 4096, 0), (1, 32, 128, 4096, 641), (2, 4, 64, 512, 7), (2, 8, 128, 1024, 99)]:
+        d = H * D
+        x = _bf(torch.randn(B, K, generator=g) * 1.3).to(dev)
+        w = _bf(torch.randn(3 * d, K, generator=g) * 0.05).to(dev)
+        nw = (1.0 + 0.2 * torch.randn(K, generator=g)).to(dev)
+        ang = torch.rand(700, D // 2, generator=g) * 6.28
+        cos_t, sin_t = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+        posd = torch.tensor([pos], dtype=torch.int32, device=dev)
+        fill = _bf(torch.randn(B, 700, H, D, generator=g)).to(dev)
+        ck_a, cv_a, ck_b, cv_b = fill.clone(), fill.clone(), fill.clone(), fill.clone()
+        ref = ops.gemv(ops.rmsnorm(x, nw, 1e-5), w)
+        ops.decode_rope_append(ref, cos_t, sin_t, ck_a, cv_a, posd, H, D)
+        got = ops.gemv_rmsnorm_rope_append(x, nw, 1e-5, w, cos_t, sin_t, ck_b, cv_b, posd, H, D)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:, :d], ref[:, :d]), (B, H, D, K, pos, "q")
+        assert torch.equal(ck_b, ck_a) and torch.equal(cv_b, cv_a), (B, H, D, K, pos, "cache")
+        assert not torch.equal(ck_b[:, pos], fill[:, pos])
+
+
 def test_gemv_with_folded_rmsnorm_is_bit_identical(dev):
     """mp_gemv_rmsnorm_bf16 (the decode steps' input_layernorm inside the qkv GEMV) against mp_rmsnorm_bf16 followed by mp_gemv_bf16: EQUAL
     bits, bf16 and fp32 outputs, one and two rows, K = 512 ... 8192 (every wave reproduces the norm kernel's summation order)."""
