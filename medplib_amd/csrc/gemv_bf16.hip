@@ -190,6 +190,73 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
   }
 }
 
+// The shared core of the norm-folded GEMVs: every wave normalises the M rows (HF rounding points, rmsnorm_bf16_kernel's summation order),
+// parks them in its own LDS region and streams its four weight rows against them in a RUNTIME loop, two steps per trip (8 weight loads in
+// flight).  Unrolled with the rows in registers the compiler kept ~320 values live in the RoPE form (256 VGPRs + 63 AGPRs, one wave per
+// SIMD, 42 us instead of 24); this form takes ~100 VGPRs, four waves per SIMD.  acc[m][r] = the wave-reduced dot products.
+template <int M, int NCH>
+__device__ __forceinline__ void gv_norm_rows_dot(const GemvArgs& g, const float* __restrict__ nw, float eps, const bf16_t* const (&wp)[4],
+                                                 int lane, int wv, float (&acc)[M][4]) {
+  __shared__ __attribute__((aligned(16))) bf16_t hsh[4][M][NCH * 512];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
+    bf16x8 hx[NCH];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      hx[k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)hx[k][j]; part[k & 3] += f * f; }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) ss += wave_sum(part[w4]);
+    const float rs = rsqrtf(ss / (float)g.K + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = (k * 64 + lane) * 8;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16_t t = (bf16_t)((float)hx[k][j] * rs);
+        o[j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
+      }
+      *reinterpret_cast<bf16x8*>(&hsh[wv][m][i]) = o;        // lane l reads back exactly the chunks it wrote: no barrier needed
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+  int kk = lane * 8;
+#pragma unroll 1
+  for (int it = 0; it + 1 < NCH; it += 2, kk += 1024) {
+    bf16x8 w0[4], w1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk + 512); }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk + 512]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+    }
+  }
+  if (NCH & 1) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + kk), acc[m][r]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+}
+
 // RMSNorm folded into the GEMV (decode steps: input_layernorm -> qkv projection, final norm -> lm_head).  Every wave normalises the
 // row itself — K bf16 (8 KB at 7B) from L2 and two wave reductions, nothing beside the 4 x K weight stream it is about to read — and
 // keeps the normalised row in registers; the stand-alone norm kernel's launch (5 us of a 130 us decode layer) disappears.  BIT-IDENTICAL
@@ -214,51 +281,8 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const flo
   const bf16_t* wp[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)min(rows[r], g.N - 1) * g.ldw;
-  bf16x8 hx[M][NCH];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      hx[m][k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = (float)hx[m][k][j]; part[k & 3] += f * f; }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 4; ++wv) ss += wave_sum(part[wv]);
-    const float rs = rsqrtf(ss / (float)g.K + eps);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int i = (k * 64 + lane) * 8;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bf16_t t = (bf16_t)((float)hx[m][k][j] * rs);          // HF: the normalised value is cast to the input dtype first
-        hx[m][k][j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
-      }
-    }
-  }
   float acc[M][4];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    bf16x8 w0[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + (k * 64 + lane) * 8);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(hx[m][k], w0[r], acc[m][r]);
-  }
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+  gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, threadIdx.x >> 6, acc);
   if (lane != 0) return;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -302,7 +326,6 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
   // the normalised row goes through a per-wave LDS region and the weight stream runs as a RUNTIME loop, two steps per trip (8 loads in
   // flight) like gemv_shared_kernel: with the row in registers and the loop unrolled the compiler kept ~320 values live (256 VGPRs + 63
   // AGPRs, one wave per SIMD) and the launch took 42 us against the 26.5 of the three launches it replaces
-  __shared__ __attribute__((aligned(16))) bf16_t hsh[4][M][NCH * 512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wid = blockIdx.x * 4 + wv;
   const int d = ra.H * ra.D, half = ra.D / 2;
@@ -316,64 +339,8 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
   const bf16_t* wp[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)(row0 + (r & 1) + (r >> 1) * step2) * g.ldw;
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
-    bf16x8 hx[NCH];
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      hx[k] = *reinterpret_cast<const bf16x8*>(xr + (k * 64 + lane) * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = (float)hx[k][j]; part[k & 3] += f * f; }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) ss += wave_sum(part[w4]);
-    const float rs = rsqrtf(ss / (float)g.K + eps);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int i = (k * 64 + lane) * 8;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bf16_t t = (bf16_t)((float)hx[k][j] * rs);
-        o[j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
-      }
-      *reinterpret_cast<bf16x8*>(&hsh[wv][m][i]) = o;        // lane l reads back exactly the chunks it wrote: no barrier needed
-    }
-  }
   float acc[M][4];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
-  int kk = lane * 8;
-#pragma unroll 1
-  for (int it = 0; it + 1 < NCH; it += 2, kk += 1024) {
-    bf16x8 w0[4], w1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk + 512); }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk + 512]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
-    }
-  }
-  if (NCH & 1) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + kk), acc[m][r]);
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+  gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, wv, acc);
   if (lane != 0) return;
   const int pos = ra.pos_dev[0];
 #pragma unroll
