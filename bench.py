@@ -525,7 +525,7 @@ def main():
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            tname = next((n for n in ("r03k_hbm_traffic.json", "r03j_hbm_traffic.json", "r03i_hbm_traffic.json", "r03h_hbm_traffic.json", "r03d_hbm_traffic.json", "r03c_hbm_traffic.json", "r03a_hbm_traffic.json", "r02s_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+            tname = next((n for n in ("r03m_hbm_traffic.json", "r03k_hbm_traffic.json", "r03j_hbm_traffic.json", "r03i_hbm_traffic.json", "r03h_hbm_traffic.json", "r03d_hbm_traffic.json", "r03c_hbm_traffic.json", "r03a_hbm_traffic.json", "r02s_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
                           if os.path.exists(os.path.join(pdir, n))), None)
             tpath = os.path.join(pdir, tname or "")
             if tname:
