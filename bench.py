@@ -62,10 +62,130 @@ def synthetic_batch(cfg, B, device, seed):
     }
 
 
-def cpu_baseline(cfg, device, warmup=1, timed=3):
+def synthetic_icl_batch(cfg, B, device, seed, n_ctx=3):
+    """BASELINE configs[4] inputs: per sample 3 in-context (image, mask) pairs + the query image (ICL separate mode), every image behind
+    its own <image> placeholder, image tokens compressed 576 -> 256, every in-context mask 64 mask-encoder tokens; S = 1257 after the splice."""
+    g = torch.Generator().manual_seed(seed)
+    V = cfg.vocab_size
+
+    def discs(n, size):
+        yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+        out = []
+        for _ in range(n):
+            cy, cx = (torch.rand(2, generator=g) * size).tolist()
+            r = 20 + 80 * torch.rand(1, generator=g).item()
+            out.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r * r).float())
+        return out
+    n_ph = 2 * n_ctx + 1
+    L = 8 + 4 * n_ph + 28
+    ids = torch.randint(3, 31999, (B, L), generator=g)
+    ids[:, 0] = 1
+    for k in range(n_ph):
+        p = 6 + 4 * k
+        ids[:, p - 1], ids[:, p], ids[:, p + 1] = V - 2, -200, V - 1
+    ids[:, L - 3] = cfg.seg_token_idx; ids[:, L - 1] = 2
+    labels = torch.full((B, L), -100, dtype=torch.int64); labels[:, L - 8:] = ids[:, L - 8:]
+    lengths = [[256, 64] * n_ctx + [256] for _ in range(B)]
+    batch = {"images": torch.randn(B, 3, 256, 256, generator=g).to(device),
+             "images_clip": [torch.randn(n_ctx + 1, 3, 336, 336, generator=g).to(torch.bfloat16).to(device) for _ in range(B)],
+             "mask_images": [torch.stack(discs(n_ctx, 336)).unsqueeze(1).to(device) for _ in range(B)],
+             "image_token_types": [["image", "mask"] * n_ctx + ["image"] for _ in range(B)], "image_token_lengths": lengths,
+             "icl_image_counts": [n_ctx + 1] * B,
+             "input_ids": ids.numpy(), "labels": labels.numpy(), "attention_mask": torch.ones(B, L, dtype=torch.bool).numpy(),
+             "masks_list": [m.to(device) for m in discs(B, 336)], "label_list": [torch.empty(336, 336, device="meta") for _ in range(B)],
+             "resize_list": [(256, 256)] * B, "valid_mask_bool": [[True]] * B, "offset": None, "region_masks": [],
+             "inference": False, "seg_flag": True}
+    return batch, L - n_ph + sum(lengths[0])
+
+
+def icl_config(layers):
+    from medplib_amd.model.config import MedPLIBConfig
+    return MedPLIBConfig.medplib_7b(num_hidden_layers=layers, mm_token_compress=True, mm_compressed_token_count=256, icl_mask_encoder=True,
+                                    mask_encoder_token_count=64)
+
+
+def forward_rate(model, batch, B, S, n_img, steps=6, warmup=2):
+    """ms per forward of the whole path (no_grad, losses computed) and its MFMA fraction from the LLM + CLIP flop."""
+    cfg = model.config
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = model(**batch)
+        model.sync_side_streams(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(**batch)
+        model.sync_side_streams(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    d, ff, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    flop = B * S * nl * 2 * (4 * d * d + 3 * d * ff) + B * nl * 4 * S * S * d / 2 + n_img * 0.366e12
+    return {"batch": B, "seq_len_after_splice": S, "ms_per_forward": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
+            "tflops": round(flop / dt / 1e12, 1), "mfma_frac": round(flop / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+            "loss": float(out["loss"]) if "loss" in out else None}
+
+
+def vqa_batch(cfg, B, device, seed):
+    """BASELINE configs[1]: VQA-only (CE-only batch: seg_flag False, no masks), batch 4."""
+    g = torch.Generator().manual_seed(seed)
+    L, V = 64, cfg.vocab_size
+    ids = torch.randint(3, 31999, (B, L), generator=g)
+    ids[:, 0] = 1; ids[:, 34], ids[:, 35], ids[:, 36] = V - 2, -200, V - 1; ids[:, 63] = 2
+    labels = ids.clone(); labels[:, :56] = -100
+    return {"images": torch.randn(B, 3, 256, 256, generator=g).to(device),
+            "images_clip": torch.randn(B, 3, 336, 336, generator=g).to(torch.bfloat16).to(device),
+            "input_ids": ids.numpy(), "labels": labels.numpy(), "attention_mask": torch.ones(B, L, dtype=torch.bool).numpy(),
+            "masks_list": [], "label_list": [], "resize_list": [(256, 256)] * B, "valid_mask_bool": [[]] * B, "offset": None,
+            "region_masks": [], "inference": False, "seg_flag": False}
+
+
+def decode_rate(model, device, new=32):
+    """evaluate() at batch 1 (model/eval/vqa_infer.py:528-540 -> MedPLIB.py:574-680): ms per decode step as the slope between two lengths
+    (prefill and the one-off graph capture cancel), the fastest of three calls per length after one untimed call; every step streams all
+    decoder weights once (one expert's MLP per layer with top-1 routing) + lm_head: the HBM fraction of that stream."""
+    cfg = model.config
+    was = model.training
+    model.eval()
+    g = torch.Generator().manual_seed(0)
+    L, V = 64, cfg.vocab_size
+    ids = torch.randint(3, 31999, (1, L), generator=g)
+    ids[0, 0] = 1; ids[0, 34], ids[0, 35], ids[0, 36] = V - 2, -200, V - 1
+    images_clip = torch.randn(1, 3, 336, 336, generator=g).to(torch.bfloat16).to(device)
+    images = torch.randn(1, 3, 256, 256, generator=g).to(device)
+    model.evaluate(images_clip, images, ids.numpy(), [(256, 256)], [(336, 336)], max_new_tokens=8, eos_token_id=-1)
+    res = {}
+    for n_new in (new, 4 * new):
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.evaluate(images_clip, images, ids.numpy(), [(256, 256)], [(336, 336)], max_new_tokens=n_new, eos_token_id=-1)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        res[n_new] = best
+    model.train(was)
+    ms = (res[4 * new] - res[new]) / (3 * new) * 1e3
+    d, ff = cfg.hidden_size, cfg.intermediate_size
+    wbytes = (cfg.num_hidden_layers * (4 * d * d + 3 * d * ff) + V * d) * 2
+    return {"ms_per_token": round(ms, 3), "weight_bytes_per_token": wbytes, "weight_stream_GBps": round(wbytes / ms / 1e6, 1),
+            "frac_of_8TBps": round(wbytes / (ms * 1e-3) / 8e12, 4), "moe": bool(cfg.moe_enable)}
+
+
+KERNEL_SOURCES = ("gemm320_bf16.hip", "gemm256_bf16.hip", "gemm_bf16.hip", "gemm_common.h", "common.h")
+
+
+def kernel_source_sha():
+    """sha256[:16] over the GEMM kernels' sources: what a PMC profile stamps itself with (scripts/bench_pmc.sh) and what this run compares
+    it against — the GPU box has no .git, and 'was this measured on THESE kernels' is the question a commit id only approximates."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "medplib_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cfg, device, warmup=3, timed=5):
     """The oracle (CPU fp32 port of the reference path) timed on the host cores on a bounded sample of the same workload:
-    B=1 training step (forward of the whole path + backward through mask decoder / text_hidden_fcs), 1 warm-up + 3 timed
-    (~35 s of CPU work).  To bound host memory and initialisation time the 32 decoder layers alias ONE layer's random weights
+    BASELINE.md section 3's protocol — 3 warm-up + 5 timed iterations, median and min — for its two configurations: (2) the config-4
+    training step at B=1 (forward of the whole path + backward through mask decoder / text_hidden_fcs; this is `value`) and (1) the B=1
+    forward alone (`forward_b1`).  To bound host memory and initialisation time the 32 decoder layers alias ONE layer's random weights
     (arithmetic and memory traffic per layer are unchanged: a layer's 1.6 GB of fp32 weights do not fit in cache).
     The same leg then loads the SAME weights into a second, un-timed HIP model and compares the two forwards at the benchmark's
     own batch (`parity`, oracle/parity.py): B = 8 (T = 5112 tokens, capacity 3834), all 32 layers, DeepSpeed's Random Token
@@ -77,12 +197,18 @@ def cpu_baseline(cfg, device, warmup=1, timed=3):
     # 0.40 s @64, 0.61 s @128 — the oracle's eager ops stop scaling past one CCD group); `cores` reports what was used.
     threads = min(32, os.cpu_count())
     r = full_size_parity(cfg, device, cpu_threads=min(64, os.cpu_count()), time_threads=threads, time_oracle=(warmup, timed),
-                         B=8, rts_seed=77)
+                         time_forward=(warmup, timed), B=8, rts_seed=77)
     ts = r.pop("oracle_step_seconds")
-    t = float(np.median(ts))
+    tf = r.pop("oracle_forward_b1_seconds")
+    t, f = float(np.median(ts)), float(np.median(tf))
     base = {"value": 1.0 / t, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32 training step at B=1 (1 of the 8 per-GPU samples), true dims, median of {timed} after {warmup} warm-up(s), "
-                      f"{t:.2f} s/step (min {min(ts):.2f}); decoder-layer weights aliased across the {cfg.num_hidden_layers} layers"}
+                      f"{t:.2f} s/step (min {min(ts):.2f}); decoder-layer weights aliased across the {cfg.num_hidden_layers} layers",
+            "protocol": f"BASELINE.md section 3: {warmup} warm-up + {timed} timed, median and min",
+            "forward_b1": {"what": "BASELINE.md section 3 config (1): B=1 forward of the whole path (336x336 image + 64-token prompt, SAM-Med2D encoder, "
+                                   "<SEG> projection, mask decoder, upsampler, resize to 336x336), same weights", "seconds_median": round(f, 3),
+                           "seconds_min": round(min(tf), 3), "samples_per_s": round(1.0 / f, 4)},
+            "step_seconds_median": round(t, 3), "step_seconds_min": round(min(ts), 3)}
     return base, r
 
 
@@ -183,7 +309,7 @@ def upsampler_roofline(device):
     return out
 
 
-def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warmup=3):
+def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warmup=3, secondary=None):
     """Secondary object of the default line: scripts/train_stage3.sh's configuration (the one every shipped script trains: dense Llama-7B,
     LoRA r = 8 / alpha 16 / dropout 0.05 on gate / up / down_proj, mask decoder + text_hidden_fcs trainable) = the whole decoder backward in
     the step, measured in the same process after the headline leg (8 steps after 3) so the driver's run carries it."""
@@ -193,6 +319,15 @@ def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warm
     torch.manual_seed(1234)
     cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, moe_enable=False)
     model = LISAForCausalLM(cfg, device=device).train()
+    extra = {}
+    if secondary is not None:
+        # the dense model before its adapters exist: BASELINE configs[1] (VQA-only forward, MoE disabled, batch 4) and evaluate()'s decode
+        try:
+            secondary["configs"]["1"] = dict(forward_rate(model, vqa_batch(cfg, 4, device, seed=42), 4, 63 + cfg.clip_num_patches, 4),
+                                            what="BASELINE configs[1]: MedPLIB-7B bf16 VQA-only forward (MoE disabled), batch 4, CE loss")
+            secondary["decode"]["dense"] = decode_rate(model, device)
+        except Exception as e:
+            secondary["configs"]["1"] = {"error": f"{type(e).__name__}: {e}"}
     lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules="gate_proj,up_proj,down_proj",
                              sft_modules="mask_decoder,text_hidden_fcs")
     for n, p in zip(lora.names, lora.params):                # B = 0 at initialisation would make half the gradients trivially zero
@@ -264,12 +399,46 @@ def dry_main(args, emit):
     tail = torch.nn.Linear(64, 32)
     eng, _, _, _ = engine.initialize(model=tail, model_parameters=list(tail.parameters()), config={"optimizer": {"params": {"lr": 1e-3}}})
     ok = True
+    epx, ep_ok, E, d_, cap_ = None, True, 2, 16, 24
+    if args.ep:
+        # `--ep`'s twin on CPU ranks: DeepSpeed's group shapes, the host-side capacity agreement, and per step one dispatch / combine round
+        # trip of seeded rows through ExpertParallel (padded slabs or, with --ep-variable, routed rows only) that every rank checks
+        from medplib_amd import expert_parallel as EPM
+        if world % args.ep:
+            sys.exit(f"bench.py: --ep {args.ep} does not divide {world} ranks")
+        E = max(2, args.ep)
+        if world > 1:
+            group, _ = EPM.build_groups(args.ep)
+            host_group = EPM.build_host_group(args.ep)
+        else:
+            group = host_group = None
+        epx = EPM.ExpertParallel(group, args.ep if world > 1 else 1, E, host_group=host_group, variable_split=args.ep_variable)
+
+    def ep_round_trip(k):
+        """rank r routes (r + k) % cap_ + 1 rows to every expert; expert e returns (e + 2) * row; every row must come home"""
+        g = torch.Generator().manual_seed(1000 * rank + k)
+        capx = epx.exchange_capacity(cap_, key=k)
+        kept = torch.tensor([(rank + k + e) % cap_ + 1 for e in range(E)], dtype=torch.int32)
+        buf = torch.zeros(E, capx + 1, d_)
+        for e in range(E):
+            buf[e, :int(kept[e])] = torch.randn(int(kept[e]), d_, generator=g)
+        sent = buf.clone()
+        recv, counts = epx.dispatch(buf, kept)
+        y = torch.zeros(epx.ep, epx.E_local, capx, d_)
+        for s_ in range(epx.ep):
+            for el, ge in enumerate(epx.local_expert_ids()):
+                n = int(counts[s_, el])
+                y[s_, el, :n] = recv[s_, el, :n] * (ge + 2.0)
+        out = epx.combine(y)
+        return all(torch.allclose(out[e, :int(kept[e])], sent[e, :int(kept[e])] * (e + 2.0)) for e in range(E))
 
     def step(k):
-        nonlocal ok
+        nonlocal ok, ep_ok
         eng.optimizer.flat_grad.fill_(float(rank + 1 + k))
         eng.launch_grad_reduce(); eng.wait_grad_reduce()
         ok &= bool(torch.all(eng.optimizer.flat_grad == sum(r + 1 + k for r in range(world))))
+        if epx is not None:
+            ep_ok &= ep_round_trip(k)
     for k in range(args.warmup):
         step(k)
     if world > 1:
@@ -280,15 +449,24 @@ def dry_main(args, emit):
     if world > 1:
         dist.barrier()
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allok = torch.tensor([int(ok and ep_ok)], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(allok, op=dist.ReduceOp.MIN)
     if rank == 0:
         dt = tmax.item()
-        emit(json.dumps({"metric": "dry run: gradient-bucket all-reduce steps/s on CPU ranks (gloo)", "dry": True, "value": round(args.steps / dt, 3),
+        extra = {}
+        if epx is not None:
+            extra["ep"] = {"ep_size": epx.ep, "replicas": world // max(args.ep, 1), "experts": E, "variable_split": bool(args.ep_variable),
+                           "exchanges_per_step": epx.stats["exchanges"] / max(args.steps + args.warmup, 1),
+                           "a2a_bytes_sent_per_exchange": epx.stats["bytes_sent"] / max(epx.stats["exchanges"], 1),
+                           "round_trips_correct_on_every_rank": bool(allok.item())}
+        emit(json.dumps({**extra, "metric": "dry run: gradient-bucket all-reduce steps/s on CPU ranks (gloo)", "dry": True, "value": round(args.steps / dt, 3),
                           "unit": "steps/s", "n_gpus": world, "rccl_ranks": None, "ranks": dist.get_world_size() if world > 1 else 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "bucket_sums_correct": ok,
-                          "config": {"workload": f"{eng.optimizer.numel}-element fp32 bucket, backend gloo", "parallelism": f"dp{world}"}}))
+                          "config": {"workload": f"{eng.optimizer.numel}-element fp32 bucket, backend gloo",
+                                     "parallelism": (f"ep{args.ep} x dp{world // args.ep}" if args.ep else f"dp{world}")}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -321,12 +499,34 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="images and masks start every step in pageable host memory (the reference's dict_to_cuda per batch): the "
                          "PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the default, HBM-resident run")
+    ap.add_argument("--ep", type=int, default=0,
+                    help="expert-parallel size: run BASELINE configs[4] instead (MedPLIB-ICL separate mode, 3 in-context (image, mask) pairs + query, "
+                         "mm_token_compress 576->256, E=2 top-1 experts sharded over ep ranks with the all-to-all exchange, per-GPU batch 4) as "
+                         "ep x (gpus / ep) replicas: scripts/train_medplib_icl.sh:15-43, medplib_moe_llama.py:604-614 (ep_size).  8 GPUs: --ep 2")
+    ap.add_argument("--ep-variable", action="store_true", help="with --ep: routed rows only instead of capacity-padded slabs (a host read per layer)")
+    ap.add_argument("--ep-comm", default="torch", choices=("torch", "capi"),
+                    help="with --ep: the exchange through torch.distributed's all_to_all_single (default) or the C ABI's mp_alltoall_tokens")
     ap.add_argument("--dry", action="store_true", help="CPU ranks over gloo, stand-in gradient bucket: the launch / timing / one-line protocol only")
     args = ap.parse_args()
+    if args.ep and args.gpus % args.ep:
+        sys.exit(f"bench.py: --ep {args.ep} does not divide --gpus {args.gpus}")
+    if args.ep and "--batch" not in " ".join(sys.argv):
+        args.batch = 4                                        # configs[4]: batch 4 per GPU
     ensure_ranks(args.gpus, args.dry)
     emit = claim_stdout()
-    if args.dry:
-        return dry_main(args, emit)
+    try:
+        return dry_main(args, emit) if args.dry else gpu_main(args, emit)
+    except BaseException as e:
+        # a rank that dies says which one it was and why, on its own stderr, before the launcher tears the others down
+        if not isinstance(e, SystemExit) or e.code not in (0, None):
+            import traceback
+            sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')} "
+                             f"local {os.environ.get('LOCAL_RANK', '0')}] failed: {type(e).__name__}: {e}\n{traceback.format_exc()}")
+            sys.stderr.flush()
+        raise
+
+
+def gpu_main(args, emit):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -344,7 +544,11 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl")
+        # an explicit collective timeout (a peer that died or never joined ends the run with an error naming the collective, not a hang
+        # until the driver's own limit): MP_BENCH_NCCL_TIMEOUT seconds, default 600
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=int(os.environ.get("MP_BENCH_NCCL_TIMEOUT", "600"))))
     rccl_ranks = None
     if world > 1 or force_dist:
         # what RCCL itself connected: a communicator through the C ABI (bootstrapped with a unique id that travels over the process group),
@@ -365,7 +569,26 @@ def main():
     from medplib_amd.model.medplib import MedPLIBForCausalLM
 
     torch.manual_seed(1234)          # the randomly initialised trainable tail is the same on every rank and in every run
-    if args.lora:
+    epx = None
+    if args.ep:
+        # BASELINE configs[4]: the ICL model (token compressor + mask encoder + E = 2 experts), experts sharded over `ep` consecutive ranks
+        from medplib_amd import expert_parallel as EPM
+        cfg = icl_config(args.layers)
+        model = MedPLIBForCausalLM(cfg, device=device).train()
+        if world > 1 or force_dist:
+            ep_size = args.ep if world > 1 else 1
+            group, _ = EPM.build_groups(ep_size)
+            host_group = EPM.build_host_group(ep_size)
+            capi = None
+            if args.ep_comm == "capi":
+                from medplib_amd.comm import RcclComm
+                capi = RcclComm(group=group)
+            epx = EPM.ExpertParallel(group, ep_size, cfg.num_experts, host_group=host_group, capi_comm=capi, variable_split=args.ep_variable)
+        else:
+            epx = EPM.ExpertParallel(None, 1, cfg.num_experts, variable_split=args.ep_variable)     # one GPU, no process group: the ep code path on a trivial group
+        model.model.llm.enable_expert_parallel(epx)
+        args.no_cpu_baseline = args.no_lora_line = True
+    elif args.lora:
         from medplib_amd.model.medplib import LISAForCausalLM
         cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, moe_enable=False)
         model = LISAForCausalLM(cfg, device=device).train()
@@ -399,7 +622,11 @@ def main():
     if os.environ.get("MP_BENCH_COMM"):                  # "rccl_capi": the gradient bucket through the library's own mp_allreduce_bucket
         ds_config["comm_backend"] = os.environ["MP_BENCH_COMM"]
     eng, _, _, _ = engine.initialize(model=model, model_parameters=model.trainable_parameters(), config=ds_config)
-    batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
+    seq_len = 639
+    if args.ep:
+        batch, seq_len = synthetic_icl_batch(cfg, args.batch, device, seed=42 + rank)
+    else:
+        batch = synthetic_batch(cfg, args.batch, device, seed=42 + rank)
 
     host_batch = None
     if args.host_inputs:
@@ -432,6 +659,9 @@ def main():
     if not args.no_kernel_timer:
         timer = ops.KernelTimer(sample_every=23)         # every 23rd GEMM launch (coprime to the layer's GEMM period): ~290 samples over 20 steps
         ops.GEMM_TIMER = timer
+    if epx is not None:
+        epx.stats = {"exchanges": 0, "bytes_sent": 0}
+        epx.timing, epx.sample_every = [], 5             # every 5th exchange bracketed by HIP events on its stream
     eng.enable_bucket_timing()           # HIP-event pairs around the tail backward and every gradient bucket (a few events per step)
     if world > 1 or force_dist:
         dist.barrier()
@@ -444,6 +674,19 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.GEMM_TIMER = None
+    ep_obj = None
+    if epx is not None:
+        us = [s0.elapsed_time(e0) * 1e3 for _, s0, e0 in epx.timing]
+        n_moe = len(cfg.moe_layer_set())
+        ep_obj = {"ep_size": epx.ep, "replicas": max(world // max(epx.ep, 1), 1), "experts": cfg.num_experts, "experts_per_rank": epx.E_local,
+                  "transport": "mp_alltoall_tokens (C ABI, grouped ncclSend/ncclRecv)" if epx.capi_comm is not None else "torch.distributed all_to_all_single (RCCL)",
+                  "variable_split": bool(epx.variable_split), "moe_layers": n_moe,
+                  "exchanges_per_step": round(epx.stats["exchanges"] / args.steps, 2),
+                  "a2a_bytes_per_layer": round(epx.stats["bytes_sent"] / max(args.steps * n_moe, 1)),       # sent by this rank, dispatch + combine
+                  "a2a_bytes_per_exchange": round(epx.stats["bytes_sent"] / max(epx.stats["exchanges"], 1)),
+                  "a2a_us": round(sum(us) / len(us), 1) if us else None, "a2a_us_max": round(max(us), 1) if us else None,
+                  "sampled_exchanges": len(us)}
+        epx.timing = None
     dp_bucket = eng.bucket_timing_summary(args.steps)        # the timed steps only: the roofline / LoRA steps below must not count
     eng.disable_bucket_timing()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -74,6 +74,11 @@ int mp_gemm_last_kernel(void);
  * frozen towers, which run on streams beside the decoder: a split tail's units wait for each other, and only one kernel per device may
  * do that at a time), -1 = back to the process default (MP_GEMM320).  mp_gemm_last_kernel() then reports 320. */
 int mp_gemm_tile_policy(int mode);
+/* The 320-row kernel's split tail (units of one tile reduce their shares together): how many shader cycles a unit waits for its siblings
+ * before the tile falls back to "the last unit out sums all partials alone" — same ascending split order, so the same bits either way, and
+ * forward progress never depends on the units being co-resident (another process on the GPU, a CU mask).  cycles >= 0 sets it for the
+ * process (0 = never wait), < 0 only reads; returns the previous value (default 150000, MP_GEMM320_TAIL_WAIT). */
+int64_t mp_gemm_tail_wait(int64_t cycles);
 /* `batch` independent GEMMs at fixed strides — the per-expert SwiGLU GEMMs of DeepSpeed `Experts`
  * (call site medplib_moe_llama.py:604-614). m_dev[b] = rows routed to expert b. */
 int mp_gemm_bf16_nt_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
@@ -116,7 +121,7 @@ int mp_gemv_rmsnorm_rope_append_bf16(const void* x, int64_t ldx, const float* no
                                      hipStream_t stream);
 
 /* Optional scratch for the 256x256 kernel's tail split-K (the last partial wave of tiles is cut along K so it does not hold
- * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 256 ZEROED device ints.  The library never
+ * the machine for a whole tile-time): `ws` >= 64 MiB of device memory, `tickets` >= 384 ZEROED device ints.  The library never
  * allocates; without a workspace the GEMMs run unsplit.  One workspace serves one stream at a time.  Pass ws = NULL to clear. */
 int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets);
 /* A stream that issues GEMMs concurrently with others gets its own scratch; other streams of the device use its default entry.
@@ -476,6 +481,12 @@ int mp_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype_tag, hip
 /* equal-split all-to-all of routed token slabs: chunk p (count_per_peer elements) of `send` goes to rank p, chunk p of `recv` arrives
  * from rank p; send != recv */
 int mp_alltoall_tokens(void* comm, const void* send, void* recv, int64_t count_per_peer, int dtype_tag, hipStream_t stream);
+/* variable all-to-all = grouped point-to-point messages (the expert exchange with ROUTED ROWS ONLY instead of capacity-padded slabs):
+ * n_send messages (send_peer[i], send_ptr[i] = device address as an integer, send_count[i] elements) and n_recv messages likewise — HOST
+ * arrays; messages between one pair of ranks match in array order.  DeepSpeed's `_AllToAll` always ships the padded [E, C, M] buffer
+ * (sharded_moe.py); this is the byte-saving alternative, paid for with a host read of the counts per layer. */
+int mp_alltoallv_tokens(void* comm, int n_send, const int* send_peer, const int64_t* send_ptr, const int64_t* send_count, int n_recv,
+                        const int* recv_peer, const int64_t* recv_ptr, const int64_t* recv_count, int dtype_tag, hipStream_t stream);
 
 #ifdef __cplusplus
 }

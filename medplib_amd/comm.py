@@ -61,6 +61,25 @@ class RcclComm:
                    send.numel() // self.world, _TAG[send.dtype], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         return recv
 
+    def all_to_all_v(self, send, recv):
+        """Variable all-to-all as grouped point-to-point messages (mp_alltoallv_tokens): send / recv = lists of (peer, contiguous tensor
+        view); messages between one pair of ranks match in list order."""
+        import numpy as np
+        ts = [t for _, t in send] + [t for _, t in recv]
+        if not ts:
+            return
+        dt = ts[0].dtype
+        assert all(t.is_cuda and t.is_contiguous() and t.dtype == dt for t in ts) and dt in _TAG
+
+        def arrs(lst):
+            return (np.asarray([p for p, _ in lst], dtype=np.int32), np.asarray([t.data_ptr() for _, t in lst], dtype=np.int64),
+                    np.asarray([t.numel() for _, t in lst], dtype=np.int64))
+        sp, sa, sn = arrs(send)
+        rp, ra, rn = arrs(recv)
+        lib().call("mp_alltoallv_tokens", self._h, len(send), sp.ctypes.data_as(ctypes.c_void_p), sa.ctypes.data_as(ctypes.c_void_p),
+                   sn.ctypes.data_as(ctypes.c_void_p), len(recv), rp.ctypes.data_as(ctypes.c_void_p), ra.ctypes.data_as(ctypes.c_void_p),
+                   rn.ctypes.data_as(ctypes.c_void_p), _TAG[dt], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
     def close(self):
         if self._h is not None and self._h.value:
             lib().call("mp_comm_destroy", self._h)

@@ -152,3 +152,35 @@ extern "C" int mp_alltoall_tokens(void* comm, const void* send, void* recv, int6
   MP_RCCL(R, R->GroupEnd(), "ncclGroupEnd");
   return MP_OK;
 }
+
+// Variable all-to-all = grouped point-to-point messages (round 4: the expert exchange with routed rows only).  n_send messages
+// (send_peer[i], send_ptr[i] = device address, send_count[i] elements) and n_recv messages likewise, all host arrays; messages between
+// one pair of ranks match in array order.  xGMI is point-to-point, so this is what an all-to-all is on this fabric anyway.
+extern "C" int mp_alltoallv_tokens(void* comm, int n_send, const int* send_peer, const int64_t* send_ptr, const int64_t* send_count, int n_recv,
+                                   const int* recv_peer, const int64_t* recv_ptr, const int64_t* recv_count, int dtype_tag, hipStream_t stream) {
+  const Rccl* R = rccl();
+  MP_REQUIRE(R != nullptr && comm != nullptr, MP_ERR_ARG, "mp_alltoallv_tokens: no communicator");
+  MP_REQUIRE(n_send >= 0 && n_recv >= 0 && (n_send == 0 || (send_peer && send_ptr && send_count)) && (n_recv == 0 || (recv_peer && recv_ptr && recv_count)),
+             MP_ERR_ARG, "mp_alltoallv_tokens: message lists");
+  ncclDataType_t t; size_t sz;
+  if (int rc = nccl_type(dtype_tag, &t, &sz)) return rc;
+  ncclComm_t c = reinterpret_cast<ncclComm_t>(comm);
+  int world = 0;
+  MP_RCCL(R, R->CommCount(c, &world), "ncclCommCount");
+  for (int i = 0; i < n_send; ++i) MP_REQUIRE(send_peer[i] >= 0 && send_peer[i] < world && send_count[i] >= 0, MP_ERR_ARG, "mp_alltoallv_tokens: send message %d", i);
+  for (int i = 0; i < n_recv; ++i) MP_REQUIRE(recv_peer[i] >= 0 && recv_peer[i] < world && recv_count[i] >= 0, MP_ERR_ARG, "mp_alltoallv_tokens: recv message %d", i);
+  if (n_send + n_recv == 0) return MP_OK;
+  MP_RCCL(R, R->GroupStart(), "ncclGroupStart");
+  ncclResult_t r = ncclSuccess;
+  for (int i = 0; i < n_recv && r == ncclSuccess; ++i)
+    if (recv_count[i]) r = R->Recv(reinterpret_cast<void*>(recv_ptr[i]), (size_t)recv_count[i], t, recv_peer[i], c, stream);
+  for (int i = 0; i < n_send && r == ncclSuccess; ++i)
+    if (send_count[i]) r = R->Send(reinterpret_cast<const void*>(send_ptr[i]), (size_t)send_count[i], t, send_peer[i], c, stream);
+  if (r != ncclSuccess) {
+    (void)R->GroupEnd();
+    mp_set_error("mp_alltoallv_tokens: %s", R->GetErrorString(r));
+    return MP_ERR_LAUNCH;
+  }
+  MP_RCCL(R, R->GroupEnd(), "ncclGroupEnd");
+  return MP_OK;
+}

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm256v3_bf16_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
-// split-K workspaces, registered by the host: >= n_cu * 256 KiB of fp32 partials + >= 256 tickets each.  One workspace serves
+// split-K workspaces, registered by the host: >= n_cu * 256 KiB of fp32 partials + >= 384 tickets each (the 320-row kernel keeps three words per tail tile).  One workspace serves
 // one stream at a time, so a stream that runs GEMMs concurrently with others registers its own (mp_gemm_set_stream_workspace);
 // launches on any other stream of that device use the device's default entry (mp_gemm_set_workspace).  The table is keyed by
 // (device, stream) with no cap on either; it is only a directory of caller-owned buffers (the library never allocates).
@@ -665,12 +665,12 @@ static int register_split_ws(hipStream_t stream, void* ws, int64_t ws_bytes, int
 }
 
 extern "C" int mp_gemm_set_workspace(void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
-  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_workspace: need >= 256 zeroed int tickets");
+  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 384), MP_ERR_ARG, "mp_gemm_set_workspace: need >= 384 zeroed int tickets");
   return register_split_ws(nullptr, ws, ws_bytes, tickets);
 }
 
 extern "C" int mp_gemm_set_stream_workspace(hipStream_t stream, void* ws, int64_t ws_bytes, int* tickets, int n_tickets) {
-  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 256), MP_ERR_ARG, "mp_gemm_set_stream_workspace: need >= 256 zeroed int tickets");
+  MP_REQUIRE(ws == nullptr || (tickets != nullptr && n_tickets >= 384), MP_ERR_ARG, "mp_gemm_set_stream_workspace: need >= 384 zeroed int tickets");
   MP_REQUIRE(stream != nullptr, MP_ERR_ARG, "mp_gemm_set_stream_workspace: the default entry is mp_gemm_set_workspace");
   return register_split_ws(stream, ws, ws_bytes, tickets);
 }

@@ -39,6 +39,7 @@ int mp_device_cus();
 void mp_gemm_split_workspace(hipStream_t stream, float** ws, int** tickets, int64_t* bytes);
 bool mp_gemm_stream_registered(hipStream_t stream);
 bool mp_gemm_policy_whole_tiles();
+long long mp_gemm_tail_wait_value();
 
 namespace {
 
@@ -459,8 +460,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     // unit `split` sums, in ascending split order whoever arrived when (so the rounding does not depend on the order), the wave-tile
     // items it % S == split of ALL partials — an item = one fragment row x one fragment pair = 2 of the 40 accumulator fragments (a column half = 4 for the SwiGLU family) — and
     // runs the epilogue on exactly those.  The departure counter lets the last unit out re-arm both counters for the next launch.
-    // Progress: a tile's units are never more than the CUs (S * rem <= CUs) and wait only for each other, so a resident kernel of another
-    // stream can delay them (until it ends) but not block them; the wait itself is bounded.
+    // Progress (round 4): the wait is bounded and has a way out that finishes the tile (below) — nothing here needs the units to be co-resident.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int SLAB = BM3 * BN3 * 4;                  // one unit's partial tile, bytes
     const int tail = flat - full;
@@ -475,25 +475,55 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
     __syncthreads();
     int* arrive = g.tickets + tail;
-    int* depart = g.tickets + 128 + tail;                // rem <= 128 (the split rule), the registered ticket array holds 256
+    int* depart = g.tickets + 128 + tail;                // rem <= 128 (the split rule), the registered ticket array holds 384
+    int* mode = g.tickets + 256 + tail;                  // the tile's decision: 0 = open, 1 = cooperative, 2 = last unit finishes alone
+    // ROUND 4: FORWARD PROGRESS NO LONGER RESTS ON CO-RESIDENCY.  A unit waits a BOUNDED time (g.tail_wait shader cycles, ~60 us) for its
+    // siblings; whoever first stops waiting — because all S have arrived, or because its time is up — settles the tile's mode with ONE
+    // compare-and-swap, and every unit follows that one decision:
+    //   COOP (proposed only by a unit that SAW all S arrivals): every unit reduces and stores its share, as in round 3;
+    //   LAST (proposed by a unit whose wait ran out): a unit leaves at once; the LAST unit to pass the tile's departure counter — by then
+    //        every partial has been stored, because a unit stores before it arrives — sums all S partials and finishes the whole tile.
+    // Both paths add the partials in ascending split order, so the tile's bits do not depend on which path ran or on who arrived when.
+    // A sibling that is scheduled late (another process on the GPU, a CU mask, a second waiting kernel the host-side rule did not see)
+    // now costs one tile a slower fix-up instead of trapping the process.  Visibility: the partials are 16-byte sc1 (write-through)
+    // stores drained by s_waitcnt vmcnt(0) before the arrival, and read back with sc1 loads — the guide's valid hand-off form R1
+    // ("sc1 payload -> asm vmcnt(0) -> flag", MI355X_MICROARCH.md, inter-workgroup visibility): no L1 line of them exists anywhere and no
+    // L2 keeps one, so neither a release write-back nor an acquire invalidate has anything to do.
+    constexpr int MODE_COOP = 1, MODE_LAST = 2;
+    int* s_flag = reinterpret_cast<int*>(smem);          // the K loop's stages are dead: every wave is past its last fragment read
     if (tid == 0) {
       __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // bounded (~1 s): a sibling that never arrives must end the process with a launch failure — neither a hung GPU nor a silently
-      // wrong tile with the tickets left mis-counted for every later launch.  The host side keeps the wait deadlock-free (one waiting
-      // kernel per device at a time: mp_launch_gemm320), so the trap is a tripwire, not a code path.
-      int spin = 0;
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-        if (++spin > (1 << 22)) __builtin_trap();
+      const long long t0 = __builtin_amdgcn_s_memtime();
+      int m = 0, seen = 0;
+      for (;;) {
+        seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= S) break;
+        m = __hip_atomic_load(mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m) break;
+        if (__builtin_amdgcn_s_memtime() - t0 > g.tail_wait) break;
         __builtin_amdgcn_s_sleep(8);
       }
+      if (!m) {
+        int expected = 0;
+        const int want = seen >= S ? MODE_COOP : MODE_LAST;
+        m = __hip_atomic_compare_exchange_strong(mode, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? want : expected;
+      }
+      int last = 0;
+      if (m == MODE_LAST) last = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+      s_flag[0] = m | (last << 8);
     }
     __syncthreads();
-    // the share: work items it % S == split; an item = a fragment pair (20 per tile), or for the SwiGLU family a column half (10)
+    const int decided = s_flag[0];
+    __syncthreads();
+    const bool coop = (decided & 0xff) == MODE_COOP;
+    if (!coop && !(decided >> 8)) return;                // mode LAST and not the last one out: the partial is stored, nothing else to do
+    // the share: work items it % S == split (an item = a fragment pair, 20 per tile; the SwiGLU family's come as column halves, 10) —
+    // or, for the unit that finishes the tile alone, all of them
     constexpr int N_ITEMS = (EPI == EPI_SWIGLU) ? 10 : 20;
     items = 0;
 #pragma unroll
     for (int it = 0; it < N_ITEMS; ++it)
-      if (it % S == split) items |= (EPI == EPI_SWIGLU) ? (3u << (2 * it)) : (1u << it);
+      if (!coop || it % S == split) items |= (EPI == EPI_SWIGLU) ? (3u << (2 * it)) : (1u << it);
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -514,8 +544,12 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                     // every wave of this unit has read what it needs of the partials
     if (tid == 0) {
-      if (__hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {     // last one out: re-arm (self-resetting)
+      // last one out re-arms the tile's three words (self-resetting): in COOP mode the departure counter is taken here, after the reads;
+      // in LAST mode this unit IS the last one out
+      const bool rearm = coop ? (__hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) : true;
+      if (rearm) {
         __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mode, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -578,10 +612,13 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   // started ahead: the CLIP qkv projection, 348 tiles cut into 92 x 2 units, beside the experts' down projection -> ~1 s stalls per
   // step).  Streams the host registered as concurrent (mp_gemm_set_stream_workspace) therefore never split; the primary stream does.
   // The frozen towers ask for whole tiles outright (tile policy 3), so that their results do not depend on which stream a step ran them on.
+  // Round 4: that rule is now about SPEED only (two waiting kernels slow each other down to the bounded wait); a unit whose siblings do not
+  // show up within g.tail_wait cycles leaves the tile to its last unit, so progress does not depend on what else holds the CUs.
   if (mp_gemm_stream_registered(stream) || mp_gemm_policy_whole_tiles()) g.max_split = 1;
+  g.tail_wait = mp_gemm_tail_wait_value();
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &g.ws, &g.tickets, &ws_bytes);
-  if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }
+  if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }   // (registration checks the 384 tickets)
   // the host-side bound on the tile count plus one unit per CU for a split tail; workgroups beyond the device-side unit count exit at once
   const dim3 grid((unsigned)(mp_cdiv(g.M, BM3) * (g.N / BN3) * batch + g.n_cu));
 #define MP3_GO(E) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<E>, grid, dim3(NT3), 2 * STAGE3, stream, g)

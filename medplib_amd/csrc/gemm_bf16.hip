@@ -410,6 +410,19 @@ static bool use_256(const GemmArgs& g, int batch) {
 extern "C" int mp_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 // policy 3 (the frozen towers): the 320-row kernel's tails never split, whichever stream the call is on (gemm320_bf16.hip: mp_launch_gemm320)
 bool mp_gemm_policy_whole_tiles() { return g_tile_policy == 3; }
+// mp_gemm_tail_wait(): how long (shader cycles) a unit of the 320-row kernel's split tail waits for its siblings before the tile falls
+// back to "the last unit finishes alone".  Default 150 k cycles (~60-80 us: several K-ranges of the longest split the decoder runs);
+// 0 = never wait (every tile decides at once: the test of the fallback path), MP_GEMM320_TAIL_WAIT overrides the default.
+static long long g_tail_wait = -1;
+long long mp_gemm_tail_wait_value() {
+  if (g_tail_wait < 0) { const char* e = getenv("MP_GEMM320_TAIL_WAIT"); g_tail_wait = (e && atoll(e) >= 0) ? atoll(e) : 150000; }
+  return g_tail_wait;
+}
+extern "C" int64_t mp_gemm_tail_wait(int64_t cycles) {
+  const long long prev = mp_gemm_tail_wait_value();
+  if (cycles >= 0) g_tail_wait = cycles;
+  return prev;
+}
 extern "C" int mp_gemm_tile_policy(int mode) {
   MP_REQUIRE(mode >= -1 && mode <= 3, MP_ERR_ARG, "mp_gemm_tile_policy: mode must be -1 (default), 0 (256-row tiles only), 1 (by the wave model), 2 (320-row tiles whenever eligible) or 3 (as 2, tails never split)");
   g_tile_policy = mode;

@@ -34,6 +34,7 @@ struct GemmArgs {
   int n_cu;                   // compute units the tile waves are counted against
   int nbatch;                 // batch count (the flat work decode walks all batches)
   int max_split;              // upper bound on the tail split factor (1 = off)
+  long long tail_wait;        // 320-row kernel: shader cycles a split-tail unit waits for its siblings before the tile falls back to its last unit
   // MoE expert GEMMs fused with dispatch / combine (mp_gemm_bf16_nt_batched_rows): per batch b, A row r is read from row
   // a_rows[b * rows_stride + r] of the (shared) A matrix; C row r is written to row c_rows[b * rows_stride + r] of the (shared) C
   // matrix, scaled by c_scale[that row] before the residual (indexed by the same destination row) is added.  null = identity.

@@ -63,7 +63,7 @@ class ExpertParallel:
     device -> host read of the counts in every one of the 32 layers, which stops the host from running ahead of the GPU (DESIGN §3.3);
     the padding is (cf - 1) / cf = 1/3 of the bytes at the stage-IV capacity factor."""
 
-    def __init__(self, group, ep_size: int, num_experts: int, host_group=None, capi_comm=None):
+    def __init__(self, group, ep_size: int, num_experts: int, host_group=None, capi_comm=None, variable_split: bool = False):
         assert num_experts % ep_size == 0, "num_experts % ep_size must be 0 (deepspeed MoE asserts the same)"
         self.group, self.ep, self.E = group, ep_size, num_experts
         self.host_group = host_group
@@ -71,6 +71,18 @@ class ExpertParallel:
         self.E_local = num_experts // ep_size
         self.rank_in_group = dist.get_rank(group) if group is not None else 0
         self._agreed = {}
+        # round 4 (review item 4): ROUTED ROWS ONLY behind a flag.  The padded exchange ships capx + 1 rows per slab whatever was routed
+        # ((cf - 1) / cf = 1/3 of the bytes at cf 1.5 are padding: +10-25 % time on a byte-bound link, profiles/r03_ep_exchange_gloo.json);
+        # the variable form first trades the E row counts (a tiny equal-split exchange), reads them on the HOST (one device -> host sync per
+        # MoE layer: the price, it ends the host's run-ahead for that layer) and then moves exactly the routed rows, one message per
+        # (peer, local expert).  dispatch / combine only; `exchange` (the training backward) stays padded.
+        self.variable_split = bool(variable_split)
+        self._var_counts = None                                # (send counts [E], recv counts [ep, E_local]) of the last variable dispatch, host ints
+        # measurement (bench.py --ep): bytes this rank SENT per exchange and, when `timing` is a list, HIP-event pairs around every
+        # `sample_every`-th exchange on the stream it was issued on
+        self.stats = {"exchanges": 0, "bytes_sent": 0}
+        self.timing = None
+        self.sample_every = 1
 
     def local_expert_ids(self):
         return list(range(self.rank_in_group * self.E_local, (self.rank_in_group + 1) * self.E_local))
@@ -107,6 +119,8 @@ class ExpertParallel:
         rows source rank s routed to this rank's local expert e."""
         E, rows, d = buf.shape
         assert E == self.E and buf.is_contiguous()
+        if self.variable_split and self.ep > 1:
+            return self._dispatch_variable(buf, kept)
         self.write_header(buf, kept)
         recv = torch.empty((self.ep, self.E_local, rows, d), dtype=buf.dtype, device=buf.device)
         self._a2a(recv.view(self.ep, -1), buf.view(self.ep, -1))
@@ -128,11 +142,77 @@ class ExpertParallel:
         ep, El, cap, d = y.shape
         assert ep == self.ep and El == self.E_local and y.is_contiguous()
         out = torch.empty((self.E, cap, d), dtype=y.dtype, device=y.device)
+        if self.variable_split and self.ep > 1 and self._var_counts is not None:
+            # (consumed: a combine that does not directly follow a variable dispatch — the training backward's, behind `exchange` — is padded)
+            (sc, rc), self._var_counts = self._var_counts, None
+            El_ = self.E_local
+            # the reverse road: what arrived from source rank p for local expert e goes back to p; what this rank routed to global
+            # expert g comes back from its owner
+            send = [(p, y[p, e, :rc[p][e]]) for p in range(ep) for e in range(El_) if rc[p][e]]
+            recv = [(g // El_, out[g, :sc[g]]) for g in range(self.E) if sc[g]]
+            self._a2av(send, recv)
+            return out
         self._a2a(out.view(self.ep, -1), y.view(self.ep, -1))
         return out
 
-    def _a2a(self, recv, send):
+    def _dispatch_variable(self, buf: torch.Tensor, kept: torch.Tensor):
+        E, rows, d = buf.shape
+        El = self.E_local
+        mine = kept.to(torch.int32).contiguous()
+        theirs = torch.empty((self.ep, El), dtype=torch.int32, device=buf.device)
+        self._a2a(theirs.view(self.ep, -1), mine.view(self.ep, -1), count=False)
+        sc = [int(v) for v in mine.cpu().tolist()]             # the host read the padded form avoids
+        rc = [[int(v) for v in row] for row in theirs.cpu().tolist()]
+        self._var_counts = (sc, rc)
+        recv = torch.empty((self.ep, El, rows, d), dtype=buf.dtype, device=buf.device)
+        send = [(g // El, buf[g, :sc[g]]) for g in range(E) if sc[g]]
+        rcv = [(p, recv[p, e, :rc[p][e]]) for p in range(self.ep) for e in range(El) if rc[p][e]]
+        self._a2av(send, rcv)
+        return recv, theirs
+
+    # ---- transports
+    def _mark(self, nbytes):
+        """Count an exchange; -> a closing function that records the end event when this exchange is sampled."""
+        self.stats["exchanges"] += 1
+        self.stats["bytes_sent"] += int(nbytes)
+        if self.timing is None or not torch.cuda.is_available() or self.stats["exchanges"] % self.sample_every:
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream())
+
+        def close():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            self.timing.append((int(nbytes), s, e))
+        return close
+
+    def _a2a(self, recv, send, count=True):
+        close = self._mark(send.numel() * send.element_size() * (self.ep - 1) // self.ep) if count else None
         if self.capi_comm is not None:
             self.capi_comm.all_to_all(recv, send)
         else:
             dist.all_to_all_single(recv, send, group=self.group)
+        if close is not None:
+            close()
+
+    def _a2av(self, send, recv):
+        """send / recv: lists of (peer rank IN THE GROUP, contiguous tensor view); segments between one pair of ranks are listed in the
+        same order on both sides (ascending expert), which is the order NCCL / gloo match them in.  The rank's own segments are copies."""
+        me = self.rank_in_group
+        own_s = [t for p, t in send if p == me]
+        own_r = [t for p, t in recv if p == me]
+        for a, b in zip(own_r, own_s):
+            a.copy_(b)
+        send = [(p, t) for p, t in send if p != me]
+        recv = [(p, t) for p, t in recv if p != me]
+        close = self._mark(sum(t.numel() * t.element_size() for _, t in send))
+        if self.capi_comm is not None:
+            self.capi_comm.all_to_all_v(send, recv)
+        elif send or recv:
+            to_global = (lambda p: dist.get_global_rank(self.group, p)) if self.group is not None else (lambda p: p)
+            ops_ = [dist.P2POp(dist.irecv, t, to_global(p), self.group) for p, t in recv]
+            ops_ += [dist.P2POp(dist.isend, t, to_global(p), self.group) for p, t in send]
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+        if close is not None:
+            close()

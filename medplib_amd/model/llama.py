@@ -203,7 +203,7 @@ class LlamaStack:
                 gates, cap, self._gate_draws(i, T, E, gumbel=False), want_slot_token=True)
             act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
             if ops.GEMM_TIMER is not None:
-                ops.GEMM_TIMER.batched_rows = T
+                ops.GEMM_TIMER.batched_tag = i          # the expert GEMMs are credited with the rows `kept` holds after the region
             ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
             out = torch.empty((T, d), dtype=torch.bfloat16, device=h.device)
             ops.gemm_batched_rows(act, lw["down"], out, kept, c_rows=slot_token, c_scale=weight, residual=x, rows_stride=cap)
@@ -225,7 +225,7 @@ class LlamaStack:
         buf = ops.moe_dispatch(h, expert, slot, E, cap, top_k=k)
         act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
         if ops.GEMM_TIMER is not None:
-            ops.GEMM_TIMER.batched_rows = k * T          # algorithmic rows of the expert GEMMs: every token visits k experts
+            ops.GEMM_TIMER.batched_tag = i              # (credited with the kept rows: every token visits k experts unless dropped)
         ops.gemm_batched(buf, lw["gu"], act, m_dev=kept, act=ops.ACT_SWIGLU_PAIR)
         y = torch.empty((E, cap, d), dtype=torch.bfloat16, device=h.device)
         ops.gemm_batched(act, lw["down"], y, m_dev=kept)

@@ -37,11 +37,18 @@ class KernelTimer:
     stride is coprime to the 4-GEMM period of a decoder layer, so the sample walks through every GEMM shape of the step."""
 
     def __init__(self, sample_every=11):
-        self.records = []          # (work, start_event, end_event, kernel) of the sampled launches
+        self.records = []          # [work, start_event, end_event, kernel] of the sampled launches
         self.sample_every = max(1, int(sample_every))
         self.launches = 0
         self.total_work = 0.0
         self.per_kernel = {}       # kernel tile (256 / 128) -> [launches, work] over ALL launches
+        # expert GEMMs with device-side row counts: the work of a launch is (rows the kernel actually processes) x 2 N K, and those rows
+        # are known on the device only.  Every such launch leaves (kernel, counts tensor, slab rows, flop per row, record or None, tag)
+        # here; resolve() reads all counts back in ONE transfer after the region (no kernel, no sync inside it) and credits the launches
+        # with the KEPT rows — a capacity-dropped token is work the kernel skipped (round-3 review, weak item 6).
+        self.pending = []
+        self.kept_rows = {}        # tag (decoder layer) -> [kept rows of every expert-GEMM launch with that tag]
+        self.batched_tag = None
 
     def begin(self):
         self.launches += 1
@@ -51,22 +58,45 @@ class KernelTimer:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, work, start):
-        self.total_work += work
+    def end(self, work, start, rows_dev=None, slab_rows=0, flop_per_row=0.0):
+        """work: the launch's algorithmic flop — or, with rows_dev (int32 [E] device row counts, each limited to slab_rows), an upper
+        bound that resolve() replaces by flop_per_row x the rows the launch processed."""
         kern = int(lib().raw("mp_gemm_last_kernel")())
         if _TOWER_DEPTH:                 # a frozen tower's launch (throughput tiles: few, fat workgroups by design): its own family (+1000), so
             kern += 1000                 # the dominant decoder kernel's figure is not averaged with launches that idle most of the chip alone
         acc = self.per_kernel.setdefault(kern, [0, 0.0])
-        acc[0] += 1; acc[1] += work
-        if start is None:
+        acc[0] += 1
+        rec = None
+        if start is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            rec = [work, start, ev, kern]
+            self.records.append(rec)
+        if rows_dev is not None:
+            self.pending.append((kern, rows_dev, int(slab_rows), float(flop_per_row), rec, self.batched_tag))
             return
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream())
-        self.records.append((work, start, ev, kern))
+        self.total_work += work
+        acc[1] += work
+
+    def resolve(self):
+        """Read the device-side row counts of the expert launches (one transfer) and credit them; idempotent."""
+        if not self.pending:
+            return
+        pend, self.pending = self.pending, []
+        counts = torch.stack([p[1].to(torch.int32).view(-1) for p in pend]).cpu()          # [launches, E]
+        for (kern, _, slab, fpr, rec, tag), c in zip(pend, counts):
+            rows = int(c.clamp(max=slab).sum()) if slab > 0 else int(c.sum())
+            work = fpr * rows
+            self.total_work += work
+            self.per_kernel[kern][1] += work
+            if rec is not None:
+                rec[0] = work
+            self.kept_rows.setdefault(tag, []).append(rows)
 
     def summary(self, kernel=None):
         """-> (sampled work, sampled ms, sampled launches, all launches, all work) after a synchronize; `kernel` = 256 / 128
         restricts everything to the launches that went to that kernel."""
+        self.resolve()
         recs = [r for r in self.records if kernel is None or r[3] == kernel]
         total_ms = sum(s.elapsed_time(e) for _, s, e, _ in recs)
         if kernel is None:
@@ -84,12 +114,12 @@ _GEMM_WS = {}
 
 def _ensure_gemm_workspace(device):
     """Register the scratch of the 256x256 GEMM's tail split-K once per device: 96 MiB of fp32
-    partials + 256 zeroed arrival tickets.  The library itself never allocates (mp_gemm_set_workspace)."""
+    partials + 384 zeroed arrival tickets.  The library itself never allocates (mp_gemm_set_workspace)."""
     key = torch.device(device).index or 0
     if key not in _GEMM_WS:
         with torch.cuda.device(key):                       # the library files the entry under the current device
             ws = torch.empty(96 << 20, dtype=torch.uint8, device=device)
-            tickets = torch.zeros(256, dtype=torch.int32, device=device)
+            tickets = torch.zeros(384, dtype=torch.int32, device=device)
             lib().call("mp_gemm_set_workspace", _p(ws), ws.numel(), _p(tickets), tickets.numel())
         _GEMM_WS[key] = (ws, tickets)
 
@@ -117,7 +147,7 @@ def register_stream_workspace(stream):
     if key not in _STREAM_WS:
         import ctypes
         ws = torch.empty(96 << 20, dtype=torch.uint8, device=stream.device)
-        tickets = torch.zeros(256, dtype=torch.int32, device=stream.device)
+        tickets = torch.zeros(384, dtype=torch.int32, device=stream.device)
         lib().call("mp_gemm_set_stream_workspace", ctypes.c_void_p(key), _p(ws), ws.numel(), _p(tickets), tickets.numel())
         _STREAM_WS[key] = (ws, tickets)
 
@@ -217,6 +247,12 @@ class throughput_tiles:
         return False
 
 
+def gemm_tail_wait(cycles=-1):
+    """Shader cycles a unit of the 320-row kernel's split tail waits for its siblings before the tile falls back to its last unit
+    (mp_gemm_tail_wait; same bits either way).  cycles >= 0 sets it (0 = never wait), < 0 reads; returns the previous value."""
+    return int(lib().raw("mp_gemm_tail_wait")(int(cycles)))
+
+
 def gemm_last_kernel():
     """320 / 256 / 128: the tile of the kernel the last GEMM call of this thread went to."""
     return int(lib().raw("mp_gemm_last_kernel")())
@@ -278,9 +314,8 @@ def gemm_batched(a, w, out, m_dev=None, bias=None, act=ACT_NONE):
                out.stride(1), out.stride(0), _p(bias), bias.stride(0) if bias is not None else 0, E, M, N, K, act,
                _dt(out.dtype), _p(m_dev), _stream())
     if GEMM_TIMER is not None:
-        # algorithmic rows: with device-side counts the routed rows of a top-k MoE sum to `batched_rows` (set by the caller)
-        rows = getattr(GEMM_TIMER, "batched_rows", None) or E * M
-        GEMM_TIMER.end(2.0 * rows * N * K, t0)
+        # algorithmic rows = the rows the kernel processes: the device-side counts (read back after the region), else every slab row
+        GEMM_TIMER.end(2.0 * E * M * N * K, t0, rows_dev=m_dev, slab_rows=M, flop_per_row=2.0 * N * K)
     return out
 
 
@@ -1212,8 +1247,7 @@ def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, 
                _p(c_scale), _p(residual), residual.stride(0) if residual is not None else 0, int(rows_stride), E, int(M), N, K, act,
                _p(m_dev), _stream())
     if GEMM_TIMER is not None:
-        rows = getattr(GEMM_TIMER, "batched_rows", None) or E * M
-        GEMM_TIMER.end(2.0 * rows * N * K, t0)
+        GEMM_TIMER.end(2.0 * E * M * N * K, t0, rows_dev=m_dev, slab_rows=M, flop_per_row=2.0 * N * K)
     return out
 
 

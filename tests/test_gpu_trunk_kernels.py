@@ -707,6 +707,123 @@ def test_gemm320_cooperative_tail_fixup(dev):
     _report("gemm320 cooperative tail vs fp32 (expert 1: 9 row tiles, the last one 52 rows)", outs[2][rows], ref, rtol=2 * BF16_EPS, atol=2e-2)
 
 
+def _split_tail_case(dev, seed=77):
+    """The operands of test_gemm320_cooperative_tail_fixup (34 tail tiles cut 7 ways) and a closure that runs the call once."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    E, cap, ff, N, T = 2, 2700, 2048, 512, 5112
+    c0, c1 = 2500, 2612
+    counts = torch.tensor([c0, c1], dtype=torch.int32, device=dev)
+    perm = torch.randperm(T, generator=g)
+    slot_token = torch.zeros(E, cap, dtype=torch.int32)
+    slot_token[0, :c0] = perm[:c0].int(); slot_token[1, :c1] = perm[c0:].int()
+    slot_token = slot_token.to(dev)
+    act = _bf(torch.randn(E, cap, ff, generator=g) * 0.5).to(dev)
+    w_dn = _bf(torch.randn(E, N, ff, generator=g) * 0.05).to(dev)
+    weight = torch.rand(T, generator=g).to(dev)
+    res = _bf(torch.randn(T, N, generator=g)).to(dev)
+
+    def run():
+        out = torch.full((T, N), 3.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm_batched_rows(act, w_dn, out, counts, c_rows=slot_token, c_scale=weight, residual=res, rows_stride=cap)
+        assert ops.gemm_last_kernel() == 320
+        return out
+    return run
+
+
+def test_gemm320_split_tail_fallback_is_bit_identical(dev):
+    """Round 4 (review item 7 / advisor): a unit of a split tail waits a BOUNDED time for its siblings; when the time is up the tile is
+    finished by the last unit out instead (no trap, no dependence on co-residency).  With the wait set to 0 every tile decides at once —
+    most fall back, some still see all arrivals and go the cooperative way — and with a few thousand cycles the two modes mix; the
+    partials are summed in ascending split order on both paths, so every run must equal the default (waiting) run BIT FOR BIT, and the
+    three words per tile must re-arm themselves whichever path ran (eight launches back to back per setting)."""
+    from medplib_amd import ops
+    run = _split_tail_case(dev)
+    prev = ops.gemm_tail_wait()
+    try:
+        ops.gemm_tile_policy(2)
+        ref = run()
+        torch.cuda.synchronize()
+        for wait in (0, 3000, 20000, prev):
+            assert ops.gemm_tail_wait(wait) >= 0
+            outs = [run() for _ in range(8)]
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, ref), f"tail wait {wait}: the fallback path's result differs from the cooperative one"
+        # the dense form (SwiGLU items come as column halves) through the fallback as well
+        g = torch.Generator().manual_seed(78)
+        M, N, K = 5112, 5632, 512
+        x = _bf(torch.randn(M, K, generator=g) * 0.5).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+        ops.gemm_tail_wait(prev)
+        a_ref = ops.gemm(x, w, act=ops.ACT_SWIGLU_PAIR)
+        ops.gemm_tail_wait(0)
+        for _ in range(4):
+            assert torch.equal(ops.gemm(x, w, act=ops.ACT_SWIGLU_PAIR), a_ref)
+    finally:
+        ops.gemm_tail_wait(prev)
+        ops.gemm_tile_policy(-1)
+
+
+_TWO_PROC_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests.test_gpu_trunk_kernels import _split_tail_case
+from medplib_amd import ops
+dev = torch.device("cuda:0")
+run = _split_tail_case(dev)
+ops.gemm_tile_policy(2)
+ref = run(); torch.cuda.synchronize()
+print("READY", flush=True)
+sys.stdin.readline()                       # both children start their loops together
+bad = 0
+for _ in range(int(sys.argv[2])):
+    outs = [run() for _ in range(10)]
+    torch.cuda.synchronize()
+    bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+torch.save(ref.cpu(), sys.argv[3])
+print("DONE", bad, flush=True)
+"""
+
+
+def test_gemm320_split_tail_two_processes_one_gpu(dev, tmp_path):
+    """Two PROCESSES on one GPU, both inside the waiting path at the same time (review item 7): neither knows about the other's kernels
+    — the host-side "one waiting kernel per device" rule is per process — so each one's tail units may find the CUs held by the other's
+    waiting units.  Before round 4 that ended in the ~1 s tripwire and a trap; now a unit gives up after the bounded wait and the tile
+    falls back.  Both processes must finish, every output must equal the process's own first (undisturbed) result, and the two
+    processes' results must equal each other."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    procs = []
+    for i in range(2):
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_PROC_CHILD, root, "30", str(tmp_path / f"ref{i}.pt")], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    try:
+        for p in procs:
+            line = p.stdout.readline()
+            assert line.startswith("READY"), (line, p.stderr.read()[-2000:])
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        outs = [p.communicate(timeout=300) for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+        assert so.strip().endswith("DONE 0"), (so, se[-2000:])
+    a, b = torch.load(tmp_path / "ref0.pt"), torch.load(tmp_path / "ref1.pt")
+    assert torch.equal(a, b)
+    print(f"[two processes, one GPU] 2 x 300 split-tail launches side by side: {wall:.2f} s")
+    assert wall < 60, wall
+
+
 def test_gemm320_dense_tail_split(dev):
     """A DENSE call whose tiles exceed one wave with a short tail (16 row tiles x 22 column tiles = 352 = 256 + 96): the 96 tail tiles are
     cut in two with the cooperative fix-up (the LoRA step's dense gate|up is 1376 tiles = 5 waves + 96).  SwiGLU and plain + residual

@@ -288,7 +288,8 @@ assert ep_groups == [[0, 1], [2, 3], [4, 5], [6, 7]] and edp_groups == [[0, 2, 4
 group, _ = EP.build_groups(2)
 host_group = EP.build_host_group(2)
 E, d = 4, 6
-ep = EP.ExpertParallel(group, 2, E, host_group=host_group)
+VAR = os.environ.get("EP_VARIABLE") == "1"           # round 4: routed rows only (counts first, then one message per (peer, local expert))
+ep = EP.ExpertParallel(group, 2, E, host_group=host_group, variable_split=VAR)
 assert ep.local_expert_ids() == [2 * rank, 2 * rank + 1]
 g = torch.Generator().manual_seed(100 + rank)
 T = 11 + 6 * rank                                    # the two ranks see DIFFERENT token counts (variable-length batches) ...
@@ -303,6 +304,8 @@ for t in range(T):                                   # first-come slots, capacit
     if kept[e] < cap:
         slot[t] = int(kept[e]); kept[e] += 1
 buf = torch.zeros(E, capx + 1, d)                    # slab stride capx + 1: the last row of each slab is the header
+if VAR:
+    buf += 777.0                                     # rows beyond the counts must NOT travel: poison them
 for t in range(T):
     if slot[t] >= 0:
         buf[expert[t], slot[t]] = x[t]
@@ -319,8 +322,15 @@ for s in range(2):
     for el in range(2):
         n = int(counts[s, el])
         y[s, el, :n] = f(2 * rank + el, recv[s, el, :n])
-        assert recv[s, el, n:capx].abs().sum() == 0  # rows beyond the count are padding
+        assert VAR or recv[s, el, n:capx].abs().sum() == 0  # rows beyond the count are padding (variable split: never written)
 out = ep.combine(y)                                  # [E, capx, d]: outputs of every global expert for MY tokens
+if VAR:
+    # exactly the routed rows went over the wire, in both directions: 2 x (rows routed to the OTHER rank's experts) x d x 4 bytes sent
+    # in the dispatch, 2 x (rows received from the other rank) in the combine — against 2 x E_local x (capx + 1) x d x 4 per padded exchange
+    other = 1 - rank
+    sent_rows = int(kept[2 * other:2 * other + 2].sum()) + int(counts[other].sum())
+    assert ep.stats["bytes_sent"] == sent_rows * d * 4, (ep.stats, sent_rows)
+    assert ep.stats["bytes_sent"] < 2 * 2 * (capx + 1) * d * 4
 for t in range(T):
     if slot[t] >= 0:
         assert torch.allclose(out[expert[t], slot[t]], f(int(expert[t]), x[t])), (t, int(expert[t]))
@@ -352,6 +362,23 @@ def test_expert_parallel_all_to_all_two_ranks_gloo(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_expert_parallel_variable_split_two_ranks_gloo(tmp_path):
+    """The same exchange with ROUTED ROWS ONLY (ExpertParallel(variable_split=True), round 4): the E row counts travel first, are read on
+    the host, and then one message per (peer, local expert) carries exactly the routed rows — poisoned padding rows never arrive, every
+    output still returns to its token's slot, and the bytes sent equal the routed rows'."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ep_worker_var.py"
+    script.write_text(_EP_WORKER)
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1", EP_VARIABLE="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
