@@ -487,6 +487,7 @@ def main():
                          "contract's default line is BASELINE configs[3] (LoRA off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lora-line", action="store_true", help="skip the secondary LoRA measurement (`lora_stage3`) of the default line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `configs` (BASELINE configs[1], [2], [4] forwards) and `decode` objects of the default line")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--towers-in-order", action="store_true",
                     help="debug / A-B: the frozen CLIP tower of a step queues behind the previous step's decoder instead of starting on its own "
@@ -531,6 +532,7 @@ def gpu_main(args, emit):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    parity_failed = False
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # the GPU leg's host work is index planning on 8 x 64 ids: a handful of threads per rank (N ranks x every core would
@@ -666,6 +668,8 @@ def gpu_main(args, emit):
     if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    mark = (lambda tag: ops.lib().call("mp_profile_marker", tag, torch.cuda.current_stream().cuda_stream)) if os.environ.get("MP_BENCH_MARKERS") == "1" else (lambda tag: None)
+    mark(1)                              # (profiling runs only, scripts/r04_profiles.sh: cut marks for scripts/rocpd_stats.py; the device is idle here)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -673,6 +677,7 @@ def gpu_main(args, emit):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    mark(2)
     ops.GEMM_TIMER = None
     ep_obj = None
     if epx is not None:
@@ -748,6 +753,12 @@ def gpu_main(args, emit):
                                        "frac": round(a_ach / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": a_launches // n_steps,
                                        "sampled_launches": a_sampled, "avg_launch_us": round(a_ms * 1e3 / max(a_sampled, 1), 2),
                                        "tflop_per_step": round(a_all / n_steps / 1e12, 2)}}
+            # the expert GEMMs are credited with the rows they PROCESSED (the device-side `kept` counts, read back after the region): a
+            # capacity-dropped token is work the kernel skips, not work it did
+            if timer.kept_rows:
+                per_layer = [round(sum(v) / len(v)) for _, v in sorted((t, v) for t, v in timer.kept_rows.items() if t is not None)]
+                roof["expert_rows"] = {"credit": "kept rows per launch (device-side counts), not tokens", "tokens": args.batch * seq_len * cfg.top_k_experts,
+                                       "kept_rows_per_layer": per_layer, "kept_rows_min": min(per_layer) if per_layer else None}
             tw = [timer.summary(1000 + k) for k in (320, 256, 128)]        # the frozen towers' launches (throughput tiles), kept apart
             tw_f, tw_ms, tw_n, tw_l = sum(t[0] for t in tw), sum(t[1] for t in tw), sum(t[2] for t in tw), sum(t[3] for t in tw)
             if tw_n:
@@ -767,20 +778,25 @@ def gpu_main(args, emit):
             # HBM-side bytes per launch of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE in separate
             # rocprofv3 runs of this same command, scripts/bench_pmc.sh), which cannot be taken from inside the process: the
             # committed summary is reported with its provenance.  (FETCH_SIZE counts L2 misses incl. Infinity-Cache hits.)
-            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            tname = next((n for n in ("r03m_hbm_traffic.json", "r03k_hbm_traffic.json", "r03j_hbm_traffic.json", "r03i_hbm_traffic.json", "r03h_hbm_traffic.json", "r03d_hbm_traffic.json", "r03c_hbm_traffic.json", "r03a_hbm_traffic.json", "r02s_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
-                          if os.path.exists(os.path.join(pdir, n))), None)
-            tpath = os.path.join(pdir, tname or "")
+            pdir = os.path.join(ROOT, "profiles")
+            import glob
+            cands = sorted(glob.glob(os.path.join(pdir, "r*_hbm_traffic.json")), key=lambda q: os.path.basename(q), reverse=True)
+            tname = os.path.basename(cands[0]) if cands else None
             if tname:
-                tjs = json.load(open(tpath))
+                tjs = json.load(open(os.path.join(pdir, tname)))
                 # (since the towers' GEMMs share the 320-row kernel's plain family, the decoder's launches are the epilogue families 1-3)
                 tj = (tjs.get("gemm320_decoder") if dom == 320 else None) or tjs.get({256: "gemm256v3", 320: "gemm320"}[dom])
-                if tj and not args.lora:
+                if tj and not args.lora and not args.ep:
+                    now, then = kernel_source_sha(), tjs.get("kernel_source_sha")
                     roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
                     roof["traffic_detail"] = {"kernel": fams[dom], "read_bytes_per_launch": tj["read_bytes_per_launch"],
                                               "write_bytes_per_launch": tj["write_bytes_per_launch"],
-                                              "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE over this same command, "
-                                                        "read = 2 x FETCH_SIZE per the gfx950 correction)"}
+                                              "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE over this same command in separate passes, "
+                                                        "read = 2 x FETCH_SIZE per the gfx950 correction): a builder-side profile, NOT measured in this run "
+                                                        "(PMC counters cannot be collected from inside the process)",
+                                              # stale = the GEMM kernels' sources changed since the profile was taken (sha over KERNEL_SOURCES; profiles
+                                              # older than round 4 carry no stamp and count as stale)
+                                              "profile_kernel_source_sha": then, "kernel_source_sha": now, "stale": then != now}
         return roof
 
     if rank == 0:
@@ -798,25 +814,31 @@ def gpu_main(args, emit):
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic" + (" (images / masks copied from pageable host memory every step)" if args.host_inputs else "")
                     + (" (frozen towers started ahead on their own streams)" if model.towers_run_ahead else ""),
-            "config": {"workload": ("MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh; "
+            "config": {"workload": (("MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh; "
                                     "whole decoder backward), " if args.lora else
                                     f"MedPLIB-7B-MoE stage-III training step (CE+BCE+Dice+Focal, LoRA off; E={args.experts} top-{args.top_k} experts x{args.layers} layers"
                                     f"{', use_residual' if args.use_residual else ''}), ") +
                                    "336x336 CLIP image + 256x256 SAM image + 64-token prompt (S=639 after splice), "
-                                   f"per-GPU batch {args.batch}, DP={world}",
-                       "global_batch": world * args.batch, "seq_len": 639, "parallelism": f"dp{world}",
+                                   f"per-GPU batch {args.batch}, DP={world}") if not args.ep else
+                                  (f"BASELINE configs[4]: MedPLIB-ICL separate mode, 3 in-context (image, mask) pairs + query, mm_token_compress 576->256, mask encoder "
+                                   f"64 tokens, E={cfg.num_experts} top-1 experts x{args.layers} layers sharded over ep={epx.ep} ranks with the expert all-to-all, stage-III-style "
+                                   f"training step (CE+BCE+Dice+Focal, LoRA off), S={seq_len} after splice, per-GPU batch {args.batch}, {world} GPU(s)"),
+                       "global_batch": world * args.batch, "seq_len": seq_len,
+                       "parallelism": (f"ep{epx.ep} x dp{max(world // epx.ep, 1)}" if args.ep else f"dp{world}"),
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel,
                        "mask_upsampler": ("fused bf16 kernel, forward + recomputing backward (in the step)" if cfg.fused_bf16_upsampler
                                           else "fp32 tail (6 launches forward, 14 backward)")},
             # algorithmic work per sample: the forward (9.15 TFLOP); with --lora also the decoder's dgrad (8.66: the frozen
             # projections' input gradients + the attention backward; no wgrad for frozen weights)
-            "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1),
+            "model_tflops_per_gpu": (round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1) if not args.ep else None),
             "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
             "roofline": roof, "roofline_timed_region": (roof_timed if timer_u is not None else None),
             # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the
             # communication stream) against the tail backward it follows — both per optimizer step, from HIP events on their streams
             "rccl_ranks": rccl_ranks, "dp_bucket": dp_bucket,
         }
+        if ep_obj is not None:
+            res["ep"] = ep_obj
         print(f"[bench] gpu leg: {value:.2f} samples/s, {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         if world == 1:
             try:
@@ -825,12 +847,39 @@ def gpu_main(args, emit):
                 res["roofline_upsampler"] = upsampler_roofline(device)
             except Exception as e:
                 res["roofline_upsampler"] = {"error": f"{type(e).__name__}: {e}"}
+        secondary = None
+        if world == 1 and not args.lora and not args.ep and not args.no_secondary and (args.experts, args.top_k, args.use_residual) == (2, 1, False):
+            # the other BASELINE configurations and evaluate()'s decode, measured in THIS run (round-3 review: they were builder-only figures)
+            secondary = {"configs": {}, "decode": {}}
+            try:
+                model.sync_side_streams(); torch.cuda.synchronize()
+                secondary["configs"]["2"] = dict(forward_rate(model, batch, args.batch, seq_len, args.batch),
+                                                what="BASELINE configs[2]: MedPLIB-7B-MoE bf16 pixel-grounding forward + SAM-Med2D decoder, batch 8 (the headline model, no_grad)")
+                secondary["decode"]["moe"] = decode_rate(model, device)
+            except Exception as e:
+                secondary["configs"]["2"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.lora and not args.no_lora_line:
             try:
                 model.sync_side_streams(); torch.cuda.synchronize()
-                res["lora_stage3"] = lora_secondary(args, device, ds_config, synthetic_batch, rank)
+                res["lora_stage3"] = lora_secondary(args, device, ds_config, synthetic_batch, rank, secondary=secondary)
             except Exception as e:
                 res["lora_stage3"] = {"error": f"{type(e).__name__}: {e}"}
+        if secondary is not None:
+            try:
+                # BASELINE configs[4] on ONE rank (its 8-GPU form with the expert all-to-all is `bench.py --gpus 8 --ep 2`)
+                from medplib_amd.model.medplib import MedPLIBForCausalLM as _M
+                icfg = icl_config(args.layers)
+                im = _M(icfg, device=device).train()
+                ib, iS = synthetic_icl_batch(icfg, 4, device, seed=42)
+                secondary["configs"]["4"] = dict(forward_rate(im, ib, 4, iS, 16),
+                                                what="BASELINE configs[4] on one rank: MedPLIB-ICL separate mode forward, 3 in-context (image, mask) pairs + query, "
+                                                     "mm_token_compress 576->256, mask encoder, E=2 top-1, batch 4")
+                im.sync_side_streams(); torch.cuda.synchronize()
+                del im, ib
+                torch.cuda.empty_cache()
+            except Exception as e:
+                secondary["configs"]["4"] = {"error": f"{type(e).__name__}: {e}"}
+            res["configs"], res["decode"] = secondary["configs"], secondary["decode"]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # (the parity model is a second set of weights in HBM beside the benchmarked one: 2 x 23 GB of 288)
@@ -839,8 +888,18 @@ def gpu_main(args, emit):
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         emit(json.dumps(res))
+        if res.get("parity"):
+            # the line's own parity object against the bounds the GPU tests assert (oracle/parity.py: check_full_size): a fast line with a
+            # wrong result is not a result — the process fails after printing it
+            from oracle.parity import check_full_size
+            bad = check_full_size(res["parity"], cfg.num_hidden_layers, True)
+            if bad:
+                print("[bench] PARITY VIOLATED: " + "; ".join(bad), file=sys.stderr, flush=True)
+                parity_failed = True
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

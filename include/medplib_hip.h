@@ -43,6 +43,9 @@ typedef struct ihipStream_t* hipStream_t;
 int mp_version(void);
 const char* mp_arch(void);
 const char* mp_last_error_string(void);
+/* Measurement aid: an empty kernel named mp_profile_marker_kernel with `tag` (1..1024) workgroups — a cut mark in a rocprofv3 kernel
+ * trace (bench.py brackets its timed steps with tags 1 / 2; scripts/rocpd_stats.py keeps what lies between). */
+int mp_profile_marker(int tag, hipStream_t stream);
 
 /* ---- bf16 trunk (CLIP ViT-L, Llama-7B(-MoE), SAM-Med2D ViT-B encoder) ------------------------------------------ */
 

@@ -25,3 +25,13 @@ int mp_check_launch(const char* what) {
 extern "C" const char* mp_last_error_string() { return g_err; }
 extern "C" int mp_version() { return 100; }  // 0.1.0
 extern "C" const char* mp_arch() { return "gfx950"; }
+
+// A kernel that does nothing, with a name and a grid size a profile can be cut at: bench.py launches it with tag 1 / 2 around its timed
+// steps (3 / 4 around the unshared roofline steps), scripts/rocpd_stats.py keeps the dispatches between the two — so a per-step kernel
+// table contains the step's kernels only (no weight initialisation, no micro-benchmark loops) and sums to the step.
+__global__ void mp_profile_marker_kernel(int tag) { (void)tag; }
+extern "C" int mp_profile_marker(int tag, hipStream_t stream) {
+  MP_REQUIRE(tag >= 1 && tag <= 1024, MP_ERR_ARG, "mp_profile_marker: tag 1..1024");
+  hipLaunchKernelGGL(mp_profile_marker_kernel, dim3((unsigned)tag), dim3(64), 0, stream, tag);
+  return mp_check_launch("mp_profile_marker");
+}

@@ -25,7 +25,7 @@ from . import ops
 class WarmupDecayLR:
     """DeepSpeed WarmupDecayLR with warmup_type 'linear' (ds_config at train_ds_medplib.py:395-404)."""
 
-    def __init__(self, total_num_steps, warmup_min_lr=0.0, warmup_max_lr=1e-3, warmup_num_steps=0, initial_lr=None, **_):
+    def __init__(self, total_num_steps, warmup_min_lr=0.0, warmup_max_lr=1e-3, warmup_num_steps=0, initial_lr=None, first_step_lr="optimizer", **_):
         self.total, self.min_lr, self.max_lr = max(1, int(total_num_steps)), warmup_min_lr, warmup_max_lr
         self.warmup = max(2, int(warmup_num_steps))            # DeepSpeed clamps warmup_num_steps to >= 2
         self.last_batch_iteration = -1
@@ -34,7 +34,14 @@ class WarmupDecayLR:
         # optimizer step runs at the optimizer's own configured lr (`initial_lr` = ds_config optimizer.params.lr = args.lr), the
         # second at lr(0) = warmup_min_lr, the third at lr(1), ...  ("initialise lr in the optimizer at construction", after which the
         # first step would run at warmup_min_lr, arrived in later DeepSpeed releases.)  Without `initial_lr`: warmup_min_lr.
-        self._lr = self.min_lr if initial_lr is None else float(initial_lr)
+        # Because that reading cannot be checked against the pinned source here, it is a ds_config key, not a constant (round-3 advisor):
+        # scheduler.params.first_step_lr = "optimizer" (default: the reading above — what a reference run of deepspeed==0.13.1 is
+        # understood to do, and what a checkpoint's Adam state would have been built with) or "warmup_min" (the first step at
+        # warmup_min_lr: the behaviour of releases that initialise the optimizer's lr at construction).  One step of difference either way.
+        if first_step_lr not in ("optimizer", "warmup_min"):
+            raise ValueError(f"scheduler.params.first_step_lr must be 'optimizer' or 'warmup_min', got {first_step_lr!r}")
+        self.first_step_lr = first_step_lr
+        self._lr = self.min_lr if (initial_lr is None or first_step_lr == "warmup_min") else float(initial_lr)
         self._initial = self._lr
 
     def _compute(self, it):
@@ -145,6 +152,7 @@ class Engine:
         # layer is done (LoRAState.grad_sink), on the communication stream, while the layers below are still computing; what
         # is left (the fp32 tail, lm_head / embed_tokens, front-end modules) goes in one last bucket after backward returns.
         self._pendings, self._reduced, self._layer_ranges = [], [], {}
+        self._open_marks = []               # closing events of overlapped buckets, recorded where the step waits for them
         lora = getattr(getattr(model, "model", None), "lora", None)
         # (attached on one rank as well: the sink is also how the decoder backward writes adapter gradients straight into the flat buffer)
         if lora is not None and int(config.get("overlap_comm", 1)):
@@ -311,10 +319,16 @@ class Engine:
                 work = None
             else:                                                # torch.distributed ("nccl" = RCCL; gloo in the CPU tests)
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-                if ev is not None and torch.cuda.is_available():
+                if ev is not None and torch.cuda.is_available() and not self._layer_ranges:
                     # the collective runs on the process group's own stream: order this stream behind it (a stream wait, the host does
-                    # not block) so the closing event brackets the RCCL kernel
+                    # not block) so the closing event brackets the RCCL kernel.  ONLY for the single bucket of stage III, which AdamW
+                    # waits for next anyway: with layer buckets this wait would put every bucket between two layers' backward and undo
+                    # the overlap inside the very region that is being timed (round-3 advisor) — those buckets close their event where
+                    # the step waits for them (wait_grad_reduce), i.e. they report issue -> needed, an upper bound of the collective.
                     work.wait()
+                elif ev is not None and work is not None:
+                    self._open_marks.append(ev)
+                    ev = None
             self._mark_end(ev)
         self._pendings.append((work, own_stream))
         self._reduced.append((s, e))
@@ -347,6 +361,9 @@ class Engine:
             if hop:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             self._pendings = []
+            for ev in self._open_marks:
+                ev.record()
+            self._open_marks = []
 
     def step(self):
         boundary = self.is_gradient_accumulation_boundary()

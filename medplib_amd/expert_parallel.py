@@ -190,6 +190,8 @@ class ExpertParallel:
         close = self._mark(send.numel() * send.element_size() * (self.ep - 1) // self.ep) if count else None
         if self.capi_comm is not None:
             self.capi_comm.all_to_all(recv, send)
+        elif self.ep == 1 and not dist.is_initialized():
+            recv.copy_(send)                                   # a one-rank "group" without a process group (bench.py --ep on one GPU): the exchange with oneself
         else:
             dist.all_to_all_single(recv, send, group=self.group)
         if close is not None:

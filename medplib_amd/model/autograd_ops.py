@@ -183,22 +183,30 @@ class FusedUpsampleMaskFn(torch.autograd.Function):
         b1, lnw, lnb, b2 = (t.detach().float().contiguous() for t in (b1, lnw, lnb, b2))
         hyper = hyper.detach().contiguous()
         _, masks = ops.mask_upsample_fused(src_bf, w1p, b1, lnw, lnb, w2p, b2, g, g, hyper=hyper, want_up=False, eps=eps)
-        ctx.save_for_backward(src, src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper)
-        ctx.dims = (n, g, eps)
+        ctx.save_for_backward(src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper)
+        ctx.dims = (n, g, eps, tuple(src.shape))
         return masks
 
     @staticmethod
     def backward(ctx, dm):
-        src, src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper = ctx.saved_tensors
-        n, g, eps = ctx.dims
+        src_bf, w1p, w2p, b1, lnw, lnb, b2, hyper = ctx.saved_tensors
+        n, g, eps, src_shape = ctx.dims
+        need = ctx.needs_input_grad
         dx2, dy1, a1, dy2, part = ops.mask_upsample_fused_bwd(src_bf, w1p, b1, lnw, lnb, w2p, b2, hyper, dm.contiguous().float(), g, g, eps=eps)
-        dx = ops.add_f32(dx2[0], dx2[1]).view_as(src)
-        # packed rows are (kh, kw, cout): back to the reference layout [Cin, Cout, 2, 2]
-        dw1 = ops.sgemm(dy1, src.view(-1, 256), trans_a=True).view(2, 2, 64, 256).permute(3, 2, 0, 1).contiguous()
-        dw2 = ops.sgemm(dy2, a1, trans_a=True).view(2, 2, 32, 64).permute(3, 2, 0, 1).contiguous()
-        cs = ops.colsum_f32(part)
-        dhyper = part[:, 224:].reshape(n, -1, 32).sum(1)
-        return dx, dw1, cs[:64], cs[64:128], cs[128:192], dw2, cs[192:224], dhyper, None, None
+        dx = ops.add_f32(dx2[0], dx2[1]).view(src_shape) if need[0] else None
+        # The weight gradient of the function that was EVALUATED: the forward (and the recomputing backward) consumed the bf16-rounded
+        # tokens, so dW1 = dy1^T . src_bf, not . src (round-3 advisor); the fp32 `src` is no longer kept for the backward at all.
+        # Packed rows are (kh, kw, cout): back to the reference layout [Cin, Cout, 2, 2].  A frozen mask decoder (needs_input_grad false
+        # for every parameter: stage-II-style runs, inference-time gradients w.r.t. the tokens only) skips the GEMMs and column sums.
+        dw1 = dw2 = None
+        if need[1]:
+            dw1 = ops.sgemm(dy1, ops.cast_to_f32(src_bf).view(-1, 256), trans_a=True).view(2, 2, 64, 256).permute(3, 2, 0, 1).contiguous()
+        if need[5]:
+            dw2 = ops.sgemm(dy2, a1, trans_a=True).view(2, 2, 32, 64).permute(3, 2, 0, 1).contiguous()
+        cs = ops.colsum_f32(part) if any(need[i] for i in (2, 3, 4, 6)) else None
+        pick = (lambda i, a, b: cs[a:b] if need[i] else None)
+        dhyper = part[:, 224:].reshape(n, -1, 32).sum(1) if need[7] else None
+        return dx, dw1, pick(2, 0, 64), pick(3, 64, 128), pick(4, 128, 192), dw2, pick(6, 192, 224), dhyper, None, None
 
 
 class BilinearResizeFn(torch.autograd.Function):

@@ -320,7 +320,7 @@ class LlamaStack:
         H, D = cfg.num_attention_heads, cfg.head_dim
         x = emb.reshape(B, d)
         self.gate_pass += 1
-        fold = ops.gemv_rmsnorm_ok(B, d)                      # input_layernorm inside the qkv GEMV (same bits, one launch less per layer)
+        fold = ops.gemv_rmsnorm_ok(B, d, head_dim=D, swiglu_n=2 * cfg.intermediate_size)   # input_layernorm inside the qkv GEMV (same bits, one launch less per layer)
         for i, lw in enumerate(self.layers):
             if fold:                                            # norm + projection + RoPE + cache append: one launch, the three launches' bits
                 qkv = ops.gemv_rmsnorm_rope_append(x, lw["ln1"], cfg.rms_norm_eps, lw["qkv"], self.cos, self.sin, kv_cache["k"][i],

@@ -284,8 +284,19 @@ def gemv_rmsnorm_rope_append(x, norm_w, eps, w_qkv, cos_t, sin_t, cache_k, cache
     return qkv
 
 
-def gemv_rmsnorm_ok(M, K):
-    return M <= 2 and K % 512 == 0 and (K // 512) in (1, 2, 4, 8, 16)
+def gemv_rmsnorm_ok(M, K, head_dim=None, swiglu_n=None):
+    """Whether the decode step may use the norm-folded GEMV launches (mp_gemv_rmsnorm_bf16 / mp_gemv_rmsnorm_rope_append_bf16) — ALL of their
+    preconditions, so that a configuration outside them falls back to rmsnorm + gemv + decode_rope_append instead of raising from C
+    (round-3 advisor): M <= 2 rows, K / 512 a power of two up to 16 (the normed rows live in 4 * M * K * 2 bytes of static LDS: 128 KiB at
+    K = 8192, M = 2), and — when the caller folds them — head_dim % 16 == 0 for the RoPE / cache-append tail and 2 * ff % 64 == 0 for the
+    SwiGLU-paired gate|up form."""
+    if not (M <= 2 and K % 512 == 0 and (K // 512) in (1, 2, 4, 8, 16) and 4 * M * K * 2 <= 160 * 1024):
+        return False
+    if head_dim is not None and head_dim % 16:
+        return False
+    if swiglu_n is not None and swiglu_n % 64:
+        return False
+    return True
 
 
 def gemv(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=torch.bfloat16, alpha=1.0, w_index=None, row_scale=None, row_keep=None):

@@ -18,9 +18,47 @@ from . import model as OM
 from . import ops as O
 
 
-MASK_LOGIT_TOL = 0.08          # stated tolerance on the mask logits of the bf16 trunk + fp32 tail against the fp32 oracle at full depth
-                               # (measured 0.02-0.04 at 32 layers); pixels whose reference logit is farther than this from a cut must
-                               # threshold identically (`flipped <= near_cut`)
+MASK_LOGIT_TOL = 0.066         # stated tolerance on the mask logits of the bf16 trunk + bf16 upsampler against the fp32 oracle at full depth =
+                               # the measured worst case + 20 % (round 4; it was a round 0.08).  Measured at 32 layers, B = 8: 0.0544 with the
+                               # fused bf16 upsampler (the default since round 3), 0.038 with the fp32 tail — the difference is the kernel's
+                               # bf16 operand rounding: `src`, W1, W2 and the intermediate a1 are bf16 MFMA operands and the upscaled
+                               # embedding is rounded to bf16 before the hypernetwork product, each 2^-9 relative on values of magnitude
+                               # 2-3 summed over 32 channels (config.fused_bf16_upsampler=False is the strict fp32 tail).  Pixels whose
+                               # reference logit is farther than the MEASURED error from a cut must threshold identically (`flipped <= near_cut`)
+HIDDEN_WORST_ALL_ROWS = 0.25   # the last hidden state's worst element over ALL rows, relative to the largest reference entry: a token that picked
+                               # the other expert in some layer is a different computation from there on and is still held to this
+                               # (measured 0.128 at 32 layers, B = 8, with 4.5 % of the rows flipped somewhere; rows that agree in every
+                               # layer: 0.035, bound 0.1)
+
+
+def check_full_size(r, layers, moe):
+    """-> list of violated bounds (empty = parity holds) for a full_size_parity() result; ONE statement of the bounds for
+    tests/test_gpu_model.py (`_assert_full_size`) and for bench.py, whose line fails (non-zero exit) when its own `parity` object
+    violates them (round-3 review, item 8)."""
+    bad = []
+
+    def need(ok, what):
+        if not ok:
+            bad.append(what)
+    need(r["max_abs_dloss_over_10"] < 5e-2, f"losses: max |d| over the 10 = {r['max_abs_dloss_over_10']:.4g} >= 5e-2")
+    need(r["hidden_rel_err_agreeing_rows"] < 0.1, f"hidden (rows agreeing in every layer): {r['hidden_rel_err_agreeing_rows']:.4g} >= 0.1")
+    need(r["hidden_rel_err"] < HIDDEN_WORST_ALL_ROWS, f"hidden (all rows, worst element): {r['hidden_rel_err']:.4g} >= {HIDDEN_WORST_ALL_ROWS}")
+    need(r["hidden_mean_rel_err"] < 2 ** -6, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= 2^-6")
+    mk = r["mask"]
+    need(mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {MASK_LOGIT_TOL}")
+    for c in ("cut_ref", "cut_zero"):
+        need(mk[c]["flipped_le_near_cut_every_mask"], f"{c}: a mask has more flipped pixels than pixels inside the error band")
+        need(mk[c]["max_abs_ddice"] <= 1e-3, f"{c}: |dDice| {mk[c]['max_abs_ddice']:.4g} > 1e-3")
+    if moe:
+        need(len(r["routing_agreement_per_layer"]) == layers, "routing report does not cover every layer")
+        need(r["routing_agreement_min"] is not None and r["routing_agreement_min"] >= 0.97, f"routing agreement min {r['routing_agreement_min']} < 0.97")
+        rt = r["routing"]
+        need(rt["kept_set_equals_deepspeed_rule_every_layer"] and rt["slots_equal_deepspeed_rule_every_layer"], "kept set / slots differ from DeepSpeed's rule")
+        need(rt["counts_equal_own_choices_every_layer"] and rt["kept_sets_bit_equal_where_choices_identical"], "expert counts / kept sets")
+        # against the oracle's own run: a token that flipped moves the capacity boundary of its old and its new expert by one each
+        need(all(d <= 2 * f for d, f in zip(rt["kept_state_differs_on_agreeing_rows_per_layer"], rt["flipped_tokens_per_layer"])),
+             "kept state differs on more agreeing rows than 2 x flipped tokens")
+    return bad
 
 
 def _to_dev(batch, device):
@@ -78,7 +116,7 @@ def routing_report(coll, routing, T, capacity, rts):
 
 
 def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0, B=1,
-                     rts_seed=None, capacity_factor=None, time_threads=None, prompt_len=64, ragged=False):
+                     rts_seed=None, capacity_factor=None, time_threads=None, prompt_len=64, ragged=False, time_forward=None):
     """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
     through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline).
     B: samples in the compared batch (8 = the benchmark's per-GPU batch, T = 5112).  rts_seed: DeepSpeed's Random Token Selection
@@ -103,7 +141,19 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
             b["images_clip"] = b["images_clip"].to(torch.bfloat16).float()
         b["images"] = b["images"].to(torch.bfloat16).float()
         return b
-    times = []
+    times, ftimes = [], []
+    if time_forward:
+        if time_threads:
+            torch.set_num_threads(time_threads)
+        b1 = make(1, batch_seed)
+        with torch.no_grad():
+            for _ in range(time_forward[0] + time_forward[1]):
+                t0 = time.time()
+                OM.model_forward(b1, W, cfg, training=True)
+                ftimes.append(time.time() - t0)
+        ftimes = ftimes[time_forward[0]:]
+        if cpu_threads:
+            torch.set_num_threads(cpu_threads)
     if time_oracle:
         if time_threads:
             torch.set_num_threads(time_threads)
@@ -219,6 +269,8 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
                           "counts_equal_own_choices_every_layer": all(p["counts_equal_own_choices"] for p in per_layer)}
     if times:
         res["oracle_step_seconds"] = times
+    if ftimes:
+        res["oracle_forward_b1_seconds"] = ftimes
     del m
     torch.cuda.empty_cache()
     return res

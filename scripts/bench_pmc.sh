@@ -24,7 +24,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 res[fam][c].append(float(r["Counter_Value"]))
             if "gemm320" in n and "kernel<0>" not in n:      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
                 res["gemm320_decoder"][c].append(float(r["Counter_Value"]))
-out = {"note": "rocprofv3 --kernel-trace --pmc <counter> over bench.py (3 steps); per-launch averages; read_bytes = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM section), write_bytes = WRITE_SIZE KiB raw (uncalibrated)"}
+import sys; sys.path.insert(0, ".")
+from bench import kernel_source_sha
+out = {"kernel_source_sha": kernel_source_sha(), "note": "rocprofv3 --kernel-trace --pmc <counter> over bench.py (3 steps); per-launch averages; read_bytes = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM section), write_bytes = WRITE_SIZE KiB raw (uncalibrated)"}
 for fam, cs in res.items():
     f, w = cs.get("FETCH_SIZE", []), cs.get("WRITE_SIZE", [])
     out[fam] = {"launches": len(f), "read_bytes_per_launch": round(2 * 1024 * sum(f) / max(len(f), 1)), "write_bytes_per_launch": round(1024 * sum(w) / max(len(w), 1))}

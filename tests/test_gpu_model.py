@@ -367,8 +367,8 @@ def test_evaluate_greedy_decode_and_mask(dev, moe):
             step = agree - n_in
             assert 0 <= step < len(dbg["gaps"]) and dbg["gaps"][step] < 5e-2, "token ids diverge at a step that is not a near tie"
         else:
-            _stat("evaluate pred_mask", masks[0], masks_ref[0], atol=0.2)
             assert masks[0].shape == masks_ref[0].shape
+            _check_mask_cuts(f"evaluate pred_mask (moe={moe}, seed={seed})", masks[0][0], masks_ref[0][0], batch["masks_list"][0], tol=TINY_MASK_LOGIT_TOL)
 
 
 @pytest.mark.parametrize("moe", [True, False])
@@ -1646,21 +1646,10 @@ def test_full_depth_parity_at_true_dims(dev, moe):
 
 
 def _assert_full_size(r, layers, moe):
-    from oracle.parity import MASK_LOGIT_TOL
-    assert r["max_abs_dloss_over_10"] < 5e-2, r
-    assert r["hidden_rel_err_agreeing_rows"] < 0.1 and r["hidden_mean_rel_err"] < 2 ** -6, r
-    mk = r["mask"]
-    assert mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, mk
-    for c in ("cut_ref", "cut_zero"):
-        assert mk[c]["flipped_le_near_cut_every_mask"], mk[c]
-        assert mk[c]["max_abs_ddice"] <= 1e-3, mk[c]
-    if moe:
-        assert len(r["routing_agreement_per_layer"]) == layers and r["routing_agreement_min"] >= 0.97, r
-        rt = r["routing"]
-        assert rt["kept_set_equals_deepspeed_rule_every_layer"] and rt["slots_equal_deepspeed_rule_every_layer"], rt
-        assert rt["counts_equal_own_choices_every_layer"] and rt["kept_sets_bit_equal_where_choices_identical"], rt
-        # against the oracle's own run: a token that flipped moves the capacity boundary of its old and its new expert by one each
-        assert all(d <= 2 * f for d, f in zip(rt["kept_state_differs_on_agreeing_rows_per_layer"], rt["flipped_tokens_per_layer"])), rt
+    """The bounds live in oracle/parity.py (check_full_size): bench.py holds its own `parity` object to the same list."""
+    from oracle.parity import check_full_size
+    bad = check_full_size(r, layers, moe)
+    assert not bad, (bad, r)
 
 
 @pytest.mark.parametrize("variant", ["top2_E4", "residual_E2", "top2_E4_residual", "argparse_defaults"])

@@ -117,6 +117,14 @@ def test_warmup_decay_lr():
     s3 = WarmupDecayLR(total_num_steps=100, warmup_min_lr=0, warmup_max_lr=1e-3, warmup_num_steps=10, initial_lr=3e-4)
     s3.load_state_dict({"last_batch_iteration": -1})
     assert s3.get_last_lr()[0] == 3e-4
+    # the other reading (a DeepSpeed that initialises the optimizer's lr at construction), selectable in ds_config: the first step at warmup_min_lr
+    s4 = WarmupDecayLR(total_num_steps=100, warmup_min_lr=1e-5, warmup_max_lr=1e-3, warmup_num_steps=10, initial_lr=3e-4, first_step_lr="warmup_min")
+    assert s4.get_last_lr()[0] == 1e-5
+    s4.step()
+    assert s4.get_last_lr()[0] == 1e-5
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        WarmupDecayLR(total_num_steps=10, first_step_lr="sometimes")
 
 
 _WORKER = r'''

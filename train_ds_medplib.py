@@ -329,7 +329,15 @@ def train_epoch(run, epoch, feed):
     board = ProgressMeter(a.steps_per_epoch, list(clock.values()) + list(meters.values()), prefix=f"Epoch: [{epoch}]")
     eng.train()
     shown, tick = [], time.time()
-    for step in range(a.steps_per_epoch):
+    # a checkpoint taken inside an epoch (`ckpt_model`, every save_steps): the epoch continues where it stopped — the optimizer steps
+    # already taken are not repeated and their micro-batches are drawn and dropped, so the step count, the LR schedule and the data
+    # position line up with an uninterrupted run (:567-578)
+    done = eng.global_steps % a.steps_per_epoch
+    if done and run.rank0:
+        print(f"[walk] skipping first {done} steps, global step is {eng.global_steps}", flush=True)
+    for _ in range(done * a.grad_accumulation_steps):
+        next(feed)
+    for step in range(done, a.steps_per_epoch):
         for _ in range(a.grad_accumulation_steps):
             batch = next(feed)
             clock["Data"].update(time.time() - tick)
