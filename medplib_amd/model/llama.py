@@ -205,10 +205,13 @@ class LlamaStack:
             if ops.GEMM_TIMER is not None:
                 ops.GEMM_TIMER.batched_tag = i          # the expert GEMMs are credited with the rows `kept` holds after the region
             ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
-            out = torch.empty((T, d), dtype=torch.bfloat16, device=h.device)
-            ops.gemm_batched_rows(act, lw["down"], out, kept, c_rows=slot_token, c_scale=weight, residual=x, rows_stride=cap)
-            ops.moe_fill_dropped(x, slot, out)
-            return out, l_aux, (expert, slot, counts)
+            # Round 4: the combine writes INTO the residual stream (out = residual = x).  Every (routed row, 16-byte column piece) has
+            # exactly one owner in the down projection's epilogue — a tile, or one unit's share of a split tail tile — which reads the
+            # residual piece and stores the sum at the same address; a capacity-dropped token's row is simply left as it is, which is
+            # DeepSpeed's result for it (x + 0).  The moe_fill_dropped launch per layer and the [T, d] output buffer are gone (same bits:
+            # test_moe_fused_gather_scatter_matches_unfused).  No gradient flows here (the LoRA path keeps its own forward).
+            ops.gemm_batched_rows(act, lw["down"], x, kept, c_rows=slot_token, c_scale=weight, residual=x, rows_stride=cap)
+            return x, l_aux, (expert, slot, counts)
         if k == 1:
             expert, slot, weight, kept, counts, l_aux = ops.moe_route_top1(gates, cap, self._gate_draws(i, T, E, gumbel=False))
         else:
