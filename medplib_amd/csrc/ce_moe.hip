@@ -102,20 +102,24 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
 // (Requesting the NEXT row's chunks before this row's arithmetic -- a wave walks 2-3 rows here -- measured 22.5 -> 32.9 us on the same box:
 // the second row buffer's registers cost more occupancy than the overlap returns.)
 template <int NCH, bool LDSW>      // 16-byte chunks per lane: dim = NCH * 512
-__global__ __launch_bounds__(256) void rmsnorm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, float eps,
+__global__ __launch_bounds__(512) void rmsnorm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, float eps,
                                                            bf16_t* __restrict__ h, int64_t ldh, const float* __restrict__ wg, int E,
                                                            float* __restrict__ logits, float* __restrict__ gates, int64_t T) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];
   constexpr int dim = NCH * 512;
   const int lane = threadIdx.x & 63;
+  // 4 or 8 waves per workgroup (blockDim).  Round 4 tried 8 (639 workgroups at the 7B shape: every row its own wave, 16-24 rows in flight per CU
+  // instead of 8 waves per CU walking 2-3 rows each): 27.3 us against 22.7 with 4 (scripts/r04_rg_ab.sh, cache-warm rows; the RMSNorm alone 14.8) —
+  // more staging traffic (48 KB of weights per workgroup) and no gain from the extra rows in flight.  4 stays; MP_RG_WAVES=8 selects the other.
+  const int nwv = blockDim.x >> 6, step4 = blockDim.x * 4;
   if constexpr (LDSW) {
-    for (int i = threadIdx.x * 4; i < dim; i += 1024) *reinterpret_cast<f32x4*>(wsh + i) = *reinterpret_cast<const f32x4*>(w + i);
-    for (int i = threadIdx.x * 4; i < E * dim; i += 1024) *reinterpret_cast<f32x4*>(wsh + dim + i) = *reinterpret_cast<const f32x4*>(wg + i);
+    for (int i = threadIdx.x * 4; i < dim; i += step4) *reinterpret_cast<f32x4*>(wsh + i) = *reinterpret_cast<const f32x4*>(w + i);
+    for (int i = threadIdx.x * 4; i < E * dim; i += step4) *reinterpret_cast<f32x4*>(wsh + dim + i) = *reinterpret_cast<const f32x4*>(wg + i);
     __syncthreads();
   }
   const float* wn = LDSW ? wsh : w;
   const float* wgs = LDSW ? wsh + dim : wg;
-  for (int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += (int64_t)gridDim.x * 4) {
+  for (int64_t tok = (int64_t)blockIdx.x * nwv + (threadIdx.x >> 6); tok < T; tok += (int64_t)gridDim.x * nwv) {
     const bf16_t* xr = x + tok * ldx;
     bf16x8 v[NCH];
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -860,7 +864,10 @@ extern "C" int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_
   if (tokens == 0) return MP_OK;
   const size_t lds = (size_t)(1 + n_experts) * dim * sizeof(float);
   const bool stage = lds <= 65536;                          // (dim 4096 with E <= 3, dim 2048 with E <= 7; else the weights stay in global memory)
-  const dim3 grid((unsigned)std::min<int64_t>(mp_cdiv(tokens, 4), stage ? 512 : (1 << 30))), blk(256);
+  static int rg_waves = -1;
+  if (rg_waves < 0) { const char* e = getenv("MP_RG_WAVES"); rg_waves = (e && atoi(e) == 8) ? 8 : 4; }       // 8: measured slower (see the kernel)
+  const int nwv = (stage && tokens >= 2048) ? rg_waves : 4;
+  const dim3 grid((unsigned)std::min<int64_t>(mp_cdiv(tokens, nwv), stage ? (nwv == 8 ? 768 : 512) : (1 << 30))), blk(64 * nwv);
 #define MP_RG(N)                                                                                                                                   \
   do {                                                                                                                                             \
     if (stage) hipLaunchKernelGGL((rmsnorm_gate_kernel<N, true>), grid, blk, lds, stream, (const bf16_t*)x, ldx, ln_w, eps, (bf16_t*)h, ldh, wg,   \

@@ -154,12 +154,6 @@ class MedPLIBForCausalLM(nn.Module):
         # before the splice, the mask tail for the SAM embedding.  Only while every module in front of the decoder is frozen.
         self.towers_run_ahead = False
         self._vision_stream_obj = None
-        # Round 4, adapters training: the mask tail (forward + backward, ~1000 launch-bound kernels on 6 x 256-token problems) sits between
-        # the decoder's forward and its backward on the CALLING stream and leaves the CUs mostly idle for ~8-10 ms.  The frozen towers of
-        # the NEXT step (started ahead, above) are gated on an event recorded where this step's decoder forward ends, so their ~7 ms of
-        # CU x time fall into that window instead of displacing GEMM workgroups of the decoder.  MP_TOWERS_IN_TAIL=0: A/B.
-        self.towers_in_tail_window = os.environ.get("MP_TOWERS_IN_TAIL", "1") != "0"
-        self._tail_gate = None
         # Training only, switched on by engine.initialize(): the fp32 mask tail (forward, and through autograd its backward; the
         # engine adds the optimizer) runs on its own stream, so its ~700 tiny launches overlap the NEXT step's CLIP tower / LLM
         # instead of holding the machine at a few percent occupancy.  The calling stream waits for the tail FORWARD before
@@ -525,8 +519,6 @@ class MedPLIBForCausalLM(nn.Module):
                                                              "model.mask_encoder.")) for n in lo_.names)
         ahead = (self.towers_run_ahead and front_frozen and not getattr(self, "_want_raw_feats", False)
                  and not (region_masks is not None and len(region_masks) > 0) and kwargs.get("mask_images") is None and torch.is_tensor(images_clip))
-        gate = self._tail_gate if (ahead and self.towers_in_tail_window) else None
-        self._tail_gate = None
         if seg_flag and self.sam_side_stream:
             main = torch.cuda.current_stream()
             side = self._side_stream()
@@ -534,15 +526,11 @@ class MedPLIBForCausalLM(nn.Module):
                 side.wait_stream(main)
             else:
                 images.record_stream(side)
-                if gate is not None:
-                    side.wait_event(gate)
             with torch.cuda.stream(side), torch.no_grad():
                 image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
         if ahead:
             main, vis = torch.cuda.current_stream(), self._vision_stream()
             images_clip.record_stream(vis)
-            if gate is not None:
-                vis.wait_event(gate)
             with torch.cuda.stream(vis), torch.no_grad():
                 plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, None, kwargs.get("image_token_types"),
                                                     kwargs.get("image_token_lengths"))
@@ -601,8 +589,6 @@ class MedPLIBForCausalLM(nn.Module):
             image_tokens.record_stream(main)
         use_tail = self.tail_side_stream and self.training and not inference and torch.is_grad_enabled()
         if not use_tail:
-            if self.towers_run_ahead and self.training and not inference and last_hidden.requires_grad:
-                self._tail_gate = main.record_event()          # the next step's towers start here: beside this step's tail (see __init__)
             self.active_tail_stream = None
             if self._tail_stream_obj is not None:
                 main.wait_stream(self._tail_stream_obj)           # parameters may still be in an optimizer step over there

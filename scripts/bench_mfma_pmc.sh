@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/mfma_pmc; rm -rf $out; mkdir -p $out
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $out/p1 -- \
-  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lora-line --no-kernel-timer > $out/p1.log 2>&1
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lora-line --no-secondary --no-kernel-timer > $out/p1.log 2>&1
 python - <<'PY'
 import csv, glob, collections, json
 res = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -7,7 +7,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/bench_pmc; rm -rf $out; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lora-line --no-kernel-timer > $out/$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lora-line --no-secondary --no-kernel-timer > $out/$c.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, json, re

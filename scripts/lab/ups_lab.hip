@@ -88,6 +88,25 @@ int main(int argc, char** argv) {
   direct_both(upsample_fused_kernel<true, false, 2, true>, "both:   no stores");
   direct_both(upsample_fused_kernel<true, false, 1, true>, "both:   no GELU");
   direct_both(upsample_fused_kernel<true, false, 3, true>, "both:   no GELU, no stores");
+  time_it("library entry again (after the direct launches)", [&](int i) {
+    if (mp_mask_upsample_fused_bf16(src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, st)) { printf("%s\n", mp_last_error_string()); exit(1); }
+  });
+  direct_both(upsample_fused_kernel<true, false, 0, true>, "both: full kernel, direct, again");
+  {   // the same through a captured graph of 24 launches (bench.py's method)
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 24; ++i)
+      if (mp_mask_upsample_fused_bf16(src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, st)) { printf("%s\n", mp_last_error_string()); exit(1); }
+    CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 40; ++i) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %7.2f us\n", "library entry, graph of 24 x 40 replays", ms * 1e3 / (40 * 24));
+  }
   // correctness of `both` against `split` on one input (bitwise: same arithmetic, different work split)
   {
     bf16_t *o1, *o2; const size_t ob = tokens * 16 * 32 * 2;
