@@ -72,8 +72,10 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(grid0), dim3(64 * nw0), UP_LDS, st, a0);
     });
   };
-  const int nwB = (int)std::min<int64_t>(UP_WAVES, std::max<int64_t>(2, 2 * mp_cdiv(groups0, 256)));
+  const char* nwe = getenv("UPS_LAB_NW");
+  const int nwB = nwe ? atoi(nwe) : (int)std::min<int64_t>(UP_WAVES, std::max<int64_t>(2, 2 * mp_cdiv(groups0, 256)));
   const int gridB = (int)std::min<int64_t>(256, mp_cdiv(groups0, nwB / 2));
+  printf("both: %d waves per workgroup, %d workgroups\n", nwB, gridB);
   auto direct_both = [&](auto kern, const char* name) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS2));
     time_it(name, [&](int i) {

@@ -14,7 +14,4 @@ print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('al
 print('lora', d['lora_stage3'].get('ms_per_step'), 'ups', d['roofline_upsampler']['sam1024'], d['roofline_upsampler']['sam256'], d['roofline_upsampler']['copy_floor'].get('upsampler_vs_copy'))
 print('parity', d['parity']['mask']['max_abs_dlogit'], d['parity']['abs_dloss'], d['parity']['hidden_rel_err'])
 PY
-MP_TOWERS_IN_TAIL=0 python bench.py --lora --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_lora_notail.json 2>/dev/null; python -c "
-import json; print('lora, towers not gated:', json.load(open('gpurun_out/${tag}_lora_notail.json'))['ms_per_step'])"
-python bench.py --lora --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_lora_tail.json 2>/dev/null; python -c "
-import json; print('lora, towers in the tail window:', json.load(open('gpurun_out/${tag}_lora_tail.json'))['ms_per_step'])"
+python scripts/decode_bench.py 2>&1 | tail -1
