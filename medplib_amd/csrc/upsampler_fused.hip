@@ -57,6 +57,7 @@ struct UpArgs {
   int B, h, w;
   float eps;
   int skew;               // MP_UPS_SKEW: waves sharing a SIMD start (wave >> 2) * skew * 64 clocks apart (0 = together)
+  int early;              // BOTH: waves 0 .. early-1 of a workgroup request their first group's tokens before the staging wait (0 = all)
   long long* dbg;         // ABL & 4 (scripts/ups_lab.hip only): per (workgroup, wave) 16 s_memrealtime stamps (100 MHz) of the first pass
 };
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (grp < n_groups) { load_tokens(grp, xa0); have_tokens = true; }
+    if (grp < n_groups && (a.early <= 0 || wave < a.early)) { load_tokens(grp, xa0); have_tokens = true; }
     __builtin_amdgcn_sched_barrier(0);
     if (have_tokens) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -910,8 +911,14 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
   MP_REQUIRE(mask == nullptr || hyper != nullptr, MP_ERR_ARG, "mp_mask_upsample_fused_bf16: mask output needs hyper");
   static int skew = -1;
   if (skew < 0) { const char* e = getenv("MP_UPS_SKEW"); skew = e ? atoi(e) : 0; }
+  // which waves request their first group's tokens before the staging wait: the first FOUR of a 16-wave workgroup (one per SIMD).  The four
+  // waves of a SIMD pass their tasks one after another (the timeline of section 3.2), so only the first of them needs its tokens at the
+  // barrier; the other twelve loads of a CU used to share the pipe with the weight DMA and held the staging barrier back from ~2.9 to ~5.3 us
+  // (17.2 -> 16.3 us per launch; 8 early waves 16.4, 2: 16.5, all 16: 17.2).  Small launches (2-4 waves per workgroup): all of them.
+  static int early_env = -2;
+  if (early_env == -2) { const char* e = getenv("MP_UPS_EARLY"); early_env = e ? atoi(e) : -1; }
   UpArgs a{(const bf16_t*)src, (const bf16_t*)w1_packed, b1, ln_w, ln_b, (const bf16_t*)w2_packed, b2, hyper, (bf16_t*)up, mask,
-           B, h, w, ln_eps, skew, nullptr};
+           B, h, w, ln_eps, skew, 0, nullptr};
   const int64_t groups = mp_cdiv((int64_t)B * h * w, 16);
   // Round 4: one (group, row parity) task per wave and pass, BOTH parities of a group in the same workgroup (neighbouring waves), up to 256
   // workgroups: 2 waves per workgroup for the model's own 16 x 16 token maps (128 groups at batch 8 -> 128 workgroups), 16 waves from 2048
@@ -938,6 +945,7 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
     nw = std::min<int>(UP_WAVES, std::max(nw, 2 * std::max(1, nw_env / 2)));
     nw = (int)std::min<int64_t>(nw, 2 * groups);
     const int grid = (int)std::min<int64_t>(256, mp_cdiv(groups, nw / 2));
+    a.early = early_env >= 0 ? early_env : (nw >= 8 ? 4 : 0);
     auto launch = [&](auto kern) {
       static bool attr_set = false;                 // one flag per instantiation of this lambda's operator()
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS2); attr_set = true; }
@@ -961,7 +969,7 @@ extern "C" int mp_mask_upsample_fused_bwd_bf16(const void* src, const void* w1_p
   MP_REQUIRE(src && w1_packed && w2_packed && w1_t && w2_t && hyper && dmask && dx2 && dy1 && a1 && dy2 && part, MP_ERR_ARG,
              "mp_mask_upsample_fused_bwd_bf16: null operand");
   UpBwdArgs g{UpArgs{(const bf16_t*)src, (const bf16_t*)w1_packed, b1, ln_w, ln_b, (const bf16_t*)w2_packed, b2, hyper, nullptr, nullptr,
-                     B, h, w, ln_eps, 0, nullptr},
+                     B, h, w, ln_eps, 0, 0, nullptr},
               (const bf16_t*)w1_t, (const bf16_t*)w2_t, dmask, dx2, dy1, a1, dy2, part};
   const int64_t groups = (int64_t)B * h * w / 16;
   const int nw = (int)std::min<int64_t>(UPB_WAVES, std::max<int64_t>(2, mp_cdiv(groups, 128)));

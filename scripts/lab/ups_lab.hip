@@ -18,7 +18,9 @@ static std::vector<uint16_t> rnd_bf16(size_t n, float scale, unsigned seed) {
   return v;
 }
 
+static int g_early = 4;
 int main(int argc, char** argv) {
+  if (getenv("UPS_LAB_EARLY")) g_early = atoi(getenv("UPS_LAB_EARLY"));
   const int B = 8, G = argc > 1 ? atoi(argv[1]) : 64, NBUF = 12;
   const size_t tokens = (size_t)B * G * G;
   std::vector<bf16_t*> src(NBUF), up(NBUF);
@@ -68,7 +70,7 @@ int main(int argc, char** argv) {
     const int grid0 = 2 * (int)(gsets0 < 128 ? gsets0 : 128);
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS));
     time_it(name, [&](int i) {
-      UpArgs a0{src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, 0, nullptr};
+      UpArgs a0{src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, 0, g_early, nullptr};
       hipLaunchKernelGGL(kern, dim3(grid0), dim3(64 * nw0), UP_LDS, st, a0);
     });
   };
@@ -79,7 +81,7 @@ int main(int argc, char** argv) {
   auto direct_both = [&](auto kern, const char* name) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS2));
     time_it(name, [&](int i) {
-      UpArgs a0{src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, 0, nullptr};
+      UpArgs a0{src[i % NBUF], w1, b1, lw, lb, w2, b2, nullptr, up[i % NBUF], nullptr, B, G, G, 1e-6f, 0, g_early, nullptr};
       hipLaunchKernelGGL(kern, dim3(gridB), dim3(64 * nwB), UP_LDS2, st, a0);
     });
   };
@@ -113,7 +115,7 @@ int main(int argc, char** argv) {
   {
     bf16_t *o1, *o2; const size_t ob = tokens * 16 * 32 * 2;
     CK(hipMalloc(&o1, ob)); CK(hipMalloc(&o2, ob)); CK(hipMemset(o1, 0, ob)); CK(hipMemset(o2, 0xff, ob));
-    UpArgs a1{src[0], w1, b1, lw, lb, w2, b2, nullptr, o1, nullptr, B, G, G, 1e-6f, 0, nullptr};
+    UpArgs a1{src[0], w1, b1, lw, lb, w2, b2, nullptr, o1, nullptr, B, G, G, 1e-6f, 0, g_early, nullptr};
     const int nw0 = (int)std::min<int64_t>(UP_WAVES, mp_cdiv(groups0, 128));
     const int grid0 = 2 * (int)std::min<int64_t>(128, mp_cdiv(groups0, nw0));
     hipLaunchKernelGGL((upsample_fused_kernel<true, false, 0, false>), dim3(grid0), dim3(64 * nw0), UP_LDS, st, a1);
@@ -131,7 +133,7 @@ int main(int argc, char** argv) {
     (void)n16;
   }
   auto timeline = [&](auto kern, const char* tname) {
-  UpArgs a{src[0], w1, b1, lw, lb, w2, b2, nullptr, up[0], nullptr, B, G, G, 1e-6f, 0, nullptr};
+  UpArgs a{src[0], w1, b1, lw, lb, w2, b2, nullptr, up[0], nullptr, B, G, G, 1e-6f, 0, g_early, nullptr};
   const int nw = nwB, grid = gridB;
   const size_t nstamp = (size_t)grid * UP_WAVES * 8 * 2;
   long long* dbg; CK(hipMalloc(&dbg, nstamp * 8)); CK(hipMemset(dbg, 0, nstamp * 8));
