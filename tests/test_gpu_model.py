@@ -900,6 +900,42 @@ def test_moe_gather_scatter_fusion_is_bit_identical(dev, cf):
         assert (outs[0][1][0][1] < 0).any(), "the small capacity factor must actually drop tokens"
 
 
+def test_gemm_timer_credits_expert_gemms_with_kept_rows(dev):
+    """bench.py's roofline credits an expert GEMM with the rows the kernel PROCESSED (round-3 review: crediting tokens overstated launches whose
+    gate drops tokens): ops.KernelTimer keeps the device-side `kept` counts of every expert launch and reads them back after the region.  At
+    capacity factor 0.6 one expert overflows: the per-layer kept rows must equal the routing's own counts, be smaller than the token count,
+    and the credited flop must equal 2 N K per KEPT row of each of the two expert launches of a layer."""
+    from medplib_amd import ops
+    cfg = MedPLIBConfig.tiny(moe_enable=True, num_hidden_layers=2, num_experts=2, capacity_factor=0.6)
+    W = OM.init_hf_weights(cfg)
+    g = torch.Generator().manual_seed(23)
+    emb = (torch.randn(3, 171, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    m = _model(cfg, dev, W)
+    timer = ops.KernelTimer(sample_every=1)
+    ops.GEMM_TIMER = timer
+    try:
+        out, aux, routing = m.model.llm.forward(emb, None, collect_routing=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_TIMER = None
+    timer.resolve()
+    T = 3 * 171
+    d, ff = cfg.hidden_size, cfg.intermediate_size
+    assert sorted(timer.kept_rows) == [0, 1]
+    for layer, (expert, slot, counts) in enumerate(routing):
+        kept = int((slot >= 0).sum())
+        assert kept < T, "capacity factor 0.6 must drop tokens"
+        assert timer.kept_rows[layer] == [kept, kept], (layer, timer.kept_rows[layer], kept)          # gate|up and down launches
+    # the sampled records of the expert launches carry flop_per_row x kept rows
+    works = sorted(r[0] for r in timer.records)
+    want = []
+    for layer, (expert, slot, counts) in enumerate(routing):
+        kept = int((slot >= 0).sum())
+        want += [2.0 * kept * (2 * ff) * d, 2.0 * kept * d * ff]
+    for w in want:
+        assert any(abs(w - x) < 1.0 for x in works), (w, works)
+
+
 def test_training_entry_point_runs_and_resumes(dev, tmp_path):
     """medplib_amd.train.main (train_ds_medplib.py control flow) at tiny dims: 2 epochs x 3 steps with a checkpoint, validation
     metrics, then a second invocation that auto-resumes from <log_dir>/ckpt_model/latest and continues at the saved global step."""

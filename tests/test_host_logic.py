@@ -688,3 +688,41 @@ def test_routing_report_top2_entries():
     assert p["flipped_tokens"] == 1 and abs(p["expert_agreement"] - 5 / 6) < 1e-6 and p["first_choice_agreement"] == 1.0
     assert p["dropped_entries_oracle"] == 2 and p["dropped_entries_hip"] == 3 and p["kept_state_differs_on_agreeing_rows"] == 1
     assert same.tolist() == [True, True, True, True, False, True]
+
+
+def test_check_full_size_names_every_violated_bound():
+    """oracle/parity.py: check_full_size is the ONE statement of the full-size parity bounds (GPU tests and bench.py's exit code use it): a
+    passing record yields no complaint, and each bound pushed over its limit is reported by name."""
+    from oracle.parity import check_full_size, MASK_LOGIT_TOL
+    cut = {"flipped_le_near_cut_every_mask": True, "max_abs_ddice": 1e-5}
+    good = {"max_abs_dloss_over_10": 7e-3, "hidden_rel_err_agreeing_rows": 0.035, "hidden_rel_err": 0.128, "hidden_mean_rel_err": 0.0127,
+            "mask": {"max_abs_dlogit": 0.054, "cut_ref": dict(cut), "cut_zero": dict(cut)},
+            "routing_agreement_per_layer": [0.99] * 4, "routing_agreement_min": 0.99,
+            "routing": {"kept_set_equals_deepspeed_rule_every_layer": True, "slots_equal_deepspeed_rule_every_layer": True,
+                        "counts_equal_own_choices_every_layer": True, "kept_sets_bit_equal_where_choices_identical": True,
+                        "kept_state_differs_on_agreeing_rows_per_layer": [2, 0, 1, 0], "flipped_tokens_per_layer": [3, 1, 1, 0]}}
+    assert check_full_size(good, 4, True) == []
+    assert check_full_size(good, 4, False) == []
+    import copy
+
+    def bad(path, value, moe=True):
+        r = copy.deepcopy(good)
+        d = r
+        for k in path[:-1]:
+            d = d[k]
+        d[path[-1]] = value
+        out = check_full_size(r, 4, moe)
+        assert len(out) >= 1, (path, value)
+        return out
+    bad(["max_abs_dloss_over_10"], 0.06)
+    bad(["hidden_rel_err_agreeing_rows"], 0.11)
+    bad(["hidden_rel_err"], float("nan"))
+    bad(["hidden_rel_err"], 1.5)
+    bad(["hidden_mean_rel_err"], 0.02)
+    bad(["mask", "max_abs_dlogit"], MASK_LOGIT_TOL + 1e-3)
+    bad(["mask", "cut_zero", "flipped_le_near_cut_every_mask"], False)
+    bad(["mask", "cut_ref", "max_abs_ddice"], 2e-3)
+    bad(["routing_agreement_min"], 0.9)
+    bad(["routing", "slots_equal_deepspeed_rule_every_layer"], False)
+    bad(["routing", "kept_state_differs_on_agreeing_rows_per_layer"], [7, 0, 1, 0])
+    assert len(check_full_size(dict(good, routing_agreement_per_layer=[0.99] * 3), 4, True)) == 1
