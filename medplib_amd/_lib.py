@@ -11,7 +11,7 @@ import torch  # noqa: F401  — MUST precede loading libmedplib_hip.so: torch br
 #                              would start a second HIP runtime instance that cannot see torch's device allocations.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmedplib_hip.so")
+LIB_PATH = os.environ.get("MEDPLIB_HIP_LIB") or os.path.join(_HERE, "lib", "libmedplib_hip.so")     # (the override serves A/B builds of the library)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "medplib_hip.h")
 
 _CT = {

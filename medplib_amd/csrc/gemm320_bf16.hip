@@ -396,14 +396,20 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     }
   };
 // the 40 MFMAs of one segment: column half HN of the wave tile, K = 64
+// MP3_PRIO (A/B builds, scripts/r04_prio_ab.sh): 0 = priority raised around every MFMA segment (the shipped schedule), 1 = no priority
+// changes, 2 = the second-dispatched N half (waves 4-7) at priority 1 for the whole K loop, no per-segment flips (MI355X_MICROARCH.md,
+// "static priority for the younger half")
+#ifndef MP3_PRIO
+#define MP3_PRIO 0
+#endif
 #define MP3_MFMA_40(HN)                                                                                     \
   do {                                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                          \
+    if (MP3_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
       _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
           acc[i][(HN) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][(HN) * 4 + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                          \
+    if (MP3_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                                       \
     MP3_BAR();                                                                                              \
   } while (0)
 
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
   }
   MP3_BAR();
   if (wc == 1) MP3_BAR();
+  if (MP3_PRIO == 2 && wc == 1) __builtin_amdgcn_s_setprio(1);
 
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE3;
@@ -450,6 +457,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm320_bf16_nt_kernel(GemmArgs g) {
     MP3_MFMA_40(1);
   }
   if (wc == 0) MP3_BAR();
+  if (MP3_PRIO == 2) __builtin_amdgcn_s_setprio(0);
   unsigned items = 0xfffffu;
   if (is_split) {
     // COOPERATIVE FIX-UP of a split tail tile (round 3; before: the last arriver summed all S partials alone — S x 320 KiB through one
