@@ -111,6 +111,10 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   bf16_t* tw = reinterpret_cast<bf16_t*>(BOTH ? smem + W1F_BYTES + W2_BYTES + wave * T1K_BYTES : smem + W1H_BYTES + W2_BYTES + wave * T_WAVE_BYTES);
+  // T1: GEMM1 issued transposed too — see the LayerNorm section (lab bit 1048576 = the earlier form: GEMM1 as tokens x channels, the
+  // intermediate transposed through LDS)
+  constexpr bool T1 = BOTH && (ABL & (1048576 | 131072 | 262144)) == 0;
+  float* sCst = reinterpret_cast<float*>(smem + W1F_BYTES + W2_BYTES);      // T1: b1 | ln weight | ln bias, 64 floats each (the transposition buffers are unused)
   long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define UPS_STAMP(i) do { if constexpr ((ABL & 4) != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts[i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
   UPS_STAMP(0);
@@ -157,6 +161,17 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w1p + (int64_t)((BOTH ? 0 : kh * 128) + n) * 256 + ((pc ^ (n & 15)) << 3)),
                                      (__attribute__((address_space(3))) void*)(sW1 + j * 1024), 16, 0, 0);
   }
+  if constexpr (T1) {
+    // W2's K axis permuted inside every 32-channel step: a lane of the transposed GEMM1 result owns channels 16jj + 4fq + r of the step
+    // (jj = 0, 1; r = 0..3), so element e of its GEMM2 operand is channel 32kk + 16(e >> 2) + 4fq + (e & 3), and the W2 fragment must
+    // carry the same channel in the same element.  4-byte DMA pieces (two channels) place them: 64 instructions of 256 bytes = 2 rows.
+    for (int j = wave; j < 64; j += nw) {
+      const int n = 2 * j + (lane >> 5), c = ((lane & 31) >> 2) ^ (n & 7), d = lane & 3;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w2p + (int64_t)n * 64 + (c >> 2) * 32 + (d >> 1) * 16 + (c & 3) * 4 + (d & 1) * 2),
+                                       (__attribute__((address_space(3))) void*)(sW2 + j * 256), 4, 0, 0);
+    }
+    if (wave == 0) { sCst[lane] = a.b1[lane]; sCst[64 + lane] = a.lnw[lane]; sCst[128 + lane] = a.lnb[lane]; }
+  } else
   for (int j = wave; j < 16; j += nw) {
     const int n = 8 * j + (lane >> 3), pc = lane & 7;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.w2p + (int64_t)n * 64 + ((pc ^ (n & 7)) << 3)),
@@ -243,14 +258,18 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
 #pragma unroll
     for (int kw = 0; kw < 2; ++kw)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc1[kw][j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (T1) acc1[kw][j] = *reinterpret_cast<const f32x4*>(sCst + j * 16 + 4 * fq);
+        else acc1[kw][j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+      }
     // GEMM1 of a wave is a chain of LDS round trips (~190 clocks each under load) with 16 clocks of matrix work per fragment, and the four
     // waves of a SIMD pass it one after another (timeline: 2.5-3 us per wave with the compiler's own order, which keeps TWO reads in flight:
     // ds_read x2, wait, MFMA, wait, MFMA).
-    if constexpr (BOTH && WITH_UP && !WITH_MASK && (ABL & 8192) == 0) {
+    if constexpr (BOTH && (T1 || (WITH_UP && !WITH_MASK)) && (ABL & 8192) == 0) {
       // four fragment reads in flight, then their four MFMAs, as a scheduling hint (sched_group_barrier) rather than a fence: with
       // sched_barrier(0) fences the allocator spilled 9-25 registers and the kernel got slower; this form compiles to 121 VGPRs without
-      // scratch.  Only the up-writing instantiation: the mask forms spill with it (36-116 bytes) and keep the compiler's own order.
+      // scratch.  With GEMM1 transposed (T1) every instantiation takes this form: left to its own order the compiler hoists the fragment
+      // reads of the whole K loop in the mask forms (268 registers spilled).
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
@@ -259,7 +278,9 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
 #pragma unroll
           for (int j = 0; j < 4; ++j) wb[j] = *reinterpret_cast<const bf16x8*>(sW1 + w1_off(kh * 128 + kw * 64 + j * 16 + fr, kk * 4 + fq));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc1[kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb[j], acc1[kw][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            acc1[kw][j] = T1 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[kk], acc1[kw][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb[j], acc1[kw][j], 0, 0, 0);
         }
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
@@ -277,7 +298,8 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
             const bf16x8 wb = (BOTH && (ABL & 262144) != 0)
                 ? *reinterpret_cast<const bf16x8*>(sW1 + (((kh * 8 + kw * 4 + j) * 8 + kk) * 1024) + lane * 16)
                 : *reinterpret_cast<const bf16x8*>(sW1 + w1_off((BOTH ? kh * 128 : 0) + kw * 64 + j * 16 + fr, kk * 4 + fq));
-            acc1[kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb, acc1[kw][j], 0, 0, 0);
+            acc1[kw][j] = T1 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa[kk], acc1[kw][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kk], wb, acc1[kw][j], 0, 0, 0);
           }
         if constexpr ((ABL & 524288) != 0) { if (kk == 0) { asm volatile("" :: "v"(acc1[1][3])); UPS_STAMP(1); } if (kk == 3) { asm volatile("" :: "v"(acc1[1][3])); UPS_STAMP(2); } }
       }
@@ -285,6 +307,57 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
     // ---------------- + bias, LayerNorm2d over the 64 channels, GELU (C layout: channel = j*16 + fr, token = fq*4 + r) ----
     if constexpr ((ABL & 4) != 0) { asm volatile("" :: "v"(acc1[1][3])); UPS_STAMP(4); }
     bf16x8 ya[2][2];                          // GEMM2's A fragments: the intermediate back in [row = token][8 consecutive channels]
+    if constexpr (T1) {
+      // GEMM1 transposed: the lane owns ONE token (column fr) and channels j*16 + 4fq + r.  The LayerNorm sums are 16 in-lane values plus two
+      // cross-row steps (the four fq rows of a token), and the normalised values already sit where GEMM2's operand wants them (W2's K axis
+      // is permuted to match at staging): no transposition through LDS, no 64 DPP adds.
+      f32x4 lwt[4], lbt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lwt[j] = *reinterpret_cast<const f32x4*>(sCst + 64 + j * 16 + 4 * fq); lbt[j] = *reinterpret_cast<const f32x4*>(sCst + 128 + j * 16 + 4 * fq); }
+      f32x2 v[2][4][2];
+      float s[2];
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        f32x2 s2 = splat2(0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[kw][j][0] = f32x2{acc1[kw][j][0], acc1[kw][j][1]}; v[kw][j][1] = f32x2{acc1[kw][j][2], acc1[kw][j][3]};
+          s2 += v[kw][j][0]; s2 += v[kw][j][1];
+        }
+        s[kw] = s2.x + s2.y;
+      }
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) s[kw] += __shfl_xor(s[kw], 16);
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) s[kw] += __shfl_xor(s[kw], 32);
+      float q[2];
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const f32x2 mean = splat2(s[kw] * (1.f / 64.f));
+        f32x2 q2 = splat2(0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) { v[kw][j][p] -= mean; q2 = __builtin_elementwise_fma(v[kw][j][p], v[kw][j][p], q2); }
+        q[kw] = q2.x + q2.y;
+      }
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) q[kw] += __shfl_xor(q[kw], 16);
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) q[kw] += __shfl_xor(q[kw], 32);
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const f32x2 rstd = splat2(__builtin_amdgcn_rsqf(fmaf(q[kw], 1.f / 64.f, a.eps)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const f32x2 y = gelu2<ABL>(__builtin_elementwise_fma(v[kw][j][p] * rstd, f32x2{lwt[j][2 * p], lwt[j][2 * p + 1]}, f32x2{lbt[j][2 * p], lbt[j][2 * p + 1]}));
+            ya[kw][j >> 1][(j & 1) * 4 + 2 * p] = (bf16_t)y[0];
+            ya[kw][j >> 1][(j & 1) * 4 + 2 * p + 1] = (bf16_t)y[1];
+          }
+      }
+    } else
 #pragma unroll
     for (int kw = 0; kw < 2; ++kw) {
       f32x2 v[2][4];                          // [token pair rp][j]: tokens r = 2rp, 2rp+1 -> packed arithmetic
