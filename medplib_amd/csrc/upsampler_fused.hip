@@ -240,6 +240,14 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
     for (int i = 0; i < k * (a.skew - 1); ++i) __builtin_amdgcn_s_sleep(1);
   }
 
+  if constexpr (BOTH && (ABL & 4194304) != 0) {     // lab: the k-th wave of a SIMD runs at priority 3 - k (oldest task first: stores start earlier)
+    switch (wave >> 2) {
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: break;
+    }
+  }
   const int OW = 4 * a.w, OH = 4 * a.h;
   // one (group, kh) task; the first task of a wave gets its tokens from the prologue (xa0), later ones load them here
   auto task_body = [&](const int64_t grp, const bf16x8 (&xa)[8]) __attribute__((always_inline)) {

@@ -86,8 +86,10 @@ int main(int argc, char** argv) {
     });
   };
   direct_split(upsample_fused_kernel<true, false, 0, false>, "split: full kernel (round 3 arrangement)");
-  direct_both(upsample_fused_kernel<true, false, 0, true>, "both: full kernel (tokens early, nt stores)");
+  direct_both(upsample_fused_kernel<true, false, 0, true>, "both: one group per wave, 16 waves");
   direct_both(upsample_fused_kernel<true, false, 1048576, true>, "both:   GEMM1 not transposed, LDS transposition");
+  direct_both(upsample_fused_kernel<true, false, 4194304, true>, "both:   priority 3 - k for the k-th wave of a SIMD");
+  direct_both(upsample_fused_kernel<true, false, 4194304 + 2, true>, "both:   same, no stores");
   direct_both(upsample_fused_kernel<true, false, 4096, true>, "both:   plain stores");
   direct_both(upsample_fused_kernel<true, false, 262144, true>, "both:   fragment-major weights in LDS");
   direct_both(upsample_fused_kernel<true, false, 2, true>, "both:   no stores");
@@ -195,6 +197,7 @@ int main(int argc, char** argv) {
     CK(hipFree(dbg));
   };
   timeline(upsample_fused_kernel<true, false, 4, true>, "both: full");
+  timeline(upsample_fused_kernel<true, false, 4 + 4194304, true>, "both: priority by wave age");
   timeline(upsample_fused_kernel<true, false, 4 + 524288, true>, "both: full; columns 2, 3 = after K step 0 / K step 3 of GEMM1");
 
   return 0;
