@@ -22,6 +22,20 @@ struct GemvArgs {
   float alpha;
 };
 
+// The weight stream: every byte is read once per token by ONE wave, so the loads are marked non-temporal (streaming lines do not displace
+// the x rows, norm weights and KV cache other kernels of the decode step re-read from L2; MP_GEMV_NT=0 at build time restores the default
+// policy for an A/B).
+#ifndef MP_GEMV_NT
+#define MP_GEMV_NT 1
+#endif
+__device__ __forceinline__ bf16x8 gv_ldw(const bf16_t* p) {
+#if MP_GEMV_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#else
+  return *reinterpret_cast<const bf16x8*>(p);
+#endif
+}
+
 __device__ __forceinline__ float gv_dot8(const bf16x8 a, const bf16x8 b, float acc) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = fmaf((float)a[j], (float)b[j], acc);
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
   for (; it + 1 < iters; it += 2, k += 1024) {              // two steps per trip: 8 weight loads in flight per lane
     bf16x8 w0[4], w1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k + 512); }
+    for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + k); w1[r] = gv_ldw(wp[r] + k + 512); }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
   if (it < iters) {
     bf16x8 w0[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + k);
+    for (int r = 0; r < 4; ++r) w0[r] = gv_ldw(wp[r] + k);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void gemv_shared_kernel(GemvArgs g) {
     for (int m = 0; m < M; ++m) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + k), acc[m][r]);
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, gv_ldw(wp[r] + k), acc[m][r]);
     }
   }
 #pragma unroll
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
       for (int u = 0; u < 4; ++u) {
         xs[u] = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k + u * 512);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ws[u][r] = *reinterpret_cast<const bf16x8*>(wp[r] + k + u * 512);
+        for (int r = 0; r < 4; ++r) ws[u][r] = gv_ldw(wp[r] + k + u * 512);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void gemv_indexed_kernel(GemvArgs g) {
     for (; k < g.K; k += 512) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(g.x + (int64_t)m * g.ldx + k);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + k), acc[r]);
+      for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x0, gv_ldw(wp[r] + k), acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]);
@@ -235,7 +249,7 @@ __device__ __forceinline__ void gv_norm_rows_dot(const GemvArgs& g, const float*
   for (int it = 0; it + 1 < NCH; it += 2, kk += 1024) {
     bf16x8 w0[4], w1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { w0[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk); w1[r] = *reinterpret_cast<const bf16x8*>(wp[r] + kk + 512); }
+    for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk + 512]);
@@ -248,7 +262,7 @@ __device__ __forceinline__ void gv_norm_rows_dot(const GemvArgs& g, const float*
     for (int m = 0; m < M; ++m) {
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[wv][m][kk]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, *reinterpret_cast<const bf16x8*>(wp[r] + kk), acc[m][r]);
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x0, gv_ldw(wp[r] + kk), acc[m][r]);
     }
   }
 #pragma unroll
