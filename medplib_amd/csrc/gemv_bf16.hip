@@ -271,6 +271,85 @@ __device__ __forceinline__ void gv_norm_rows_dot(const GemvArgs& g, const float*
     for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
 }
 
+// Round 4, K a multiple of 2048: the WORKGROUP normalises the rows once — rmsnorm_bf16_kernel's own 256-thread row (thread t owns the
+// 16-byte chunks c * 256 + t, block_sum in its order: the same bits by construction) — into one LDS copy its four waves share, instead
+// of every wave normalising them for itself: a quarter of the L2 reads of x and the norm weights (3072 waves x 24 KB = 74 MB per
+// qkv launch at 7B, all on the same lines, now 18 MB), a quarter of the LDS.  And the first trip of the weight stream is requested BEFORE
+// the norm, so the prologue runs under the HBM latency of the first eight loads instead of in front of it.  Must be called by all 256
+// threads (`wp` must be valid addresses for waves without work, which skip the epilogue).
+template <int M, int NCH>
+__device__ __forceinline__ void gv_norm_rows_dot_block(const GemvArgs& g, const float* __restrict__ nw, float eps, const bf16_t* const (&wp)[4],
+                                                       int lane, float (&acc)[M][4]) {
+  static_assert(NCH % 4 == 0, "block form: K a multiple of 2048");
+  constexpr int NC = NCH / 4;
+  __shared__ __attribute__((aligned(16))) bf16_t hsh[M][NCH * 512];
+  __shared__ float red[16];
+  int kk = lane * 8;
+  bf16x8 w0[4], w1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
+    bf16x8 hx[NC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      hx[c] = *reinterpret_cast<const bf16x8*>(xr + (c * 256 + (int)threadIdx.x) * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)hx[c][j]; ss += f * f; }
+    }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)g.K + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = (c * 256 + (int)threadIdx.x) * 8;
+      const f32x4 n0 = *reinterpret_cast<const f32x4*>(nw + i), n1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16_t t = (bf16_t)((float)hx[c][j] * rs);
+        o[j] = (bf16_t)((j < 4 ? n0[j & 3] : n1[j & 3]) * (float)t);
+      }
+      *reinterpret_cast<bf16x8*>(&hsh[m][i]) = o;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {                              // the first trip: its weights are already on their way
+    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+  }
+  kk += 1024;
+#pragma unroll 1
+  for (int it = 2; it + 1 < NCH; it += 2, kk += 1024) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
+}
+
+template <int M, int NCH>
+__device__ __forceinline__ void gv_norm_rows_dot_any(const GemvArgs& g, const float* __restrict__ nw, float eps, const bf16_t* const (&wp)[4],
+                                                     int lane, int wv, float (&acc)[M][4]) {
+  if constexpr (NCH % 4 == 0) gv_norm_rows_dot_block<M, NCH>(g, nw, eps, wp, lane, acc);
+  else gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, wv, acc);
+}
+
 // RMSNorm folded into the GEMV (decode steps: input_layernorm -> qkv projection, final norm -> lm_head).  Every wave normalises the
 // row itself — K bf16 (8 KB at 7B) from L2 and two wave reductions, nothing beside the 4 x K weight stream it is about to read — and
 // keeps the normalised row in registers; the stand-alone norm kernel's launch (5 us of a 130 us decode layer) disappears.  BIT-IDENTICAL
@@ -291,13 +370,12 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_kernel(GemvArgs g, const flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
   }
-  if (rows[0] >= g.N) return;
   const bf16_t* wp[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)min(rows[r], g.N - 1) * g.ldw;
   float acc[M][4];
-  gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, threadIdx.x >> 6, acc);
-  if (lane != 0) return;
+  gv_norm_rows_dot_any<M, NCH>(g, nw, eps, wp, lane, threadIdx.x >> 6, acc);      // (waves beyond N take part: the block form has barriers)
+  if (lane != 0 || rows[0] >= g.N) return;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (SWIGLU) {                                           // the shared kernel's SwiGLU epilogue, rounding points included
@@ -344,8 +422,9 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
   const int wid = blockIdx.x * 4 + wv;
   const int d = ra.H * ra.D, half = ra.D / 2;
   const int per_region = d / 4;                            // waves per third
-  if (wid >= 3 * per_region) return;
-  const int region = wid / per_region, idx = wid % per_region;
+  const bool idle = wid >= 3 * per_region;                 // (takes part in the block-wide norm, computes a valid wave's rows, stores nothing)
+  const int widc = idle ? 3 * per_region - 1 : wid;
+  const int region = widc / per_region, idx = widc % per_region;
   const int per_head = ra.D / 4;
   const int head = idx / per_head, c = (idx % per_head) * 2;
   const int row0 = region < 2 ? region * d + head * ra.D + c : 2 * d + idx * 4;          // wave-uniform
@@ -354,8 +433,8 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
 #pragma unroll
   for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)(row0 + (r & 1) + (r >> 1) * step2) * g.ldw;
   float acc[M][4];
-  gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, wv, acc);
-  if (lane != 0) return;
+  gv_norm_rows_dot_any<M, NCH>(g, nw, eps, wp, lane, wv, acc);
+  if (lane != 0 || idle) return;
   const int pos = ra.pos_dev[0];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
