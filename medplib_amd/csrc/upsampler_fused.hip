@@ -198,6 +198,10 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
       const bf16_t* xrow = a.src + t0 * 256;
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(xrow + kk * 512 + lane * 8);
+    } else if constexpr ((ABL & 8388608) != 0) {   // lab: non-temporal token loads
+      const bf16_t* xrow = a.src + (t0 + fr) * 256;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) xa[kk] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(xrow + (kk * 4 + fq) * 8));
     } else {
       const bf16_t* xrow = a.src + (t0 + fr) * 256;
 #pragma unroll
