@@ -545,6 +545,11 @@ def gpu_main(args, emit):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     parity_failed = False
+    # debug, one-GPU boxes: MP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and MP_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two
+    # ranks on one device) — N real processes through the multi-rank code path with real kernels (tests/test_gpu_bench_dp.py)
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
+    if os.environ.get("MP_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # the GPU leg's host work is index planning on 8 x 64 ids: a handful of threads per rank (N ranks x every core would
@@ -562,9 +567,9 @@ def gpu_main(args, emit):
         # until the driver's own limit): MP_BENCH_NCCL_TIMEOUT seconds, default 600
         import datetime
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
-        dist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=int(os.environ.get("MP_BENCH_NCCL_TIMEOUT", "600"))))
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=int(os.environ.get("MP_BENCH_NCCL_TIMEOUT", "600"))))
     rccl_ranks = None
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and backend == "nccl":
         # what RCCL itself connected: a communicator through the C ABI (bootstrapped with a unique id that travels over the process group),
         # its own rank count (ncclCommCount) and a SUM of ones over it
         try:
