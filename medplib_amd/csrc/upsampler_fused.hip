@@ -68,6 +68,18 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 template <int ABL>
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   if constexpr (ABL & 1) return x;
+  if constexpr ((ABL & 16777216) != 0) {     // lab: the same arithmetic as scalar instructions (build the lab with -fno-slp-vectorize)
+    f32x2 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float xi = x[i], xp = fmaxf(xi, 0.f), a = fmaf(2.f, xp, -xi);
+      float q = fmaf(-0.0248856320977211f, a, -0.4988200068473816f);
+      q = fmaf(q, a, -1.1292459964752197f);
+      q = fmaf(q, a, -1.0035316944122314f);
+      r[i] = fmaf(-a, __builtin_amdgcn_exp2f(q), xp);
+    }
+    return r;
+  }
   // Round 4: log2 Phi(-a) by a DEGREE-3 polynomial (minimax on the absolute error of a Phi(-a) over [0, 12]: 5.5e-5 — a bf16 ulp of the
   // values this feeds is 4e-3 at 1 and 6e-5 at 0.01; both GELUs of this kernel are rounded to bf16 immediately; the leading coefficient
   // is negative, so the tail still underflows to 0).  Two packed FMAs fewer per pair than the degree-5 fit of the GEMM epilogues
@@ -253,12 +265,14 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
     }
   }
   const int OW = 4 * a.w, OH = 4 * a.h;
+  const unsigned up_lane_off = 2u * ((unsigned)(4 * fq) * (unsigned)(OH * OW) + 4u * (unsigned)fr);   // BYTES (a 32-bit offset beside a scalar base: < 2^32 for maps up to 8192 x 8192 pixels)
   // one (group, kh) task; the first task of a wave gets its tokens from the prologue (xa0), later ones load them here
   auto task_body = [&](const int64_t grp, const bf16x8 (&xa)[8]) __attribute__((always_inline)) {
     const int64_t t0 = grp * 16;
-    const int b = (int)(t0 / tokens_per_img);
-    const int ti = (int)(t0 % tokens_per_img);
-    const int irow = ti / a.w, j0 = ti % a.w;
+    // (wave-uniform by construction; said explicitly so that everything derived from them — the output bases above all — lives in scalar registers)
+    const int b = __builtin_amdgcn_readfirstlane((int)(t0 / tokens_per_img));
+    const int ti = __builtin_amdgcn_readfirstlane((int)(t0 % tokens_per_img));
+    const int irow = __builtin_amdgcn_readfirstlane(ti / a.w), j0 = __builtin_amdgcn_readfirstlane(ti % a.w);
     // four waves per SIMD hide this latency; a register prefetch would cost 32 VGPRs across the whole body.  Measured: issuing the
     // first group's loads before the weight-staging wait (one pass per wave at the 1024-px geometry) is 10 % SLOWER (24.7 vs
     // 22.5 us, same box) -- 16 waves x 8 KiB of token reads queue in front of the 80 KiB of weight DMA every wave waits for.
@@ -503,7 +517,11 @@ __global__ __launch_bounds__(UP_THREADS, 1) void upsample_fused_kernel(UpArgs a)
           for (int r = 0; r < 4; ++r) {
             const bf16x4 o = {(bf16_t)g[0][0][r >> 1][r & 1], (bf16_t)g[0][1][r >> 1][r & 1], (bf16_t)g[1][0][r >> 1][r & 1], (bf16_t)g[1][1][r >> 1][r & 1]};
             if (WITH_UP) {
-              bf16_t* dst = a.up + (((int64_t)b * 32 + half * 16 + 4 * fq + r) * OH + line) * OW + 4 * (j0 + fr);
+              // wave-uniform base (scalar registers) + one per-lane offset for all sixteen stores of a task: the lane's own four channels
+              // 4fq + r sit 4fq planes above the base, its token 4 fr pixels along the line
+              bf16_t* dst = (ABL & 33554432) != 0      // lab: the earlier form, the whole address per lane and store
+                  ? a.up + (((int64_t)b * 32 + half * 16 + 4 * fq + r) * OH + line) * OW + 4 * (j0 + fr)
+                  : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(a.up + (((int64_t)b * 32 + half * 16 + r) * OH + line) * OW + 4 * j0) + up_lane_off);
               if constexpr ((ABL & 2) != 0) { asm volatile("" :: "v"(o)); }
               else if constexpr ((ABL & 4096) != 0) *reinterpret_cast<bf16x4*>(dst) = o;
               else __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(dst));     // streaming: see the note at the 16-byte form below

@@ -88,9 +88,11 @@ int main(int argc, char** argv) {
   direct_split(upsample_fused_kernel<true, false, 0, false>, "split: full kernel (round 3 arrangement)");
   direct_both(upsample_fused_kernel<true, false, 0, true>, "both: one group per wave, 16 waves");
   direct_both(upsample_fused_kernel<true, false, 1048576, true>, "both:   GEMM1 not transposed, LDS transposition");
-  direct_both(upsample_fused_kernel<true, false, 8388608, true>, "both:   non-temporal token loads");
+  direct_both(upsample_fused_kernel<true, false, 33554432, true>, "both:   store addresses computed per lane and store");
   direct_both(upsample_fused_kernel<true, false, 0, true>, "both: one group per wave, 16 waves (again)");
-  direct_both(upsample_fused_kernel<true, false, 8388608, true>, "both:   non-temporal token loads (again)");
+  direct_both(upsample_fused_kernel<true, false, 33554432, true>, "both:   store addresses per lane and store (again)");
+  direct_both(upsample_fused_kernel<true, false, 16777216, true>, "both:   GELU as scalar f32 instructions");
+  direct_both(upsample_fused_kernel<true, false, 8388608, true>, "both:   non-temporal token loads");
   direct_both(upsample_fused_kernel<true, false, 4194304, true>, "both:   priority 3 - k for the k-th wave of a SIMD");
   direct_both(upsample_fused_kernel<true, false, 4194304 + 2, true>, "both:   same, no stores");
   direct_both(upsample_fused_kernel<true, false, 4096, true>, "both:   plain stores");
