@@ -291,12 +291,52 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = si[0];
 }
 
+// The decode step's form (cols % 4 == 0, up to 32768 columns: the 32000-entry vocabulary): 1024 threads, every thread's <= 8 float4 loads
+// requested at once, wave reductions by shuffles, one pass through LDS for the sixteen waves.  The 256-thread kernel above walks 125
+// dependent trips per thread: 37 us of a 3.3 ms decode step for 128 KB of logits; this one ~5 us.  Same result (first index on ties).
+__device__ __forceinline__ void argmax_take(float& bv, int& bi, float v, int i) {
+  if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+__global__ __launch_bounds__(1024) void argmax_rows_wide_kernel(const float* __restrict__ x, int64_t ld, int cols, int64_t* __restrict__ out) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const float* r = x + (int64_t)blockIdx.x * ld;
+  const int n4 = cols >> 2, tid = threadIdx.x;
+  float4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i4 = tid + k * 1024;
+    v[k] = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (i4 < n4) v[k] = *reinterpret_cast<const float4*>(r + 4 * i4);
+  }
+  float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = 4 * (tid + k * 1024);
+    if (tid + k * 1024 < n4) { argmax_take(bv, bi, v[k].x, i); argmax_take(bv, bi, v[k].y, i + 1); argmax_take(bv, bi, v[k].z, i + 2); argmax_take(bv, bi, v[k].w, i + 3); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    argmax_take(bv, bi, ov, oi);
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) argmax_take(bv, bi, sv[w], si[w]);
+    out[blockIdx.x] = bi;
+  }
+}
+
 }  // namespace
 
 extern "C" int mp_argmax_rows_f32(const float* x, int64_t ld, int64_t rows, int cols, int64_t* out, hipStream_t stream) {
   MP_REQUIRE(cols > 0, MP_ERR_SHAPE, "mp_argmax_rows_f32: bad shape");
   if (rows == 0) return MP_OK;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ld, cols, out);
+  if (cols % 4 == 0 && cols <= 32768 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(argmax_rows_wide_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, x, ld, cols, out);
+  else
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ld, cols, out);
   return mp_check_launch("mp_argmax_rows_f32");
 }
 

@@ -438,6 +438,29 @@ def test_attention_decode_single_query(dev, D, H):
         _report(f"decode attention vs tiled kernel D={D} Sk={n}", out, out2.float().cpu(), rtol=3 * BF16_EPS, atol=2e-2)
 
 
+def test_argmax_rows_first_index_on_ties(dev):
+    """mp_argmax_rows_f32 (greedy decoding's pick) in both forms — the 1024-thread one the 32000-entry vocabulary takes (cols % 4 == 0,
+    <= 32768) and the general one — against torch.argmax on the host: exact ties resolve to the FIRST index, wherever the tie sits
+    (inside one thread's float4, across threads of a wave, across waves), -inf rows and a maximum in the last column included."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for rows, cols in [(1, 32000), (3, 32000), (2, 32768), (2, 4096), (3, 100), (2, 7), (1, 40000), (2, 32004)]:
+        x = torch.randn(rows, cols, generator=g)
+        x[0, cols - 1] = 9.0                                        # the maximum in the last column
+        if rows > 1:
+            top = 7.5
+            for c in (cols // 3, cols // 3 + 1, cols // 3 + 260, cols - 2, cols // 3 + 5000):   # five equal maxima (clamped into the row)
+                x[1, min(c, cols - 1)] = top
+        if rows > 2:
+            x[2] = float("-inf"); x[2, cols // 2] = -1e30; x[2, cols // 2 + 1] = -1e30
+        ref = torch.stack([torch.nonzero(x[r] == x[r].max())[0, 0] for r in range(rows)])
+        got = ops.argmax_rows(x.to(dev)).cpu()
+        assert torch.equal(got, ref), (rows, cols, got, ref)
+        xs = torch.zeros(rows, cols + 3); xs[:, 1:cols + 1] = x          # a view that is not 16-byte aligned: the general kernel
+        got2 = ops.argmax_rows(xs.to(dev)[:, 1:cols + 1]).cpu()
+        assert torch.equal(got2, ref), (rows, cols, "unaligned", got2, ref)
+
+
 def test_decode_norm_gate_route_equals_separate_kernels(dev):
     """mp_decode_norm_gate_route (one launch per layer of a decode step) vs mp_rmsnorm_bf16 + mp_moe_gate_bf16 + mp_moe_route_top1:
     identical bits for the normed rows, the expert / slot indices, the combine weights, the counts and l_aux — including an
