@@ -462,6 +462,71 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
   }
 }
 
+// K-SPLIT form for the narrow projections of a decode step (N <= 4096: o_proj and the down projections, one row of x or the indexed
+// expert form).  With a wave per four W rows those launches are 256 workgroups of four waves — one wave per SIMD, 8-16 KB of loads in
+// flight per wave and nothing to hide their latency behind: the o projection streamed at 3.2 TB/s, the expert down projection at 4.2
+// (gate|up, 1376 workgroups: 5.9).  Here a workgroup of SIXTEEN waves owns the same sixteen W rows: wave (rg, kp) takes the four rows
+// of row group rg and the 512-element steps s = kp, kp + 4, kp + 8, ... of K, so a CU has four times the loads in flight and four waves
+// per SIMD; the four K parts of a row are added in ascending kp order through LDS (a fixed order: deterministic, but not the
+// single-wave order of gemv_shared_kernel — the two forms agree to fp32 rounding, not bit for bit).
+__global__ __launch_bounds__(1024) void gemv_ksplit_kernel(GemvArgs g) {
+  __shared__ float red[4][4][4];                            // [kp][rg][r]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rg = wv & 3, kp = wv >> 2;
+  const int row0 = (blockIdx.x * 4 + rg) * 4;
+  for (int m = 0; m < g.M; ++m) {
+    const bf16_t* Wm = g.W + (g.w_index ? (int64_t)g.w_index[m] * g.strideW : 0);
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wp[r] = Wm + (int64_t)min(row0 + r, g.N - 1) * g.ldw;
+    const bf16_t* xr = g.x + (int64_t)m * g.ldx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = lane * 8 + kp * 512;
+    for (; k + 2048 < g.K; k += 4096) {                     // two of this wave's steps per trip: 8 weight loads in flight per lane
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xr + k), x1 = *reinterpret_cast<const bf16x8*>(xr + k + 2048);
+      bf16x8 w0[4], w1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + k); w1[r] = gv_ldw(wp[r] + k + 2048); }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[r]));
+    }
+    if (k < g.K) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xr + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = gv_dot8(x0, gv_ldw(wp[r] + k), acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]);
+    if (m > 0) __syncthreads();                             // the previous row's partials have been read
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[kp][rg][r] = acc[r];
+    }
+    __syncthreads();
+    if (kp != 0 || lane >= 4) continue;
+    const int n = row0 + lane;                               // lane r of the kp = 0 wave finishes row r of its group
+    if (n >= g.N) continue;
+    const float a = ((red[0][rg][lane] + red[1][rg][lane]) + red[2][rg][lane]) + red[3][rg][lane];
+    if (g.w_index) {                                        // gemv_indexed_kernel's epilogue: combine weight on the bf16-rounded expert output, then the residual
+      float scale = g.row_scale ? g.row_scale[m] : 1.f;
+      if (g.row_keep && g.row_keep[m] < 0) scale = 0.f;
+      float v = scale * (float)(bf16_t)a;
+      if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+      reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+    } else {                                                // gemv_shared_kernel's
+      float v = apply_act(a * g.alpha + (g.bias ? g.bias[n] : 0.f), g.act);
+      if (g.out_f32) {
+        if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+        reinterpret_cast<float*>(g.y)[(int64_t)m * g.ldy + n] = v;
+      } else {
+        v = (float)(bf16_t)v;
+        if (g.residual) v += (float)g.residual[(int64_t)m * g.ldr + n];
+        reinterpret_cast<bf16_t*>(g.y)[(int64_t)m * g.ldy + n] = (bf16_t)v;
+      }
+    }
+  }
+}
+
 template <int M>
 void launch_shared(const GemvArgs& g, dim3 grid, hipStream_t s) {
   if (g.act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL((gemv_shared_kernel<M, true>), grid, dim3(256), 0, s, g);
@@ -485,6 +550,13 @@ extern "C" int mp_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t l
              M, N, K, act, out_dtype == MP_F32, alpha};
   const int waves = act == ACT_SWIGLU_PAIR ? N / 4 : (int)mp_cdiv(N, 4);
   const dim3 grid((unsigned)mp_cdiv(waves, 4));
+  // narrow projections with a long K (o_proj, the down projections of a decode step): sixteen waves per sixteen rows, K split four ways
+  static int ksplit = -1;
+  if (ksplit < 0) { const char* e = getenv("MP_GEMV_KSPLIT"); ksplit = (e && atoi(e) == 0) ? 0 : 1; }     // 0: the one-wave-per-four-rows kernels (A/B)
+  if (ksplit && act != ACT_SWIGLU_PAIR && N <= 4096 && K >= 4096 && (w_index || M == 1)) {
+    hipLaunchKernelGGL(gemv_ksplit_kernel, grid, dim3(1024), 0, stream, g);
+    return mp_check_launch("mp_gemv_bf16(ksplit)");
+  }
   if (w_index) {
     if (act == ACT_SWIGLU_PAIR) hipLaunchKernelGGL(gemv_indexed_kernel<true>, grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL(gemv_indexed_kernel<false>, grid, dim3(256), 0, stream, g);

@@ -374,6 +374,30 @@ def test_gemv_decode_projections(dev):
     assert torch.equal(out[2].cpu(), res[2]), "a capacity-dropped row keeps the residual stream exactly"
 
 
+def test_gemv_ksplit_narrow_projections(dev):
+    """The K-split form mp_gemv_bf16 takes for N <= 4096, K >= 4096 (o_proj and the down projections of a decode step: sixteen waves per
+    sixteen W rows, four K parts added in a fixed order) at the 7B shapes — K = 11008 has a ragged last step (21.5 steps of 512) — vs the
+    fp32 reference: plain, residual, fp32 output, and the indexed expert form with combine weight, capacity drop and residual."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(43)
+    for N, K in ((4096, 4096), (4096, 11008), (1000, 4104)):
+        x = _bf(torch.randn(1, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.02); res = _bf(torch.randn(1, N, generator=g))
+        ref = O.linear(x.float(), w.float())
+        _report(f"gemv ksplit {N}x{K}", ops.gemv(x.to(dev), w.to(dev)), ref, rtol=2 * BF16_EPS, atol=1e-3 * math.sqrt(K))
+        _report(f"gemv ksplit f32 out {N}x{K}", ops.gemv(x.to(dev), w.to(dev), out_dtype=torch.float32), ref, rtol=1e-4, atol=2e-3)
+        out = ops.gemv(x.to(dev), w.to(dev), residual=res.to(dev))
+        _report(f"gemv ksplit residual {N}x{K}", out, ref.to(torch.bfloat16).float() + res.float(), rtol=2 * BF16_EPS, atol=2e-2)
+        again = ops.gemv(x.to(dev), w.to(dev), residual=res.to(dev))
+        assert torch.equal(out, again), "fixed summation order: the same bits on every launch"
+    E, N, K, M = 2, 4096, 11008, 3
+    x = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(E, N, K, generator=g) * 0.02); res = _bf(torch.randn(M, N, generator=g))
+    idx = torch.tensor([1, 0, 1], dtype=torch.int32); scale = torch.tensor([0.7, 0.9, 0.55]); keep = torch.tensor([0, -1, 1], dtype=torch.int32)
+    out = ops.gemv(x.to(dev), w.to(dev), residual=res.to(dev), w_index=idx.to(dev), row_scale=scale.to(dev), row_keep=keep.to(dev))
+    ref = torch.stack([res[m].float() + (0.0 if keep[m] < 0 else scale[m]) * (x[m].float() @ w[idx[m]].float().t()).to(torch.bfloat16).float() for m in range(M)])
+    _report("gemv ksplit experts", out, ref, rtol=2 * BF16_EPS, atol=2e-2)
+    assert torch.equal(out[1].cpu(), res[1]), "a capacity-dropped row keeps the residual stream exactly"
+
+
 def test_decode_qkv_launch_equals_norm_gemv_rope_append(dev):
     """mp_gemv_rmsnorm_rope_append_bf16 (a decode step's input_layernorm -> q|k|v projection -> RoPE at the device-side position -> KV-cache
     append in ONE launch) against mp_rmsnorm_bf16 + mp_gemv_bf16 + mp_decode_rope_append_bf16: the rotated q and the appended cache rows
