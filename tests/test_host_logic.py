@@ -127,6 +127,14 @@ def test_warmup_decay_lr():
         WarmupDecayLR(total_num_steps=10, first_step_lr="sometimes")
 
 
+
+def _free_port():
+    """A port the kernel just handed out (a pid-derived one can sit in TIME_WAIT from an earlier run or belong to someone else)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
@@ -231,7 +239,7 @@ def test_layer_bucketed_overlapped_allreduce_two_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker_overlap.py"
     script.write_text(_WORKER_OVERLAP)
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
@@ -245,7 +253,7 @@ def test_gradient_bucket_allreduce_two_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
@@ -366,7 +374,7 @@ def test_expert_parallel_all_to_all_two_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ep_worker.py"
     script.write_text(_EP_WORKER)
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1")
@@ -383,7 +391,7 @@ def test_expert_parallel_variable_split_two_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ep_worker_var.py"
     script.write_text(_EP_WORKER)
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1", EP_VARIABLE="1")
@@ -642,7 +650,7 @@ def test_expert_data_parallel_gradient_scaling_four_ranks_gloo(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "edp_worker.py"
     script.write_text(_EDP_WORKER)
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(4):
         env = dict(os.environ, RANK=str(r), PORT=str(port), REPO=repo, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
