@@ -268,6 +268,45 @@ def test_fused_upsampler_matches_reference_chain(dev, grid, B):
     _close(f"fused upsampler mask (grid {grid})", mask, ref_mask, rtol=1e-2, atol=8e-2)
 
 
+@pytest.mark.parametrize("h,w,B", [(64, 64, 8), (64, 64, 9), (8, 48, 5), (128, 64, 3), (1, 16, 1)])
+def test_fused_upsampler_large_launches_and_output_forms(dev, h, w, B):
+    """The launch shapes the two cases above do not reach: sixteen waves per workgroup with one pass per wave (64 x 64 x 8 = 2048 groups: the
+    benchmark's geometry, the first four waves' tokens requested before the staging wait), more groups than 256 workgroups x 8 (a second pass
+    for some waves: 2304 and 1536 x ... groups), non-square maps, a group count that leaves waves without work, one group.  Against the fp32
+    reference chain, and the three output forms against each other: the `up` of (up, mask) and of up alone, the mask of (up, mask) and of
+    mask alone are the same bits (same arithmetic, only the stores differ)."""
+    from medplib_amd import ops
+    from oracle import sam as OS
+    W = OS.init_weights(seed=7)
+    g = torch.Generator().manual_seed(h * 1000 + w + B)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    src = bf(torch.randn(B, 256, h, w, generator=g))
+    Wq = dict(W)
+    Wq["mask_decoder.output_upscaling.0.weight"] = bf(W["mask_decoder.output_upscaling.0.weight"])
+    Wq["mask_decoder.output_upscaling.3.weight"] = bf(W["mask_decoder.output_upscaling.3.weight"])
+    hyper = torch.randn(B, 32, generator=g)
+    w1p, w2p = ops.pack_upsampler_weights(W["mask_decoder.output_upscaling.0.weight"].to(dev), W["mask_decoder.output_upscaling.3.weight"].to(dev))
+    tok = src.permute(0, 2, 3, 1).reshape(B, h * w, 256).contiguous().to(torch.bfloat16).to(dev)
+    d = lambda k: W[k].to(dev)
+    args = (tok, w1p, d("mask_decoder.output_upscaling.0.bias"), d("mask_decoder.output_upscaling.1.weight"),
+            d("mask_decoder.output_upscaling.1.bias"), w2p, d("mask_decoder.output_upscaling.3.bias"), h, w)
+    up, mask = ops.mask_upsample_fused(*args, hyper=hyper.to(dev))
+    up_only, none = ops.mask_upsample_fused(*args)
+    none2, mask_only = ops.mask_upsample_fused(*args, hyper=hyper.to(dev), want_up=False)
+    torch.cuda.synchronize()
+    assert none is None and none2 is None
+    assert torch.equal(up, up_only), "up of (up, mask) vs up alone"
+    assert torch.equal(mask, mask_only), "mask of (up, mask) vs mask alone"
+    n_ref = min(B, 2)                                             # the fp32 chain on the host for the first and the last image
+    for b in sorted({0, B - 1})[:n_ref]:
+        ref_up = OS.output_upscaling(src[b:b + 1], Wq)
+        ref_mask = (hyper[b:b + 1, None, :] @ bf(ref_up).view(1, 32, -1)).view(1, 4 * h, 4 * w)
+        _close(f"fused upsampler up ({h}x{w}x{B}, image {b})", up[b:b + 1], ref_up, rtol=2 ** -7, atol=2e-2)
+        _close(f"fused upsampler mask ({h}x{w}x{B}, image {b})", mask[b:b + 1], ref_mask, rtol=1e-2, atol=8e-2)
+    again, _ = ops.mask_upsample_fused(*args)
+    assert torch.equal(again, up_only), "same bits on every launch"
+
+
 def test_fused_upsampler_backward_vs_fp32_autograd(dev):
     """The training form of the fused upsampler (A.FusedUpsampleMaskFn: forward = mp_mask_upsample_fused_bf16 with the hypernetwork
     product, backward = mp_mask_upsample_fused_bwd_bf16 + two `tn` GEMMs + column sums) against torch's own fp32 ConvTranspose2d ->
