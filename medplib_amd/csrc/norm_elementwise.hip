@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = si[0];
 }
 
-// The decode step's form (cols % 4 == 0, up to 32768 columns: the 32000-entry vocabulary): 1024 threads, every thread's <= 8 float4 loads
+// The decode step's form (up to 32768 columns: the 32267-entry vocabulary): 1024 threads, every thread's <= 8 float4 loads
 // requested at once, wave reductions by shuffles, one pass through LDS for the sixteen waves.  The 256-thread kernel above walks 125
 // dependent trips per thread: 37 us of a 3.3 ms decode step for 128 KB of logits; this one ~5 us.  Same result (first index on ties).
 __device__ __forceinline__ void argmax_take(float& bv, int& bi, float v, int i) {
@@ -301,19 +301,33 @@ __global__ __launch_bounds__(1024) void argmax_rows_wide_kernel(const float* __r
   __shared__ float sv[16];
   __shared__ int si[16];
   const float* r = x + (int64_t)blockIdx.x * ld;
-  const int n4 = cols >> 2, tid = threadIdx.x;
-  float4 v[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i4 = tid + k * 1024;
-    v[k] = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (i4 < n4) v[k] = *reinterpret_cast<const float4*>(r + 4 * i4);
-  }
+  const int tid = threadIdx.x;
   float bv = -INFINITY; int bi = 0x7fffffff;
+  if ((reinterpret_cast<uintptr_t>(r) & 15) == 0) {          // (wave-uniform) 16-byte pieces + up to three single columns at the end
+    const int n4 = cols >> 2;
+    float4 v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = 4 * (tid + k * 1024);
-    if (tid + k * 1024 < n4) { argmax_take(bv, bi, v[k].x, i); argmax_take(bv, bi, v[k].y, i + 1); argmax_take(bv, bi, v[k].z, i + 2); argmax_take(bv, bi, v[k].w, i + 3); }
+    for (int k = 0; k < 8; ++k) {
+      const int i4 = tid + k * 1024;
+      v[k] = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (i4 < n4) v[k] = *reinterpret_cast<const float4*>(r + 4 * i4);
+    }
+    const int it = 4 * n4 + tid;
+    const float vt = (tid < 3 && it < cols) ? r[it] : -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = 4 * (tid + k * 1024);
+      if (tid + k * 1024 < n4) { argmax_take(bv, bi, v[k].x, i); argmax_take(bv, bi, v[k].y, i + 1); argmax_take(bv, bi, v[k].z, i + 2); argmax_take(bv, bi, v[k].w, i + 3); }
+    }
+    if (tid < 3 && it < cols) argmax_take(bv, bi, vt, it);
+  } else {                                                   // a row that does not start on 16 bytes: single columns, eight requests at a time
+    for (int k0 = 0; k0 < 32; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int i = tid + (k0 + k) * 1024; v[k] = i < cols ? r[i] : -INFINITY; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int i = tid + (k0 + k) * 1024; if (i < cols) argmax_take(bv, bi, v[k], i); }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_wide_kernel(const float* __r
 extern "C" int mp_argmax_rows_f32(const float* x, int64_t ld, int64_t rows, int cols, int64_t* out, hipStream_t stream) {
   MP_REQUIRE(cols > 0, MP_ERR_SHAPE, "mp_argmax_rows_f32: bad shape");
   if (rows == 0) return MP_OK;
-  if (cols % 4 == 0 && cols <= 32768 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+  if (cols <= 32768)
     hipLaunchKernelGGL(argmax_rows_wide_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, x, ld, cols, out);
   else
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ld, cols, out);

@@ -463,12 +463,12 @@ def test_attention_decode_single_query(dev, D, H):
 
 
 def test_argmax_rows_first_index_on_ties(dev):
-    """mp_argmax_rows_f32 (greedy decoding's pick) in both forms — the 1024-thread one the 32000-entry vocabulary takes (cols % 4 == 0,
-    <= 32768) and the general one — against torch.argmax on the host: exact ties resolve to the FIRST index, wherever the tie sits
+    """mp_argmax_rows_f32 (greedy decoding's pick) in both forms — the 1024-thread one rows of up to 32768 columns take (16-byte pieces when
+    the row starts on 16 bytes, single columns otherwise) and the general one — against torch.argmax on the host: exact ties resolve to the FIRST index, wherever the tie sits
     (inside one thread's float4, across threads of a wave, across waves), -inf rows and a maximum in the last column included."""
     from medplib_amd import ops
     g = torch.Generator().manual_seed(31)
-    for rows, cols in [(1, 32000), (3, 32000), (2, 32768), (2, 4096), (3, 100), (2, 7), (1, 40000), (2, 32004)]:
+    for rows, cols in [(1, 32267), (3, 32000), (3, 32267), (2, 32768), (2, 4096), (3, 100), (2, 7), (1, 40000), (2, 32004), (2, 32766)]:
         x = torch.randn(rows, cols, generator=g)
         x[0, cols - 1] = 9.0                                        # the maximum in the last column
         if rows > 1:
