@@ -193,6 +193,17 @@ int mp_gather_rows_bf16_to_f32(const void* src, int64_t ld, const int64_t* idx, 
 int mp_gather_rows_f32(const float* src, const int64_t* idx, float* out, int64_t n_rows, int64_t dim, hipStream_t stream);
 int mp_scale_f32(float* x, int64_t n, float s, hipStream_t stream);
 
+/* The whole trainable fp32 tail of one direction as ONE launch: text_hidden_fcs (MedPLIB.py:152-164) -> TwoWayTransformer
+ * (transformer.py:62-106,151-182,185-244) -> hypernetwork / IoU heads (mask_decoder.py:113-153), forward or backward, lowered by the host
+ * (medplib_amd/tail_program.py) into a table of 256-byte op descriptors that a persistent grid executes phase by phase with grid barriers.
+ * ops: n_ops x 256 bytes on the device {int type, flags, ntiles, tile_begin, M, N, K, i0..i3, pad; float f0..f3; int64 ld[12]; uint64 p[12]},
+ * operand address = (slot << 56) | byte offset, 0 = absent; op types 1 GEMM, 2 REDUCE, 3 LN_FWD, 4 LN_BWD, 5 ATTN_FWD, 6 ATTN_BWD, 7 COPY2D.
+ * phase_ops [n_phases + 1], phase_tiles [n_phases]: device int arrays.  slots: EIGHT base addresses in HOST memory, slots[0] == 0.
+ * sync: 128 device bytes (zeroed here per call; 32-bit word 1 != 0 afterwards = a barrier gave up).  stamps: n_phases x 8 device bytes or NULL
+ * (100 MHz clock per phase end).  grid: workgroups, clamped to the compute-unit count. */
+int mp_tail_program_run(const void* ops, const int* phase_ops, const int* phase_tiles, int n_phases, const uint64_t* slots, void* sync,
+                        void* stamps, int grid, hipStream_t stream);
+
 /* ---- mask head: resize, losses, metrics -------------------------------------------------------------------------- */
 
 /* Fused inference upsampler: ConvT2x2/s2(256->64) + LayerNorm2d + GELU + ConvT2x2/s2(64->32) + GELU [+ hyper_in @ upscaled]

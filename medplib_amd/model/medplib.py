@@ -632,10 +632,11 @@ class MedPLIBForCausalLM(nn.Module):
         if n < image_tokens.shape[0]:
             image_tokens = image_tokens[:n].contiguous()
         fc = m.text_hidden_fcs[0]
-        pred_emb = A.linear(A.linear(hidden_rows, fc[0].weight, fc[0].bias, ops.SACT_RELU), fc[2].weight, fc[2].bias)
         pe = m.visual_model.prompt_encoder
-        low_res, iou_pred = m.visual_model.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight,
-                                                         pred_emb.view(n, 1, -1))
+        # text_hidden_fcs (MedPLIB.py:152-164) runs inside the mask decoder's call: with the tail program the whole trainable chain up to the
+        # upsampler is one launch forward and one backward
+        low_res, iou_pred = m.visual_model.mask_decoder(image_tokens, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None,
+                                                         fcs=(fc[0], fc[2]), hidden_rows=hidden_rows)
         shapes = [tuple(l.shape[-2:]) for l in label_list[:n]]
         full, pred_masks = self._postprocess(low_res, resize_list[:n], shapes)
         if inference:

@@ -7,6 +7,8 @@
   dense = no_mask_embed broadcast; dense PE is a model constant computed once (prompt_encoder.py:204-226).
 * `MaskDecoder` — trainable fp32 tail with the reference's parameter names (mask_decoder.py:16-153, transformer.py:16-244),
   batched over all prompts (the reference loops one prompt at a time, model/MedPLIB.py:473-502)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -324,24 +326,48 @@ class MaskDecoder(nn.Module):
         self.iou_prediction_head = _MLP(dim, 256, 4, 3)
         self.fused_bf16_upsampler = False       # opt-in inference path (config.fused_bf16_upsampler); packed weights cached
         self._packed = None
+        # text_hidden_fcs + two-way transformer + heads as one launch each way (tail_program.py); MP_TAIL_PROGRAM=0: the op-by-op path (A/B)
+        self.use_program = os.environ.get("MP_TAIL_PROGRAM", "1") != "0"
+        self._runner, self._runner_key = None, None
 
     def train(self, mode=True):
         self._packed = None                     # weights may change while training: re-pack on the next inference call
         return super().train(mode)
 
-    def forward(self, image_tokens, dense_pe_tokens, no_mask_embed, text_embeds):
+    def _runner_for(self, dense_pe_tokens, no_mask_embed, fcs):
+        """The program runner bound to these constants / this text_hidden_fcs pair (tail_program.TailRunner), built on first use."""
+        from ..tail_program import TailRunner
+        key = (dense_pe_tokens.data_ptr(), no_mask_embed.data_ptr(), None if fcs is None else (id(fcs[0]), id(fcs[1])))
+        if self._runner is None or self._runner_key != key:
+            self._runner, self._runner_key = TailRunner(self, dense_pe_tokens, no_mask_embed, fcs=fcs), key
+        return self._runner
+
+    def forward(self, image_tokens, dense_pe_tokens, no_mask_embed, text_embeds, fcs=None, hidden_rows=None):
         """image_tokens [n, h*w, C] fp32 (NHWC order), dense_pe_tokens [h*w, C], no_mask_embed [1, C], text_embeds [n,1,C]
-        -> low-res mask logits [n, 4h, 4w] (mask token 0, multimask_output=False) and iou prediction [n]."""
+        -> low-res mask logits [n, 4h, 4w] (mask token 0, multimask_output=False) and iou prediction [n].
+        fcs = (fc1, fc2) + hidden_rows [n, hidden]: text_hidden_fcs runs in front (text_embeds is then ignored) — the form the training
+        step uses, so that the whole trainable tail up to the upsampler is ONE launch each way (tail_program.py)."""
         n, T, C = image_tokens.shape
         g = self.grid
+        if self.use_program and n > 0 and T == g * g and C == self.dim:
+            x_in = hidden_rows if fcs is not None else text_embeds.reshape(n, C)
+            src, hyper0, iou = self._runner_for(dense_pe_tokens, no_mask_embed, fcs)(x_in.float(), image_tokens)
+            return self._upscale(src, hyper0, n), iou
+        if fcs is not None:
+            text_embeds = A.linear(A.linear(hidden_rows, fcs[0].weight, fcs[0].bias, ops.SACT_RELU), fcs[1].weight, fcs[1].bias).view(n, 1, -1)
         tokens = A.BuildTokensFn.apply(self.iou_token.weight, self.mask_tokens.weight, text_embeds)
         src = A.add(image_tokens, no_mask_embed.view(-1))                 # src = image_embeddings + dense (broadcast over tokens)
         hs, src = self.transformer(src, dense_pe_tokens, tokens)
         iou_tok, mask_tok0 = hs[:, 0, :], hs[:, 1, :]
+        hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)              # [n, 32]; mask slice 0 (mask_decoder.py:102-108)
+        return self._upscale(src, hyper0, n), self.iou_prediction_head(iou_tok)[:, 0]
+
+    def _upscale(self, src, hyper0, n):
+        """output_upscaling + hyper_in @ upscaled_embedding (mask_decoder.py:53-59,141-148): src [n, h*w, C], hyper0 [n, C/8] -> [n, 4h, 4w]."""
+        g, C = self.grid, self.dim
         if self.fused_bf16_upsampler and not torch.is_grad_enabled() and g % 16 == 0:
             # inference: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hypernetwork product in ONE bf16 pass over HBM
             # (mp_mask_upsample_fused_bf16), the arithmetic the reference itself runs under `--precision bf16`
-            hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)
             if self._packed is None:
                 ct1, ln, ct2 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
                 w1p, w2p = ops.pack_upsampler_weights(ct1.weight.detach(), ct2.weight.detach())
@@ -350,18 +376,14 @@ class MaskDecoder(nn.Module):
             w1p, b1, lw, lb, w2p, b2, eps = self._packed
             _, masks = ops.mask_upsample_fused(ops.cast_to_bf16(src.contiguous()).view(n, g * g, C), w1p, b1, lw, lb, w2p, b2, g, g,
                                                hyper=hyper0.contiguous(), want_up=False, eps=eps)
-            return masks, self.iou_prediction_head(iou_tok)[:, 0]
+            return masks
         if self.fused_bf16_upsampler and g % 16 == 0:
             # training: the same kernel, differentiated by one recomputing backward kernel (A.FusedUpsampleMaskFn)
             ct1, ln, ct2 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
-            hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)
-            masks = A.FusedUpsampleMaskFn.apply(src, ct1.weight, ct1.bias, ln.weight, ln.bias, ct2.weight, ct2.bias, hyper0, g, float(ln.eps))
-            return masks, self.iou_prediction_head(iou_tok)[:, 0]
+            return A.FusedUpsampleMaskFn.apply(src, ct1.weight, ct1.bias, ln.weight, ln.bias, ct2.weight, ct2.bias, hyper0, g, float(ln.eps))
         up = A.ConvT2x2Fn.apply(src.view(n, g, g, C), self.output_upscaling[0].weight, self.output_upscaling[0].bias)
         ln = self.output_upscaling[1]
         up = A.GeluFn.apply(A.layernorm(up, ln.weight, ln.bias, ln.eps))
         up = A.GeluFn.apply(A.ConvT2x2Fn.apply(up, self.output_upscaling[3].weight, self.output_upscaling[3].bias))
-        hyper0 = self.output_hypernetworks_mlps[0](mask_tok0)              # [n, 32]; mask slice 0 (mask_decoder.py:102-108)
         masks = A.HyperDotFn.apply(hyper0, up.view(n, 16 * g * g, C // 8))
-        iou = self.iou_prediction_head(iou_tok)[:, 0]
-        return masks.view(n, 4 * g, 4 * g), iou
+        return masks.view(n, 4 * g, 4 * g)

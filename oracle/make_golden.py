@@ -14,8 +14,17 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def _ref_sam():
-    sys.path.insert(0, os.path.join(REF, "model", "segment_anything_med2d"))
-    import modeling  # noqa: the reference's own package (torch-only)
+    sam_dir = os.path.join(REF, "model", "segment_anything_med2d")
+    sys.path.insert(0, sam_dir)
+    try:
+        import modeling  # noqa: the reference's own package (torch-only)
+    finally:
+        # the SAM-Med2D directory has a `utils` package of its own: left on sys.path (or in sys.modules) it shadows the reference's root
+        # `utils` when a later target of the same process imports model.MedPLIB (round-4 review: the documented default run failed there)
+        sys.path.remove(sam_dir)
+        for name in [k for k, v in sys.modules.items() if (k == "utils" or k.startswith("utils."))
+                     and os.path.abspath(getattr(v, "__file__", "") or "").startswith(sam_dir)]:
+            del sys.modules[name]
     from functools import partial
     enc = modeling.ImageEncoderViT(depth=12, embed_dim=768, img_size=256, mlp_ratio=4,
                                    norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=12, patch_size=16,
@@ -96,8 +105,9 @@ def _import_reference_medplib():
     sys.modules["torchvision.transforms.functional"].to_pil_image = lambda *a, **k: None
     sys.modules["torchvision.ops.boxes"].batched_nms = lambda *a, **k: None
     sys.modules["torchvision.ops.boxes"].box_area = lambda *a, **k: None
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
+    if REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, REF)                                # first: `utils`, `model`, `datasets` must resolve to the reference's root packages
     try:
         import model.MedPLIB as M
     except Exception as e:  # pragma: no cover

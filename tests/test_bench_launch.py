@@ -67,3 +67,16 @@ def test_bench_ep_must_divide_the_rank_count():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--ep", "2", "--dry"], env=_clean_env(), capture_output=True,
                        text=True, timeout=120)
     assert p.returncode != 0 and "does not divide" in (p.stderr + p.stdout)
+
+
+def test_bench_eight_ranks_dry_the_drivers_own_commands():
+    """The 8-GPU node's first contact cannot fail for a reason a CPU could have caught (round-4 review, item 6): the driver's exact command
+    lines at the full rank count — `--gpus 8` and `--gpus 8 --ep 2 --ep-variable` (reference: scripts/train_medplib_icl.sh:15-43, 4 ranks there;
+    train_ds_medplib.py:412-419) — through the self-launch, eight gloo ranks, the gradient bucket over all of them, four expert-parallel
+    groups of two exchanging side by side; ONE line on stdout, n_gpus = ranks = 8."""
+    r = _dry("--gpus", "8")
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["config"]["parallelism"] == "dp8" and r["bucket_sums_correct"] is True
+    r = _dry("--gpus", "8", "--ep", "2", "--ep-variable")
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["config"]["parallelism"] == "ep2 x dp4" and r["bucket_sums_correct"] is True
+    ep = r["ep"]
+    assert ep["ep_size"] == 2 and ep["replicas"] == 4 and ep["variable_split"] is True and ep["round_trips_correct_on_every_rank"] is True
