@@ -223,6 +223,10 @@ int mp_mask_upsample_fused_bwd_bf16(const void* src, const void* w1_packed, cons
                                     const void* w2_packed, const float* b2, const float* hyper, const void* w1_t, const void* w2_t,
                                     const float* dmask, float* dx2, float* dy1, float* a1, float* dy2, float* part,
                                     int B, int h, int w, float ln_eps, hipStream_t stream);
+/* The bf16 operand images of the two ConvTranspose2d weights (w [Cin, Cout, 2, 2] fp32, mask_decoder.py:53-59) in one launch:
+ * w?p [(kh, kw, cout), cin] = what mp_mask_upsample_fused_bf16 reads, w?t = its transpose (mp_mask_upsample_fused_bwd_bf16; may be NULL). */
+int mp_upsampler_pack_bf16(const float* w1, const float* w2, void* w1p, void* w2p, void* w1t, void* w2t, int ci1, int co1, int ci2, int co2,
+                           hipStream_t stream);
 /* postprocess_masks (MedPLIB.py:682-701): crop window (already resolved with Python slice semantics by the caller)
  * then F.interpolate(bilinear, align_corners=False) to (out_h, out_w). */
 int mp_bilinear_resize_fwd(const void* in, int in_dtype, float* out, int n, int in_h, int in_w, int crop_y0, int crop_x0,
@@ -404,6 +408,11 @@ int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, v
  * mp_add3_bf16 with the same rounding points.  R in {8, 16, 32}; out may alias dx. */
 int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
                         int K, int R, float p, uint64_t seed, const int* rows_dev, hipStream_t stream);   /* rows_dev (optional, both kernels): device-side row count */
+/* The same followed by the SwiGLU backward in ONE pass (dense LlamaMLP with an adapter on down_proj, HF modeling_llama.py LlamaMLP.forward via
+ * medplib_moe_llama.py:127-141): dgu[tokens, 2 ff] (gate|up interleaved in blocks of 32, the layout of mp_gemm_swiglu_keep_bf16's gu_out) from
+ * d_act' = bf16(dact + dropout(bf16(dt A))) — bit-identical with mp_lora_up_add_bf16 followed by mp_swiglu_pair_bwd_bf16. */
+int mp_lora_up_add_swiglu_bwd_bf16(const void* dt, int64_t lddt, const void* AT, const void* dact, int64_t lddact, const void* gu, void* dgu,
+                                   int tokens, int ff, int R, float p, uint64_t seed, hipStream_t stream);
 /* The adapter's down-projection with lora_dropout inline, written as the K-extension of the projection's input (peft lora.Linear.forward,
  * tuners/lora/layer.py: result + lora_B(lora_A(dropout(x))) * scaling; call sites train_ds_medplib.py:262-303): t[token, 0..63] =
  * bf16(drop(x)[token, :] . A[j, :]) for the R rank rows of A (A: [>= 16 * ceil(R / 16), K], rows >= R zero), zeros beyond; xd (optional) =

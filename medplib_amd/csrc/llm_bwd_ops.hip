@@ -571,10 +571,14 @@ __global__ void lora_down_finish_kernel(const float* __restrict__ partial, bf16_
 // token ranges of the same chunk.  Rounding points as the three kernels it replaces: the product rounded to bf16 (the GEMM's output),
 // scaled by 1 / (1 - p) and rounded (mp_dropout_bf16), added to dx and rounded (mp_add3_bf16).
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-template <int RP>                                            // rank pairs: R / 2 in {4, 8, 16}
+// SW: the SwiGLU backward in the same pass (the down projection's input gradient is consumed by exactly one kernel, mp_swiglu_pair_bwd_bf16):
+// dx + dropout(bf16(dt A)) is rounded to bf16 exactly as the stored form was, then d gate / d up of the same 8 channels are written to
+// dgu [tokens, 2 K] (gate|up interleaved in blocks of 32) from gu — one pass over d_act instead of a read-modify-write and a read.
+template <int RP, bool SW = false>                           // rank pairs: R / 2 in {4, 8, 16}
 __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restrict__ dt, int64_t lddt, const bf16_t* __restrict__ AT,
                                                           const bf16_t* __restrict__ dx, int64_t lddx, bf16_t* __restrict__ out, int64_t ldo,
-                                                          int T, int K, float p, uint64_t seed, int tpw, const int* __restrict__ rows_dev) {
+                                                          int T, int K, float p, uint64_t seed, int tpw, const int* __restrict__ rows_dev,
+                                                          const bf16_t* __restrict__ gu = nullptr, bf16_t* __restrict__ dgu = nullptr) {
   if (rows_dev) T = min(T, *rows_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)(blockIdx.y * 4 + wave) * tpw >= T) return;
@@ -596,11 +600,16 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
   constexpr int U = 4;                                       // tokens whose loads are in flight together
   for (int tb = t_beg; tb < t_end; tb += U) {
     const int n = min(U, t_end - tb);
-    bf16x8 dv[U], dtv[U][RP / 4];
+    bf16x8 dv[U], dtv[U][RP / 4], gv[SW ? U : 1], uv[SW ? U : 1];
+    const int64_t gcol = (int64_t)(kc >> 5) * 64 + (kc & 31);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (u < n) {
         dv[u] = *reinterpret_cast<const bf16x8*>(dx + (int64_t)(tb + u) * lddx + kc);
+        if constexpr (SW) {
+          gv[u] = *reinterpret_cast<const bf16x8*>(gu + (int64_t)(tb + u) * 2 * K + gcol);
+          uv[u] = *reinterpret_cast<const bf16x8*>(gu + (int64_t)(tb + u) * 2 * K + gcol + 32);
+        }
 #pragma unroll
         for (int q = 0; q < RP / 4; ++q) dtv[u][q] = *reinterpret_cast<const bf16x8*>(dt + (int64_t)(tb + u) * lddt + q * 8);   // same address in every lane
       }
@@ -631,7 +640,22 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
             o[h * 4 + j] = (bf16_t)((float)dv[u][h * 4 + j] + v);
           }
         }
-        if (col_live) *reinterpret_cast<bf16x8*>(out + (int64_t)(tb + u) * ldo + kc) = o;
+        if constexpr (SW) {
+          bf16x8 dg, du;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float gf = (float)gv[u][j], uf = (float)uv[u][j], df = (float)o[j];
+            const float sg = mp_sigmoid_fast(gf);
+            du[j] = (bf16_t)(df * gf * sg);
+            dg[j] = (bf16_t)(df * uf * sg * (1.f + gf * (1.f - sg)));
+          }
+          if (col_live) {
+            *reinterpret_cast<bf16x8*>(dgu + (int64_t)(tb + u) * 2 * K + gcol) = dg;
+            *reinterpret_cast<bf16x8*>(dgu + (int64_t)(tb + u) * 2 * K + gcol + 32) = du;
+          }
+        } else {
+          if (col_live) *reinterpret_cast<bf16x8*>(out + (int64_t)(tb + u) * ldo + kc) = o;
+        }
       }
     }
   }
@@ -1088,6 +1112,20 @@ extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT,
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
   return mp_check_launch("mp_lora_up_add_bf16");
+}
+
+extern "C" int mp_lora_up_add_swiglu_bwd_bf16(const void* dt, int64_t lddt, const void* AT, const void* dact, int64_t lddact, const void* gu, void* dgu,
+                                              int tokens, int ff, int R, float p, uint64_t seed, hipStream_t stream) {
+  MP_REQUIRE(tokens >= 0 && ff > 0 && ff % 32 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_swiglu_bwd_bf16: ff %% 32 == 0, R in {8, 16, 32} (got ff %d, R %d)", ff, R);
+  MP_REQUIRE(lddt % 8 == 0 && lddact % 8 == 0 && p >= 0.f && p < 1.f && gu && dgu, MP_ERR_ARG, "mp_lora_up_add_swiglu_bwd_bf16: bad strides / p / null");
+  if (tokens == 0) return MP_OK;
+  const int64_t chunks = mp_cdiv(ff, 512);
+  const int tpw = (int)std::min<int64_t>(32, std::max<int64_t>(8, (chunks * tokens / 4096 + 3) / 4 * 4));
+  const dim3 grid((unsigned)chunks, (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
+#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP, true>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dact, lddact, (bf16_t*)nullptr, (int64_t)0, tokens, ff, p, seed, tpw, (const int*)nullptr, (const bf16_t*)gu, (bf16_t*)dgu)
+  switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
+#undef MP_GO
+  return mp_check_launch("mp_lora_up_add_swiglu_bwd_bf16");
 }
 
 extern "C" int mp_lora_grad_unpack_f32(const float* dB, const float* dAT, const int64_t* rows, int R, int k0, int r, int fin, int fout, float* gB,

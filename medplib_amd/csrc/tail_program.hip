@@ -21,7 +21,7 @@
 namespace {
 
 enum { OP_GEMM = 1, OP_REDUCE = 2, OP_LN_FWD = 3, OP_LN_BWD = 4, OP_ATTN_FWD = 5, OP_ATTN_BWD = 6, OP_COPY2D = 7 };
-enum { F_TRANS_A = 1, F_TRANS_B = 2, F_RELU = 4, F_ACCUM = 8, F_CS_ACCUM = 16 };
+enum { F_TRANS_A = 1, F_TRANS_B = 2, F_RELU = 4, F_ACCUM = 8, F_CS_ACCUM = 16, F_A_BF16 = 32 };
 
 struct TailOp {
   int type, flags, ntiles, tile_begin;
@@ -107,10 +107,11 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
   const int64_t lda = g.ld[0], ldb = g.ld[1], lda2 = g.ld[6], ldb2 = g.ld[7];
   const int splits = g.i0 > 1 ? g.i0 : 1;
   // 16-byte staging: row strides and bases on 16 bytes, and the contiguous extent a multiple of 4 (a 16-byte group is inside or outside)
-  const bool vecA = !(lda & 3) && al16(A) && !((tA ? g.M : g.K) & 3) && (!A2 || (!(lda2 & 3) && al16(A2)));
+  const bool a_bf16 = g.flags & F_A_BF16;                   // A holds bf16 values (the upsampler's tokens): scalar staging, converted on the way
+  const bool vecA = !a_bf16 && !(lda & 3) && al16(A) && !((tA ? g.M : g.K) & 3) && (!A2 || (!(lda2 & 3) && al16(A2)));
   const bool vecB = !(ldb & 3) && al16(B) && !((tB ? g.K : g.N) & 3) && (!B2 || (!(ldb2 & 3) && al16(B2)));
   if (g.K <= 16 && tA && !tB && splits == 1 && vecA && vecB && !A2 && !B2 && !g.p[3] && !g.p[6] && !g.p[7] && !g.p[8] && !(g.flags & F_RELU) &&
-      !(g.ld[2] & 3) && al16(ptr(S, g.p[2]))) {
+      !(g.ld[2] & 3) && g.ld[9] <= 1 && !a_bf16 && al16(ptr(S, g.p[2]))) {
     gemm_smallk_tile(g, S, tile);
     return;
   }
@@ -134,7 +135,7 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
   float* cs_out = (tA && tn == 0) ? ptr(S, g.p[9]) : nullptr;
   // one operand's slab into registers.  kc = contiguous along k (non-transposed A / transposed B): scalar form element (x = id / 64, k = id % 64),
   // vector form group (x = id4 / 16, k = 4 (id4 % 16)); otherwise contiguous along x: scalar (k = id / 64, x = id % 64), vector (k = id4 / 16, x = 4 (id4 % 16))
-  auto load = [&](const float* P, const float* P2, int64_t ld, int64_t ld2, int rows2, bool kc, bool vec, int x0, int X, int k0, float* r) __attribute__((always_inline)) {
+  auto load = [&](const float* P, const float* P2, int64_t ld, int64_t ld2, int rows2, bool kc, bool vec, int x0, int X, int k0, float* r, bool bf) __attribute__((always_inline)) {
     if (vec) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -156,7 +157,7 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
         float v = 0.f;
         if (x < X && k < kend) {
           const int row = kc ? x : k, col = kc ? k : x;
-          v = P[(int64_t)row * ld + col];
+          v = bf ? (float)((const bf16_t*)P)[(int64_t)row * ld + col] : P[(int64_t)row * ld + col];
           if (P2) v += P2[(int64_t)wrap(row, rows2) * ld2 + col];
         }
         r[i] = v;
@@ -185,8 +186,8 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
     }
   };
   auto gload = [&](int k0) __attribute__((always_inline)) {
-    load(A, A2, lda, lda2, a2_rows, !tA, vecA, m0, g.M, k0, ra);
-    load(B, B2, ldb, ldb2, b2_rows, tB, vecB, n0, g.N, k0, rb);
+    load(A, A2, lda, lda2, a2_rows, !tA, vecA, m0, g.M, k0, ra, a_bf16);
+    load(B, B2, ldb, ldb2, b2_rows, tB, vecB, n0, g.N, k0, rb, false);
   };
   if (kbeg < kend) gload(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -227,6 +228,7 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
   }
   float* C = ptr(S, g.p[2]);
   const int64_t ldc = g.ld[2];
+  const int64_t csc = g.ld[9] > 0 ? g.ld[9] : 1;            // column stride of C (a weight gradient written straight into a [Cin, Cout, 2, 2] tensor)
   const int gn = n0 + qn + (lane & 31);
   if (splits > 1) {
     C += (int64_t)sp * g.ld[8];
@@ -248,7 +250,7 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
     rv[r] = (R && in) ? R[(int64_t)gm * g.ld[3] + gn] : 0.f;
     mv[r] = (MK && in) ? MK[(int64_t)gm * g.ld[4] + gn] : 1.f;
     c2v[r] = (C2 && in) ? C2[(int64_t)gm * g.ld[5] + gn] : 0.f;
-    cv[r] = ((g.flags & F_ACCUM) && in) ? C[(int64_t)gm * ldc + gn] : 0.f;
+    cv[r] = ((g.flags & F_ACCUM) && in) ? C[(int64_t)gm * ldc + gn * csc] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -258,7 +260,7 @@ __device__ void gemm_tile(const TailOp& g, const Slots& S, int tile, float* smem
     if (g.flags & F_RELU) v = fmaxf(v, 0.f);
     if (!(mv[r] > 0.f)) v = 0.f;
     if (C2) C2[(int64_t)gm * g.ld[5] + gn] = c2v[r] + v;
-    C[(int64_t)gm * ldc + gn] = cv[r] + v;
+    C[(int64_t)gm * ldc + gn * csc] = cv[r] + v;
   }
 }
 
@@ -270,6 +272,7 @@ __device__ void reduce_tile(const TailOp& g, const Slots& S, int tile) {
   const float* in = ptr(S, g.p[0]); float* out = ptr(S, g.p[1]);
   const float* bias = ptr(S, g.p[2]); const float* R = ptr(S, g.p[3]); const float* MK = ptr(S, g.p[4]);
   const int64_t total = (int64_t)g.M * g.N;
+  const int64_t ocs = g.ld[5] > 0 ? g.ld[5] : 1;          // column stride of `out`
   const float* src[4]; float acc[4]; int rr[4], cc[4]; bool ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -296,7 +299,7 @@ __device__ void reduce_tile(const TailOp& g, const Slots& S, int tile) {
   for (int j = 0; j < 4; ++j) {
     rv[j] = (R && ok[j]) ? R[(int64_t)rr[j] * g.ld[3] + cc[j]] : 0.f;
     mv[j] = (MK && ok[j]) ? MK[(int64_t)rr[j] * g.ld[4] + cc[j]] : 1.f;
-    ov[j] = ((g.flags & F_ACCUM) && ok[j]) ? out[(int64_t)rr[j] * g.ld[1] + cc[j]] : 0.f;
+    ov[j] = ((g.flags & F_ACCUM) && ok[j]) ? out[(int64_t)rr[j] * g.ld[1] + cc[j] * ocs] : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -306,7 +309,7 @@ __device__ void reduce_tile(const TailOp& g, const Slots& S, int tile) {
     v += rv[j];
     if (g.flags & F_RELU) v = fmaxf(v, 0.f);
     if (!(mv[j] > 0.f)) v = 0.f;
-    out[(int64_t)rr[j] * g.ld[1] + cc[j]] = ov[j] + v;
+    out[(int64_t)rr[j] * g.ld[1] + cc[j] * ocs] = ov[j] + v;
   }
 }
 

@@ -1082,3 +1082,32 @@ extern "C" int mp_mask_upsample_fused_bwd_bf16(const void* src, const void* w1_p
   hipLaunchKernelGGL(upsample_fused_bwd_kernel, dim3(grid), dim3(64 * nw), UPB_LDS, stream, g);
   return mp_check_launch("mp_mask_upsample_fused_bwd_bf16");
 }
+
+// The four bf16 operand images of the two ConvTranspose2d weights in ONE launch (the training step re-packs them every step: the weights train).
+// w [Cin, Cout, 2, 2] fp32 (the reference layout, mask_decoder.py:53-59) -> packed [(kh, kw, cout), cin] and its transpose [cin, (kh, kw, cout)].
+namespace {
+__global__ void upsampler_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16_t* __restrict__ w1p, bf16_t* __restrict__ w2p,
+                                      bf16_t* __restrict__ w1t, bf16_t* __restrict__ w2t, int ci1, int co1, int ci2, int co2) {
+  const int64_t n1 = (int64_t)ci1 * co1 * 4, n2 = (int64_t)ci2 * co2 * 4;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float* w; bf16_t* wp; bf16_t* wt; int ci, co;
+  if (i < n1) { w = w1; wp = w1p; wt = w1t; ci = ci1; co = co1; }
+  else if (i < n1 + n2) { i -= n1; w = w2; wp = w2p; wt = w2t; ci = ci2; co = co2; }
+  else return;
+  // i enumerates the source [ci][co][kh*2+kw]
+  const int q = (int)(i & 3), o = (int)((i >> 2) % co), c = (int)((i >> 2) / co);
+  const bf16_t v = (bf16_t)w[i];
+  const int j = q * co + o;                               // packed row (kh, kw, cout)
+  wp[(int64_t)j * ci + c] = v;
+  if (wt) wt[(int64_t)c * (4 * co) + j] = v;
+}
+}  // namespace
+
+extern "C" int mp_upsampler_pack_bf16(const float* w1, const float* w2, void* w1p, void* w2p, void* w1t, void* w2t, int ci1, int co1, int ci2,
+                                      int co2, hipStream_t stream) {
+  MP_REQUIRE(w1 && w2 && w1p && w2p && ci1 > 0 && co1 > 0 && ci2 > 0 && co2 > 0, MP_ERR_ARG, "mp_upsampler_pack_bf16: null / bad shape");
+  const int64_t n = (int64_t)ci1 * co1 * 4 + (int64_t)ci2 * co2 * 4;
+  hipLaunchKernelGGL(upsampler_pack_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, w1, w2, (bf16_t*)w1p, (bf16_t*)w2p, (bf16_t*)w1t,
+                     (bf16_t*)w2t, ci1, co1, ci2, co2);
+  return mp_check_launch("mp_upsampler_pack_bf16");
+}

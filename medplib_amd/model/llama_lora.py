@@ -315,6 +315,9 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_FUSE_UP_SWIGLU = os.environ.get("MP_FUSE_UP_SWIGLU", "1") != "0"      # A/B: 0 = lora_up_add then swiglu_pair_bwd (two passes over d_act)
+
+
 def _adapter_down(lora, ops_pad, x, t, seed):
     """t = bf16(dropout(x) A^T) into the extension columns -> x (the wgrad regenerates the mask from the seed: nothing dropped is stored)."""
     A, _, _, _, R, _ = ops_pad
@@ -618,14 +621,20 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed):
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
-    adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed."""
+    adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed.  dx = None: nothing trainable lies in front of
+    this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
     A, AT, B, BT, R, _ = ops_pad
     # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
     dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
     dB = ops.tn_skinny(dy, t, R, lora.scaling)                     # [out, R] = scaling * dy^T t
     dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed)        # [in, R]  = dropout(x)^T (scaling * dy B)
+    if dx is None:
+        return None, dB, dAT
+    if swiglu_gu is not None and R <= 32 and dx.stride(0) % 8 == 0 and _FUSE_UP_SWIGLU:
+        # the adapter on down_proj: its input gradient has ONE consumer, the SwiGLU backward — both in one pass, the gate|up gradient comes back
+        return ops.lora_up_add_swiglu_bwd(dt, AT, dx, swiglu_gu, R, lora.p_active, seed), dB, dAT
     if R <= 32 and dx.stride(0) % 8 == 0:
         dx = ops.lora_up_add(dt, AT, dx, R, lora.p_active, seed)       # dx += dropout(dt A): the same mask and 1/(1-p) as the forward
     elif lora.p_active > 0:
@@ -636,8 +645,13 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed):
     return dx, dB, dAT
 
 
-def backward(llm, saved, d_hidden, d_aux=None):
-    """d_hidden [B,S,d] bf16 (gradient of the stack's output), d_aux [1] fp32 (gradient of the summed l_aux) -> {parameter name: fp32 gradient}."""
+def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
+    """d_hidden [B,S,d] bf16 (gradient of the stack's output), d_aux [1] fp32 (gradient of the summed l_aux) -> {parameter name: fp32 gradient}.
+    need_d_embeds=False: the decoder's input rows are frozen (embed_tokens and every front-end module: the shipped stage-III configuration,
+    scripts/train_stage3.sh:29-33), so in the LOWEST layer the chain stops at the last tensor a trainable parameter reads: with adapters on
+    gate / up / down only that is the gate|up gradient — the layer's main gate|up dgrad GEMM, both RMSNorm backward passes, the o_proj and
+    qkv dgrad GEMMs, the attention backward and the RoPE transpose would only produce the gradient of frozen embeddings (HF + peft compute
+    it and drop it; ~1.7 ms of the 132 ms step)."""
     cfg, lora = llm.cfg, llm.lora
     B, S = saved["B"], saved["S"]
     H, D, d = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size
@@ -683,14 +697,29 @@ def backward(llm, saved, d_hidden, d_aux=None):
             d_h2 = (_moe_bwd_ep if s.get("ep") else _moe_bwd)(llm, lora, i, lw, s, dx, d_aux, grads, take_e)
         else:
             d_act = ops.gemm(dx, lw["down_T"])
+            d_gu = None
             if "down" in pad:
-                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1)
+                fused = _FUSE_UP_SWIGLU and pad["down"][4] <= 32 and d_act.stride(0) % 8 == 0
+                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None)
                 take(i, pad["down"], dB, dAT)
-            d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
-            d_h2 = ops.gemm(d_gu, lw["gu_T"])
+                if fused:
+                    d_gu, d_act = d_act, None
+            if d_gu is None:
+                d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
+            # the lowest layer with frozen input rows: nothing trainable reads anything in front of the gate|up input unless the attention
+            # projections carry adapters or a norm of this layer trains
+            stop_here = (i == 0 and not need_d_embeds and "o" not in pad and "qkv" not in pad
+                         and (i, "ln1") not in lora.norm_names and (i, "ln2") not in lora.norm_names)
+            d_h2 = None if stop_here else ops.gemm(d_gu, lw["gu_T"])
             if "gu" in pad:
                 d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
                 take(i, pad["gu"], dB, dAT)
+            if stop_here:
+                dx = None
+                if lora.grad_sink is not None:
+                    pre = f"model.layers.{i}."
+                    lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
+                break
         if (i, "ln2") in lora.norm_names:
             d_mid, grads[lora.norm_names[(i, "ln2")]] = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx, want_wgrad=True)
         else:
@@ -730,7 +759,7 @@ class LlamaLoRAFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_hidden, d_aux):
         llm = ctx.llm
-        grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous())
+        grads = backward(llm, ctx.saved, d_hidden.contiguous(), None if d_aux is None else d_aux.contiguous(), need_d_embeds=bool(ctx.needs_input_grad[1]))
         d_emb = grads.pop("__d_embeds__").view(ctx.saved["B"], ctx.saved["S"], -1) if ctx.needs_input_grad[1] else None
         ctx.saved = None
         # one slot per parameter forward() took; None where the engine's grad sink already accumulated the gradient

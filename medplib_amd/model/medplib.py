@@ -588,6 +588,7 @@ class MedPLIBForCausalLM(nn.Module):
             main.wait_stream(self._side_stream())
             image_tokens.record_stream(main)
         use_tail = self.tail_side_stream and self.training and not inference and torch.is_grad_enabled()
+        m.visual_model.mask_decoder.program_grid = 64 if use_tail else 256       # hidden beside the decoder: fewer resident workgroups (sam.py)
         if not use_tail:
             self.active_tail_stream = None
             if self._tail_stream_obj is not None:

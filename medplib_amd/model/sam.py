@@ -17,6 +17,7 @@ from .. import ops
 from . import autograd_ops as A
 
 GELU = ops.ACT_GELU
+_FUSED_TAIL = os.environ.get("MP_TAIL_FUSED_UPSAMPLER", "1") != "0"     # A/B: 0 = the program and FusedUpsampleMaskFn as two autograd nodes
 
 
 def _conv_taps(k, pad):
@@ -329,17 +330,24 @@ class MaskDecoder(nn.Module):
         # text_hidden_fcs + two-way transformer + heads as one launch each way (tail_program.py); MP_TAIL_PROGRAM=0: the op-by-op path (A/B)
         self.use_program = os.environ.get("MP_TAIL_PROGRAM", "1") != "0"
         self._runner, self._runner_key = None, None
+        # workgroups of the program's persistent grid: 256 (one per CU) when the tail is on the step's critical path (decoder adapters training);
+        # the model sets 64 while the tail runs hidden on its own stream beside the next step's decoder — resident workgroups that wait at a
+        # barrier still hold their CU against the decoder's GEMM tiles (measured round 5, headline step: 61.45 ms at 256, 59.58 at 64, 59.4-59.5
+        # with the op-by-op tail; LoRA step: 131.6 at 256 vs 131.7-131.8).  MP_TAIL_GRID overrides both.
+        self.program_grid = 256
 
     def train(self, mode=True):
         self._packed = None                     # weights may change while training: re-pack on the next inference call
         return super().train(mode)
 
-    def _runner_for(self, dense_pe_tokens, no_mask_embed, fcs):
+    def _runner_for(self, dense_pe_tokens, no_mask_embed, fcs, fused=False):
         """The program runner bound to these constants / this text_hidden_fcs pair (tail_program.TailRunner), built on first use."""
         from ..tail_program import TailRunner
-        key = (dense_pe_tokens.data_ptr(), no_mask_embed.data_ptr(), None if fcs is None else (id(fcs[0]), id(fcs[1])))
+        key = (dense_pe_tokens.data_ptr(), no_mask_embed.data_ptr(), None if fcs is None else (id(fcs[0]), id(fcs[1])), bool(fused))
         if self._runner is None or self._runner_key != key:
-            self._runner, self._runner_key = TailRunner(self, dense_pe_tokens, no_mask_embed, fcs=fcs), key
+            self._runner, self._runner_key = TailRunner(self, dense_pe_tokens, no_mask_embed, fcs=fcs, fused_upsampler=fused), key
+        if "MP_TAIL_GRID" not in os.environ:
+            self._runner.grid = int(self.program_grid)
         return self._runner
 
     def forward(self, image_tokens, dense_pe_tokens, no_mask_embed, text_embeds, fcs=None, hidden_rows=None):
@@ -351,6 +359,9 @@ class MaskDecoder(nn.Module):
         g = self.grid
         if self.use_program and n > 0 and T == g * g and C == self.dim:
             x_in = hidden_rows if fcs is not None else text_embeds.reshape(n, C)
+            if self.fused_bf16_upsampler and g % 16 == 0 and torch.is_grad_enabled() and C == 256 and _FUSED_TAIL:
+                # training through the fused bf16 upsampler: program + upsampler as ONE autograd node (tail_program.TailFusedFn)
+                return self._runner_for(dense_pe_tokens, no_mask_embed, fcs, fused=True)(x_in.float(), image_tokens)
             src, hyper0, iou = self._runner_for(dense_pe_tokens, no_mask_embed, fcs)(x_in.float(), image_tokens)
             return self._upscale(src, hyper0, n), iou
         if fcs is not None:

@@ -531,6 +531,19 @@ def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None, rows_dev=None):
     return out
 
 
+def lora_up_add_swiglu_bwd(dt, AT, dact, gu, R, p=0.0, seed=0):
+    """swiglu_pair_bwd(gu, lora_up_add(dt, AT, dact)) in one pass (mp_lora_up_add_swiglu_bwd_bf16), bit-identical with the two kernels:
+    dt [T, >= R] bf16, AT [ff, 64] bf16, dact [T, ff] bf16 (not modified), gu [T, 2 ff] bf16 -> d gate|up [T, 2 ff] bf16."""
+    _chk(dt, torch.bfloat16, "lora_up_add_swiglu_bwd.dt"); _chk(dact, torch.bfloat16, "lora_up_add_swiglu_bwd.dact"); _chk(gu, torch.bfloat16, "lora_up_add_swiglu_bwd.gu")
+    T, ff = dact.shape
+    assert AT.shape == (ff, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dact.stride(1) == 1
+    assert gu.shape == (T, 2 * ff) and gu.is_contiguous()
+    dgu = torch.empty_like(gu)
+    lib().call("mp_lora_up_add_swiglu_bwd_bf16", _p(dt), dt.stride(0), _p(AT), _p(dact), dact.stride(0), _p(gu), _p(dgu), T, ff, int(R), float(p), int(seed),
+               _stream())
+    return dgu
+
+
 def moe_combine_bwd(dout, y, expert, slot, weight, capacity, top_k=1):
     """-> (d_y [E, cap, d] bf16 (zeros where no token sits), d_w [top_k * T] fp32)."""
     T, d = dout.shape
@@ -934,6 +947,18 @@ def pack_upsampler_weights(w1, w2):
     return w1p, w2p
 
 
+def pack_upsampler_weights_all(w1, w2):
+    """-> (w1p, w2p, w1t, w2t): pack_upsampler_weights and the two transposes the backward reads, in ONE launch (mp_upsampler_pack_bf16)."""
+    _chk(w1, torch.float32, "pack_upsampler.w1"); _chk(w2, torch.float32, "pack_upsampler.w2")
+    assert w1.is_contiguous() and w2.is_contiguous() and w1.shape[2:] == (2, 2) and w2.shape[2:] == (2, 2)
+    ci1, co1, ci2, co2 = w1.shape[0], w1.shape[1], w2.shape[0], w2.shape[1]
+    dev, bf = w1.device, torch.bfloat16
+    w1p, w2p = torch.empty((4 * co1, ci1), dtype=bf, device=dev), torch.empty((4 * co2, ci2), dtype=bf, device=dev)
+    w1t, w2t = torch.empty((ci1, 4 * co1), dtype=bf, device=dev), torch.empty((ci2, 4 * co2), dtype=bf, device=dev)
+    lib().call("mp_upsampler_pack_bf16", _p(w1), _p(w2), _p(w1p), _p(w2p), _p(w1t), _p(w2t), ci1, co1, ci2, co2, _stream())
+    return w1p, w2p, w1t, w2t
+
+
 def mask_upsample_fused(src, w1p, b1, ln_w, ln_b, w2p, b2, h, w, hyper=None, want_up=True, eps=1e-6):
     """src [B, h*w, 256] bf16 -> (up [B,32,4h,4w] bf16 or None, mask [B,4h,4w] f32 or None)."""
     _chk(src, torch.bfloat16, "upsample.src"); assert src.is_contiguous() and src.shape[1] == h * w and src.shape[2] == 256
@@ -945,14 +970,38 @@ def mask_upsample_fused(src, w1p, b1, ln_w, ln_b, w2p, b2, h, w, hyper=None, wan
     return up, mask
 
 
-def mask_upsample_fused_bwd(src, w1p, b1, ln_w, ln_b, w2p, b2, hyper, dmask, h, w, eps=1e-6):
+def upsample_bwd_layout(B, T):
+    """Float offsets of (dx2, dy1, a1, dy2, part) inside ONE buffer + its length: the backward's five outputs as one allocation, so that a
+    consumer (the mask-tail program) addresses them all from one base."""
+    sizes = (2 * B * T * 256, B * T * 256, B * T * 4 * 64, B * T * 4 * 128, (B * T // 8) * 256)
+    offs, tot = [], 0
+    for k in sizes:
+        offs.append(tot)
+        tot += -(-k // 64) * 64
+    return offs, tot
+
+
+def mask_upsample_fused_bwd(src, w1p, b1, ln_w, ln_b, w2p, b2, hyper, dmask, h, w, eps=1e-6, w1t=None, w2t=None, one_buffer=False):
     """Backward of mask_upsample_fused(..., hyper=...) -> (dx2 [2,B,h*w,256], dy1 [B*h*w,256], a1 [B*h*w*4,64], dy2 [B*h*w*4,128],
-    part [B*h*w/8,256]); see mp_mask_upsample_fused_bwd_bf16 for what the caller finishes (two `tn` GEMMs + column sums)."""
+    part [B*h*w/8,256]); see mp_mask_upsample_fused_bwd_bf16 for what the caller finishes (two `tn` GEMMs + column sums).
+    one_buffer: the five are views of one allocation at upsample_bwd_layout's offsets (returned as a sixth value)."""
     _chk(src, torch.bfloat16, "upsample_bwd.src"); _chk(dmask, torch.float32, "upsample_bwd.dmask")
     assert src.is_contiguous() and dmask.is_contiguous() and hyper.is_contiguous() and w % 16 == 0
     B, T = src.shape[0], h * w
     dev = src.device
-    w1t, w2t = w1p.t().contiguous(), w2p.t().contiguous()
+    if w1t is None:
+        w1t, w2t = w1p.t().contiguous(), w2p.t().contiguous()
+    if one_buffer:
+        offs, tot = upsample_bwd_layout(B, T)
+        buf = torch.empty(tot, dtype=torch.float32, device=dev)
+        dx2 = buf[offs[0]:offs[0] + 2 * B * T * 256].view(2, B, T, 256)
+        dy1 = buf[offs[1]:offs[1] + B * T * 256].view(B * T, 256)
+        a1 = buf[offs[2]:offs[2] + B * T * 256].view(B * T * 4, 64)
+        dy2 = buf[offs[3]:offs[3] + B * T * 512].view(B * T * 4, 128)
+        part = buf[offs[4]:offs[4] + (B * T // 8) * 256].view(B * T // 8, 256)
+        lib().call("mp_mask_upsample_fused_bwd_bf16", _p(src), _p(w1p), _p(b1), _p(ln_w), _p(ln_b), _p(w2p), _p(b2), _p(hyper), _p(w1t), _p(w2t),
+                   _p(dmask), _p(dx2), _p(dy1), _p(a1), _p(dy2), _p(part), B, h, w, float(eps), _stream())
+        return dx2, dy1, a1, dy2, part, buf
     dx2 = torch.empty((2, B, T, 256), dtype=torch.float32, device=dev)
     dy1 = torch.empty((B * T, 256), dtype=torch.float32, device=dev)
     a1 = torch.empty((B * T * 4, 64), dtype=torch.float32, device=dev)

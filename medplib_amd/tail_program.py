@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 OP_GEMM, OP_REDUCE, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_COPY2D = 1, 2, 3, 4, 5, 6, 7
-F_TRANS_A, F_TRANS_B, F_RELU, F_ACCUM, F_CS_ACCUM = 1, 2, 4, 8, 16
+F_TRANS_A, F_TRANS_B, F_RELU, F_ACCUM, F_CS_ACCUM, F_A_BF16 = 1, 2, 4, 8, 16, 32
 OP_NAMES = {1: "gemm", 2: "reduce", 3: "ln_fwd", 4: "ln_bwd", 5: "attn_fwd", 6: "attn_bwd", 7: "copy2d"}
 OP_DTYPE = np.dtype([("type", "<i4"), ("flags", "<i4"), ("ntiles", "<i4"), ("tile_begin", "<i4"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
                      ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"), ("i3", "<i4"), ("pad0", "<i4"), ("f0", "<f4"), ("f1", "<f4"), ("f2", "<f4"),
@@ -113,7 +113,7 @@ class Prog:
 
     # ------------------------------------------------------------------ op constructors
     def gemm(self, A, B, C, ta=False, tb=False, a2=None, a2_rows=0, b2=None, b2_rows=0, bias=None, res=None, relu=False, mask=None,
-             accum=False, c2=None, colsum=None, cs_accum=False, alpha=1.0, splits=1, note=""):
+             accum=False, c2=None, colsum=None, cs_accum=False, alpha=1.0, splits=1, a_bf16=False, c_cs=0, note=""):
         M, K = (A.cols, A.rows) if ta else (A.rows, A.cols)
         Kb, N = (B.cols, B.rows) if tb else (B.rows, B.cols)
         assert K == Kb, f"gemm {note}: inner dims {K} vs {Kb}"
@@ -127,9 +127,11 @@ class Prog:
         for x, sh in ((bias, (1, N)), (res, (M, N)), (mask, (M, N)), (c2, (M, N))):
             assert x is None or (x.rows, x.cols) == sh, f"gemm {note}: epilogue operand shape {(x.rows, x.cols)} vs {sh}"
         assert colsum is None or (ta and colsum.cols == M)
-        flags = (F_TRANS_A if ta else 0) | (F_TRANS_B if tb else 0) | (F_RELU if relu else 0) | (F_ACCUM if accum else 0) | (F_CS_ACCUM if cs_accum else 0)
+        flags = ((F_TRANS_A if ta else 0) | (F_TRANS_B if tb else 0) | (F_RELU if relu else 0) | (F_ACCUM if accum else 0) | (F_CS_ACCUM if cs_accum else 0)
+                 | (F_A_BF16 if a_bf16 else 0))
+        assert not (a_bf16 and a2 is not None) and not (c_cs and (splits > 1 or c2 is not None))
         ld = [A.ld, B.ld, C.ld, res.ld if res else 0, mask.ld if mask else 0, c2.ld if c2 else 0, a2.ld if a2 else 0, b2.ld if b2 else 0,
-              M * N if splits > 1 else 0, 0, 0, 0]
+              M * N if splits > 1 else 0, c_cs, 0, 0]
         p = [self._a(A), self._a(B), self._a(C), self._a(bias), self._a(a2), self._a(b2), self._a(res), self._a(mask), self._a(c2), self._a(colsum), 0, 0]
         f = dict(type=OP_GEMM, flags=flags, ntiles=_cdiv(M, 64) * _cdiv(N, 64) * splits, M=M, N=N, K=K, i0=splits, i1=a2_rows, i2=b2_rows,
                  f0=alpha, ld=ld, p=p, note=note)
@@ -138,10 +140,11 @@ class Prog:
         writes = [C] + ([c2] if c2 else []) + ([colsum] if colsum is not None else [])
         return self._emit(f, reads, writes)
 
-    def reduce(self, src, out, S, split_stride, M=None, N=None, bias=None, res=None, relu=False, mask=None, accum=False, alpha=1.0, ld_in=None, note=""):
+    def reduce(self, src, out, S, split_stride, M=None, N=None, bias=None, res=None, relu=False, mask=None, accum=False, alpha=1.0, ld_in=None, out_cs=0,
+               note=""):
         M = out.rows if M is None else M
         N = out.cols if N is None else N
-        ld = [src.ld if ld_in is None else ld_in, out.ld, split_stride, res.ld if res else 0, mask.ld if mask else 0] + [0] * 7
+        ld = [src.ld if ld_in is None else ld_in, out.ld, split_stride, res.ld if res else 0, mask.ld if mask else 0, out_cs] + [0] * 6
         p = [self._a(src), self._a(out), self._a(bias), self._a(res), self._a(mask)] + [0] * 7
         flags = (F_RELU if relu else 0) | (F_ACCUM if accum else 0)
         f = dict(type=OP_REDUCE, flags=flags, ntiles=_cdiv(M * N, 1024), M=M, N=N, K=S, f0=alpha, ld=ld, p=p, note=note)
@@ -371,9 +374,13 @@ class TailProgram:
     """The two programs for `n` prompts of one MaskDecoder (+ optionally text_hidden_fcs in front of it), bound to the CURRENT addresses of
     the parameters, their gradients (flat buffer offsets) and the two constants.  Rebuilt by `get_program` when any of those move."""
 
-    def __init__(self, dec, n, dense_pe, no_mask_embed, fcs=None, grad_offsets=None, hidden_grad=True, text_grad=True):
+    def __init__(self, dec, n, dense_pe, no_mask_embed, fcs=None, grad_offsets=None, hidden_grad=True, text_grad=True, fused_upsampler=False):
         """dec: model.sam.MaskDecoder; fcs: (fc1 Linear, fc2 Linear) or None (then the text embedding [n, C] is the input);
-        grad_offsets: {id(param): byte offset into the gradient buffer the backward is given} for the parameters that train."""
+        grad_offsets: {id(param): byte offset into the gradient buffer the backward is given} for the parameters that train.
+        fused_upsampler: the backward's inputs are the outputs of mp_mask_upsample_fused_bwd_bf16 in ONE buffer (ops.upsample_bwd_layout) and
+        the bf16 tokens the upsampler consumed — the program then also finishes that kernel's work: d src = the sum of its two halves,
+        d hyper0 and the bias / LayerNorm2d gradients from its per-task rows, and the two ConvTranspose2d weight gradients (dW1 = dy1^T src,
+        dW2 = dy2^T a1) written straight into the [Cin, Cout, 2, 2] gradient tensors (mask_decoder.py:53-59)."""
         self.n, self.C, self.Tk = n, dec.dim, dec.grid * dec.grid
         self.device = dec.iou_token.weight.device
         n, C, Tk = self.n, self.C, self.Tk
@@ -466,10 +473,44 @@ class TailProgram:
         L.set_grad(iou_x, g_hs.view(0, n, 0, C, row_step=6, part="r0"))
         L.set_grad(msk_x, g_hs.view(1, n, 0, C, row_step=6, part="r1"))
         g_keys, _ = L.grad(keys)
-        d_src = Ref(S_IN1, 0, n * Tk, C)
-        bw.copy2d(g_keys, a=d_src, b=Ref(S_IN1, 4 * n * Tk * C, n * Tk, C), note="d src = the two halves of the upsampler's dx")
         g_hy, _ = L.grad(hyper0)
-        bw.copy2d(g_hy, a=Ref(S_IN2, 0, n, hyper0.cols), note="d hyper0")
+        self.fused_upsampler = bool(fused_upsampler)
+        if not fused_upsampler:
+            d_src = Ref(S_IN1, 0, n * Tk, C)
+            bw.copy2d(g_keys, a=d_src, b=Ref(S_IN1, 4 * n * Tk * C, n * Tk, C), note="d src = the two halves of the upsampler's dx")
+            bw.copy2d(g_hy, a=Ref(S_IN2, 0, n, hyper0.cols), note="d hyper0")
+        else:
+            from . import ops
+            assert C == 256 and hyper0.cols == 32 and Tk % 8 == 0
+            offs, _ = ops.upsample_bwd_layout(n, Tk)
+            rows1, rows4, tasks = n * Tk, 4 * n * Tk, n * Tk // 8
+
+            def ub(k, rows, cols, ld=None, c0=0):
+                return Ref(S_IN1, 4 * (offs[k] + c0), rows, cols, cols if ld is None else ld, root=(S_IN1, offs[k]))
+            bw.copy2d(g_keys, a=ub(0, rows1, C), b=Ref(S_IN1, 4 * (offs[0] + rows1 * C), rows1, C), note="d src = dx2[0] + dx2[1]")
+            # part [tasks, 256]: db1[64] | dln_w[64] | dln_b[64] | db2[32] | dhyper[32]; a prompt's tasks are consecutive rows
+            bw.reduce(ub(4, n, 32, ld=(Tk // 8) * 256, c0=224), g_hy, Tk // 8, 256, M=n, N=32, note="d hyper0 = its prompt's task rows summed")
+            up = dec.output_upscaling
+            for t_, c0, w_ in ((up[0].bias, 0, 64), (up[1].weight, 64, 64), (up[1].bias, 128, 64), (up[3].bias, 192, 32)):
+                gt_ = grad_of(t_)
+                if gt_ is not None:
+                    bw.reduce(ub(4, 1, w_, ld=256, c0=c0), gt_, tasks, 256, M=1, N=w_, accum=True, note="upsampler bias / LayerNorm2d gradient")
+            src_bf = Ref(S_IN2, 0, rows1, C)                      # bf16 tokens: the ld is in ELEMENTS
+            for wt, A_, a_bf, rowsK, co, ci, kB in ((up[0].weight, src_bf, True, rows1, 64, 256, 1), (up[3].weight, ub(2, rows4, 64), False, rows4, 32, 64, 3)):
+                gw_ = grad_of(wt)
+                if gw_ is None:
+                    continue
+                base = Ref(S_GRAD, gw_.off, ci, co * 4)           # the [Cin, Cout, 2, 2] gradient as [Cin, Cout * 4]
+                sw = _splits(_cdiv(ci, 64) * _cdiv(co, 64), rowsK)
+                for k in range(4):                                # one product per (kh, kw): column k of every (cin, cout) cell, column stride 4
+                    B_ = ub(kB, rowsK, co, ld=4 * co, c0=k * co)
+                    Ck = Ref(S_GRAD, gw_.off + 4 * k, ci, co, co * 4, root=base.root)
+                    if sw > 1:
+                        pw = L.wb.alloc(sw * ci, co, L._name("ups.dWpart"))
+                        bw.gemm(A_, B_, pw, ta=True, splits=sw, a_bf16=a_bf, note=f"ups.dW{co}.{k}")
+                        bw.reduce(pw, Ck, sw, ci * co, accum=True, ld_in=co, out_cs=4, note=f"ups.dW{co}.{k}.sum")
+                    else:
+                        bw.gemm(A_, B_, Ck, ta=True, accum=True, a_bf16=a_bf, c_cs=4, note=f"ups.dW{co}.{k}")
         g_iou, _ = L.grad(iou4)
         bw.copy2d(g_iou, note="zero d iou4")
         bw.copy2d(g_iou.view(0, n, 0, 1), a=Ref(S_IN3, 0, n, 1), accum=True, note="d iou[:, 0]")
@@ -531,8 +572,21 @@ class TailProgram:
         for t in (d_src2, d_hyper0, d_iou):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert d_src2.numel() == 2 * self.n * self.Tk * self.C and d_hyper0.numel() == self.n * self.out["hyper0"].cols and d_iou.numel() == self.n
+        assert not self.fused_upsampler, "a fused-upsampler program takes run_backward_fused"
         d = self._upload()
         self._launch("b", [0, ws.data_ptr(), d["wb"].data_ptr(), 0, int(grad_base), d_src2.data_ptr(), d_hyper0.data_ptr(), d_iou.data_ptr()], grid, stamps)
+        if self.d_in is None:
+            return None
+        r = self.d_in
+        flat = d["wb"][r.off // 4: r.off // 4 + (r.rows - 1) * r.ld + r.cols]
+        return flat.as_strided((r.rows, r.cols), (r.ld, 1))
+
+    def run_backward_fused(self, ws, ups_buf, src_bf16, d_iou, grad_base, grid=256, stamps=None):
+        """The fused-upsampler form: ups_buf = mask_upsample_fused_bwd's one-buffer outputs, src_bf16 = the bf16 tokens its forward read."""
+        assert self.fused_upsampler and ups_buf.dtype == torch.float32 and src_bf16.dtype == torch.bfloat16 and src_bf16.is_contiguous()
+        assert d_iou.dtype == torch.float32 and d_iou.is_contiguous() and d_iou.numel() == self.n
+        d = self._upload()
+        self._launch("b", [0, ws.data_ptr(), d["wb"].data_ptr(), 0, int(grad_base), ups_buf.data_ptr(), src_bf16.data_ptr(), d_iou.data_ptr()], grid, stamps)
         if self.d_in is None:
             return None
         r = self.d_in
@@ -582,13 +636,61 @@ class TailProgramFn(torch.autograd.Function):
         return (None, d_in if ctx.needs_input_grad[1] else None, None, *grads)
 
 
+class TailFusedFn(torch.autograd.Function):
+    """(x_in, image_tokens) -> (low-res mask logits [n, 4g, 4g], iou [n]): the forward program, the fused bf16 upsampler kernel
+    (mp_mask_upsample_fused_bf16, hypernetwork product included), and in the backward that kernel's recomputing twin followed by the
+    backward program, which also finishes the upsampler's weight / bias / LayerNorm2d gradients (TailProgram(fused_upsampler=True)).  Five
+    launches forward (program, cast, weight pack, upsampler, + the program's counter reset), three backward; no torch arithmetic."""
+
+    @staticmethod
+    def forward(ctx, runner, x_in, image_tokens, *params):
+        from . import ops
+        ctx.set_materialize_grads(False)
+        dec = runner.dec
+        n, g = x_in.shape[0], dec.grid
+        prog, base, layout = runner.program(n, params, x_in.requires_grad)
+        ws, src, hyper0, iou4 = prog.run_forward(x_in.detach().contiguous(), image_tokens.detach().contiguous(), grid=runner.grid)
+        up = dec.output_upscaling
+        w1p, w2p, w1t, w2t = ops.pack_upsampler_weights_all(up[0].weight.detach(), up[3].weight.detach())
+        src_bf = ops.cast_to_bf16(src).view(n, g * g, dec.dim)
+        eps = float(up[1].eps)
+        _, masks = ops.mask_upsample_fused(src_bf, w1p, up[0].bias.detach(), up[1].weight.detach(), up[1].bias.detach(), w2p, up[3].bias.detach(), g, g,
+                                           hyper=hyper0, want_up=False, eps=eps)
+        ctx.prog, ctx.ws, ctx.runner, ctx.base, ctx.layout, ctx.n_params = prog, ws, runner, base, layout, len(params)
+        ctx.ups = (src_bf, w1p, w2p, w1t, w2t, hyper0, eps)
+        return masks, iou4[:, 0]
+
+    @staticmethod
+    def backward(ctx, d_masks, d_iou):
+        from . import ops
+        prog, runner = ctx.prog, ctx.runner
+        dec = runner.dec
+        n, dev, g = prog.n, prog.device, dec.grid
+        up = dec.output_upscaling
+        src_bf, w1p, w2p, w1t, w2t, hyper0, eps = ctx.ups
+        zeros = runner.zeros(n, dev)
+        dm = zeros["masks"] if d_masks is None else d_masks.contiguous().float()
+        *_, ubuf = ops.mask_upsample_fused_bwd(src_bf, w1p, up[0].bias.detach(), up[1].weight.detach(), up[1].bias.detach(), w2p, up[3].bias.detach(),
+                                               hyper0, dm, g, g, eps=eps, w1t=w1t, w2t=w2t, one_buffer=True)
+        d_io = zeros["iou"] if d_iou is None else d_iou.contiguous()
+        if ctx.base is not None:
+            d_in = prog.run_backward_fused(ctx.ws, ubuf, src_bf, d_io, ctx.base, grid=runner.grid)
+            grads = [None] * ctx.n_params
+        else:
+            gflat = torch.zeros(ctx.layout["total"], dtype=torch.float32, device=dev)
+            d_in = prog.run_backward_fused(ctx.ws, ubuf, src_bf, d_io, gflat.data_ptr(), grid=runner.grid)
+            grads = [gflat[o:o + k].view(shape) if o is not None else None for (o, k, shape) in ctx.layout["views"]]
+        return (None, d_in if ctx.needs_input_grad[1] else None, None, *grads)
+
+
 class TailRunner:
     """Per-MaskDecoder cache of TailPrograms, keyed by what a program is bound to: the prompt count, the addresses of the parameters and of
     their gradients, which of them train."""
 
-    def __init__(self, dec, dense_pe, no_mask_embed, fcs=None, grid=None):
+    def __init__(self, dec, dense_pe, no_mask_embed, fcs=None, grid=None, fused_upsampler=False):
         import os
         self.dec, self.dense_pe, self.no_mask, self.fcs = dec, dense_pe, no_mask_embed, fcs
+        self.fused_upsampler = bool(fused_upsampler)
         self.grid = int(os.environ.get("MP_TAIL_GRID", grid or 256))
         self._cache, self._zeros = {}, {}
 
@@ -600,6 +702,9 @@ class TailRunner:
         d = self.dec
         ps += list(d.transformer.parameters()) + [d.iou_token.weight, d.mask_tokens.weight]
         ps += list(d.output_hypernetworks_mlps[0].parameters()) + list(d.iou_prediction_head.parameters())
+        if self.fused_upsampler:
+            up = d.output_upscaling
+            ps += [up[0].weight, up[0].bias, up[1].weight, up[1].bias, up[3].weight, up[3].bias]
         return ps
 
     def zeros(self, n, dev):
@@ -607,7 +712,8 @@ class TailRunner:
         if z is None:
             z = {"src2": torch.zeros((2, n, self.dec.grid ** 2, self.dec.dim), dtype=torch.float32, device=dev),
                  "src2_one": torch.zeros((2, n, self.dec.grid ** 2, self.dec.dim), dtype=torch.float32, device=dev),
-                 "hy": torch.zeros((n, self.dec.dim // 8), dtype=torch.float32, device=dev), "iou": torch.zeros(n, dtype=torch.float32, device=dev)}
+                 "hy": torch.zeros((n, self.dec.dim // 8), dtype=torch.float32, device=dev), "iou": torch.zeros(n, dtype=torch.float32, device=dev),
+                 "masks": torch.zeros((n, 4 * self.dec.grid, 4 * self.dec.grid), dtype=torch.float32, device=dev)}
             self._zeros[n] = z
         return z
 
@@ -636,9 +742,11 @@ class TailRunner:
         if hit is None:
             if len(self._cache) > 16:
                 self._cache.clear()
-            prog = TailProgram(self.dec, n, self.dense_pe, self.no_mask.detach(), fcs=self.fcs, grad_offsets=offs, hidden_grad=bool(hidden_grad))
+            prog = TailProgram(self.dec, n, self.dense_pe, self.no_mask.detach(), fcs=self.fcs, grad_offsets=offs, hidden_grad=bool(hidden_grad),
+                               fused_upsampler=self.fused_upsampler)
             hit = self._cache[key] = prog
         return hit, base, layout
 
     def __call__(self, x_in, image_tokens):
-        return TailProgramFn.apply(self, x_in, image_tokens, *self.params())
+        """-> (src, hyper0, iou), or (masks, iou) from a fused-upsampler runner."""
+        return (TailFusedFn if self.fused_upsampler else TailProgramFn).apply(self, x_in, image_tokens, *self.params())

@@ -12,14 +12,33 @@ import torch.nn.functional as F
 from . import llm, ops, sam
 
 
-def init_hf_weights(cfg, seed=0, sam_seed=1234):
+class UpcastDict(dict):
+    """A weight dict whose bf16 entries read as fp32 (a fresh copy per access): DISTINCT decoder weights for all 32 layers at 7B dims are
+    21.6 GB stored as the bf16 values they are (every such entry is bf16-representable by construction) instead of 43 GB of fp32; the oracle
+    upcasts one matrix at a time."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return v.float() if torch.is_tensor(v) and v.dtype == torch.bfloat16 else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return ((k, self[k]) for k in self.keys())
+
+
+def init_hf_weights(cfg, seed=0, sam_seed=1234, store_bf16=False):
     """Seeded random weights in the HF checkpoint key layout, values rounded to bf16 where the product
-    stores bf16 so both sides see identical numbers.  SAM-Med2D part: sam.init_weights under `model.visual_model.`."""
+    stores bf16 so both sides see identical numbers.  SAM-Med2D part: sam.init_weights under `model.visual_model.`.
+    store_bf16: keep the decoder layers' matrices AS bf16 tensors in an UpcastDict (same values; see there)."""
     g = torch.Generator().manual_seed(seed)
     d, ff, V, C, I = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.clip_hidden_size, cfg.clip_intermediate_size
 
     def rn(*shape, s=0.02, bf=True):
         t = torch.randn(*shape, generator=g) * s
+        if bf and store_bf16 and len(shape) == 2 and shape[0] * shape[1] >= (1 << 20):
+            return t.to(torch.bfloat16)
         return t.to(torch.bfloat16).float() if bf else t
     W = {"model.embed_tokens.weight": rn(V, d, s=0.5), "lm_head.weight": rn(V, d, s=0.05), "model.norm.weight": 1 + rn(d, s=0.1)}
     moe = cfg.moe_layer_set()
@@ -76,7 +95,7 @@ def init_hf_weights(cfg, seed=0, sam_seed=1234):
                 and "neck.1" not in k and "neck.3" not in k:
             v = v.to(torch.bfloat16).float()          # the product stores these GEMM operands in bf16
         W["model.visual_model." + k] = v
-    return W
+    return UpcastDict(W) if store_bf16 else W
 
 
 def init_decoder_layer_weights(cfg, seed=3):

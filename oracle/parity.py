@@ -25,12 +25,15 @@ MASK_LOGIT_TOL = 0.066         # stated tolerance on the mask logits of the bf16
                                # embedding is rounded to bf16 before the hypernetwork product, each 2^-9 relative on values of magnitude
                                # 2-3 summed over 32 channels (config.fused_bf16_upsampler=False is the strict fp32 tail).  Pixels whose
                                # reference logit is farther than the MEASURED error from a cut must threshold identically (`flipped <= near_cut`)
-HIDDEN_WORST_ALL_ROWS = 1.0    # the last hidden state's worst element over ALL rows, relative to the largest reference entry.  A token that picked the
-                               # other expert in some layer is a different computation from there on: its row differs by O(its own magnitude) and
-                               # only mixes back through attention, so no tight bound exists for it — measured 0.128 at 32 layers (B = 8, 4.5 % of
-                               # the rows flipped somewhere) and 0.49 at 8 layers (0.6 % flipped, the flips in the last layers not yet averaged
-                               # out).  What IS asserted for every row: finite, and never off by more than the largest entry of the reference;
-                               # rows that agree in every layer are held to 0.1 (measured 0.035-0.076)
+HIDDEN_P999_ALL_ROWS = 0.05    # the 99.9th-percentile element error of the last hidden state over ALL rows, relative to the largest reference entry.
+HIDDEN_BAD_ROW = 0.1           # a row is "bad" when its worst element is off by more than this (same scale).  A token that picked the other
+                               # expert in some layer is a different computation from there on: its row differs by O(its own magnitude) and
+                               # only mixes back through attention, so no tight bound holds for THAT row (measured worst element 0.128 at 32
+                               # layers with 4.5 % of the rows flipped somewhere, 0.49 at 8 layers) — but flips are the ONLY licence for a bad
+                               # row.  Three bounds that can fail (round-4 review; the former all-rows bound of 1.0 caught NaN and nothing else):
+                               # rows agreeing in every layer: worst element <= 0.1 (measured 0.035-0.076); all rows: 99.9th percentile element
+                               # <= 0.05; bad rows <= 2 x the flipped tokens summed over the layers (a flip damages its own row and, through
+                               # the capacity boundary it moves, at most one more)
 
 def check_full_size(r, layers, moe):
     """-> list of violated bounds (empty = parity holds) for a full_size_parity() result; ONE statement of the bounds for
@@ -43,8 +46,11 @@ def check_full_size(r, layers, moe):
             bad.append(what)
     need(r["max_abs_dloss_over_10"] < 5e-2, f"losses: max |d| over the 10 = {r['max_abs_dloss_over_10']:.4g} >= 5e-2")
     need(r["hidden_rel_err_agreeing_rows"] < 0.1, f"hidden (rows agreeing in every layer): {r['hidden_rel_err_agreeing_rows']:.4g} >= 0.1")
-    need(r["hidden_rel_err"] == r["hidden_rel_err"] and r["hidden_rel_err"] < HIDDEN_WORST_ALL_ROWS,
-         f"hidden (all rows, worst element): {r['hidden_rel_err']:.4g} not below {HIDDEN_WORST_ALL_ROWS}")
+    need(r["hidden_rel_err"] == r["hidden_rel_err"] and r["hidden_rel_err"] < float("inf"), "hidden: not finite")
+    need(r["hidden_p999_rel_err"] <= HIDDEN_P999_ALL_ROWS,
+         f"hidden (all rows, 99.9th percentile element): {r['hidden_p999_rel_err']:.4g} > {HIDDEN_P999_ALL_ROWS}")
+    need(r["hidden_bad_rows"] <= 2 * r["flipped_tokens_total"],
+         f"hidden: {r['hidden_bad_rows']} rows off by more than {HIDDEN_BAD_ROW} with only {r['flipped_tokens_total']} flipped tokens over all layers")
     need(r["hidden_mean_rel_err"] < 2 ** -6, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= 2^-6")
     mk = r["mask"]
     need(mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {MASK_LOGIT_TOL}")
@@ -118,7 +124,7 @@ def routing_report(coll, routing, T, capacity, rts):
 
 
 def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0, B=1,
-                     rts_seed=None, capacity_factor=None, time_threads=None, prompt_len=64, ragged=False, time_forward=None):
+                     rts_seed=None, capacity_factor=None, time_threads=None, prompt_len=64, ragged=False, time_forward=None, distinct_weights=False):
     """-> dict of plain numbers.  `time_oracle=(warmup, timed)`: also time the oracle's B = 1 training step (forward + backward
     through the trainable tail) that many times and return the per-step seconds (bench.py's cpu_baseline).
     B: samples in the compared batch (8 = the benchmark's per-GPU batch, T = 5112).  rts_seed: DeepSpeed's Random Token Selection
@@ -132,7 +138,9 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     cfg.moe_gate_sampling = False
     if capacity_factor is not None:
         cfg.capacity_factor = capacity_factor
-    W = OM.init_hf_weights_aliased(cfg, seed=seed)
+    # distinct_weights: every decoder layer gets its OWN seeded weights (a per-layer weight-indexing error at depth cannot hide behind
+    # aliasing; scripts/r05_distinct_parity.py) — stored as the bf16 values they are and upcast one matrix at a time (model.UpcastDict)
+    W = OM.init_hf_weights(cfg, seed=seed, store_bf16=True) if distinct_weights else OM.init_hf_weights_aliased(cfg, seed=seed)
 
     def make(B_, bseed):
         if icl_ctx:                               # BASELINE config 5 shape: icl_ctx in-context (image, mask) pairs + the query, separate mode
@@ -238,6 +246,9 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "mask_loss_gpu": losses_gpu["mask_loss"], "mask_loss_cpu": losses_cpu["mask_loss"],
            "hidden_rel_err": float((hid - href).abs().max() / href.abs().max()),
            "hidden_mean_rel_err": float((hid - href).abs().mean() / href.abs().mean()),
+           "hidden_p999_rel_err": float(torch.kthvalue((hid - href).abs().flatten(), max(1, int(0.999 * hid.numel()))).values / href.abs().max()),
+           "hidden_bad_rows": int(((hid - href).abs().view(-1, hid.shape[-1]).max(1).values > HIDDEN_BAD_ROW * href.abs().max()).sum()),
+           "flipped_tokens_total": int(sum(p["flipped_tokens"] for p in per_layer)),
            # a token that picked the other expert somewhere is a different computation from there on: bound the rest
            "hidden_rel_err_agreeing_rows": float((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().max() / href.abs().max()),
            "rows_agreeing_in_every_layer": float(same.float().mean()),
@@ -250,7 +261,8 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "routing_agreement_mean": (sum(agree) / len(agree)) if agree else None,
            "routing_agreement_per_layer": [round(a, 4) for a in agree],
            "oracle_forward_seconds": round(t_oracle, 2),
-           "weights": "one decoder layer's seeded weights aliased over all layers, both sides"}
+           "weights": ("DISTINCT seeded weights in every decoder layer, both sides" if distinct_weights
+                       else "one decoder layer's seeded weights aliased over all layers, both sides")}
     if per_layer and "first_choice_agreement" in per_layer[0]:        # top-2 layers
         res["routing"] = {"top_k": 2, "flipped_tokens_per_layer": [p["flipped_tokens"] for p in per_layer],
                           "dropped_entries_hip_per_layer": [p["dropped_entries_hip"] for p in per_layer],

@@ -13,17 +13,28 @@ import numpy as np
 from medplib_amd import tail_program as TP
 
 
-def _mat(slots, addr, rows, cols, ld):
-    """A writable fp32 [rows, cols] view (row stride ld floats) of host memory at the operand address."""
+def _mat(slots, addr, rows, cols, ld, cs=1):
+    """A writable fp32 [rows, cols] view (row stride ld floats, column stride cs floats) of host memory at the operand address."""
     addr = int(addr)
     if addr == 0:
         return None
     base = int(slots[addr >> 56]) + (addr & ((1 << 56) - 1))
     if rows <= 0 or cols <= 0:
         return np.zeros((max(rows, 0), max(cols, 0)), np.float32)
-    count = (rows - 1) * ld + cols
+    cs = max(int(cs), 1)
+    count = (rows - 1) * ld + (cols - 1) * cs + 1
     flat = np.ctypeslib.as_array((ctypes.c_float * count).from_address(base))
-    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(4 * ld, 4))
+    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(4 * ld, 4 * cs))
+
+
+def _mat_bf16(slots, addr, rows, cols, ld):
+    """bf16 values (row stride ld ELEMENTS) read as fp32."""
+    addr = int(addr)
+    base = int(slots[addr >> 56]) + (addr & ((1 << 56) - 1))
+    count = (rows - 1) * ld + cols
+    flat = np.ctypeslib.as_array((ctypes.c_uint16 * count).from_address(base))
+    u = np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(2 * ld, 2)).astype(np.uint32) << 16
+    return u.view(np.float32)
 
 
 def _wrap_rows(x, rows_total, period):
@@ -39,7 +50,7 @@ def run_op(op, slots):
     if t == TP.OP_GEMM:
         ta, tb = bool(fl & TP.F_TRANS_A), bool(fl & TP.F_TRANS_B)
         splits = max(int(op["i0"]), 1)
-        A = _mat(slots, p[0], K if ta else M, M if ta else K, ld[0]).copy()
+        A = (_mat_bf16 if fl & TP.F_A_BF16 else _mat)(slots, p[0], K if ta else M, M if ta else K, ld[0]).copy()
         B = _mat(slots, p[1], N if tb else K, K if tb else N, ld[1]).copy()
         if p[4]:
             per = int(op["i1"])
@@ -77,7 +88,7 @@ def run_op(op, slots):
         if p[8]:
             C2 = _mat(slots, p[8], M, N, ld[5])
             C2[...] = C2 + v
-        C = _mat(slots, p[2], M, N, ld[2])
+        C = _mat(slots, p[2], M, N, ld[2], ld[9])
         C[...] = C + v if fl & TP.F_ACCUM else v
     elif t == TP.OP_REDUCE:
         acc = np.zeros((M, N), np.float32)
@@ -92,7 +103,7 @@ def run_op(op, slots):
             v = np.maximum(v, 0)
         if p[4]:
             v = np.where(_mat(slots, p[4], M, N, ld[4]) > 0, v, 0)
-        out = _mat(slots, p[1], M, N, ld[1])
+        out = _mat(slots, p[1], M, N, ld[1], ld[5])
         out[...] = (out + v if fl & TP.F_ACCUM else v).astype(np.float32)
     elif t == TP.OP_LN_FWD:
         x = _mat(slots, p[0], M, N, ld[0])
@@ -183,10 +194,10 @@ def check_phase_hazards(packed):
             ta, tb, s = fl & TP.F_TRANS_A, fl & TP.F_TRANS_B, max(int(op["i0"]), 1)
             R += [rng(p[0], K if ta else M, M if ta else K, ld[0]), rng(p[1], N if tb else K, K if tb else N, ld[1]), rng(p[3], 1, N, N),
                   rng(p[6], M, N, ld[3]), rng(p[7], M, N, ld[4])]
-            W += [rng(p[2], M * s, N, ld[2]), rng(p[8], M, N, ld[5]), rng(p[9], 1, M * s, M * s)]
+            W += [rng(p[2], M * s, (N - 1) * max(ld[9], 1) + 1, ld[2]), rng(p[8], M, N, ld[5]), rng(p[9], 1, M * s, M * s)]
         elif t == TP.OP_REDUCE:
             R += [rng(p[0] + 4 * s * ld[2], M, N, ld[0]) for s in range(K)] + [rng(p[2], 1, N, N), rng(p[3], M, N, ld[3]), rng(p[4], M, N, ld[4])]
-            W += [rng(p[1], M, N, ld[1])]
+            W += [rng(p[1], M, (N - 1) * max(ld[5], 1) + 1, ld[1])]
         elif t == TP.OP_LN_FWD:
             R += [rng(p[0], M, N, ld[0])]
             W += [rng(p[3], M, N, ld[1]), rng(p[4], 1, M, M), rng(p[5], 1, M, M)]

@@ -168,3 +168,36 @@ def test_direct_accumulation_into_preset_grads(dev):
             assert b is None or b.abs().max() == 0
         else:
             assert (a - b).abs().max() <= 1e-5 * a.abs().max() + 1e-7
+
+
+def test_fused_upsampler_node_matches_two_node_path(dev):
+    """Training through the fused bf16 upsampler: ONE autograd node (program + upsampler kernels; the backward program also finishes the
+    upsampler's weight / bias / LayerNorm2d gradients) against the program and FusedUpsampleMaskFn as two nodes: same kernels forward (bit-equal
+    masks), every gradient within fp32 summation-order noise."""
+    from medplib_amd.model import sam as SAM
+    n, Dh = 8, 256
+    torch.manual_seed(5)
+    x, img = torch.randn(n, Dh, device=dev), torch.randn(n, 256, 256, device=dev) * 0.5
+    gl, gi = torch.randn(n, 64, 64, device=dev), torch.randn(n, device=dev)
+    res = []
+    keep = SAM._FUSED_TAIL
+    try:
+        for fused in (True, False):
+            SAM._FUSED_TAIL = fused
+            dec, pe, fc1, fc2 = _modules(51, Dh, dev)
+            dec.fused_bf16_upsampler = True
+            xi = x.clone().requires_grad_()
+            low, iou = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=xi)
+            ((low * gl).sum() + (iou * gi).sum()).backward()
+            named = list(dec.named_parameters()) + [("fc1.w", fc1.weight), ("fc1.b", fc1.bias), ("fc2.w", fc2.weight), ("fc2.b", fc2.bias)]
+            res.append((low.detach(), iou.detach(), xi.grad, {k: p.grad for k, p in named}))
+    finally:
+        SAM._FUSED_TAIL = keep
+    (l0, i0, dx0, g0), (l1, i1, dx1, g1) = res
+    assert torch.equal(l0, l1) and torch.equal(i0, i1)
+    assert (dx0 - dx1).abs().max() <= 1e-5 * dx1.abs().max()
+    for k in g1:
+        if g1[k] is None:
+            assert g0[k] is None or g0[k].abs().max() == 0, k
+            continue
+        assert (g0[k] - g1[k]).abs().max() <= 2e-5 * g1[k].abs().max() + 2e-6, k

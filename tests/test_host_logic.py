@@ -704,6 +704,7 @@ def test_check_full_size_names_every_violated_bound():
     from oracle.parity import check_full_size, MASK_LOGIT_TOL
     cut = {"flipped_le_near_cut_every_mask": True, "max_abs_ddice": 1e-5}
     good = {"max_abs_dloss_over_10": 7e-3, "hidden_rel_err_agreeing_rows": 0.035, "hidden_rel_err": 0.128, "hidden_mean_rel_err": 0.0127,
+            "hidden_p999_rel_err": 0.02, "hidden_bad_rows": 5, "flipped_tokens_total": 5,
             "mask": {"max_abs_dlogit": 0.054, "cut_ref": dict(cut), "cut_zero": dict(cut)},
             "routing_agreement_per_layer": [0.99] * 4, "routing_agreement_min": 0.99,
             "routing": {"kept_set_equals_deepspeed_rule_every_layer": True, "slots_equal_deepspeed_rule_every_layer": True,
@@ -725,7 +726,9 @@ def test_check_full_size_names_every_violated_bound():
     bad(["max_abs_dloss_over_10"], 0.06)
     bad(["hidden_rel_err_agreeing_rows"], 0.11)
     bad(["hidden_rel_err"], float("nan"))
-    bad(["hidden_rel_err"], 1.5)
+    bad(["hidden_rel_err"], float("inf"))
+    bad(["hidden_p999_rel_err"], 0.06)                 # the bulk of the elements moved: no count of flipped tokens licenses that
+    bad(["hidden_bad_rows"], 11)                       # more damaged rows than 2 x the flipped tokens can explain
     bad(["hidden_mean_rel_err"], 0.02)
     bad(["mask", "max_abs_dlogit"], MASK_LOGIT_TOL + 1e-3)
     bad(["mask", "cut_zero", "flipped_le_near_cut_every_mask"], False)

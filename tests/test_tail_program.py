@@ -112,3 +112,53 @@ def test_op_table_layout():
     assert "int type, flags, ntiles, tile_begin;" in src and "int64_t ld[12];" in src and "uint64_t p[12];" in src
     for name, val in (("OP_GEMM", 1), ("OP_REDUCE", 2), ("OP_LN_FWD", 3), ("OP_LN_BWD", 4), ("OP_ATTN_FWD", 5), ("OP_ATTN_BWD", 6), ("OP_COPY2D", 7)):
         assert f"{name} = {val}" in src and getattr(TP, name) == val
+
+
+def test_fused_upsampler_backward_program():
+    """TailProgram(fused_upsampler=True): the backward takes mp_mask_upsample_fused_bwd_bf16's five outputs in one buffer + the bf16 tokens and
+    finishes that kernel's work itself.  Interpreter run on random stand-ins for the kernel's outputs against (a) the plain program fed the
+    same d src halves / d hyper0 (every transformer / fcs gradient identical) and (b) the host formulas of autograd_ops.FusedUpsampleMaskFn
+    for the six upsampler gradients (the weight gradients land in the reference's [Cin, Cout, 2, 2] layout directly)."""
+    from medplib_amd import ops as MO
+    n, Dh = 2, 192
+    W, dec, pe, fcs, params, offs, tot = _setup(n, Dh, seed=17)
+    plain = TP.TailProgram(dec, n, pe.dense_pe_tokens(), pe.no_mask_embed.weight.detach(), fcs=fcs, grad_offsets=offs)
+    fused = TP.TailProgram(dec, n, pe.dense_pe_tokens(), pe.no_mask_embed.weight.detach(), fcs=fcs, grad_offsets=offs, fused_upsampler=True)
+    assert EMU.check_phase_hazards(fused.bwd_packed) == 0
+    Tk = 256
+    o, total = MO.upsample_bwd_layout(n, Tk)
+    ubuf = torch.randn(total) * 0.1
+    dx2 = ubuf[o[0]:o[0] + 2 * n * Tk * 256].view(2, n, Tk, 256)
+    dy1 = ubuf[o[1]:o[1] + n * Tk * 256].view(n * Tk, 256)
+    a1 = ubuf[o[2]:o[2] + n * Tk * 256].view(n * Tk * 4, 64)
+    dy2 = ubuf[o[3]:o[3] + n * Tk * 512].view(n * Tk * 4, 128)
+    part = ubuf[o[4]:o[4] + (n * Tk // 8) * 256].view(n * Tk // 8, 256)
+    src_bf = (torch.randn(n * Tk, 256) * 0.5).to(torch.bfloat16)
+    x_in, img, d_iou = torch.randn(n, Dh), torch.randn(n, 256, 256) * 0.5, torch.randn(n)
+    d_hy = part[:, 224:].reshape(n, -1, 32).sum(1).contiguous()
+    res = []
+    for prog in (plain, fused):
+        ws, g, wb = torch.zeros(prog.fwd_bytes // 4), torch.zeros(tot), torch.zeros(max(prog.bwd_bytes, 256) // 4)
+        EMU.run(prog.fwd_packed, [0, ws.data_ptr(), 0, x_in.data_ptr(), 0, img.data_ptr(), 0, 0])
+        if prog is plain:
+            EMU.run(prog.bwd_packed, [0, ws.data_ptr(), wb.data_ptr(), 0, g.data_ptr(), dx2.data_ptr(), d_hy.data_ptr(), d_iou.data_ptr()])
+        else:
+            EMU.run(prog.bwd_packed, [0, ws.data_ptr(), wb.data_ptr(), 0, g.data_ptr(), ubuf.data_ptr(), src_bf.data_ptr(), d_iou.data_ptr()])
+        res.append(g)
+    up = dec.output_upscaling
+    ups = {id(p) for p in (up[0].weight, up[0].bias, up[1].weight, up[1].bias, up[3].weight, up[3].bias)}
+
+    def grad(g, p):
+        return g[offs[id(p)] // 4: offs[id(p)] // 4 + p.numel()].view(p.shape)
+    for p in params:
+        if id(p) not in ups:
+            a, b = grad(res[0], p), grad(res[1], p)
+            assert (a - b).abs().max() <= 1e-5 * a.abs().max() + 2e-6, tuple(p.shape)     # (floor: the k_proj biases, whose gradient is rounding noise)
+    assert all(grad(res[0], p).abs().max() == 0 for p in params if id(p) in ups)         # the plain program leaves them to FusedUpsampleMaskFn
+    cs = part.sum(0)
+    want = {id(up[0].weight): (dy1.t() @ src_bf.float()).view(2, 2, 64, 256).permute(3, 2, 0, 1), id(up[3].weight): (dy2.t() @ a1).view(2, 2, 32, 64).permute(3, 2, 0, 1),
+            id(up[0].bias): cs[0:64], id(up[1].weight): cs[64:128], id(up[1].bias): cs[128:192], id(up[3].bias): cs[192:224]}
+    for p in params:
+        if id(p) in ups:
+            got, ref = grad(res[1], p), want[id(p)]
+            assert (got - ref).abs().max() <= 2e-5 * ref.abs().max(), tuple(p.shape)
