@@ -297,6 +297,9 @@ class LlamaStack:
             else:
                 attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
             x = lin(attn.view(B * S, d), lw["o"], residual=x)
+            # (tests / parity only: the layer's own gate input, copied before the combine writes the MLP output into the residual stream — the
+            #  layer-local routing check of oracle/parity.py recomputes the gate from it)
+            x_gate_in = x.clone() if (collect_routing and i in self.moe_layers) else None
             if i in self.moe_layers and d in ops.RMSNORM_GATE_DIMS and B * S > 8:
                 # post-attention norm and the MoE gate in one pass over the rows (bit-identical with the two kernels)
                 h, lg, gt = ops.rmsnorm_gate(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"])
@@ -307,7 +310,7 @@ class LlamaStack:
             if l_aux is not None:
                 aux.append(l_aux)
                 if collect_routing:
-                    routing.append(r)
+                    routing.append(tuple(r) + (x_gate_in,))
         if kv_cache is not None:
             kv_cache["len"] = pos0 + S
         out = ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps)

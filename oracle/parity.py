@@ -47,11 +47,18 @@ def check_full_size(r, layers, moe):
     need(r["max_abs_dloss_over_10"] < 5e-2, f"losses: max |d| over the 10 = {r['max_abs_dloss_over_10']:.4g} >= 5e-2")
     need(r["hidden_rel_err_agreeing_rows"] < 0.1, f"hidden (rows agreeing in every layer): {r['hidden_rel_err_agreeing_rows']:.4g} >= 0.1")
     need(r["hidden_rel_err"] == r["hidden_rel_err"] and r["hidden_rel_err"] < float("inf"), "hidden: not finite")
-    need(r["hidden_p999_rel_err"] <= HIDDEN_P999_ALL_ROWS,
+    # rows that agree in every layer: always; ALL rows: while at most 5 % of the rows flipped somewhere (every standing configuration: 0.6-4.5 %).
+    # With distinct random gates in 32 layers a sixth of the rows flips at least once (scripts/r05_distinct_parity.py: 16 %) and the percentile
+    # lands inside the flipped rows, which no bound can hold — there the agreeing rows and the bad-row count carry the check
+    need(r["hidden_p999_rel_err_agreeing_rows"] <= HIDDEN_P999_ALL_ROWS,
+         f"hidden (agreeing rows, 99.9th percentile element): {r['hidden_p999_rel_err_agreeing_rows']:.4g} > {HIDDEN_P999_ALL_ROWS}")
+    few_flips = r["rows_agreeing_in_every_layer"] >= 0.95
+    need(not few_flips or r["hidden_p999_rel_err"] <= HIDDEN_P999_ALL_ROWS,
          f"hidden (all rows, 99.9th percentile element): {r['hidden_p999_rel_err']:.4g} > {HIDDEN_P999_ALL_ROWS}")
     need(r["hidden_bad_rows"] <= 2 * r["flipped_tokens_total"],
          f"hidden: {r['hidden_bad_rows']} rows off by more than {HIDDEN_BAD_ROW} with only {r['flipped_tokens_total']} flipped tokens over all layers")
-    need(r["hidden_mean_rel_err"] < 2 ** -6, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= 2^-6")
+    need(r["hidden_mean_rel_err_agreeing_rows"] < 2 ** -6, f"hidden mean error over the agreeing rows {r['hidden_mean_rel_err_agreeing_rows']:.4g} >= 2^-6")
+    need(r["rows_agreeing_in_every_layer"] < 0.95 or r["hidden_mean_rel_err"] < 2 ** -6, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= 2^-6")
     mk = r["mask"]
     need(mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {MASK_LOGIT_TOL}")
     for c in ("cut_ref", "cut_zero"):
@@ -60,6 +67,12 @@ def check_full_size(r, layers, moe):
     if moe:
         need(len(r["routing_agreement_per_layer"]) == layers, "routing report does not cover every layer")
         need(r["routing_agreement_min"] is not None and r["routing_agreement_min"] >= 0.97, f"routing agreement min {r['routing_agreement_min']} < 0.97")
+        ll = r.get("routing_layer_local")
+        need(ll is not None and ll["layers"] == layers, "layer-local routing report missing or incomplete")
+        if ll is not None:
+            # identical inputs, identical rounding points: only a tie within rounding may flip (measured margins of such ties: <= 1e-4 on logits of O(1))
+            need(ll["agreement_min"] >= 0.9995, f"layer-local routing agreement {ll['agreement_min']} < 0.9995")
+            need(ll["max_flip_margin"] <= 2e-3, f"a token flipped against a logit margin of {ll['max_flip_margin']:.3g} > 2e-3 on its own layer's input")
         rt = r["routing"]
         need(rt["kept_set_equals_deepspeed_rule_every_layer"] and rt["slots_equal_deepspeed_rule_every_layer"], "kept set / slots differ from DeepSpeed's rule")
         need(rt["counts_equal_own_choices_every_layer"] and rt["kept_sets_bit_equal_where_choices_identical"], "expert counts / kept sets")
@@ -121,6 +134,39 @@ def routing_report(coll, routing, T, capacity, rts):
                     "kept_set_equals_rule": bool(torch.equal(kept_hip, kept_rule)), "slots_equal_rule": bool(torch.equal(s_hip, slot_rule)),
                     "counts_equal_own_choices": bool(torch.equal(c_hip[:E], torch.bincount(e_hip, minlength=E)))})
     return per, same_all
+
+
+def layer_local_routing(routing, W, cfg, top_k):
+    """The routing of every MoE layer recomputed on the host from the HIP path's OWN input to that layer's gate (the residual stream in
+    front of the post-attention norm, which the model hands over in collect mode): fp32 RMSNorm, rounded to bf16 as the kernel's normed row
+    is, fp32 logits, argmax.  With identical inputs and identical rounding points only the summation order differs, so a token may pick
+    another expert only when its two best logits are within rounding of each other — upstream bf16 noise, which makes 1 % of the tokens of
+    the full-depth comparison against the fp32 oracle flip, cannot enter here: a routing error of any rate shows as flips with a real margin.
+    -> {"agreement_min", "flips_total", "max_flip_margin", "tokens"} (round-4 review, parity item c)."""
+    agree, flips, worst, T = [], 0, 0.0, 0
+    moe_ids = sorted(cfg.moe_layer_set())
+    for li, r in zip(moe_ids, routing):
+        if len(r) < 4 or r[3] is None:
+            return None
+        x = r[3].float().cpu()
+        T = x.shape[0]
+        p = f"model.layers.{li}."
+        # the kernel's (= HF LlamaRMSNorm's) two rounding points: the normalised value is cast to bf16 BEFORE the weight multiplies it, the
+        # product is cast again (csrc/ce_moe.hip rmsnorm_gate_kernel; one rounding here instead made 19 of 20 448 tokens flip with margins up
+        # to 0.017 in the first distinct-weights run, profiles/r05_distinct_parity_first.json: exactly the tie rate one bf16 rounding predicts)
+        rs = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps)
+        h = (W[p + "post_attention_layernorm.weight"].float() * (x * rs).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+        logits = h @ W[p + "mlp.deepspeed_moe.gate.wg.weight"].float().t()
+        ref = logits.argmax(1)
+        hip = r[0].cpu().long().view(-1)[:T]                       # first choices (top-2 entry arrays start with them)
+        diff = ref != hip
+        top2 = logits.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])
+        agree.append(1.0 - float(diff.float().mean()))
+        flips += int(diff.sum())
+        if diff.any():
+            worst = max(worst, float(margin[diff].max()))
+    return {"agreement_min": min(agree) if agree else None, "flips_total": flips, "max_flip_margin": worst, "tokens": T, "layers": len(agree)}
 
 
 def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_threads=None, time_oracle=None, icl_ctx=0, B=1,
@@ -218,6 +264,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
         # the per-layer routing report restates top-1 selection; top-2 layers are compared through their outputs only
         per_layer, same = routing_report(coll, routing, T, m.model.llm.capacity(T), rts_list) if routing else ([], torch.ones(T, dtype=torch.bool))
         agree = [p["expert_agreement"] for p in per_layer]
+        local = layer_local_routing(routing, W, cfg, cfg.top_k_experts) if routing else None
         masks = m(**dict(gb, inference=True))["pred_masks"]
     losses_cpu = {k: float(ref[k]) for k in O.LOSS_KEYS}
     # the masks, where a comparison can fail (oracle/ops.py: mask_cut_report): per mask at the reference's cut and at logit 0
@@ -248,6 +295,9 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "hidden_mean_rel_err": float((hid - href).abs().mean() / href.abs().mean()),
            "hidden_p999_rel_err": float(torch.kthvalue((hid - href).abs().flatten(), max(1, int(0.999 * hid.numel()))).values / href.abs().max()),
            "hidden_bad_rows": int(((hid - href).abs().view(-1, hid.shape[-1]).max(1).values > HIDDEN_BAD_ROW * href.abs().max()).sum()),
+           "hidden_p999_rel_err_agreeing_rows": float(torch.kthvalue((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().flatten(),
+                                                                     max(1, int(0.999 * int(same.sum()) * d))).values / href.abs().max()) if same.any() else 0.0,
+           "hidden_mean_rel_err_agreeing_rows": float((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().mean() / href.view(-1, d)[same].abs().mean()) if same.any() else 0.0,
            "flipped_tokens_total": int(sum(p["flipped_tokens"] for p in per_layer)),
            # a token that picked the other expert somewhere is a different computation from there on: bound the rest
            "hidden_rel_err_agreeing_rows": float((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().max() / href.abs().max()),
@@ -260,6 +310,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "routing_agreement_min": min(agree) if agree else None,
            "routing_agreement_mean": (sum(agree) / len(agree)) if agree else None,
            "routing_agreement_per_layer": [round(a, 4) for a in agree],
+           "routing_layer_local": local,
            "oracle_forward_seconds": round(t_oracle, 2),
            "weights": ("DISTINCT seeded weights in every decoder layer, both sides" if distinct_weights
                        else "one decoder layer's seeded weights aliased over all layers, both sides")}

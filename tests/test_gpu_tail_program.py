@@ -196,8 +196,12 @@ def test_fused_upsampler_node_matches_two_node_path(dev):
     (l0, i0, dx0, g0), (l1, i1, dx1, g1) = res
     assert torch.equal(l0, l1) and torch.equal(i0, i1)
     assert (dx0 - dx1).abs().max() <= 1e-5 * dx1.abs().max()
+    worst = {}
     for k in g1:
         if g1[k] is None:
             assert g0[k] is None or g0[k].abs().max() == 0, k
             continue
-        assert (g0[k] - g1[k]).abs().max() <= 2e-5 * g1[k].abs().max() + 2e-6, k
+        worst[k] = ((g0[k] - g1[k]).abs().max() / (g1[k].abs().max() + 1e-12)).item()
+    # (k_proj biases: their gradient is mathematically zero — softmax is invariant to a per-query shift — so both sides hold rounding noise)
+    bad = {k: v for k, v in worst.items() if v > 2e-5 and (g0[k] - g1[k]).abs().max() > 2e-6 and not k.endswith("k_proj.bias")}
+    assert not bad, bad

@@ -704,9 +704,11 @@ def test_check_full_size_names_every_violated_bound():
     from oracle.parity import check_full_size, MASK_LOGIT_TOL
     cut = {"flipped_le_near_cut_every_mask": True, "max_abs_ddice": 1e-5}
     good = {"max_abs_dloss_over_10": 7e-3, "hidden_rel_err_agreeing_rows": 0.035, "hidden_rel_err": 0.128, "hidden_mean_rel_err": 0.0127,
-            "hidden_p999_rel_err": 0.02, "hidden_bad_rows": 5, "flipped_tokens_total": 5,
+            "hidden_p999_rel_err": 0.02, "hidden_bad_rows": 5, "flipped_tokens_total": 5, "rows_agreeing_in_every_layer": 0.955,
+            "hidden_p999_rel_err_agreeing_rows": 0.015, "hidden_mean_rel_err_agreeing_rows": 0.011,
             "mask": {"max_abs_dlogit": 0.054, "cut_ref": dict(cut), "cut_zero": dict(cut)},
             "routing_agreement_per_layer": [0.99] * 4, "routing_agreement_min": 0.99,
+            "routing_layer_local": {"agreement_min": 0.9998, "flips_total": 1, "max_flip_margin": 3e-5, "tokens": 639, "layers": 4},
             "routing": {"kept_set_equals_deepspeed_rule_every_layer": True, "slots_equal_deepspeed_rule_every_layer": True,
                         "counts_equal_own_choices_every_layer": True, "kept_sets_bit_equal_where_choices_identical": True,
                         "kept_state_differs_on_agreeing_rows_per_layer": [2, 0, 1, 0], "flipped_tokens_per_layer": [3, 1, 1, 0]}}
@@ -729,11 +731,18 @@ def test_check_full_size_names_every_violated_bound():
     bad(["hidden_rel_err"], float("inf"))
     bad(["hidden_p999_rel_err"], 0.06)                 # the bulk of the elements moved: no count of flipped tokens licenses that
     bad(["hidden_bad_rows"], 11)                       # more damaged rows than 2 x the flipped tokens can explain
+    bad(["hidden_p999_rel_err_agreeing_rows"], 0.06)
+    bad(["hidden_mean_rel_err_agreeing_rows"], 0.02)
+    r16 = dict(good, rows_agreeing_in_every_layer=0.84, hidden_p999_rel_err=0.081, hidden_mean_rel_err=0.033)    # a sixth of the rows flipped: the all-rows figures are not held
+    assert check_full_size(r16, 4, True) == []
     bad(["hidden_mean_rel_err"], 0.02)
     bad(["mask", "max_abs_dlogit"], MASK_LOGIT_TOL + 1e-3)
     bad(["mask", "cut_zero", "flipped_le_near_cut_every_mask"], False)
     bad(["mask", "cut_ref", "max_abs_ddice"], 2e-3)
     bad(["routing_agreement_min"], 0.9)
+    bad(["routing_layer_local", "agreement_min"], 0.99)        # 1 % of the tokens flipping on the layer's OWN input is a routing bug, not bf16 noise
+    bad(["routing_layer_local", "max_flip_margin"], 0.05)
+    bad(["routing_layer_local"], None)
     bad(["routing", "slots_equal_deepspeed_rule_every_layer"], False)
     bad(["routing", "kept_state_differs_on_agreeing_rows_per_layer"], [7, 0, 1, 0])
     assert len(check_full_size(dict(good, routing_agreement_per_layer=[0.99] * 3), 4, True)) == 1
