@@ -712,6 +712,21 @@ def gpu_main(args, emit):
                   "sampled_exchanges": len(us)}
         epx.timing = None
     dp_bucket = eng.bucket_timing_summary(args.steps)        # the timed steps only: the roofline / LoRA steps below must not count
+    # how the trainable fp32 tail ran in the timed steps: as the two program launches (csrc/tail_program.hip) or op by op (MP_TAIL_PROGRAM=0)
+    tail_obj = None
+    try:
+        dec_ = model.model.visual_model.mask_decoder
+        run_ = getattr(dec_, "_runner", None)
+        if dec_.use_program and run_ is not None and run_._cache:
+            pg = next(iter(run_._cache.values()))
+            tail_obj = {"form": "program: one launch forward, one backward" + (" (fused upsampler's gradients finished in-program)" if run_.fused_upsampler else ""),
+                        "grid": run_.grid, "forward": {"ops": len(pg.fwd_packed[0]), "phases": len(pg.fwd_packed[2])},
+                        "backward": {"ops": len(pg.bwd_packed[0]), "phases": len(pg.bwd_packed[2])},
+                        "workspace_MB": round((pg.fwd_bytes + pg.bwd_bytes) / 1e6, 1), "barrier_gave_up": not pg.check_sync()}
+        else:
+            tail_obj = {"form": "op by op (autograd Functions over mp_sgemm_f32 and the fp32 row kernels)"}
+    except Exception as e:
+        tail_obj = {"error": f"{type(e).__name__}: {e}"}
     eng.disable_bucket_timing()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1 or force_dist:
@@ -855,7 +870,7 @@ def gpu_main(args, emit):
             "roofline": roof, "roofline_timed_region": (roof_timed if timer_u is not None else None),
             # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the
             # communication stream) against the tail backward it follows — both per optimizer step, from HIP events on their streams
-            "rccl_ranks": rccl_ranks, "dp_bucket": dp_bucket,
+            "rccl_ranks": rccl_ranks, "dp_bucket": dp_bucket, "mask_tail": tail_obj,
         }
         if ep_obj is not None:
             res["ep"] = ep_obj

@@ -57,8 +57,13 @@ def check_full_size(r, layers, moe):
          f"hidden (all rows, 99.9th percentile element): {r['hidden_p999_rel_err']:.4g} > {HIDDEN_P999_ALL_ROWS}")
     need(r["hidden_bad_rows"] <= 2 * r["flipped_tokens_total"],
          f"hidden: {r['hidden_bad_rows']} rows off by more than {HIDDEN_BAD_ROW} with only {r['flipped_tokens_total']} flipped tokens over all layers")
-    need(r["hidden_mean_rel_err_agreeing_rows"] < 2 ** -6, f"hidden mean error over the agreeing rows {r['hidden_mean_rel_err_agreeing_rows']:.4g} >= 2^-6")
-    need(r["rows_agreeing_in_every_layer"] < 0.95 or r["hidden_mean_rel_err"] < 2 ** -6, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= 2^-6")
+    # mean element error: a bf16 residual stream takes about four roundings of 2^-9 per layer (attention output, its residual add, MLP output, its
+    # residual add) that accumulate as a random walk: sqrt(4 L) 2^-9 = 0.0156 at 8 layers (= the 2^-6 this bound has always been), 0.0221 at 32.
+    # Measured at 32 layers: 0.0127 with aliased weights (B = 8), 0.0174 over the agreeing rows with distinct weights (B = 1)
+    mean_bound = max(2 ** -6, (4 * layers) ** 0.5 * 2 ** -9)
+    need(r["hidden_mean_rel_err_agreeing_rows"] < mean_bound,
+         f"hidden mean error over the agreeing rows {r['hidden_mean_rel_err_agreeing_rows']:.4g} >= {mean_bound:.4g}")
+    need(r["rows_agreeing_in_every_layer"] < 0.95 or r["hidden_mean_rel_err"] < mean_bound, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= {mean_bound:.4g}")
     mk = r["mask"]
     need(mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {MASK_LOGIT_TOL}")
     for c in ("cut_ref", "cut_zero"):
