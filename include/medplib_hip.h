@@ -403,6 +403,14 @@ int mp_lora_grad_unpack_f32(const float* dB, const float* dAT, const int64_t* ro
                             hipStream_t stream);
 int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout, int k0,
                  int W, float bscale, void* Bx, int64_t ldbx, float xscale, hipStream_t stream);
+/* mp_lora_grad_unpack_f32 fed with the CHUNK PARTIALS of the two weight-gradient products (mp_tn_skinny_f32 called with out = NULL leaves
+ * partial[chunks][N * R], chunks = ceil(tokens / 256)): gB += scaleB * sum_c dBp[c][rows[o], k0 + j], gA += scaleA * sum_c dATp[c][col, k0 + i],
+ * ascending c — the same sums in the same order as the reduce it replaces.  W = rows of the padded B (the stride of a dBp chunk is W * R). */
+int mp_lora_grad_unpack_partials_f32(const float* dBp, const float* dATp, int chunksB, int chunksA, float scaleB, float scaleA, const int64_t* rows,
+                                     int R, int k0, int r, int fin, int fout, int W, float* gB, float* gA, hipStream_t stream);
+/* mp_lora_pack for `n` adapters in one launch: descs = n x 104 bytes on the device {const float* a, b; const int64_t* rows; bf16* A, AT, B, BT, Bx;
+ * int64 ldbx; int r, fin, fout, k0, W; float bscale, xscale; int pad}, max_elems = the largest r * fin + fout * r among them. */
+int mp_lora_pack_batched(const void* descs, int n, int64_t max_elems, hipStream_t stream);
 /* Backward of the adapter branch into the projection's input gradient in one pass: out = dx + dropout(bf16(dt A)) with the forward's mask
  * (dt [tokens, >= R] = scaling * dY B, AT [K, 64] = A^T padded: mp_lora_pack; p = 0: no mask).  Replaces a thin GEMM, mp_dropout_bf16 and
  * mp_add3_bf16 with the same rounding points.  R in {8, 16, 32}; out may alias dx. */

@@ -822,7 +822,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, float* __r
   // partial values into registers — and only then combines them, in the same ascending split order with the same operations (same
   // bits).  Before, two runtime loops of agent-scope loads made 2 x NS dependent trips to the memory-side coherence point (the partials
   // are sc1 data of other XCDs' workgroups): ~10 of the kernel's 14 us per layer and token at NS = 8.
-  constexpr int MAX_NS = 32;                               // launch_attn_decode: NS <= 16 by choice, more only for caches beyond 31 k keys (refused beyond 32)
+  constexpr int MAX_NS = 32;                               // launch_attn_decode: NS <= 16 by choice, more only for caches beyond 31 k keys
+  if (NS > MAX_NS) {
+    // beyond 32 splits (caches past ~31 k keys): the loop form — dependent trips to the coherence point, slow but correct, same ascending
+    // order (round-4 advisor: the register form alone refused such caches)
+    if (tid < D) {
+      float M = -INFINITY;
+      for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, __hip_atomic_load(wsh + sp * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      float L = 0.f, acc = 0.f;
+      for (int sp = 0; sp < NS; ++sp) {
+        const float ms = __hip_atomic_load(wsh + sp * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+        L += w * __hip_atomic_load(wsh + sp * (D + 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc += w * __hip_atomic_load(wsh + sp * (D + 2) + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      Op[tid] = (bf16_t)(L > 0.f ? acc / L : 0.f);
+    }
+    return;
+  }
   float* s_ms = sc;                                        // (the score array is dead by now)
   float* s_sum = sc + MAX_NS;
   if (tid < NS) {
@@ -862,7 +879,7 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t stream) {
   }
   while ((a.Sk + NS - 1) / NS + 64 > DEC_MAX_CHUNK) ++NS;               // a split's scores must fit the LDS array
   if (NS > 1 && !ws) return -1;
-  if (NS > 32) { mp_set_error("mp_attention_fwd_bf16(decode): %d keys need more than 32 splits", a.Sk); return MP_ERR_SHAPE; }
+  if ((int64_t)a.B * a.H * NS * (D + 2) * 4 > bytes) { mp_set_error("mp_attention_fwd_bf16(decode): %d keys in %d splits do not fit the split workspace", a.Sk, NS); return MP_ERR_WORKSPACE; }
   hipLaunchKernelGGL((attn_decode_kernel<D>), dim3(a.B * a.H, NS), dim3(256), 0, stream, a, ws, tickets, NS);
   return mp_check_launch("mp_attention_fwd_bf16(decode)");
 }

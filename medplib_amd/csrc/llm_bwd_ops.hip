@@ -678,6 +678,34 @@ __global__ void lora_grad_unpack_kernel(const float* __restrict__ dB, const floa
   }
 }
 
+// lora_grad_unpack_kernel reading the weight-gradient kernels' CHUNK PARTIALS directly (dBp [chunksB][W * R], dATp [chunksA][fin * R], each to be
+// summed in ascending chunk order and scaled: exactly tn_skinny_reduce_kernel's arithmetic) — the two reduce launches per adapter group go away
+// (128 launches of ~8 us per LoRA step); eight chunk loads in flight per thread.
+__global__ void lora_grad_unpack_partials_kernel(const float* __restrict__ dBp, const float* __restrict__ dATp, int chunksB, int chunksA, float scaleB,
+                                                 float scaleA, const int64_t* __restrict__ rows, int R, int k0, int r, int fin, int fout, int W,
+                                                 float* __restrict__ gB, float* __restrict__ gA) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nb = (int64_t)fout * r, na = (int64_t)r * fin;
+  const float* src; int64_t stride; int chunks; float scale; float* dst;
+  if (idx < nb) {
+    const int o = (int)(idx / r), j = (int)(idx % r);
+    src = dBp + rows[o] * R + k0 + j; stride = (int64_t)W * R; chunks = chunksB; scale = scaleB; dst = gB + idx;
+  } else if (idx < nb + na) {
+    const int64_t e = idx - nb;
+    const int i = (int)(e / fin), c = (int)(e % fin);
+    src = dATp + (int64_t)c * R + k0 + i; stride = (int64_t)fin * R; chunks = chunksA; scale = scaleA; dst = gA + e;
+  } else return;
+  float s = 0.f;
+  for (int c0 = 0; c0 < chunks; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (c0 + u < chunks) ? src[(int64_t)(c0 + u) * stride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (c0 + u < chunks) s += v[u];
+  }
+  *dst += scale * s;
+}
+
 // One adapter's fp32 parameters written into the padded bf16 GEMM operands of its group (both orientations): A [64, fin] rows
 // k0..k0+r-1, A^T [fin, 64] columns k0.., B [W, 64] rows rows[o] columns k0.., B^T [64, W] rows k0.. columns rows[o]
 __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ rows, bf16_t* __restrict__ A,
@@ -698,6 +726,36 @@ __global__ void lora_pack_kernel(const float* __restrict__ a, const float* __res
     B[ro * 64 + k0 + j] = v;
     BT[(int64_t)(k0 + j) * W + ro] = v;
     if (Bx) Bx[ro * ldbx + k0 + j] = (bf16_t)(b[e] * xscale);      // the K-extension columns of [W | scaling B] (mp_lora_down_bf16)
+  }
+}
+
+// Every adapter of the decoder in ONE launch (blockIdx.y = adapter): the training step re-packs all of them once per step (96 launches of the
+// kernel above at r = 8 on gate / up / down of 32 layers).  The descriptor table lives on the device and is rebuilt only when a pointer moves.
+struct LoraPackDesc {
+  const float* a; const float* b; const int64_t* rows; bf16_t* A; bf16_t* AT; bf16_t* B; bf16_t* BT; bf16_t* Bx;
+  int64_t ldbx;
+  int r, fin, fout, k0, W;
+  float bscale, xscale;
+  int pad;
+};
+static_assert(sizeof(LoraPackDesc) == 104, "LoraPackDesc is packed by medplib_amd/model/llama_lora.py as 104 bytes");
+__global__ void lora_pack_batched_kernel(const LoraPackDesc* __restrict__ descs) {
+  const LoraPackDesc g = descs[blockIdx.y];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t na = (int64_t)g.r * g.fin, nb = (int64_t)g.fout * g.r;
+  if (idx < na) {
+    const int i = (int)(idx / g.fin), c = (int)(idx % g.fin);
+    const bf16_t v = (bf16_t)g.a[idx];
+    g.A[(int64_t)(g.k0 + i) * g.fin + c] = v;
+    g.AT[(int64_t)c * 64 + g.k0 + i] = v;
+  } else if (idx < na + nb) {
+    const int64_t e = idx - na;
+    const int o = (int)(e / g.r), j = (int)(e % g.r);
+    const int64_t ro = g.rows[o];
+    const bf16_t v = (bf16_t)(g.b[e] * g.bscale);
+    g.B[ro * 64 + g.k0 + j] = v;
+    g.BT[(int64_t)(g.k0 + j) * g.W + ro] = v;
+    if (g.Bx) g.Bx[ro * g.ldbx + g.k0 + j] = (bf16_t)(g.b[e] * g.xscale);
   }
 }
 
@@ -1046,7 +1104,8 @@ extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64
   else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
   else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
   const int64_t NR = (int64_t)N * R;
-  hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
+  if (out)                                                  // out == NULL: the caller consumes the chunk partials itself (mp_lora_grad_unpack_partials_f32)
+    hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
   return mp_check_launch("mp_tn_skinny_f32");
 }
 
@@ -1136,6 +1195,16 @@ extern "C" int mp_lora_grad_unpack_f32(const float* dB, const float* dAT, const 
   return mp_check_launch("mp_lora_grad_unpack_f32");
 }
 
+extern "C" int mp_lora_grad_unpack_partials_f32(const float* dBp, const float* dATp, int chunksB, int chunksA, float scaleB, float scaleA,
+                                                const int64_t* rows, int R, int k0, int r, int fin, int fout, int W, float* gB, float* gA,
+                                                hipStream_t stream) {
+  MP_REQUIRE(R > 0 && r > 0 && k0 >= 0 && k0 + r <= R && fin > 0 && fout > 0 && W >= 1 && chunksB >= 1 && chunksA >= 1 && dBp && dATp && rows && gB && gA,
+             MP_ERR_ARG, "mp_lora_grad_unpack_partials_f32: bad arguments");
+  const int64_t n = (int64_t)fout * r + (int64_t)r * fin;
+  hipLaunchKernelGGL(lora_grad_unpack_partials_kernel, GRID1D(n), dBp, dATp, chunksB, chunksA, scaleB, scaleA, rows, R, k0, r, fin, fout, W, gB, gA);
+  return mp_check_launch("mp_lora_grad_unpack_partials_f32");
+}
+
 extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows, void* A, void* AT, void* B, void* BT, int r, int fin, int fout,
                             int k0, int W, float bscale, void* Bx, int64_t ldbx, float xscale, hipStream_t stream) {
   MP_REQUIRE(r > 0 && k0 >= 0 && k0 + r <= 64 && fin > 0 && fout > 0 && W >= fout, MP_ERR_SHAPE, "mp_lora_pack: bad shape");
@@ -1143,6 +1212,12 @@ extern "C" int mp_lora_pack(const float* a, const float* b, const int64_t* rows,
   hipLaunchKernelGGL(lora_pack_kernel, GRID1D(n), a, b, rows, (bf16_t*)A, (bf16_t*)AT, (bf16_t*)B, (bf16_t*)BT, r, fin, fout, k0, W, bscale,
                      (bf16_t*)Bx, ldbx, xscale);
   return mp_check_launch("mp_lora_pack");
+}
+
+extern "C" int mp_lora_pack_batched(const void* descs, int n, int64_t max_elems, hipStream_t stream) {
+  MP_REQUIRE(descs && n >= 1 && max_elems >= 1, MP_ERR_ARG, "mp_lora_pack_batched: bad arguments");
+  hipLaunchKernelGGL(lora_pack_batched_kernel, dim3((unsigned)mp_cdiv(max_elems, 256), (unsigned)n), dim3(256), 0, stream, (const LoraPackDesc*)descs);
+  return mp_check_launch("mp_lora_pack_batched");
 }
 
 extern "C" int mp_moe_combine_bwd_bf16(const void* dout, const void* y, const int* expert, const int* slot, const float* weight, void* dy,

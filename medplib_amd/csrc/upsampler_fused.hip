@@ -1050,8 +1050,15 @@ extern "C" int mp_mask_upsample_fused_bf16(const void* src, const void* w1_packe
     const int grid = (int)std::min<int64_t>(256, mp_cdiv(groups, nw / 2));
     a.early = early_env >= 0 ? early_env : (nw >= 8 ? 4 : 0);
     auto launch = [&](auto kern) {
-      static bool attr_set = false;                 // one flag per instantiation of this lambda's operator()
-      if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS2); attr_set = true; }
+      // function attributes are per DEVICE: one flag per (instantiation of this lambda's operator(), device) — a process that drives a second
+      // GPU sets it there too (round-4 advisor)
+      static bool attr_set[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS2);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+      }
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), UP_LDS2, stream, a);
     };
     if (up && !mask && abl == 1) launch(upsample_fused_kernel<true, false, 1, true>);

@@ -320,7 +320,11 @@ class LlamaStack:
         """One token per sequence against the KV cache with the cache length held ON THE DEVICE (`counters` int32 [2] =
         [position of the new token, number of valid keys after appending it]): no launch argument depends on the step, so the
         whole step can be captured once into a HIP graph and replayed per token (evaluate()).  emb [B, 1, d] -> hidden [B, 1, d].
-        The caller advances `counters` (ops.advance_ints) after the step."""
+        The caller advances `counters` (ops.advance_ints) after the step.
+        Reproducibility note (round-4 advisor): the narrow projections (o_proj, down) take the K-split GEMV when B == 1 or an expert index is
+        given and the shared-weight form otherwise; the two add their partial dot products in different orders, so the SAME prompt decoded at
+        batch 1 and at batch 2 may differ in the last fp32 bit of those projections (and, at a near-tie of two logits, in a greedy token).
+        Within one batch size every step is bit-reproducible; MP_GEMV_KSPLIT=0 selects the shared form for every batch size."""
         cfg = self.cfg
         B, _, d = emb.shape
         H, D = cfg.num_attention_heads, cfg.head_dim

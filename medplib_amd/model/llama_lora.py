@@ -17,6 +17,7 @@ into the gate and a trainable `wg` (scripts/train_stage4.sh's `--sft_modules wg,
 import math
 import os
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -255,10 +256,13 @@ class LoRAState(torch.nn.Module):
                     self._bufs[i][grp] = (torch.zeros(lead + (64, fin), dtype=bf, device=dev), torch.zeros(lead + (fin, 64), dtype=bf, device=dev),
                                           torch.zeros(lead + (W, 64), dtype=bf, device=dev), torch.zeros(lead + (64, W), dtype=bf, device=dev), tg)
         out = {}
+        fresh = getattr(self, "_packed_at", None) == self.step and self.step > 0       # pack_all() already rewrote every slice this step
         for grp, (A, AT, B, BT, tg) in self._bufs[i].items():
             batched = A.dim() == 3
             for k, t in enumerate(tg):
                 for e in range(self.E if batched else 1):
+                    if fresh:
+                        continue
                     a, b = self.get(i, t, "A", e).detach(), self.get(i, t, "B", e).detach()
                     if batched:
                         wx = self.ext.get((i, grp))                # [E, out, in + 64]: expert e's scaling * B behind its frozen weight
@@ -271,6 +275,42 @@ class LoRAState(torch.nn.Module):
             R = len(tg) * r
             out[grp] = (A, AT, B, BT, 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64, tg)
         return out
+
+
+_PACK_DESC = np.dtype([("a", "<u8"), ("b", "<u8"), ("rows", "<u8"), ("A", "<u8"), ("AT", "<u8"), ("B", "<u8"), ("BT", "<u8"), ("Bx", "<u8"), ("ldbx", "<i8"),
+                       ("r", "<i4"), ("fin", "<i4"), ("fout", "<i4"), ("k0", "<i4"), ("W", "<i4"), ("bscale", "<f4"), ("xscale", "<f4"), ("pad", "<i4")])
+assert _PACK_DESC.itemsize == 104
+
+
+def pack_all(lora, n_layers):
+    """Every adapter's slices of the padded bf16 operands rewritten in ONE launch (mp_lora_pack_batched) instead of one mp_lora_pack per adapter and
+    layer (96 per step at the shipped stage-III configuration).  The device-side descriptor table is rebuilt only when a pointer moved
+    (the engine re-homes the parameters into its flat buffer once).  Same kernel body, same values."""
+    for i in range(n_layers):                                  # make sure every layer's persistent buffers exist (first call)
+        if i not in lora._bufs:
+            lora.padded(i)
+    recs = []
+    r = lora.r
+    for i in range(n_layers):
+        moe = i in lora.moe_layers
+        for grp, (A, AT, B, BT, tg) in lora._bufs[i].items():
+            batched = A.dim() == 3
+            wx = lora.ext.get((i, grp))
+            for k, t in enumerate(tg):
+                for e in range(lora.E if batched else 1):
+                    a, b = lora.get(i, t, "A", e).detach(), lora.get(i, t, "B", e).detach()
+                    Ae, ATe, Be, BTe = (A[e], AT[e], B[e], BT[e]) if batched else (A, AT, B, BT)
+                    bx = None if wx is None else (wx[e][:, wx.shape[2] - 64:] if batched else wx[:, wx.shape[1] - 64:])
+                    recs.append((a.data_ptr(), b.data_ptr(), lora.rows[t].data_ptr(), Ae.data_ptr(), ATe.data_ptr(), Be.data_ptr(), BTe.data_ptr(),
+                                 0 if bx is None else bx.data_ptr(), 0 if bx is None else bx.stride(0), a.shape[0], a.shape[1], b.shape[0], k * r, Be.shape[0],
+                                 lora.scaling if batched else 1.0, lora.scaling, 0))
+    key = tuple(recs)
+    if getattr(lora, "_pack_key", None) != key:
+        arr = np.array(recs, dtype=_PACK_DESC)
+        lora._pack_tab = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(lora.rows["q_proj"].device)
+        lora._pack_key, lora._pack_max = key, max(int(x[9]) * int(x[10]) + int(x[11]) * int(x[9]) for x in recs)
+    ops.lib().call("mp_lora_pack_batched", lora._pack_tab.data_ptr(), len(recs), int(lora._pack_max), ops._stream())
+    lora._packed_at = lora.step
 
 
 def _transposed(w):
@@ -315,6 +355,8 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_UNPACK_PARTIALS = os.environ.get("MP_LORA_UNPACK_PARTIALS", "1") != "0"  # A/B: 0 = a reduce launch per weight-gradient product, then the unpack
+_PACK_BATCHED = os.environ.get("MP_LORA_PACK_BATCHED", "1") != "0"       # A/B: 0 = one mp_lora_pack launch per adapter and layer
 _FUSE_UP_SWIGLU = os.environ.get("MP_FUSE_UP_SWIGLU", "1") != "0"      # A/B: 0 = lora_up_add then swiglu_pair_bwd (two passes over d_act)
 
 
@@ -555,6 +597,8 @@ def forward_train(llm, embeds, key_valid):
     x = embeds.reshape(T, d)
     lora.step += 1
     lora.p_active = lora.p if llm.training else 0.0
+    if _PACK_BATCHED:
+        pack_all(lora, len(llm.layers))
     llm.gate_pass += 1
     saved, aux = [], []
     for i, lw in enumerate(llm.layers):
@@ -621,15 +665,17 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None):
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
     adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed.  dx = None: nothing trainable lies in front of
     this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
     A, AT, B, BT, R, _ = ops_pad
     # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
     dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
-    dB = ops.tn_skinny(dy, t, R, lora.scaling)                     # [out, R] = scaling * dy^T t
-    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed)        # [in, R]  = dropout(x)^T (scaling * dy B)
+    # partials: the chunk partials are handed on unsummed (ops.SkinnyPartial) — the gradient unpack into the flat buffer adds them up itself
+    partials = partials and R <= 32
+    dB = ops.tn_skinny(dy, t, R, lora.scaling, reduce=not partials)                     # [out, R] = scaling * dy^T t
+    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials)        # [in, R]  = dropout(x)^T (scaling * dy B)
     if dx is None:
         return None, dB, dAT
     if swiglu_gu is not None and R <= 32 and dx.stride(0) % 8 == 0 and _FUSE_UP_SWIGLU:
@@ -665,8 +711,16 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
         for k, t in enumerate(ops_pad[5]):
             nb, na = f"model.layers.{i}.{_module(t)}.lora_B.default.weight", f"model.layers.{i}.{_module(t)}.lora_A.default.weight"
             pb, pa = lora.params[lora.index[nb]], lora.params[lora.index[na]]
-            if (lora.grad_sink is not None and pb.grad is not None and pa.grad is not None and pb.grad.is_contiguous() and pa.grad.is_contiguous()
-                    and pb.grad.dtype == torch.float32 and dB.is_contiguous() and dAT.is_contiguous()):
+            direct = (lora.grad_sink is not None and pb.grad is not None and pa.grad is not None and pb.grad.is_contiguous() and pa.grad.is_contiguous()
+                      and pb.grad.dtype == torch.float32)
+            if direct and isinstance(dB, ops.SkinnyPartial) and isinstance(dAT, ops.SkinnyPartial):
+                ops.lora_grad_unpack_partials(dB, dAT, lora.rows[t], k * r, pb.grad, pa.grad)
+                continue
+            if isinstance(dB, ops.SkinnyPartial):
+                dB = dB.finish()
+            if isinstance(dAT, ops.SkinnyPartial):
+                dAT = dAT.finish()
+            if direct and dB.is_contiguous() and dAT.is_contiguous():
                 ops.lora_grad_unpack(dB, dAT, lora.rows[t], k * r, pb.grad, pa.grad)
             else:
                 grads[nb] = dB[lora.rows[t], k * r:(k + 1) * r]
@@ -688,6 +742,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                     grads[nb] = dB[e][lora.rows[t], k * r:(k + 1) * r]
                     grads[na] = dAT[e][:, k * r:(k + 1) * r].t()
 
+    part_ok = lora.grad_sink is not None and _UNPACK_PARTIALS and lora.r <= 32      # the unpack into the flat gradient buffer sums the chunk partials itself
     dx = ops.rmsnorm_bwd(saved["x_last"], llm.norm_w, d_hidden.reshape(T, d).contiguous(), cfg.rms_norm_eps)
     for i in range(len(llm.layers) - 1, -1, -1):
         lw, s = llm.layers[i], saved["layers"][i]
@@ -700,7 +755,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             d_gu = None
             if "down" in pad:
                 fused = _FUSE_UP_SWIGLU and pad["down"][4] <= 32 and d_act.stride(0) % 8 == 0
-                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None)
+                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok)
                 take(i, pad["down"], dB, dAT)
                 if fused:
                     d_gu, d_act = d_act, None
@@ -712,7 +767,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                          and (i, "ln1") not in lora.norm_names and (i, "ln2") not in lora.norm_names)
             d_h2 = None if stop_here else ops.gemm(d_gu, lw["gu_T"])
             if "gu" in pad:
-                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"])
+                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok)
                 take(i, pad["gu"], dB, dAT)
             if stop_here:
                 dx = None
@@ -727,7 +782,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
         # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]
         d_attn = ops.gemm(d_mid, lw["o_T"])
         if "o" in pad:
-            d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3)
+            d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3, partials=part_ok)
             take(i, pad["o"], dB, dAT)
         q5 = s["qkv"].unflatten(0, (B, S)).unflatten(2, (3, H, D))
         _, _, _, dqkv = ops.attention_bwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], s["attn"], d_attn.view(B, S, d), s["lse"], causal=True,
@@ -736,7 +791,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
         ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)           # the transpose of a rotation is the rotation by -theta
         d_h1 = ops.gemm(dqkv, lw["qkv_T"])
         if "qkv" in pad:
-            d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2)
+            d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2, partials=part_ok)
             take(i, pad["qkv"], dB, dAT)
         if (i, "ln1") in lora.norm_names:
             dx, grads[lora.norm_names[(i, "ln1")]] = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid, want_wgrad=True)

@@ -83,7 +83,10 @@ class KernelTimer:
         if not self.pending:
             return
         pend, self.pending = self.pending, []
-        counts = torch.stack([p[1].to(torch.int32).view(-1) for p in pend]).cpu()          # [launches, E]
+        # one transfer for all launches; the count vectors may differ in length (expert parallelism: [E] on the dense-parallel launches,
+        # [experts per rank] on the sharded ones — round-4 advisor), so they travel flattened and are split again by length
+        flat = [p[1].to(torch.int32).view(-1) for p in pend]
+        counts = torch.cat(flat).cpu().split([f.numel() for f in flat])
         for (kern, _, slab, fpr, rec, tag), c in zip(pend, counts):
             rows = int(c.clamp(max=slab).sum()) if slab > 0 else int(c.sum())
             work = fpr * rows
@@ -448,7 +451,24 @@ def swiglu_pair_bwd(gu, dact, counts=None, cap=0):
     return dgu
 
 
-def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None):
+class SkinnyPartial:
+    """The chunk partials of one tn_skinny product, not yet summed: [chunks, N * R] fp32 + the scale the sum takes.  lora_grad_unpack_partials
+    consumes it directly; .finish() is the reduce (same values as tn_skinny(..., reduce=True))."""
+    __slots__ = ("partial", "chunks", "scale", "N", "R")
+
+    def __init__(self, partial, chunks, scale, N, R):
+        self.partial, self.chunks, self.scale, self.N, self.R = partial, chunks, scale, N, R
+
+    def finish(self):
+        return colsum_scaled(self.partial.view(self.chunks, self.N * self.R), self.scale).view(self.N, self.R)
+
+
+def colsum_scaled(x2d, scale):
+    out = colsum_f32(x2d)
+    return out if scale == 1.0 else scale_f32_(out, scale)
+
+
+def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None, reduce=True):
     """out[n, j] = scale * sum_t drop(x)[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= 16 * ceil(R / 16)] bf16; p > 0: x is the
     undropped tensor and the lora_dropout mask (mp_dropout_bf16 over the contiguous [T, N]) is applied on the way.  rows_dev: int32 device
     scalar, only the first min(T, rows_dev) rows count (an expert's routed rows on its capacity slab)."""
@@ -461,12 +481,21 @@ def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None):
         gp = torch.zeros((T, need), dtype=torch.bfloat16, device=g.device)
         gp[:, :g.shape[1]] = g
         g = gp
-    out = torch.empty((N, R), dtype=torch.float32, device=x.device)
     chunks = (T + 255) // 256
     partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
+    out = torch.empty((N, R), dtype=torch.float32, device=x.device) if reduce else None
     lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), T, N, int(R), float(scale),
                float(p), int(seed), _p(rows_dev), _stream())
-    return out
+    return out if reduce else SkinnyPartial(partial, chunks, float(scale), N, int(R))
+
+
+def lora_grad_unpack_partials(dB, dAT, rows, k0, gB, gA):
+    """lora_grad_unpack from two SkinnyPartial (mp_lora_grad_unpack_partials_f32): the chunk sums happen in the unpack itself."""
+    fout, r = gB.shape
+    fin = gA.shape[1]
+    assert dB.R == dAT.R and dAT.N == fin and gB.is_contiguous() and gA.is_contiguous() and rows.numel() == fout
+    lib().call("mp_lora_grad_unpack_partials_f32", _p(dB.partial), _p(dAT.partial), dB.chunks, dAT.chunks, dB.scale, dAT.scale, _p(rows), dB.R, int(k0), r, fin,
+               fout, dB.N, _p(gB), _p(gA), _stream())
 
 
 def ce_rows_bwd(logits, labels, gscale, gconst, ldo):
