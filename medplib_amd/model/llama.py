@@ -273,7 +273,7 @@ class LlamaStack:
         B, S, d = inputs_embeds.shape
         H, D = cfg.num_attention_heads, cfg.head_dim
         x = inputs_embeds.reshape(B * S, d)
-        aux, routing = [], []
+        aux, routing, gate_inputs = [], [], []
         self.gate_pass += 1
         pos0 = kv_cache["len"] if kv_cache is not None else 0
         # a handful of rows (the single-token decode steps): the projections are weight streams -> GEMV kernel (HBM-bound)
@@ -310,10 +310,13 @@ class LlamaStack:
             if l_aux is not None:
                 aux.append(l_aux)
                 if collect_routing:
-                    routing.append(tuple(r) + (x_gate_in,))
+                    routing.append(r)
+                    gate_inputs.append(x_gate_in)
         if kv_cache is not None:
             kv_cache["len"] = pos0 + S
         out = ops.rmsnorm(x, self.norm_w, cfg.rms_norm_eps)
+        if collect_routing:
+            self.last_gate_inputs = gate_inputs            # per MoE layer: the residual stream in front of the post-attention norm (oracle/parity.py)
         return out.view(B, S, d), aux, (routing if collect_routing else None)
 
     def decode_step(self, emb, kv_cache, counters):

@@ -144,7 +144,7 @@ def routing_report(coll, routing, T, capacity, rts):
     return per, same_all
 
 
-def layer_local_routing(routing, W, cfg, top_k):
+def layer_local_routing(routing, W, cfg, top_k, gate_inputs=None):
     """The routing of every MoE layer recomputed on the host from the HIP path's OWN input to that layer's gate (the residual stream in
     front of the post-attention norm, which the model hands over in collect mode): fp32 RMSNorm, rounded to bf16 as the kernel's normed row
     is, fp32 logits, argmax.  With identical inputs and identical rounding points only the summation order differs, so a token may pick
@@ -153,10 +153,12 @@ def layer_local_routing(routing, W, cfg, top_k):
     -> {"agreement_min", "flips_total", "max_flip_margin", "tokens"} (round-4 review, parity item c)."""
     agree, flips, worst, T = [], 0, 0.0, 0
     moe_ids = sorted(cfg.moe_layer_set())
-    for li, r in zip(moe_ids, routing):
-        if len(r) < 4 or r[3] is None:
+    if not gate_inputs or len(gate_inputs) != len(routing):
+        return None
+    for li, r, xg in zip(moe_ids, routing, gate_inputs):
+        if xg is None:
             return None
-        x = r[3].float().cpu()
+        x = xg.float().cpu()
         T = x.shape[0]
         p = f"model.layers.{li}."
         # the kernel's (= HF LlamaRMSNorm's) two rounding points: the normalised value is cast to bf16 BEFORE the weight multiplies it, the
@@ -272,7 +274,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
         # the per-layer routing report restates top-1 selection; top-2 layers are compared through their outputs only
         per_layer, same = routing_report(coll, routing, T, m.model.llm.capacity(T), rts_list) if routing else ([], torch.ones(T, dtype=torch.bool))
         agree = [p["expert_agreement"] for p in per_layer]
-        local = layer_local_routing(routing, W, cfg, cfg.top_k_experts) if routing else None
+        local = layer_local_routing(routing, W, cfg, cfg.top_k_experts, getattr(m.model.llm, "last_gate_inputs", None)) if routing else None
         masks = m(**dict(gb, inference=True))["pred_masks"]
     losses_cpu = {k: float(ref[k]) for k in O.LOSS_KEYS}
     # the masks, where a comparison can fail (oracle/ops.py: mask_cut_report): per mask at the reference's cut and at logit 0
