@@ -15,7 +15,7 @@
 // Inter-workgroup visibility follows the microarchitecture guide's XCD-hierarchical barrier: every wave drains its stores, the last
 // workgroup of an XCD issues the agent-scope release (L2 write-back) and meets the other XCDs on a top counter, everyone polls ONE word
 // relaxed with s_sleep, then ONE agent-scope acquire (L1 invalidate) + __syncthreads covers the workgroup.  Data produced inside the launch is never read through const __restrict__
-// pointers (no scalar-cache path).  The spin is bounded: a barrier that cannot complete sets sync[1] and lets the kernel run out.
+// pointers (no scalar-cache path).  The spin is bounded: a barrier that cannot complete within tens of seconds sets sync[1] and traps the launch.
 #include "common.h"
 
 namespace {
@@ -585,7 +585,11 @@ __device__ __forceinline__ bool spin_until(unsigned* w, unsigned target, unsigne
   unsigned spins = 0;
   while (__hip_atomic_load(w, RLX_AGENT) < target) {
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1u << 24)) { __hip_atomic_store(flag, 1u, RLX_AGENT); return false; }     // seconds: give up, say so, let the kernel run out
+    if (++spins > (1u << 24)) {          // tens of seconds: a workgroup of this grid never became resident.  Say so and ABORT the launch — results
+      __hip_atomic_store(flag, 1u, RLX_AGENT);   // computed past a barrier that did not hold would be silently wrong; a trapped kernel surfaces as a
+      __builtin_trap();                          // launch failure at the caller's next synchronisation
+      return false;
+    }
   }
   return true;
 }
