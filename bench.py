@@ -32,6 +32,18 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI
 FWD_TFLOP_PER_SAMPLE = 9.15
 
 
+def pruned_tflop_per_step(model, cfg, lora):
+    """TFLOP per step the last decoder layer's MLP does NOT execute because nothing reads those rows (medplib.model_forward: the MLP of
+    the last layer runs on the supervised + <SEG> rows; MP_PRUNE_LAST_MLP=0 turns that off) — taken out of `model_tflops_per_gpu`, which
+    therefore counts executed algorithmic work.  -> (TFLOP, "n of T" text or None)."""
+    nr = getattr(model.model.llm, "needed_rows", None)
+    if nr is None:
+        return 0.0, None
+    n, T = int(nr[0].numel()), int(nr[1].numel())
+    per_row = 6.0 * cfg.hidden_size * cfg.intermediate_size            # gate, up, down: 2 flop per multiply-add
+    return (T - n) * per_row * (2 if lora else 1) / 1e12, f"{n} of {T}"     # with adapters also the three input-gradient GEMMs
+
+
 def synthetic_batch(cfg, B, device, seed):
     """SURVEY §8(d) synthetic inputs: N(0,1) images, 64-token prompt with one <image> placeholder at position 35 bracketed
     by <im_start>/<im_end>, <SEG> at 61, EOS at 63, labels supervised from position 56, one binary disc mask per sample."""
@@ -396,7 +408,8 @@ def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warm
     res = {"workload": "MedPLIB-7B dense stage-III training step WITH LoRA (r=8 on gate/up/down_proj, dropout 0.05: scripts/train_stage3.sh), "
                        f"whole decoder backward, per-GPU batch {args.batch}", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2), "host_issue_ms_per_step": round(dt_issue / steps * 1e3, 2), "samples_per_s": round(args.batch * steps / dt, 2),
-           "model_tflops_per_gpu": round((FWD_TFLOP_PER_SAMPLE + 8.66) * args.batch * steps / dt, 1),
+           "model_tflops_per_gpu": round(((FWD_TFLOP_PER_SAMPLE + 8.66) * args.batch - pruned_tflop_per_step(model, cfg, True)[0]) * steps / dt, 1),
+           "last_layer_mlp_rows": pruned_tflop_per_step(model, cfg, True)[1] or "all",
            "trainable_params": eng.optimizer.numel, "loss_last": float(out["loss"].detach())}
     model.sync_side_streams(); torch.cuda.synchronize()
     del eng, model, lora, out
@@ -915,11 +928,16 @@ def gpu_main(args, emit):
                        "global_batch": world * args.batch, "seq_len": seq_len,
                        "parallelism": (f"ep{epx.ep} x dp{max(world // epx.ep, 1)}" if args.ep else f"dp{world}"),
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel,
+                       # the last decoder layer's MLP runs on the rows the filtered CE and the <SEG> gather read (bit-identical losses and
+                       # gradients: tests/test_gpu_prune_last_mlp.py); "all" under MP_PRUNE_LAST_MLP=0
+                       "last_layer_mlp_rows": pruned_tflop_per_step(model, cfg, args.lora)[1] or "all",
                        "mask_upsampler": ("fused bf16 kernel, forward + recomputing backward (in the step)" if cfg.fused_bf16_upsampler
                                           else "fp32 tail (6 launches forward, 14 backward)")},
             # algorithmic work per sample: the forward (9.15 TFLOP); with --lora also the decoder's dgrad (8.66: the frozen
             # projections' input gradients + the attention backward; no wgrad for frozen weights)
-            "model_tflops_per_gpu": (round((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch * args.steps / dt, 1) if not args.ep else None),
+            # minus what the last layer's MLP skips on rows nothing reads (config.last_layer_mlp_rows)
+            "model_tflops_per_gpu": (round(((FWD_TFLOP_PER_SAMPLE + (8.66 if args.lora else 0.0)) * args.batch
+                                            - pruned_tflop_per_step(model, cfg, args.lora)[0]) * args.steps / dt, 1) if not args.ep else None),
             "loss_after_warmup": loss0, "loss_last": float(out["loss"].detach()),
             "roofline": roof, "roofline_timed_region": (roof_timed if timer_u is not None else None),
             # data parallel: what RCCL connected, and the gradient bucket (one SUM all-reduce of the flat fp32 gradient on the

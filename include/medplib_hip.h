@@ -293,6 +293,15 @@ int mp_clip_embed_bf16(const void* patch, const void* cls, const void* pos, void
 int mp_copy_rows_bf16(const void* src, void* dst, int64_t rows, int dim, int rows_per_batch, int src_batch_rows, int src_row0,
                       hipStream_t stream);
 
+/* Rows of the LAST decoder layer that something reads (the supervised rows of the filtered CE, medplib_moe_llama.py:392-408, and the <SEG> rows,
+ * MedPLIB.py:456-466): that layer's MLP runs on those rows only — row-wise identical results, unread rows are not computed.
+ * mp_gather_rows_bf16: out[r] = src[idx[r]] (scatter = 0) or out[idx[r]] = src[r] (scatter = 1), bf16 rows of `dim`.
+ * mp_moe_filter_slots: per expert, the routed slots whose token is marked in needed[tokens] (uint8), compacted in slot order. */
+int mp_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, void* out, int64_t ld_out, int64_t n_rows, int dim, int scatter,
+                        hipStream_t stream);
+int mp_moe_filter_slots(const int* slot_token, const int* kept, const uint8_t* needed, int* slot_token_out, int* kept_out, int n_experts,
+                        int capacity, hipStream_t stream);
+
 /* ---- CE and MoE routing ------------------------------------------------------------------------------------------- */
 
 /* per-row -log softmax(logits)[label] on fp32 logits (medplib_moe_llama.py:388-408). */

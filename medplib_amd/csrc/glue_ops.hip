@@ -502,3 +502,62 @@ extern "C" int mp_region_point_mean_bf16(const void* fmap, const float* xy, cons
                      offsets, map_index, (bf16_t*)out, n_masks, h, w, C);
   return mp_check_launch("mp_region_point_mean_bf16");
 }
+
+// ---- rows of the LAST decoder layer that something reads (round 5: the MLP of that layer runs on those rows only) ----
+namespace {
+// out[r, :] = src[idx[r], :] (bf16, 16-byte pieces); gather: out compact / src strided; scatter: the reverse
+__global__ void gather_rows_bf16_kernel(const bf16_t* __restrict__ src, int64_t lds_, const int64_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                        int64_t ldo, int64_t n, int dim8, int scatter) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim8) return;
+  const int64_t r = i / dim8;
+  const int c = (int)(i - r * dim8) * 8;
+  const int64_t row = idx[r];
+  if (scatter) *reinterpret_cast<bf16x8*>(out + row * ldo + c) = *reinterpret_cast<const bf16x8*>(src + r * lds_ + c);
+  else *reinterpret_cast<bf16x8*>(out + r * ldo + c) = *reinterpret_cast<const bf16x8*>(src + row * lds_ + c);
+}
+// Per expert: the slots (in slot order) whose token is marked in `needed` -> compacted slot_token_out[e, 0 .. kept_out[e])
+__global__ __launch_bounds__(1024) void moe_filter_slots_kernel(const int* __restrict__ slot_token, const int* __restrict__ kept,
+                                                               const uint8_t* __restrict__ needed, int* __restrict__ slot_token_out,
+                                                               int* __restrict__ kept_out, int cap) {
+  __shared__ int wtot[16];
+  __shared__ int s_base;
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = min(kept[e], cap);
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < n; b0 += 1024) {
+    const int s = b0 + tid;
+    const int tok = s < n ? slot_token[(int64_t)e * cap + s] : -1;
+    const bool f = tok >= 0 && needed[tok] != 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wv] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wv; ++w) off += wtot[w];
+    if (f) slot_token_out[(int64_t)e * cap + off + before] = tok;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wtot[w]; s_base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) kept_out[e] = s_base;
+}
+}  // namespace
+
+extern "C" int mp_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, void* out, int64_t ld_out, int64_t n_rows, int dim,
+                                   int scatter, hipStream_t stream) {
+  MP_REQUIRE(dim % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0, MP_ERR_SHAPE, "mp_gather_rows_bf16: dim and strides must be multiples of 8");
+  const int64_t n = n_rows * (dim / 8);
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)mp_cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)src, ld_src, idx, (bf16_t*)out, ld_out,
+                     n_rows, dim / 8, scatter);
+  return mp_check_launch("mp_gather_rows_bf16");
+}
+
+extern "C" int mp_moe_filter_slots(const int* slot_token, const int* kept, const uint8_t* needed, int* slot_token_out, int* kept_out, int n_experts,
+                                   int capacity, hipStream_t stream) {
+  MP_REQUIRE(n_experts >= 1 && capacity >= 1 && slot_token && kept && needed && slot_token_out && kept_out, MP_ERR_ARG, "mp_moe_filter_slots: bad arguments");
+  hipLaunchKernelGGL(moe_filter_slots_kernel, dim3((unsigned)n_experts), dim3(1024), 0, stream, slot_token, kept, needed, slot_token_out, kept_out, capacity);
+  return mp_check_launch("mp_moe_filter_slots");
+}

@@ -171,7 +171,7 @@ class LlamaStack:
             self._draws_key = key
         return self._draws_all[i * T * E:(i + 1) * T * E]
 
-    def _mlp(self, i, lw, h, x, gate=None):
+    def _mlp(self, i, lw, h, x, gate=None, needed=None):
         """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]; gate = (logits, gates) when the caller's fused
         norm kernel already produced them (ops.rmsnorm_gate)."""
         cfg = self.cfg
@@ -202,6 +202,10 @@ class LlamaStack:
             expert, slot, weight, kept, counts, l_aux, slot_token = ops.moe_route_top1(
                 gates, cap, self._gate_draws(i, T, E, gumbel=False), want_slot_token=True)
             act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
+            if needed is not None:
+                # the last layer: only the rows something reads go through the experts (the routing above saw every token: capacity drops,
+                # l_aux and the counts are those of the whole batch); a row that is not computed keeps the residual stream, which nobody reads
+                slot_token, kept = ops.moe_filter_slots(slot_token, kept, needed)
             if ops.GEMM_TIMER is not None:
                 ops.GEMM_TIMER.batched_tag = i          # the expert GEMMs are credited with the rows `kept` holds after the region
             ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
@@ -274,6 +278,8 @@ class LlamaStack:
         H, D = cfg.num_attention_heads, cfg.head_dim
         x = inputs_embeds.reshape(B * S, d)
         aux, routing, gate_inputs = [], [], []
+        nr = getattr(self, "needed_rows", None)             # (rows, mask) from model_forward: the output rows something reads, or None
+        needed_mask = nr[1] if (nr is not None and not collect_routing and kv_cache is None and nr[1].numel() == B * S) else None
         self.gate_pass += 1
         pos0 = kv_cache["len"] if kv_cache is not None else 0
         # a handful of rows (the single-token decode steps): the projections are weight streams -> GEMV kernel (HBM-bound)
@@ -303,7 +309,7 @@ class LlamaStack:
             if i in self.moe_layers and d in ops.RMSNORM_GATE_DIMS and B * S > 8:
                 # post-attention norm and the MoE gate in one pass over the rows (bit-identical with the two kernels)
                 h, lg, gt = ops.rmsnorm_gate(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"])
-                x, l_aux, r = self._mlp(i, lw, h, x, gate=(lg, gt))
+                x, l_aux, r = self._mlp(i, lw, h, x, gate=(lg, gt), needed=needed_mask if i == len(self.layers) - 1 else None)
             else:
                 h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
                 x, l_aux, r = self._mlp(i, lw, h, x)

@@ -355,6 +355,7 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_PRUNE_ROWS = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"            # A/B: 0 = the last layer's MLP on every row
 _UNPACK_PARTIALS = os.environ.get("MP_LORA_UNPACK_PARTIALS", "1") != "0"  # A/B: 0 = a reduce launch per weight-gradient product, then the unpack
 _PACK_BATCHED = os.environ.get("MP_LORA_PACK_BATCHED", "1") != "0"       # A/B: 0 = one mp_lora_pack launch per adapter and layer
 _FUSE_UP_SWIGLU = os.environ.get("MP_FUSE_UP_SWIGLU", "1") != "0"      # A/B: 0 = lora_up_add then swiglu_pair_bwd (two passes over d_act)
@@ -601,6 +602,9 @@ def forward_train(llm, embeds, key_valid):
         pack_all(lora, len(llm.layers))
     llm.gate_pass += 1
     saved, aux = [], []
+    needed = getattr(llm, "needed_rows", None)                  # (rows int64, mask uint8) of the output rows something reads, or None
+    if needed is not None and needed[1].numel() != T:
+        needed = None
     for i, lw in enumerate(llm.layers):
         pad = lora.padded(i)
         s = {"x": x, "pad": pad}
@@ -636,6 +640,33 @@ def forward_train(llm, embeds, key_valid):
         if i in llm.moe_layers:
             x_out, l_aux = (_moe_fwd_ep if llm.ep is not None else _moe_fwd)(llm, lora, i, lw, pad, h2, x_mid, s, seed)
             aux.append(l_aux)
+        elif (_PRUNE_ROWS and needed is not None and i == len(llm.layers) - 1 and _SWIGLU_KEEP and (i, "ln2") not in lora.norm_names):
+            # The LAST layer's MLP on the rows something reads (model_forward: supervised rows + <SEG> rows, ~1 % of the tokens): the MLP is
+            # row-wise, every read row gets the result of the same arithmetic on a compact [n, d] tensor (the lora_dropout mask is a function of
+            # the position inside the tensor it is drawn for, so it is another sample of the same distribution than the full-size pass would
+            # have drawn; forward and backward use the same one).  x_mid's read rows are replaced in place: it becomes this layer's output.
+            rows = needed[0]
+            n_r = rows.numel()
+            if "gu_x" in lw:
+                h2x_c, h2_c, t3_c = _ext_rows(n_r, d, x.device)
+                ops.gather_rows_bf16(h2, rows, out=h2_c)
+                s["h2d"], s["t_gu"] = _adapter_down(lora, pad["gu"], h2_c, t3_c, seed), t3_c
+                gin, gw = h2x_c, lw["gu_x"]
+            else:
+                gin, gw = ops.gather_rows_bf16(h2, rows), lw["gu"]
+            if "down_x" in lw:
+                actx, act, t4 = _ext_rows(n_r, cfg.intermediate_size, x.device)
+            else:
+                act = None
+            act, gu = ops.gemm_swiglu_keep(gin, gw, act_out=act)
+            xm_c = ops.gather_rows_bf16(x_mid, rows)
+            if "down_x" in lw:
+                s["actd"], s["t_d"] = _adapter_down(lora, pad["down"], act, t4, seed + 1), t4
+                out_c = ops.gemm(actx, lw["down_x"], residual=xm_c)
+            else:
+                out_c = ops.gemm(act, lw["down"], residual=xm_c)
+            x_out = ops.scatter_rows_bf16_(x_mid, rows, out_c)
+            s.update(gu=gu, rows_last=rows, xm_c=xm_c, x_mid=None)
         else:
             # gate|up: silu(gate) * up from the GEMM's epilogue, which also stores the gate|up values the backward reads
             if "down_x" in lw:
@@ -751,11 +782,13 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
         if s.get("moe"):
             d_h2 = (_moe_bwd_ep if s.get("ep") else _moe_bwd)(llm, lora, i, lw, s, dx, d_aux, grads, take_e)
         else:
-            d_act = ops.gemm(dx, lw["down_T"])
+            rows_last = s.get("rows_last")
+            dy_mlp = dx if rows_last is None else ops.gather_rows_bf16(dx, rows_last)      # the pruned last layer: its MLP saw these rows only
+            d_act = ops.gemm(dy_mlp, lw["down_T"])
             d_gu = None
             if "down" in pad:
                 fused = _FUSE_UP_SWIGLU and pad["down"][4] <= 32 and d_act.stride(0) % 8 == 0
-                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dx, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok)
+                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dy_mlp, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok)
                 take(i, pad["down"], dB, dAT)
                 if fused:
                     d_gu, d_act = d_act, None
@@ -763,7 +796,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                 d_gu = ops.swiglu_pair_bwd(s["gu"], d_act)
             # the lowest layer with frozen input rows: nothing trainable reads anything in front of the gate|up input unless the attention
             # projections carry adapters or a norm of this layer trains
-            stop_here = (i == 0 and not need_d_embeds and "o" not in pad and "qkv" not in pad
+            stop_here = (i == 0 and not need_d_embeds and "o" not in pad and "qkv" not in pad and rows_last is None
                          and (i, "ln1") not in lora.norm_names and (i, "ln2") not in lora.norm_names)
             d_h2 = None if stop_here else ops.gemm(d_gu, lw["gu_T"])
             if "gu" in pad:
@@ -775,7 +808,11 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                     pre = f"model.layers.{i}."
                     lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
                 break
-        if (i, "ln2") in lora.norm_names:
+        if s.get("rows_last") is not None:
+            # compact rows back into the layer's full gradient: every other row of dx is zero and stays zero (no MLP branch, no residual)
+            d_mid_c = ops.rmsnorm_bwd(s["xm_c"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dy_mlp)
+            d_mid = ops.scatter_rows_bf16_(dx, s["rows_last"], d_mid_c)
+        elif (i, "ln2") in lora.norm_names:
             d_mid, grads[lora.norm_names[(i, "ln2")]] = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx, want_wgrad=True)
         else:
             d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)

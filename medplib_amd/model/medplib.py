@@ -32,6 +32,9 @@ LOSS_KEYS = ["loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", 
              "unscale_mask_dice_loss", "unscale_mask_loss", "unscale_mask_iou_loss", "unscale_mask_focal_loss"]
 
 
+_PRUNE_LAST_MLP = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"
+
+
 def _h2d(arr, device):
     """Host index array -> device tensor without stalling the host: a pageable-memory copy is synchronous for the caller AND
     ordered behind everything already queued on the stream, so one such copy after the LLM launches makes the host wait for the
@@ -553,6 +556,18 @@ class MedPLIBForCausalLM(nn.Module):
             if kwargs.get("icl_image_counts") is not None and n_masks_given > 0:
                 seg_rows = seg_rows[-n_masks_given:]                   # MedPLIB.py:462-463
             seg_rows_d = _h2d(seg_rows, dev) if seg_flag else None
+            # The rows of the decoder's output that anything reads: the supervised rows of the filtered CE and the <SEG> rows.  The LAST layer's
+            # MLP is row-wise, so it runs on those rows only (unread rows are not computed; every read row has the bits it
+            # would have had).  Off while a test captures the whole hidden state, at inference, or by MP_PRUNE_LAST_MLP=0.
+            m.llm.needed_rows = None
+            if (_PRUNE_LAST_MLP and self.training and not inference and not self.capture_intermediates
+                    and kwargs.get("icl_image_counts") is None):
+                need = np.union1d(np.asarray(sup_rows, dtype=np.int64), np.asarray(seg_rows if seg_flag else [], dtype=np.int64))
+                T_all = B * plan.seq_len
+                if 0 < need.size < T_all // 2:
+                    mask = np.zeros(T_all, dtype=np.uint8)
+                    mask[need] = 1
+                    m.llm.needed_rows = (_h2d(need, dev), _h2d(mask, dev))
             exp = self.expand_index(valid_mask_bool, B) if seg_flag else None
             exp_d = _h2d(np.asarray(exp, dtype=np.int64), dev) if (seg_flag and exp != list(range(B))) else None
             if getattr(m.llm, "lora", None) is not None:

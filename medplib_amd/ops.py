@@ -1321,6 +1321,32 @@ def decode_norm_gate_route(x, ln_w, eps, wg, capacity, rts_uniform=None):
     return h, expert, slot, weight, kept, counts, l_aux
 
 
+def gather_rows_bf16(src, idx, out=None):
+    """out[r] = src[idx[r]]: bf16 rows (src any row stride), idx int64 on the device."""
+    _chk(src, torch.bfloat16, "gather_rows_bf16.src")
+    n, dim = idx.numel(), src.shape[-1]
+    if out is None:
+        out = torch.empty((n, dim), dtype=torch.bfloat16, device=src.device)
+    lib().call("mp_gather_rows_bf16", _p(src), src.stride(0), _p(idx), _p(out), out.stride(0), n, dim, 0, _stream())
+    return out
+
+
+def scatter_rows_bf16_(dst, idx, src):
+    """dst[idx[r]] = src[r] in place (rows of idx distinct)."""
+    _chk(src, torch.bfloat16, "scatter_rows_bf16.src"); _chk(dst, torch.bfloat16, "scatter_rows_bf16.dst")
+    lib().call("mp_gather_rows_bf16", _p(src), src.stride(0), _p(idx), _p(dst), dst.stride(0), idx.numel(), src.shape[-1], 1, _stream())
+    return dst
+
+
+def moe_filter_slots(slot_token, kept, needed):
+    """-> (slot_token' [E, cap], kept' [E]): the routed slots whose token is marked in `needed` (uint8 [T]), compacted in slot order."""
+    E, cap = slot_token.shape
+    st = torch.empty_like(slot_token)
+    kp = torch.empty_like(kept)
+    lib().call("mp_moe_filter_slots", _p(slot_token), _p(kept), _p(needed), _p(st), _p(kp), E, cap, _stream())
+    return st, kp
+
+
 def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, residual=None, act=ACT_NONE, rows_stride=0):
     """Expert GEMMs with dispatch / combine folded in.  With a_rows: a is the shared [tokens, K] matrix and expert b reads rows
     a_rows[b*rows_stride + r]; else a is [E, M, K].  With c_rows: out is the shared [tokens, N] matrix, row c_rows[...] receives
