@@ -388,7 +388,7 @@ def lora_secondary(args, device, ds_config, synthetic_batch, rank, steps=8, warm
             secondary["decode"]["dense"] = decode_rate(model, device)
         except Exception as e:
             secondary["configs"]["1"] = {"error": f"{type(e).__name__}: {e}"}
-    lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules="gate_proj,up_proj,down_proj",
+    lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=float(os.environ.get("MP_BENCH_LORA_DROPOUT", "0.05")), lora_target_modules="gate_proj,up_proj,down_proj",
                              sft_modules="mask_decoder,text_hidden_fcs")
     for n, p in zip(lora.names, lora.params):                # B = 0 at initialisation would make half the gradients trivially zero
         if "lora_B" in n:
@@ -663,7 +663,7 @@ def gpu_main(args, emit):
         from medplib_amd.model.medplib import LISAForCausalLM
         cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, moe_enable=False)
         model = LISAForCausalLM(cfg, device=device).train()
-        lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules="gate_proj,up_proj,down_proj",
+        lora = model.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=float(os.environ.get("MP_BENCH_LORA_DROPOUT", "0.05")), lora_target_modules="gate_proj,up_proj,down_proj",
                                  sft_modules="mask_decoder,text_hidden_fcs")
         for n, p in zip(lora.names, lora.params):            # B = 0 at initialisation would make half the gradients trivially zero
             if "lora_B" in n:

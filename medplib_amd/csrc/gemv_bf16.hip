@@ -28,6 +28,9 @@ struct GemvArgs {
 #ifndef MP_GEMV_NT
 #define MP_GEMV_NT 1
 #endif
+#ifndef MP_GEMV_PIPE
+#define MP_GEMV_PIPE 1        // 0 at build time: the norm-folded GEMVs request a trip only after the previous one was consumed (round 4; A/B)
+#endif
 __device__ __forceinline__ bf16x8 gv_ldw(const bf16_t* p) {
 #if MP_GEMV_NT
   return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
@@ -277,7 +280,7 @@ __device__ __forceinline__ void gv_norm_rows_dot(const GemvArgs& g, const float*
 // qkv launch at 7B, all on the same lines, now 18 MB), a quarter of the LDS.  And the first trip of the weight stream is requested BEFORE
 // the norm, so the prologue runs under the HBM latency of the first eight loads instead of in front of it.  Must be called by all 256
 // threads (`wp` must be valid addresses for waves without work, which skip the epilogue).
-template <int M, int NCH>
+template <int M, int NCH, bool PIPE_OK>
 __device__ __forceinline__ void gv_norm_rows_dot_block(const GemvArgs& g, const float* __restrict__ nw, float eps, const bf16_t* const (&wp)[4],
                                                        int lane, float (&acc)[M][4]) {
   static_assert(NCH % 4 == 0, "block form: K a multiple of 2048");
@@ -285,9 +288,14 @@ __device__ __forceinline__ void gv_norm_rows_dot_block(const GemvArgs& g, const 
   __shared__ __attribute__((aligned(16))) bf16_t hsh[M][NCH * 512];
   __shared__ float red[16];
   int kk = lane * 8;
-  bf16x8 w0[4], w1[4];
+  constexpr bool PIPE = MP_GEMV_PIPE && PIPE_OK && NCH >= 8;
+  bf16x8 w0[4], w1[4], u0[4], u1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { u0[r] = gv_ldw(wp[r] + kk + 1024); u1[r] = gv_ldw(wp[r] + kk + 1536); }
+  }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const bf16_t* xr = g.x + (int64_t)m * g.ldx;
@@ -319,22 +327,56 @@ __device__ __forceinline__ void gv_norm_rows_dot_block(const GemvArgs& g, const 
   for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
-#pragma unroll
-  for (int m = 0; m < M; ++m) {                              // the first trip: its weights are already on their way
-    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
-  }
-  kk += 1024;
+  if constexpr (PIPE) {
+    // Round 5: the trips overlap.  With a trip's eight loads per lane requested only after the previous trip had been multiplied, the 768
+    // workgroups of the qkv launch (one round of the chip, all started together) moved in lockstep through four dependent round trips with
+    // the HBM queue draining between them (5.0 TB/s).  Two register sets: trips 0 and 1 are requested before the norm, trip t + 2 as soon as
+    // trip t has been multiplied, so 8-16 loads per lane are in flight for the whole row.  The same products in the same order.  20.1 ->
+    // 19.25 us per qkv launch (profiles/r05a / r05b_decode_timeline_dense.md); the dense gate|up launch (1376 workgroups = 1.3 rounds,
+    // their waves already out of step) measured 30.5 -> 30.9 with it at three waves per SIMD instead of four, so only the qkv form asks for it.
+    constexpr int T = NCH / 2;                               // trips of two 512-element steps (NCH % 4 == 0: T is even)
 #pragma unroll 1
-  for (int it = 2; it + 1 < NCH; it += 2, kk += 1024) {
+    for (int t = 0; t < T; t += 2, kk += 2048) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
+      for (int m = 0; m < M; ++m) {
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
+        for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+      }
+      if (t + 2 < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk + 2048); w1[r] = gv_ldw(wp[r] + kk + 2560); }
+      }
+      __builtin_amdgcn_sched_barrier(0);                     // (one register set's conversions at a time)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 1024]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 1536]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, u1[r], gv_dot8(x0, u0[r], acc[m][r]));
+      }
+      if (t + 2 < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { u0[r] = gv_ldw(wp[r] + kk + 3072); u1[r] = gv_ldw(wp[r] + kk + 3584); }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {                            // the first trip: its weights are already on their way
       const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+    }
+    kk += 1024;
+#pragma unroll 1
+    for (int it = 2; it + 1 < NCH; it += 2, kk += 1024) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { w0[r] = gv_ldw(wp[r] + kk); w1[r] = gv_ldw(wp[r] + kk + 512); }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk]), x1 = *reinterpret_cast<const bf16x8*>(&hsh[m][kk + 512]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = gv_dot8(x1, w1[r], gv_dot8(x0, w0[r], acc[m][r]));
+      }
     }
   }
 #pragma unroll
@@ -343,10 +385,10 @@ __device__ __forceinline__ void gv_norm_rows_dot_block(const GemvArgs& g, const 
     for (int r = 0; r < 4; ++r) acc[m][r] = wave_sum(acc[m][r]);
 }
 
-template <int M, int NCH>
+template <int M, int NCH, bool PIPE_OK = false>
 __device__ __forceinline__ void gv_norm_rows_dot_any(const GemvArgs& g, const float* __restrict__ nw, float eps, const bf16_t* const (&wp)[4],
                                                      int lane, int wv, float (&acc)[M][4]) {
-  if constexpr (NCH % 4 == 0) gv_norm_rows_dot_block<M, NCH>(g, nw, eps, wp, lane, acc);
+  if constexpr (NCH % 4 == 0) gv_norm_rows_dot_block<M, NCH, PIPE_OK>(g, nw, eps, wp, lane, acc);
   else gv_norm_rows_dot<M, NCH>(g, nw, eps, wp, lane, wv, acc);
 }
 
@@ -433,7 +475,7 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
 #pragma unroll
   for (int r = 0; r < 4; ++r) wp[r] = g.W + (int64_t)(row0 + (r & 1) + (r >> 1) * step2) * g.ldw;
   float acc[M][4];
-  gv_norm_rows_dot_any<M, NCH>(g, nw, eps, wp, lane, wv, acc);
+  gv_norm_rows_dot_any<M, NCH, true>(g, nw, eps, wp, lane, wv, acc);      // overlapped trips: one round of workgroups in lockstep (see the core)
   if (lane != 0 || idle) return;
   const int pos = ra.pos_dev[0];
 #pragma unroll
@@ -469,6 +511,11 @@ __global__ __launch_bounds__(256) void gemv_rmsnorm_rope_kernel(GemvArgs g, cons
 // of row group rg and the 512-element steps s = kp, kp + 4, kp + 8, ... of K, so a CU has four times the loads in flight and four waves
 // per SIMD; the four K parts of a row are added in ascending kp order through LDS (a fixed order: deterministic, but not the
 // single-wave order of gemv_shared_kernel — the two forms agree to fp32 rounding, not bit for bit).
+// Round 5, measured and dropped: the same kernel with EVERY weight load of a row requested before the first multiply (five steps of 4 x 16
+// bytes per lane up front, the x row through LDS; a CU's 352 KB share of the down projection fits its register file): 21.4 us against this
+// form's 18.8 on the 90 MB down projection, bit-identical.  A launch here is ~4 us of fixed cost (dispatch, first latency, reduction,
+// epilogue) + bytes / 6.3 TB/s — qkv 16.0 + 3.3, o 5.3 + 3.9, gate|up 28.6 + 1.9, down 14.3 + 4.5 (profiles/r05a_decode_timeline_dense.md) —
+// and the eight loads per lane it keeps in flight already cover the latency; deeper queues only lengthen the register-file fill.
 __global__ __launch_bounds__(1024) void gemv_ksplit_kernel(GemvArgs g) {
   __shared__ float red[4][4][4];                            // [kp][rg][r]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
