@@ -396,8 +396,21 @@ int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* dgu, int64_t
  * dA^T = x^T (dY B) — reads X once (p > 0: X is the UNdropped adapter input and mp_dropout_bf16's mask over the contiguous [tokens, N]
  * tensor is applied on the way; G must be readable for 16 columns per 16 ranks: the padded [tokens, 64] adapter tensors are); `partial` (>= ceil(tokens / 256) * N * R floats) holds per-chunk sums that are added in ascending
  * order (fixed summation order). */
+/* keep_bits (optional, with p > 0; every kernel below that takes them): the mask as bytes [tokens, ld_bits], bit j of byte c = element 8 c + j
+ * is kept — what mp_lora_down_bf16 wrote in the forward; the kernel then reads them instead of regenerating the mask from the seed (same mask,
+ * same results; the generator is two 64-bit hashes and eight compares per 8 elements, which made these passes VALU-bound). */
 int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                     int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, hipStream_t stream);   /* rows_dev (optional): device-side row count <= tokens */
+                     int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, const uint8_t* keep_bits,
+                     int64_t ld_bits, hipStream_t stream);   /* rows_dev (optional): device-side row count <= tokens */
+/* The two products of an adapter's backward that read its output gradient dY = X [tokens, N], in ONE pass over it (peft lora.Linear backward:
+ * lora_B.weight.grad = dY^T (x A^T) and the gradient flowing into lora_A's output, dY B; call sites train_ds_medplib.py:262-303):
+ * out / partial as mp_tn_skinny_f32(X, G = the forward's t) — the same bits — and dt[token, 0..63] = bf16(alpha * X[token, :] . Bt[j, :]) for the
+ * rank rows of Bt (B^T padded to [>= 16 * ceil(R / 16), N]: mp_lora_pack's BT), zeros beyond, as mp_lora_down_bf16 with p = 0 computes it (here
+ * the fp32 partials are summed over ceil(N / 256) column blocks instead of eight K ranges: equal to rounding).  dt_partial: >= ceil(N / 256) *
+ * tokens * 16 * ceil(R / 16) floats of scratch. */
+int mp_tn_skinny_down_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
+                          const void* Bt, int64_t ldb, void* dt, int64_t lddt, float* dt_partial, int64_t dt_partial_floats, int64_t tokens,
+                          int N, int R, float scale, float alpha, hipStream_t stream);
 /* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
  * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
 int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,
@@ -424,12 +437,13 @@ int mp_lora_pack_batched(const void* descs, int n, int64_t max_elems, hipStream_
  * (dt [tokens, >= R] = scaling * dY B, AT [K, 64] = A^T padded: mp_lora_pack; p = 0: no mask).  Replaces a thin GEMM, mp_dropout_bf16 and
  * mp_add3_bf16 with the same rounding points.  R in {8, 16, 32}; out may alias dx. */
 int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
-                        int K, int R, float p, uint64_t seed, const int* rows_dev, hipStream_t stream);   /* rows_dev (optional, both kernels): device-side row count */
+                        int K, int R, float p, uint64_t seed, const int* rows_dev, const uint8_t* keep_bits, int64_t ld_bits,
+                        hipStream_t stream);   /* rows_dev (optional, both kernels): device-side row count */
 /* The same followed by the SwiGLU backward in ONE pass (dense LlamaMLP with an adapter on down_proj, HF modeling_llama.py LlamaMLP.forward via
  * medplib_moe_llama.py:127-141): dgu[tokens, 2 ff] (gate|up interleaved in blocks of 32, the layout of mp_gemm_swiglu_keep_bf16's gu_out) from
  * d_act' = bf16(dact + dropout(bf16(dt A))) — bit-identical with mp_lora_up_add_bf16 followed by mp_swiglu_pair_bwd_bf16. */
 int mp_lora_up_add_swiglu_bwd_bf16(const void* dt, int64_t lddt, const void* AT, const void* dact, int64_t lddact, const void* gu, void* dgu,
-                                   int tokens, int ff, int R, float p, uint64_t seed, hipStream_t stream);
+                                   int tokens, int ff, int R, float p, uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits, hipStream_t stream);
 /* The adapter's down-projection with lora_dropout inline, written as the K-extension of the projection's input (peft lora.Linear.forward,
  * tuners/lora/layer.py: result + lora_B(lora_A(dropout(x))) * scaling; call sites train_ds_medplib.py:262-303): t[token, 0..63] =
  * bf16(drop(x)[token, :] . A[j, :]) for the R rank rows of A (A: [>= 16 * ceil(R / 16), K], rows >= R zero), zeros beyond; xd (optional) =
@@ -438,6 +452,7 @@ int mp_lora_up_add_swiglu_bwd_bf16(const void* dt, int64_t lddt, const void* AT,
  * t is scaled by alpha before its rounding; with p = 0 and A = B^T the same kernel is the backward's dt = scaling * dY B (reads dY once). */
 int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
                       int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, float* partial, int64_t partial_floats,
+                      uint8_t* keep_bits, int64_t ld_bits,   /* optional OUTPUT with p > 0 (LDS-staged form only): the mask bytes the backward kernels read */
                       hipStream_t stream);   /* partial (optional, >= 8 * tokens * 16 * ceil(R / 16) floats): room for the K-split sums of the LDS-staged kernel (K % 256 == 0) */
 /* MoE layer backward, top-1 / top-2 (autograd of DeepSpeed MOELayer + top1gating / top2gating; entries = choice * tokens +
  * token; top-2 weights are the kept pair renormalised; l_aux uses the first choices' counts): the combine's d_y[e, slot] = w d_out and

@@ -125,6 +125,26 @@ __device__ __forceinline__ uint64_t hash64(uint64_t k) {
 }
 __device__ __forceinline__ uint64_t dropout_bits4(uint64_t seed, uint64_t i4) { return hash64(seed * 0x100000001b3ull + i4); }   // i4 = index / 4
 __device__ __forceinline__ unsigned dropout_thresh(float p) { return (unsigned)(p * 65536.f); }
+// The keep decisions of 8 consecutive elements (i4 = index of the first / 4) as a byte: bit j set = element j is kept.  Round 5: the
+// forward writes these bytes ([tokens, features / 8], 1/16 of the tensor) and the two backward kernels that need the same mask read them
+// instead of hashing again: two splitmix64 values + eight 16-bit compares per 8 elements made the backward's weight-gradient pass over the
+// adapter input VALU-bound (54 us against 26 for the [5112, 11008] input of the down adapter, scripts/r05_skinny_bench.py).
+__device__ __forceinline__ unsigned dropout_keep8(uint64_t seed, uint64_t i4, unsigned th) {
+  unsigned m = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint64_t bits = dropout_bits4(seed, i4 + q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= ((((unsigned)(bits >> (16 * j)) & 0xffffu) >= th) ? 1u : 0u) << (q * 4 + j);
+  }
+  return m;
+}
+__device__ __forceinline__ bf16x8 dropout_apply8(bf16x8 v, unsigned m, float keep_scale) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(((m >> j) & 1u) ? (float)v[j] * keep_scale : 0.f);
+  return o;
+}
 // out[n, j] = scale * sum_t X[t, n] * G[t, j]   (j < R <= 32).  Pass 1: a workgroup owns 256 columns x a chunk of 256 token rows;
 // the chunk's G rows sit in LDS as fp32 (every lane reads the same row: broadcast), a thread owns 4 columns (8-byte loads of X) and
 // R accumulators per column, the 4 waves take the chunk's rows round-robin and meet in LDS in wave order -> partial[chunk][n][R].
@@ -213,7 +233,8 @@ __device__ __forceinline__ bf16x8 tn_tr_frag(const char* tile, int kp, int n, in
 }
 template <int RG>                                           // 16-wide rank groups: R <= 16 * RG
 __global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
-                                                             float* __restrict__ partial, int64_t T, int N, int R, float p, uint64_t seed, const int* __restrict__ rows_dev) {
+                                                             float* __restrict__ partial, int64_t T, int N, int R, float p, uint64_t seed, const int* __restrict__ rows_dev,
+                                                             const uint8_t* __restrict__ keep_bits, int64_t ld_bits) {
   if (rows_dev) T = min(T, (int64_t)*rows_dev);        // device-side row count (an expert's routed rows): chunks beyond it write zeros
   __shared__ __attribute__((aligned(16))) char xt[64 * 512];      // [64 tokens][256 columns] bf16, 16-byte chunk c of row r at (c ^ (r & 7))
   __shared__ __attribute__((aligned(16))) char gt[64 * 128];      // [64 tokens][64 columns] bf16 (columns >= 16 * RG never read)
@@ -234,23 +255,19 @@ __global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __res
   const int xr = tid >> 5, xc = tid & 31;
   const int xn = n_base + xc * 8;
   bf16x8 xv[8], gv[(64 * 2 * RG + 255) / 256];
+  unsigned km[8];                                          // p > 0: the keep bits of xv[i], applied when the step is written to LDS
   auto load_step = [&](int step) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = step * 64 + i * 8 + xr;
       xv[i] = bf16x8{};
+      km[i] = 0;
       if (r < rows && xn < N) {
         xv[i] = *reinterpret_cast<const bf16x8*>(X + (t0 + r) * ldx + xn);
-        if (p > 0.f) {
-          const uint64_t i4 = ((uint64_t)(t0 + r) * (uint64_t)N + (uint64_t)xn) >> 2;
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const uint64_t bits = dropout_bits4(seed, i4 + q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              xv[i][q * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)xv[i][q * 4 + j] * keep_scale : 0.f);
-          }
-        }
+        // the mask does not depend on the loaded values: it is read / hashed while they travel, and applied a step later (round 5: applied
+        // here it made every step wait for its own loads before the previous step's MFMAs — 54 us against 26 without dropout)
+        if (p > 0.f) km[i] = keep_bits ? keep_bits[(t0 + r) * ld_bits + (xn >> 3)]
+                                       : dropout_keep8(seed, ((uint64_t)(t0 + r) * (uint64_t)N + (uint64_t)xn) >> 2, th);
       }
     }
 #pragma unroll
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256) void tn_skinny_mfma_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = i * 8 + xr;
-      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = xv[i];
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = p > 0.f ? dropout_apply8(xv[i], km[i], keep_scale) : xv[i];
     }
 #pragma unroll
     for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
@@ -456,6 +473,124 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const bf16_t* __restrict
   }
 }
 
+// Round 5: the backward's two products over the SAME operand in one pass.  For an adapter with output gradient dY [T, N] the backward needs
+// dB = dY^T t (tn_skinny_mfma_kernel: [N, R], a reduction over tokens) and dt = dY B (lora_down_staged_kernel: [T, R], a reduction over
+// columns) — two kernels that stage the identical [64 tokens x 256 columns] tile of dY in the identical LDS image, i.e. dY was read twice
+// (225 MB each time for the fused gate|up adapter).  Here the workgroup of tn_skinny_mfma_kernel (256 columns x a chunk of 256 tokens, four
+// steps of 64) also keeps the [16 RG x 256] piece of B^T for ITS columns in LDS and, per step, multiplies the tile row-major against it: the
+// 64 x 16 RG partial of dt over this column block goes to dt_partial[column block][token][16 RG] (fp32), which lora_down_finish_kernel adds
+// over the column blocks in ascending order (fixed order: bit-reproducible), scales and rounds — the finish launch the split-K form needs
+// anyway.  No dropout on this side (dY is a gradient).  dB: tn_skinny_mfma_kernel's arithmetic, bit for bit.
+template <int RG>
+__global__ __launch_bounds__(256) void tn_skinny_down_mfma_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ G, int64_t ldg,
+                                                                  float* __restrict__ partial, const bf16_t* __restrict__ Bt, int64_t ldb,
+                                                                  float* __restrict__ dt_partial, int64_t T, int N, int R) {
+  __shared__ __attribute__((aligned(16))) char xt[64 * 512];      // [64 tokens][256 columns] bf16, 16-byte chunk c of row r at (c ^ (r & 7))
+  __shared__ __attribute__((aligned(16))) char gt[64 * 128];      // [64 tokens][64 columns] bf16 (columns >= 16 * RG never read)
+  __shared__ __attribute__((aligned(16))) char at[16 * RG * 512]; // [16 RG rank rows of B^T][this block's 256 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n_base = blockIdx.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
+  const int rows = (int)max((int64_t)0, min((int64_t)TN_CHUNK, T - t0));
+  const int nsteps = (rows + 63) / 64;
+  f32x4 acc[4][RG];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xr = tid >> 5, xc = tid & 31;
+  const int xn = n_base + xc * 8;
+  // B^T piece of this column block (columns beyond N: zeros), once per workgroup
+#pragma unroll
+  for (int u = 0; u < (16 * RG * 32 + 255) / 256; ++u) {
+    const int idx = tid + u * 256;
+    if (idx < 16 * RG * 32) {
+      const int r = idx >> 5, c = idx & 31;
+      bf16x8 v = bf16x8{};
+      if (n_base + c * 8 < N) v = *reinterpret_cast<const bf16x8*>(Bt + (int64_t)r * ldb + n_base + c * 8);
+      *reinterpret_cast<bf16x8*>(at + r * 512 + ((c ^ (r & 7)) << 4)) = v;
+    }
+  }
+  bf16x8 xv[8], gv[(64 * 2 * RG + 255) / 256];
+  auto load_step = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = step * 64 + i * 8 + xr;
+      xv[i] = bf16x8{};
+      if (r < rows && xn < N) xv[i] = *reinterpret_cast<const bf16x8*>(X + (t0 + r) * ldx + xn);
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = step * 64 + idx / (2 * RG), c = idx % (2 * RG);
+      gv[u] = bf16x8{};
+      if (idx < 64 * 2 * RG && r < rows) gv[u] = *reinterpret_cast<const bf16x8*>(G + (t0 + r) * ldg + c * 8);
+    }
+  };
+  if (nsteps > 0) load_step(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();                                       // the previous step's fragment reads are done (and, first time, `at` is written)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + xr;
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = xv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = idx / (2 * RG), c = idx % (2 * RG);
+      if (idx < 64 * 2 * RG) *reinterpret_cast<bf16x8*>(gt + r * 128 + ((c ^ (r & 7)) << 4)) = gv[u];
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) load_step(step + 1);            // in flight under this step's MFMAs
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 gf[RG];
+#pragma unroll
+      for (int jf = 0; jf < RG; ++jf) gf[jf] = tn_tr_frag<128>(gt, kp, jf, fr, fq);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const bf16x8 xf = tn_tr_frag<512>(xt, kp, wave * 4 + nf, fr, fq);
+#pragma unroll
+        for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[jf], acc[nf][jf], 0, 0, 0);
+      }
+    }
+    // dt partial of this step's 64 tokens over this block's 256 columns: wave w owns tokens w * 16 .. + 15 (lora_down_staged_kernel's reads)
+    f32x4 dacc[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) dacc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int c = kk * 4 + fq;
+      const int xrow = wave * 16 + fr;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + xrow * 512 + ((c ^ (xrow & 7)) << 4));
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        const int arow = rg * 16 + fr;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(at + arow * 512 + ((c ^ (arow & 7)) << 4));
+        dacc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, dacc[rg], 0, 0, 0);
+      }
+    }
+    const int64_t tok = t0 + step * 64 + wave * 16 + fr;
+    if (tok < T) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        *reinterpret_cast<f32x4*>(dt_partial + ((int64_t)blockIdx.x * T + tok) * (16 * RG) + rg * 16 + fq * 4) = dacc[rg];
+    }
+  }
+  float* po = partial + ((int64_t)blockIdx.y * N) * R;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_base + (wave * 4 + nf) * 16 + fq * 4 + r, j = jf * 16 + fr;
+        if (n < N && j < R) po[(int64_t)n * R + j] = acc[nf][jf][r];
+      }
+}
+
 // The same down-projection with the x tile STAGED THROUGH LDS (K % 256 == 0): the kernel above feeds the MFMA from global memory with
 // fragment-shaped loads (16 bytes of sixteen different rows per instruction: nothing coalesces, 2.5-3 TB/s); here a workgroup loads a
 // [64 tokens x 256] tile with whole-row 16-byte accesses (the dropout and the optional store of the dropped values happen on the way,
@@ -465,7 +600,8 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const bf16_t* __restrict
 template <int RG>
 __global__ __launch_bounds__(256) void lora_down_staged_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ A, int64_t lda,
                                                                float* __restrict__ partial, bf16_t* __restrict__ xd, int64_t ldxd, int T, int K,
-                                                               float p, uint64_t seed, const int* __restrict__ rows_dev) {
+                                                               float p, uint64_t seed, const int* __restrict__ rows_dev,
+                                                               uint8_t* __restrict__ keep_bits, int64_t ld_bits) {
   __shared__ __attribute__((aligned(16))) char xt[64 * 512];            // [64 tokens][256 k] bf16, chunk c of row r at c ^ (r & 7)
   __shared__ __attribute__((aligned(16))) char at[16 * RG * 512];       // [16 RG rank rows][256 k]
   if (rows_dev) T = min(T, *rows_dev);
@@ -482,24 +618,21 @@ __global__ __launch_bounds__(256) void lora_down_staged_kernel(const bf16_t* __r
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 xv[8], av[(16 * RG * 32 + 255) / 256];
+  unsigned km[8];                                          // p > 0: the keep bits of xv[i], applied when the step is written to LDS
+  int k_held = 0;                                          // the K offset of the step held in xv (for the optional store of the dropped values)
   auto load_step = [&](int st) {
     const int k = st * 256 + xc * 8;
+    k_held = k;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int tok = tok0 + i * 8 + xr;
       xv[i] = bf16x8{};
+      km[i] = 0;
       if (tok < T) {
         xv[i] = *reinterpret_cast<const bf16x8*>(x + (int64_t)tok * ldx + k);
-        if (p > 0.f) {
-          const uint64_t i4 = ((uint64_t)tok * (uint64_t)K + (uint64_t)k) >> 2;
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const uint64_t bits = dropout_bits4(seed, i4 + q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              xv[i][q * 4 + j] = (bf16_t)(((unsigned)(bits >> (16 * j)) & 0xffffu) >= th ? (float)xv[i][q * 4 + j] * keep_scale : 0.f);
-          }
-          if (xd) *reinterpret_cast<bf16x8*>(xd + (int64_t)tok * ldxd + k) = xv[i];
+        if (p > 0.f) {                                     // hashed while the loads travel, applied a step later (see tn_skinny_mfma_kernel)
+          km[i] = dropout_keep8(seed, ((uint64_t)tok * (uint64_t)K + (uint64_t)k) >> 2, th);
+          if (keep_bits) keep_bits[(int64_t)tok * ld_bits + (k >> 3)] = (uint8_t)km[i];  // (each (token, chunk) belongs to exactly one workgroup of the K split)
         }
       }
     }
@@ -516,7 +649,9 @@ __global__ __launch_bounds__(256) void lora_down_staged_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = i * 8 + xr;
-      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = xv[i];
+      const bf16x8 v = p > 0.f ? dropout_apply8(xv[i], km[i], keep_scale) : xv[i];
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((xc ^ (r & 7)) << 4)) = v;
+      if (p > 0.f && xd && tok0 + r < T) *reinterpret_cast<bf16x8*>(xd + (int64_t)(tok0 + r) * ldxd + k_held) = v;
     }
 #pragma unroll
     for (int u = 0; u < (16 * RG * 32 + 255) / 256; ++u) {
@@ -557,8 +692,18 @@ __global__ void lora_down_finish_kernel(const float* __restrict__ partial, bf16_
   if (idx >= (int64_t)T * 16) return;
   const int tok = (int)(idx >> 4), c = (int)(idx & 15) * 4;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-  if (c < RW)
-    for (int sp = 0; sp < splits; ++sp) sum += *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * T + tok) * RW + c);
+  if (c < RW) {
+    // eight partials in flight per thread, added in ascending order (mp_tn_skinny_down_f32 brings one partial per 256-column block: 86 of them)
+    const float* src = partial + (int64_t)tok * RW + c;
+    const int64_t stride = (int64_t)T * RW;
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (s0 + u < splits) ? *reinterpret_cast<const f32x4*>(src + (s0 + u) * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (s0 + u < splits) sum += v[u];
+    }
+  }
   sum *= alpha;
   *reinterpret_cast<bf16x4*>(t + (int64_t)tok * ldt + c) = bf16x4{(bf16_t)sum[0], (bf16_t)sum[1], (bf16_t)sum[2], (bf16_t)sum[3]};
 }
@@ -578,6 +723,7 @@ template <int RP, bool SW = false>                           // rank pairs: R / 
 __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restrict__ dt, int64_t lddt, const bf16_t* __restrict__ AT,
                                                           const bf16_t* __restrict__ dx, int64_t lddx, bf16_t* __restrict__ out, int64_t ldo,
                                                           int T, int K, float p, uint64_t seed, int tpw, const int* __restrict__ rows_dev,
+                                                          const uint8_t* __restrict__ keep_bits, int64_t ld_bits,
                                                           const bf16_t* __restrict__ gu = nullptr, bf16_t* __restrict__ dgu = nullptr) {
   if (rows_dev) T = min(T, *rows_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -601,11 +747,14 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
   for (int tb = t_beg; tb < t_end; tb += U) {
     const int n = min(U, t_end - tb);
     bf16x8 dv[U], dtv[U][RP / 4], gv[SW ? U : 1], uv[SW ? U : 1];
+    unsigned km[U];
     const int64_t gcol = (int64_t)(kc >> 5) * 64 + (kc & 31);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      km[u] = 0xffu;
       if (u < n) {
         dv[u] = *reinterpret_cast<const bf16x8*>(dx + (int64_t)(tb + u) * lddx + kc);
+        if (p > 0.f && keep_bits) km[u] = keep_bits[(int64_t)(tb + u) * ld_bits + (kc >> 3)];
         if constexpr (SW) {
           gv[u] = *reinterpret_cast<const bf16x8*>(gu + (int64_t)(tb + u) * 2 * K + gcol);
           uv[u] = *reinterpret_cast<const bf16x8*>(gu + (int64_t)(tb + u) * 2 * K + gcol + 32);
@@ -629,16 +778,12 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
             for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_fdot2_f32_bf16(a[j][q * 4 + r], d2, acc[j], false);
           }
         bf16x8 o;
-        const uint64_t i4 = ((uint64_t)(tb + u) * (uint64_t)K + (uint64_t)kc) >> 2;
+        const unsigned m = (p > 0.f && !keep_bits) ? dropout_keep8(seed, ((uint64_t)(tb + u) * (uint64_t)K + (uint64_t)kc) >> 2, th) : km[u];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint64_t bits = p > 0.f ? dropout_bits4(seed, i4 + h) : ~0ull;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = (float)(bf16_t)acc[h * 4 + j];
-            if (p > 0.f) v = (((unsigned)(bits >> (16 * j)) & 0xffffu) >= th) ? (float)(bf16_t)(v * keep_scale) : 0.f;
-            o[h * 4 + j] = (bf16_t)((float)dv[u][h * 4 + j] + v);
-          }
+        for (int j = 0; j < 8; ++j) {
+          float v = (float)(bf16_t)acc[j];
+          if (p > 0.f) v = ((m >> j) & 1u) ? (float)(bf16_t)(v * keep_scale) : 0.f;
+          o[j] = (bf16_t)((float)dv[u][j] + v);
         }
         if constexpr (SW) {
           bf16x8 dg, du;
@@ -1085,7 +1230,9 @@ extern "C" int mp_swiglu_pair_bwd_bf16(const void* gu, const void* dact, void* d
 }
 
 extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
-                                int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, hipStream_t stream) {
+                                int64_t tokens, int N, int R, float scale, float p, uint64_t seed, const int* rows_dev, const uint8_t* keep_bits,
+                                int64_t ld_bits, hipStream_t stream) {
+  MP_REQUIRE(!keep_bits || (p > 0.f && ld_bits * 8 >= N), MP_ERR_ARG, "mp_tn_skinny_f32: keep_bits come with p > 0 and a row stride of >= N / 8 bytes");
   MP_REQUIRE(N > 0 && tokens > 0 && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 4 == 0 && p >= 0.f && p < 1.f, MP_ERR_SHAPE,
              "mp_tn_skinny_f32: R must be 8, 16 or 32; ldx %% 4, ldg %% 8; 0 <= p < 1");
   const int chunks = (int)mp_cdiv(tokens, TN_CHUNK);
@@ -1098,8 +1245,8 @@ extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64
   MP_REQUIRE(mfma || p == 0.f, MP_ERR_ARG, "mp_tn_skinny_f32: inline dropout needs ldx %% 8 == 0 and N %% 8 == 0");
   if (mfma) {
     // G must be readable for 16 columns per rank group (the padded [tokens, 64] adapter tensors are)
-    if (R <= 16) hipLaunchKernelGGL(tn_skinny_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev);
-    else hipLaunchKernelGGL(tn_skinny_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev);
+    if (R <= 16) hipLaunchKernelGGL(tn_skinny_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev, keep_bits, ld_bits);
+    else hipLaunchKernelGGL(tn_skinny_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, R, p, seed, rows_dev, keep_bits, ld_bits);
   } else if (R == 8) hipLaunchKernelGGL(tn_skinny_partial_kernel<8>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
   else if (R == 16) hipLaunchKernelGGL(tn_skinny_partial_kernel<16>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
   else hipLaunchKernelGGL(tn_skinny_partial_kernel<32>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, tokens, N, rows_dev);
@@ -1107,6 +1254,26 @@ extern "C" int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64
   if (out)                                                  // out == NULL: the caller consumes the chunk partials itself (mp_lora_grad_unpack_partials_f32)
     hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
   return mp_check_launch("mp_tn_skinny_f32");
+}
+
+extern "C" int mp_tn_skinny_down_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
+                                     const void* Bt, int64_t ldb, void* dt, int64_t lddt, float* dt_partial, int64_t dt_partial_floats, int64_t tokens,
+                                     int N, int R, float scale, float alpha, hipStream_t stream) {
+  MP_REQUIRE(N > 0 && tokens > 0 && tokens < (1ll << 31) && (R == 8 || R == 16 || R == 32) && ldg % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && ldb % 8 == 0 && lddt % 4 == 0,
+             MP_ERR_SHAPE, "mp_tn_skinny_down_f32: R must be 8, 16 or 32; ldx, ldg, ldb, N %% 8; lddt %% 4");
+  const int chunks = (int)mp_cdiv(tokens, TN_CHUNK), blocks = (int)mp_cdiv(N, 256), rg = (R + 15) / 16;
+  MP_REQUIRE(partial && partial_floats >= (int64_t)chunks * N * R, MP_ERR_WORKSPACE, "mp_tn_skinny_down_f32: partial needs %lld floats",
+             (long long)((int64_t)chunks * N * R));
+  MP_REQUIRE(dt_partial && dt_partial_floats >= (int64_t)blocks * tokens * 16 * rg, MP_ERR_WORKSPACE, "mp_tn_skinny_down_f32: dt_partial needs %lld floats",
+             (long long)((int64_t)blocks * tokens * 16 * rg));
+  const dim3 grid((unsigned)blocks, (unsigned)chunks);
+  if (rg == 1) hipLaunchKernelGGL(tn_skinny_down_mfma_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, (const bf16_t*)Bt, ldb, dt_partial, tokens, N, R);
+  else hipLaunchKernelGGL(tn_skinny_down_mfma_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)G, ldg, partial, (const bf16_t*)Bt, ldb, dt_partial, tokens, N, R);
+  hipLaunchKernelGGL(lora_down_finish_kernel, GRID1D(tokens * 16), dt_partial, (bf16_t*)dt, lddt, (int)tokens, 16 * rg, blocks, alpha, (const int*)nullptr);
+  const int64_t NR = (int64_t)N * R;
+  if (out)
+    hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
+  return mp_check_launch("mp_tn_skinny_down_f32");
 }
 
 extern "C" int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits,
@@ -1134,7 +1301,8 @@ extern "C" int mp_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
 
 extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int64_t lda, void* t, int64_t ldt, void* xd, int64_t ldxd, int tokens,
                                  int K, int R, float p, uint64_t seed, float alpha, const int* rows_dev, float* partial, int64_t partial_floats,
-                                 hipStream_t stream) {
+                                 uint8_t* keep_bits, int64_t ld_bits, hipStream_t stream) {
+  MP_REQUIRE(!keep_bits || (p > 0.f && ld_bits * 8 >= K), MP_ERR_ARG, "mp_lora_down_bf16: keep_bits come with p > 0 and a row stride of >= K / 8 bytes");
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 64 == 0 && R > 0 && R <= 64, MP_ERR_SHAPE, "mp_lora_down_bf16: K %% 64 == 0 and 0 < R <= 64 (got K %d, R %d)", K, R);
   MP_REQUIRE(ldx % 8 == 0 && lda % 8 == 0 && ldt % 4 == 0 && (!xd || ldxd % 8 == 0) && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_down_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
@@ -1145,12 +1313,13 @@ extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int6
   if (staged < 0) { const char* e = getenv("MP_LORA_DOWN_STAGED"); staged = (e && atoi(e) == 0) ? 0 : 1; }                // 0: fragment-shaped loads (A/B)
   if (staged && K % 256 == 0 && partial && partial_floats >= (int64_t)splits * tokens * 16 * rg) {
     const dim3 grid((unsigned)mp_cdiv(tokens, 64), (unsigned)splits), blk(256);
-#define MP_GO(RG) hipLaunchKernelGGL((lora_down_staged_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, partial, (bf16_t*)xd, ldxd, tokens, K, p, seed, rows_dev)
+#define MP_GO(RG) hipLaunchKernelGGL((lora_down_staged_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, partial, (bf16_t*)xd, ldxd, tokens, K, p, seed, rows_dev, keep_bits, ld_bits)
     switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
 #undef MP_GO
     hipLaunchKernelGGL(lora_down_finish_kernel, GRID1D((int64_t)tokens * 16), partial, (bf16_t*)t, ldt, tokens, 16 * rg, splits, alpha, rows_dev);
     return mp_check_launch("mp_lora_down_bf16(staged)");
   }
+  MP_REQUIRE(!keep_bits, MP_ERR_ARG, "mp_lora_down_bf16: keep_bits need the staged form (K %% 256 == 0 and the partial workspace)");
   const dim3 grid((unsigned)mp_cdiv(tokens, 16)), blk(512);
 #define MP_GO(RG) hipLaunchKernelGGL((lora_down_kernel<RG>), grid, blk, 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, (bf16_t*)xd, ldxd, tokens, K, p, seed, alpha, rows_dev)
   switch (rg) { case 1: MP_GO(1); break; case 2: MP_GO(2); break; case 3: MP_GO(3); break; default: MP_GO(4); }
@@ -1159,7 +1328,9 @@ extern "C" int mp_lora_down_bf16(const void* x, int64_t ldx, const void* A, int6
 }
 
 extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
-                                   int K, int R, float p, uint64_t seed, const int* rows_dev, hipStream_t stream) {
+                                   int K, int R, float p, uint64_t seed, const int* rows_dev, const uint8_t* keep_bits, int64_t ld_bits,
+                                   hipStream_t stream) {
+  MP_REQUIRE(!keep_bits || (p > 0.f && ld_bits * 8 >= K), MP_ERR_ARG, "mp_lora_up_add_bf16: keep_bits come with p > 0 and a row stride of >= K / 8 bytes");
   MP_REQUIRE(tokens >= 0 && K > 0 && K % 8 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_bf16: K %% 8 == 0, R in {8, 16, 32} (got K %d, R %d)", K, R);
   MP_REQUIRE(lddt % 8 == 0 && lddx % 8 == 0 && ldo % 8 == 0 && p >= 0.f && p < 1.f, MP_ERR_ARG, "mp_lora_up_add_bf16: bad strides / p");
   if (tokens == 0) return MP_OK;
@@ -1167,21 +1338,23 @@ extern "C" int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT,
   const int64_t chunks = mp_cdiv(K, 512);
   const int tpw = (int)std::min<int64_t>(32, std::max<int64_t>(8, (chunks * tokens / 4096 + 3) / 4 * 4));
   const dim3 grid((unsigned)chunks, (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
-#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw, rows_dev)
+#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dx, lddx, (bf16_t*)out, ldo, tokens, K, p, seed, tpw, rows_dev, keep_bits, ld_bits)
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
   return mp_check_launch("mp_lora_up_add_bf16");
 }
 
 extern "C" int mp_lora_up_add_swiglu_bwd_bf16(const void* dt, int64_t lddt, const void* AT, const void* dact, int64_t lddact, const void* gu, void* dgu,
-                                              int tokens, int ff, int R, float p, uint64_t seed, hipStream_t stream) {
+                                              int tokens, int ff, int R, float p, uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits,
+                                              hipStream_t stream) {
+  MP_REQUIRE(!keep_bits || (p > 0.f && ld_bits * 8 >= ff), MP_ERR_ARG, "mp_lora_up_add_swiglu_bwd_bf16: keep_bits come with p > 0 and a row stride of >= ff / 8 bytes");
   MP_REQUIRE(tokens >= 0 && ff > 0 && ff % 32 == 0 && (R == 8 || R == 16 || R == 32), MP_ERR_SHAPE, "mp_lora_up_add_swiglu_bwd_bf16: ff %% 32 == 0, R in {8, 16, 32} (got ff %d, R %d)", ff, R);
   MP_REQUIRE(lddt % 8 == 0 && lddact % 8 == 0 && p >= 0.f && p < 1.f && gu && dgu, MP_ERR_ARG, "mp_lora_up_add_swiglu_bwd_bf16: bad strides / p / null");
   if (tokens == 0) return MP_OK;
   const int64_t chunks = mp_cdiv(ff, 512);
   const int tpw = (int)std::min<int64_t>(32, std::max<int64_t>(8, (chunks * tokens / 4096 + 3) / 4 * 4));
   const dim3 grid((unsigned)chunks, (unsigned)mp_cdiv(tokens, 4 * tpw)), blk(256);
-#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP, true>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dact, lddact, (bf16_t*)nullptr, (int64_t)0, tokens, ff, p, seed, tpw, (const int*)nullptr, (const bf16_t*)gu, (bf16_t*)dgu)
+#define MP_GO(RP) hipLaunchKernelGGL((lora_up_add_kernel<RP, true>), grid, blk, 0, stream, (const bf16_t*)dt, lddt, (const bf16_t*)AT, (const bf16_t*)dact, lddact, (bf16_t*)nullptr, (int64_t)0, tokens, ff, p, seed, tpw, (const int*)nullptr, keep_bits, ld_bits, (const bf16_t*)gu, (bf16_t*)dgu)
   switch (R) { case 8: MP_GO(4); break; case 16: MP_GO(8); break; default: MP_GO(16); }
 #undef MP_GO
   return mp_check_launch("mp_lora_up_add_swiglu_bwd_bf16");

@@ -355,6 +355,8 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_FUSE_DY = os.environ.get("MP_LORA_FUSE_DY", "1") != "0"                # A/B: 0 = dy B and dy^T t as two kernels, two reads of dy
+_KEEP_BITS = os.environ.get("MP_LORA_KEEP_BITS", "1") != "0"            # A/B: 0 = every kernel regenerates the lora_dropout mask from the seed
 _PRUNE_ROWS = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"            # A/B: 0 = the last layer's MLP on every row
 _UNPACK_PARTIALS = os.environ.get("MP_LORA_UNPACK_PARTIALS", "1") != "0"  # A/B: 0 = a reduce launch per weight-gradient product, then the unpack
 _PACK_BATCHED = os.environ.get("MP_LORA_PACK_BATCHED", "1") != "0"       # A/B: 0 = one mp_lora_pack launch per adapter and layer
@@ -364,7 +366,11 @@ _FUSE_UP_SWIGLU = os.environ.get("MP_FUSE_UP_SWIGLU", "1") != "0"      # A/B: 0 
 def _adapter_down(lora, ops_pad, x, t, seed):
     """t = bf16(dropout(x) A^T) into the extension columns -> x (the wgrad regenerates the mask from the seed: nothing dropped is stored)."""
     A, _, _, _, R, _ = ops_pad
-    ops.lora_down(x, A, t, R, lora.p_active, seed)
+    kb = None
+    if lora.p_active > 0 and _KEEP_BITS and x.shape[1] % 256 == 0:
+        # the mask as bytes (1 / 16 of x): the two backward kernels that need the same mask read it instead of hashing again
+        kb = lora.keep_bits[seed] = ops.keep_bits_for(x)
+    ops.lora_down(x, A, t, R, lora.p_active, seed, keep_bits=kb)
     return x
 
 
@@ -598,6 +604,7 @@ def forward_train(llm, embeds, key_valid):
     x = embeds.reshape(T, d)
     lora.step += 1
     lora.p_active = lora.p if llm.training else 0.0
+    lora.keep_bits = {}                                         # seed -> the mask bytes _adapter_down left for this step's backward
     if _PACK_BATCHED:
         pack_all(lora, len(llm.layers))
     llm.gate_pass += 1
@@ -702,15 +709,20 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=Fal
     this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
     A, AT, B, BT, R, _ = ops_pad
     # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
-    dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
     # partials: the chunk partials are handed on unsummed (ops.SkinnyPartial) — the gradient unpack into the flat buffer adds them up itself
     partials = partials and R <= 32
-    dB = ops.tn_skinny(dy, t, R, lora.scaling, reduce=not partials)                     # [out, R] = scaling * dy^T t
-    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials)        # [in, R]  = dropout(x)^T (scaling * dy B)
+    if _FUSE_DY and R <= 32 and dy.stride(0) % 8 == 0 and dy.shape[1] % 8 == 0:
+        dB, dt = ops.tn_skinny_down(dy, t, BT, R, lora.scaling, lora.scaling, reduce=not partials)       # both products of dy in one pass over it
+    else:
+        dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
+        dB = ops.tn_skinny(dy, t, R, lora.scaling, reduce=not partials)                 # [out, R] = scaling * dy^T t
+    kb = getattr(lora, "keep_bits", {}).get(seed)              # the forward's mask bytes (None: regenerate from the seed)
+    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials, keep_bits=kb)        # [in, R]  = dropout(x)^T (scaling * dy B)
     if dx is None:
         return None, dB, dAT
     if swiglu_gu is not None and R <= 32 and dx.stride(0) % 8 == 0 and _FUSE_UP_SWIGLU:
         # the adapter on down_proj: its input gradient has ONE consumer, the SwiGLU backward — both in one pass, the gate|up gradient comes back
+        # (these two regenerate the mask from the seed: they are bound by their 560 MB of traffic either way — 133 us with the hash, 136 with the bytes)
         return ops.lora_up_add_swiglu_bwd(dt, AT, dx, swiglu_gu, R, lora.p_active, seed), dB, dAT
     if R <= 32 and dx.stride(0) % 8 == 0:
         dx = ops.lora_up_add(dt, AT, dx, R, lora.p_active, seed)       # dx += dropout(dt A): the same mask and 1/(1-p) as the forward

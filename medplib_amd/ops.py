@@ -468,14 +468,14 @@ def colsum_scaled(x2d, scale):
     return out if scale == 1.0 else scale_f32_(out, scale)
 
 
-def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None, reduce=True):
+def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None, reduce=True, keep_bits=None):
     """out[n, j] = scale * sum_t drop(x)[t, n] * g[t, j], j < R: fp32 [N, R].  x [T, N] bf16, g [T, >= 16 * ceil(R / 16)] bf16; p > 0: x is the
     undropped tensor and the lora_dropout mask (mp_dropout_bf16 over the contiguous [T, N]) is applied on the way.  rows_dev: int32 device
     scalar, only the first min(T, rows_dev) rows count (an expert's routed rows on its capacity slab)."""
     _chk(x, torch.bfloat16, "tn_skinny.x"); _chk(g, torch.bfloat16, "tn_skinny.g")
     T, N = x.shape
     if R > 32:                      # wider than the kernel's register budget: two passes over column halves of g
-        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale, p, seed, rows_dev) for j in range(0, R, 32)], dim=1)
+        return torch.cat([tn_skinny(x, g[:, j:j + 32], 32, scale, p, seed, rows_dev, keep_bits=keep_bits) for j in range(0, R, 32)], dim=1)
     need = (R + 15) // 16 * 16                                  # the MFMA kernel reads g in 16-column groups
     if g.shape[1] < need:
         gp = torch.zeros((T, need), dtype=torch.bfloat16, device=g.device)
@@ -484,9 +484,27 @@ def tn_skinny(x, g, R, scale=1.0, p=0.0, seed=0, rows_dev=None, reduce=True):
     chunks = (T + 255) // 256
     partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
     out = torch.empty((N, R), dtype=torch.float32, device=x.device) if reduce else None
+    kb = keep_bits if p > 0 else None
     lib().call("mp_tn_skinny_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), T, N, int(R), float(scale),
-               float(p), int(seed), _p(rows_dev), _stream())
+               float(p), int(seed), _p(rows_dev), _p(kb), kb.stride(0) if kb is not None else 0, _stream())
     return out if reduce else SkinnyPartial(partial, chunks, float(scale), N, int(R))
+
+
+def tn_skinny_down(x, g, Bt, R, scale=1.0, alpha=1.0, reduce=True):
+    """(tn_skinny(x, g, R, scale), lora_down(x, Bt, ., R, alpha=alpha)) from ONE pass over x [T, N] (mp_tn_skinny_down_f32): the weight gradient
+    dB = scale * x^T g [N, R] fp32 (or its chunk partials) and dt [T, 64] bf16 = alpha * x Bt^T.  Bt [>= 16 * ceil(R / 16), N] bf16."""
+    _chk(x, torch.bfloat16, "tn_skinny_down.x"); _chk(g, torch.bfloat16, "tn_skinny_down.g"); _chk(Bt, torch.bfloat16, "tn_skinny_down.Bt")
+    T, N = x.shape
+    rg = (R + 15) // 16
+    assert R <= 32 and g.shape[1] >= 16 * rg and Bt.shape[1] == N and Bt.shape[0] >= 16 * rg and x.stride(1) == 1 and Bt.stride(1) == 1 and g.stride(1) == 1
+    chunks, blocks = (T + 255) // 256, (N + 255) // 256
+    partial = torch.empty(chunks * N * R, dtype=torch.float32, device=x.device)
+    dtp = torch.empty(blocks * T * 16 * rg, dtype=torch.float32, device=x.device)
+    dt = torch.empty((T, 64), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((N, R), dtype=torch.float32, device=x.device) if reduce else None
+    lib().call("mp_tn_skinny_down_f32", _p(x), x.stride(0), _p(g), g.stride(0), _p(out), _p(partial), partial.numel(), _p(Bt), Bt.stride(0), _p(dt), dt.stride(0),
+               _p(dtp), dtp.numel(), T, N, int(R), float(scale), float(alpha), _stream())
+    return (out if reduce else SkinnyPartial(partial, chunks, float(scale), N, int(R))), dt
 
 
 def lora_grad_unpack_partials(dB, dAT, rows, k0, gB, gA):
@@ -534,7 +552,14 @@ def lora_grad_unpack(dB, dAT, rows, k0, gB, gA):
     lib().call("mp_lora_grad_unpack_f32", _p(dB), _p(dAT), _p(rows), dB.shape[1], int(k0), r, fin, fout, _p(gB), _p(gA), _stream())
 
 
-def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0, rows_dev=None):
+def keep_bits_for(x):
+    """Room for the lora_dropout mask of x [T, K] as bytes [T, K / 8] (mp_lora_down_bf16 writes it, the backward kernels read it), or None when
+    the kernel that writes it does not take this shape (K % 256 != 0: the mask is then regenerated from the seed as before)."""
+    T, K = x.shape
+    return torch.empty((T, K // 8), dtype=torch.uint8, device=x.device) if K % 256 == 0 else None
+
+
+def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0, rows_dev=None, keep_bits=None):
     """t[:, :64] = bf16(dropout(x) @ A[:R]^T) (zeros beyond R), the dropped x into xd when given (mp_lora_down_bf16).  x [T, K] bf16 (any row
     stride), A [>= 16 * ceil(R / 16), K] bf16, t a [T, 64] view (typically columns K.. of x's own row-padded buffer)."""
     _chk(x, torch.bfloat16, "lora_down.x"); _chk(A, torch.bfloat16, "lora_down.A"); _chk(t, torch.bfloat16, "lora_down.t")
@@ -544,23 +569,25 @@ def lora_down(x, A, t, R, p=0.0, seed=0, xd=None, alpha=1.0, rows_dev=None):
         assert xd.shape == (T, K) and xd.stride(1) == 1
     partial = torch.empty(8 * T * 16 * ((R + 15) // 16), dtype=torch.float32, device=x.device) if K % 256 == 0 else None
     lib().call("mp_lora_down_bf16", _p(x), x.stride(0), _p(A), A.stride(0), _p(t), t.stride(0), _p(xd), xd.stride(0) if xd is not None else 0,
-               T, K, int(R), float(p), int(seed), float(alpha), _p(rows_dev), _p(partial), partial.numel() if partial is not None else 0, _stream())
+               T, K, int(R), float(p), int(seed), float(alpha), _p(rows_dev), _p(partial), partial.numel() if partial is not None else 0,
+               _p(keep_bits) if p > 0 else None, keep_bits.stride(0) if (keep_bits is not None and p > 0) else 0, _stream())
     return t
 
 
-def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None, rows_dev=None):
+def lora_up_add(dt, AT, dx, R, p=0.0, seed=0, out=None, rows_dev=None, keep_bits=None):
     """dx + dropout(bf16(dt @ AT^T)) with mp_dropout_bf16's mask (mp_lora_up_add_bf16): dt [T, >= R] bf16, AT [K, 64] bf16 (A^T, padded),
     dx [T, K] bf16; in place on dx unless `out` is given."""
     _chk(dt, torch.bfloat16, "lora_up_add.dt"); _chk(AT, torch.bfloat16, "lora_up_add.AT"); _chk(dx, torch.bfloat16, "lora_up_add.dx")
     T, K = dx.shape
     assert AT.shape == (K, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dx.stride(1) == 1
     out = dx if out is None else out
+    kb = keep_bits if p > 0 else None
     lib().call("mp_lora_up_add_bf16", _p(dt), dt.stride(0), _p(AT), _p(dx), dx.stride(0), _p(out), out.stride(0), T, K, int(R), float(p), int(seed),
-               _p(rows_dev), _stream())
+               _p(rows_dev), _p(kb), kb.stride(0) if kb is not None else 0, _stream())
     return out
 
 
-def lora_up_add_swiglu_bwd(dt, AT, dact, gu, R, p=0.0, seed=0):
+def lora_up_add_swiglu_bwd(dt, AT, dact, gu, R, p=0.0, seed=0, keep_bits=None):
     """swiglu_pair_bwd(gu, lora_up_add(dt, AT, dact)) in one pass (mp_lora_up_add_swiglu_bwd_bf16), bit-identical with the two kernels:
     dt [T, >= R] bf16, AT [ff, 64] bf16, dact [T, ff] bf16 (not modified), gu [T, 2 ff] bf16 -> d gate|up [T, 2 ff] bf16."""
     _chk(dt, torch.bfloat16, "lora_up_add_swiglu_bwd.dt"); _chk(dact, torch.bfloat16, "lora_up_add_swiglu_bwd.dact"); _chk(gu, torch.bfloat16, "lora_up_add_swiglu_bwd.gu")
@@ -568,8 +595,9 @@ def lora_up_add_swiglu_bwd(dt, AT, dact, gu, R, p=0.0, seed=0):
     assert AT.shape == (ff, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dact.stride(1) == 1
     assert gu.shape == (T, 2 * ff) and gu.is_contiguous()
     dgu = torch.empty_like(gu)
+    kb = keep_bits if p > 0 else None
     lib().call("mp_lora_up_add_swiglu_bwd_bf16", _p(dt), dt.stride(0), _p(AT), _p(dact), dact.stride(0), _p(gu), _p(dgu), T, ff, int(R), float(p), int(seed),
-               _stream())
+               _p(kb), kb.stride(0) if kb is not None else 0, _stream())
     return dgu
 
 

@@ -35,6 +35,11 @@ for name, N, R in (("dB_down: dy[T,4096]^T t", 4096, 8), ("dA_down: act[T,11008]
             continue
         us = timed(lambda i: ops.tn_skinny(xs[i % n], ts[i % n], R, 1.0, p, 1234, reduce=False), n)
         res[f"tn_skinny {name} p={p}"] = {"us": round(us, 1), "GBps": round(T * N * 2 / us / 1e3, 1)}
+        if p > 0:
+            kbs = [torch.randint(0, 256, (T, N // 8), dtype=torch.uint8, device=dev) for _ in range(n)]
+            us = timed(lambda i: ops.tn_skinny(xs[i % n], ts[i % n], R, 1.0, p, 1234, reduce=False, keep_bits=kbs[i % n]), n)
+            res[f"tn_skinny {name} p={p} mask bytes"] = {"us": round(us, 1), "GBps": round(T * N * 2 / us / 1e3, 1)}
+            del kbs
     del xs, ts
 for name, K, R in (("t_gu = h2[T,4096] A^T", 4096, 16), ("t_down = act[T,11008] A^T", 11008, 8), ("dt_down = dy[T,4096] B", 4096, 8), ("dt_gu = d_gu[T,22016] B", 22016, 16)):
     n = max(4, int(600e6 // (T * K * 2)) + 1)
@@ -45,11 +50,22 @@ for name, K, R in (("t_gu = h2[T,4096] A^T", 4096, 16), ("t_down = act[T,11008] 
         us = timed(lambda i: ops.lora_down(xs[i % n], A, ts[i % n], R, p, 99), n)
         res[f"lora_down {name} p={p}"] = {"us": round(us, 1), "GBps": round(T * K * 2 / us / 1e3, 1)}
     del xs, ts
-# the floor beside them: a plain read of the same bytes (torch sum over bf16)
+# the input-gradient pass of the down adapter with the SwiGLU backward behind it: d_act [T, 11008] + gu [T, 22016] -> d gate|up [T, 22016]
+ff = 11008
+n = 3
+dacts = ring((T, ff), n); gus = ring((T, 2 * ff), n); dts = ring((T, 64), n); AT = ring((ff, 64), 1)[0]
+for p in (0.0, 0.05):
+    us = timed(lambda i: ops.lora_up_add_swiglu_bwd(dts[i % n], AT, dacts[i % n], gus[i % n], 8, p, 77), n)
+    res[f"lora_up_add_swiglu_bwd p={p}"] = {"us": round(us, 1), "GBps": round(T * ff * 2 * 5 / us / 1e3, 1)}
+kbs = [torch.randint(0, 256, (T, ff // 8), dtype=torch.uint8, device=dev) for _ in range(n)]
+us = timed(lambda i: ops.lora_up_add_swiglu_bwd(dts[i % n], AT, dacts[i % n], gus[i % n], 8, 0.05, 77, keep_bits=kbs[i % n]), n)
+res["lora_up_add_swiglu_bwd p=0.05 mask bytes"] = {"us": round(us, 1), "GBps": round(T * ff * 2 * 5 / us / 1e3, 1)}
+del dacts, gus, dts, kbs
+# beside them: torch's sum over the same bf16 bytes (a reduction kernel, not a tuned read)
 for N in (4096, 11008, 22016):
     n = max(4, int(600e6 // (T * N * 2)) + 1)
     xs = ring((T, N), n)
-    us = timed(lambda i: ops.prefetch(xs[i % n], workgroups=2048) if hasattr(ops, "prefetch") else xs[i % n].sum(), n)
+    us = timed(lambda i: xs[i % n].sum(), n)
     res[f"read floor [T,{N}]"] = {"us": round(us, 1), "GBps": round(T * N * 2 / us / 1e3, 1)}
     del xs
 for k, v in res.items():

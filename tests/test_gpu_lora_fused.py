@@ -23,3 +23,69 @@ def test_lora_up_add_swiglu_bwd_is_the_two_kernels_in_one_pass(T, ff, R, p):
     torch.cuda.synchronize()
     assert torch.equal(dact, keep)                                   # the input gradient itself is left alone
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), f"{(got != ref).sum().item()} of {got.numel()} values differ"
+
+
+@pytest.mark.parametrize("T,K,R,p", [(300, 1024, 8, 0.05), (777, 2816, 16, 0.1), (65, 512, 32, 0.5)])
+def test_lora_dropout_mask_bytes_replace_the_regenerated_mask(T, K, R, p):
+    """Round 5: mp_lora_down_bf16 leaves lora_dropout's mask as bytes [T, K / 8] and the two backward kernels that need the same mask read
+    them instead of hashing again.  The bytes ARE mp_dropout_bf16's mask, and each kernel gives the same bits with them as without."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T + K)
+    seed = 424242 + R
+    x = torch.randn(T, K, generator=g, device=dev).to(torch.bfloat16)
+    A = torch.zeros(64, K, dtype=torch.bfloat16, device=dev)
+    A[:R] = (torch.randn(R, K, generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    t0 = torch.empty((T, 64), dtype=torch.bfloat16, device=dev); t1 = torch.empty_like(t0)
+    kb = ops.keep_bits_for(x)
+    assert kb is not None and kb.shape == (T, K // 8)
+    ops.lora_down(x, A, t0, R, p, seed)
+    ops.lora_down(x, A, t1, R, p, seed, keep_bits=kb)
+    assert torch.equal(t0, t1)
+    # the bytes against the materialised mask (ones through mp_dropout_bf16: kept elements are 1 / (1 - p), dropped ones 0)
+    kept = ops.dropout_bf16(torch.ones(T, K, dtype=torch.bfloat16, device=dev), p, seed) != 0
+    bits = ((kb.view(T, K // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).bool().view(T, K)
+    assert torch.equal(bits, kept)
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.02
+    # weight gradient: dropout(x)^T dt
+    dt = (torch.randn(T, 64, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    a = ops.tn_skinny(x, dt, R, 1.0, p, seed)
+    b = ops.tn_skinny(x, dt, R, 1.0, p, seed, keep_bits=kb)
+    assert torch.equal(a, b) and a.abs().max() > 0
+    # input gradient: dx + dropout(dt A), alone and with the SwiGLU backward behind it
+    if R <= 32:
+        AT = A.t().contiguous()
+        dx = torch.randn(T, K, generator=g, device=dev).to(torch.bfloat16)
+        a = ops.lora_up_add(dt, AT, dx.clone(), R, p, seed)
+        b = ops.lora_up_add(dt, AT, dx.clone(), R, p, seed, keep_bits=kb)
+        assert torch.equal(a, b) and not torch.equal(a, dx)
+        if K % 32 == 0:
+            gu = torch.randn(T, 2 * K, generator=g, device=dev).to(torch.bfloat16)
+            a = ops.lora_up_add_swiglu_bwd(dt, AT, dx, gu, R, p, seed)
+            b = ops.lora_up_add_swiglu_bwd(dt, AT, dx, gu, R, p, seed, keep_bits=kb)
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("T,N,R", [(300, 1024, 8), (5112, 4096, 8), (777, 2816, 16), (1000, 22016, 16), (65, 520, 32)])
+def test_tn_skinny_down_is_the_two_kernels_in_one_pass(T, N, R):
+    """Round 5: dB = dY^T t and dt = dY B from one pass over dY (mp_tn_skinny_down_f32).  dB: the bits of mp_tn_skinny_f32 (reduced and as chunk
+    partials); dt: mp_lora_down_bf16's value with the fp32 partial sums taken over 256-column blocks instead of eight K ranges — equal to
+    the rounding of the bf16 result, and the same bits on every launch."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T + N + R)
+    dy = torch.randn(T, N, generator=g, device=dev).to(torch.bfloat16)
+    t = (torch.randn(T, 64, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    Bt = torch.zeros(64, N, dtype=torch.bfloat16, device=dev)
+    Bt[:R] = (torch.randn(R, N, generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    ref_dB = ops.tn_skinny(dy, t, R, 2.0)
+    dB, dt = ops.tn_skinny_down(dy, t, Bt, R, 2.0, 2.0)
+    assert torch.equal(dB, ref_dB)
+    part, dt2 = ops.tn_skinny_down(dy, t, Bt, R, 2.0, 2.0, reduce=False)
+    assert torch.equal(part.partial, ops.tn_skinny(dy, t, R, 2.0, reduce=False).partial) and torch.equal(dt, dt2)
+    want = 2.0 * (dy.float() @ Bt[:R].float().t())
+    assert not dt[:, R:].any()                                       # zero beyond the R rank columns, up to the 64 of the padded tensor
+    err = (dt[:, :R].float() - want).abs().max().item()
+    assert err <= 2 ** -8 * want.abs().max().item() + 1e-6, (err, want.abs().max().item())
+    if N % 256 == 0:
+        old = ops.lora_down(dy, Bt, torch.empty((T, 64), dtype=torch.bfloat16, device=dev), R, alpha=2.0)
+        d = (old[:, :R].float() - dt[:, :R].float()).abs().max().item()
+        assert d <= 2 ** -7 * want.abs().max().item(), d              # one bf16 ulp of the largest entry: different fp32 summation order only
