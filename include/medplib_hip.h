@@ -439,6 +439,12 @@ int mp_lora_pack_batched(const void* descs, int n, int64_t max_elems, hipStream_
 int mp_lora_up_add_bf16(const void* dt, int64_t lddt, const void* AT, const void* dx, int64_t lddx, void* out, int64_t ldo, int tokens,
                         int K, int R, float p, uint64_t seed, const int* rows_dev, const uint8_t* keep_bits, int64_t ld_bits,
                         hipStream_t stream);   /* rows_dev (optional, both kernels): device-side row count */
+/* mp_lora_up_add_bf16 folded into the mp_rmsnorm_bwd_bf16 that reads its result (the adapter on gate / up_proj: its input gradient is the
+ * post-attention norm's output gradient): dx = rmsnorm_bwd(x, w, dy', add) with dy' = bf16(dy + dropout(bf16(dt A))).  Bit-identical with
+ * the two calls.  dim must be 4096, R 8 or 16 (the rank vectors live in LDS: 128 KiB at R = 16); keep_bits: see mp_tn_skinny_f32. */
+int mp_rmsnorm_bwd_up_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
+                           int64_t ldo, int64_t rows, int dim, float eps, const void* dt, int64_t lddt, const void* AT, int R, float p,
+                           uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits, hipStream_t stream);
 /* The same followed by the SwiGLU backward in ONE pass (dense LlamaMLP with an adapter on down_proj, HF modeling_llama.py LlamaMLP.forward via
  * medplib_moe_llama.py:127-141): dgu[tokens, 2 ff] (gate|up interleaved in blocks of 32, the layout of mp_gemm_swiglu_keep_bf16's gu_out) from
  * d_act' = bf16(dact + dropout(bf16(dt A))) — bit-identical with mp_lora_up_add_bf16 followed by mp_swiglu_pair_bwd_bf16. */

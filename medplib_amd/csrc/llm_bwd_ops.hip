@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include "gemm_common.h"
 
+int mp_device_cus();            // gemm256_bf16.hip (cached per device)
+
 namespace {
 
 constexpr int RB_THREADS = 256, RB_MAXC = 4;
@@ -806,6 +808,117 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(const bf16_t* __restri
   }
 }
 
+// Round 5: mp_lora_up_add_bf16 folded into the RMSNorm backward that reads its result.  The gate|up adapter's input gradient
+// d_h2' = bf16(d_h2 + dropout(bf16(dt A))) has ONE reader, the post-attention norm's backward: here that kernel forms d_h2' from d_h2, the
+// token's dt row and the lane's eight A^T rank vectors (held in registers: a workgroup walks rows, 512 threads = one 16-byte chunk each at
+// dim 4096) on its way in — one read-modify-write pass over [T, d] less per layer.  BIT-IDENTICAL with the two kernels: the adapter term is
+// lora_up_add_kernel's dot2 chain and rounding points; the two row reductions reproduce rmsnorm_bwd_kernel's order (its thread t sums chunk
+// t, then chunk 256 + t, element by element; waves 4-7 here continue the chains waves 0-3 started, lane for lane, so the wave and block sums
+// see the same operands in the same order).
+template <int RP>
+__global__ __launch_bounds__(1024) void rmsnorm_bwd_up_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                              const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, float eps, int64_t ldx, int64_t ldy,
+                                                              int64_t lda, int64_t ldo, int rows, const bf16_t* __restrict__ dt, int64_t lddt,
+                                                              const bf16_t* __restrict__ AT, float p, uint64_t seed, const uint8_t* __restrict__ keep_bits,
+                                                              int64_t ld_bits) {
+  // FOUR rows per trip: threads 256 s .. 256 s + 255 are rmsnorm_bwd_kernel's 256-thread row (thread t: the 16-byte chunks t and 256 + t, its
+  // two block sums over four waves), so a trip costs that kernel's four barriers for four rows and a CU has 96 KB of loads in flight.  A^T sits
+  // in LDS as [chunk c][channel j][rank piece q][thread]: 16 bytes per thread and (c, j, q), consecutive threads consecutive pieces
+  // (conflict-free), 128 KiB at R = 16, the norm weight behind it.  (Rank vectors in registers, one row per 512-thread workgroup: 64 registers
+  // per lane, one workgroup per CU, six barriers per row to reproduce the summation order — 77-95 us against 78 for the two kernels.)
+  constexpr int dim = 4096, NQ = RP / 4;
+  extern __shared__ __attribute__((aligned(16))) char up_lds[];
+  uint4* alds = reinterpret_cast<uint4*>(up_lds);            // [2][8][NQ][256]
+  float* wlds = reinterpret_cast<float*>(up_lds + 2 * 8 * NQ * 256 * 16);      // [dim]
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, slot = tid >> 8, t = tid & 255, ws = (tid >> 6) & 3;
+  for (int idx = tid; idx < 2 * 8 * NQ * 256; idx += 1024) {
+    const int c = idx / (8 * NQ * 256), j = (idx / (NQ * 256)) & 7, q = (idx / 256) % NQ, tt = idx & 255;
+    alds[idx] = *reinterpret_cast<const uint4*>(AT + (int64_t)((c * 256 + tt) * 8 + j) * 64 + q * 8);
+  }
+  for (int idx = tid; idx < dim; idx += 1024) wlds[idx] = w[idx];
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  __syncthreads();
+  for (int base = blockIdx.x * 4; base < rows; base += gridDim.x * 4) {
+    const int row = base + slot;
+    const bool live = row < rows;
+    bf16x8 xv[2], gv[2], av[2], dtv[NQ];
+    unsigned m[2] = {0xffu, 0xffu};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { xv[c] = bf16x8{}; gv[c] = bf16x8{}; av[c] = bf16x8{}; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dtv[q] = bf16x8{};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int i = (c * 256 + t) * 8;
+        xv[c] = *reinterpret_cast<const bf16x8*>(x + (int64_t)row * ldx + i);
+        gv[c] = *reinterpret_cast<const bf16x8*>(dy + (int64_t)row * ldy + i);
+        if (add) av[c] = *reinterpret_cast<const bf16x8*>(add + (int64_t)row * lda + i);
+        if (p > 0.f) m[c] = keep_bits ? keep_bits[(int64_t)row * ld_bits + c * 256 + t] : dropout_keep8(seed, ((uint64_t)row * (uint64_t)dim + (uint64_t)i) >> 2, th);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dtv[q] = *reinterpret_cast<const bf16x8*>(dt + (int64_t)row * lddt + q * 8);      // the same address in every lane
+    }
+    // ---- d_h2' = d_h2 + dropout(bf16(dt A)): lora_up_add_kernel's arithmetic (rank pairs ascending per channel), written over gv
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const uint4 piece = alds[((c * 8 + j) * NQ + q) * 256 + t];
+          const unsigned pr[4] = {piece.x, piece.y, piece.z, piece.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bf16x2_t d2 = bf16x2_t{dtv[q][2 * r], dtv[q][2 * r + 1]};
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pr[r]), d2, acc, false);
+          }
+        }
+        float v = (float)(bf16_t)acc;
+        if (p > 0.f) v = ((m[c] >> j) & 1u) ? (float)(bf16_t)(v * keep_scale) : 0.f;
+        gv[c][j] = (bf16_t)((float)gv[c][j] + v);
+      }
+    // ---- from here on: rmsnorm_bwd_kernel on (xv, gv), per row slot
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)xv[c][j]; ss += f * f; }
+    ss = wave_sum(ss);
+    __syncthreads();                                         // the previous trip's red[] reads are done
+    if (lane == 0) red[slot][ws] = ss;
+    __syncthreads();
+    ss = ((0.f + red[slot][0]) + red[slot][1]) + red[slot][2] + red[slot][3];
+    const float rs = rsqrtf(ss / (float)dim + eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += (float)gv[c][j] * wlds[(c * 256 + t) * 8 + j] * ((float)xv[c][j] * rs);
+    dot = wave_sum(dot);
+    __syncthreads();
+    if (lane == 0) red[slot][ws] = dot;
+    __syncthreads();
+    dot = (((0.f + red[slot][0]) + red[slot][1]) + red[slot][2] + red[slot][3]) / (float)dim;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int i = (c * 256 + t) * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (float)xv[c][j] * rs;
+        float v = rs * ((float)gv[c][j] * wlds[i + j] - xh * dot);
+        if (add) v += (float)av[c][j];
+        o[j] = (bf16_t)v;
+      }
+      if (live) *reinterpret_cast<bf16x8*>(dx + (int64_t)row * ldo + i) = o;
+    }
+  }
+}
+
 // The inverse of lora_pack for gradients: one adapter's slices of the fused group's padded gradients (dB [W, R] rows rows[o] columns k0..,
 // dA^T [fin, R] columns k0..) ADDED into the parameter-shaped gradient tensors (lora_B.grad [fout, r], lora_A.grad [r, fin]) -- the engine's
 // flat buffer; one launch instead of a gather, a transpose-copy and two adds per adapter (192 adapters' worth of 5-us kernels per step).
@@ -1211,6 +1324,34 @@ extern "C" int mp_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, c
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)rows), dim3(RB_THREADS), 0, stream, (const bf16_t*)x, w, (const bf16_t*)dy,
                      (const bf16_t*)add, (bf16_t*)dx, dim, eps, ldx, ldy, lda, ldo, rs_out);
   return mp_check_launch("mp_rmsnorm_bwd_bf16");
+}
+
+extern "C" int mp_rmsnorm_bwd_up_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
+                                     int64_t ldo, int64_t rows, int dim, float eps, const void* dt, int64_t lddt, const void* AT, int R, float p,
+                                     uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits, hipStream_t stream) {
+  MP_REQUIRE(dim == 4096 && ldx % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && (!add || lda % 8 == 0) && lddt % 8 == 0 && rows < (1ll << 31), MP_ERR_SHAPE,
+             "mp_rmsnorm_bwd_up_bf16: dim must be 4096 (got %d), strides multiples of 8", dim);
+  MP_REQUIRE((R == 8 || R == 16) && p >= 0.f && p < 1.f && dt && AT && (!keep_bits || (p > 0.f && ld_bits * 8 >= dim)), MP_ERR_ARG,
+             "mp_rmsnorm_bwd_up_bf16: R in {8, 16}, 0 <= p < 1, keep_bits only with p > 0");
+  if (rows == 0) return MP_OK;
+  MP_REQUIRE(R <= 16, MP_ERR_SHAPE, "mp_rmsnorm_bwd_up_bf16: R = %d: the rank vectors of R = 32 do not fit the LDS (use mp_lora_up_add_bf16 + mp_rmsnorm_bwd_bf16)", R);
+  const int lds = 2 * 8 * (R / 8) * 256 * 16 + 4096 * 4;    // [2][8][R / 8][256] 16-byte pieces of A^T + the norm weight
+  {
+    static bool attr_set[64][2] = {};
+    int devi = 0;
+    (void)hipGetDevice(&devi);
+    const int k = R == 8 ? 0 : 1;
+    if (devi >= 0 && devi < 64 && !attr_set[devi][k]) {
+      if (k == 0) (void)hipFuncSetAttribute((const void*)rmsnorm_bwd_up_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      else (void)hipFuncSetAttribute((const void*)rmsnorm_bwd_up_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set[devi][k] = true;
+    }
+  }
+  const dim3 grid((unsigned)std::min<int64_t>((rows + 3) / 4, mp_device_cus())), blk(1024);
+#define MP_GO(RP) hipLaunchKernelGGL((rmsnorm_bwd_up_kernel<RP>), grid, blk, lds, stream, (const bf16_t*)x, w, (const bf16_t*)dy, (const bf16_t*)add, (bf16_t*)dx, eps, ldx, ldy, lda, ldo, (int)rows, (const bf16_t*)dt, lddt, (const bf16_t*)AT, p, seed, keep_bits, ld_bits)
+  if (R == 8) MP_GO(4); else MP_GO(8);
+#undef MP_GO
+  return mp_check_launch("mp_rmsnorm_bwd_up_bf16");
 }
 
 extern "C" int mp_swiglu_pair_fwd_bf16(const void* gu, void* act, int64_t ldact, int64_t tokens, int ff, const int* counts, int cap, hipStream_t stream) {

@@ -355,6 +355,7 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_FUSE_NORM_UP = os.environ.get("MP_LORA_FUSE_NORM_UP", "1") != "0"      # A/B: 0 = mp_lora_up_add_bf16, then mp_rmsnorm_bwd_bf16
 _FUSE_DY = os.environ.get("MP_LORA_FUSE_DY", "1") != "0"                # A/B: 0 = dy B and dy^T t as two kernels, two reads of dy
 _KEEP_BITS = os.environ.get("MP_LORA_KEEP_BITS", "1") != "0"            # A/B: 0 = every kernel regenerates the lora_dropout mask from the seed
 _PRUNE_ROWS = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"            # A/B: 0 = the last layer's MLP on every row
@@ -703,7 +704,7 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False):
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False, defer_up=False):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
     adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed.  dx = None: nothing trainable lies in front of
     this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
@@ -724,6 +725,9 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=Fal
         # the adapter on down_proj: its input gradient has ONE consumer, the SwiGLU backward — both in one pass, the gate|up gradient comes back
         # (these two regenerate the mask from the seed: they are bound by their 560 MB of traffic either way — 133 us with the hash, 136 with the bytes)
         return ops.lora_up_add_swiglu_bwd(dt, AT, dx, swiglu_gu, R, lora.p_active, seed), dB, dAT
+    if defer_up and R <= 16:
+        # the caller's next kernel is the only reader of dx + dropout(dt A) and forms it itself (ops.rmsnorm_bwd_up): dx comes back untouched
+        return (dx, (dt, AT, R, lora.p_active, seed, kb)), dB, dAT
     if R <= 32 and dx.stride(0) % 8 == 0:
         dx = ops.lora_up_add(dt, AT, dx, R, lora.p_active, seed)       # dx += dropout(dt A): the same mask and 1/(1-p) as the forward
     elif lora.p_active > 0:
@@ -811,8 +815,14 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             stop_here = (i == 0 and not need_d_embeds and "o" not in pad and "qkv" not in pad and rows_last is None
                          and (i, "ln1") not in lora.norm_names and (i, "ln2") not in lora.norm_names)
             d_h2 = None if stop_here else ops.gemm(d_gu, lw["gu_T"])
+            up_late = None
             if "gu" in pad:
-                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok)
+                # the adapter's input gradient has one reader, the post-attention norm's backward below: that kernel adds it on its way in
+                defer = (_FUSE_NORM_UP and not stop_here and rows_last is None and d == 4096 and (i, "ln2") not in lora.norm_names
+                         and pad["gu"][4] <= 16 and d_h2.stride(0) % 8 == 0)
+                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok, defer_up=defer)
+                if defer:
+                    d_h2, up_late = d_h2
                 take(i, pad["gu"], dB, dAT)
             if stop_here:
                 dx = None
@@ -826,6 +836,9 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             d_mid = ops.scatter_rows_bf16_(dx, s["rows_last"], d_mid_c)
         elif (i, "ln2") in lora.norm_names:
             d_mid, grads[lora.norm_names[(i, "ln2")]] = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx, want_wgrad=True)
+        elif not s.get("moe") and up_late is not None:
+            dt_, AT_, R_, p_, seed_, kb_ = up_late
+            d_mid = ops.rmsnorm_bwd_up(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, dt_, AT_, R_, p_, seed_, add=dx, keep_bits=kb_)
         else:
             d_mid = ops.rmsnorm_bwd(s["x_mid"], lw["ln2"], d_h2, cfg.rms_norm_eps, add=dx)
         # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]

@@ -435,6 +435,19 @@ def rmsnorm_bwd(x, w, dy, eps, add=None, want_wgrad=False):
     return out, dw
 
 
+def rmsnorm_bwd_up(x, w, dy, eps, dt, AT, R, p=0.0, seed=0, add=None, keep_bits=None):
+    """rmsnorm_bwd(x, w, lora_up_add(dt, AT, dy, R, p, seed), eps, add) in one pass (mp_rmsnorm_bwd_up_bf16; dy is not modified), bit-identical."""
+    _chk(x, torch.bfloat16, "rmsnorm_bwd_up.x"); _chk(dy, torch.bfloat16, "rmsnorm_bwd_up.dy"); _chk(dt, torch.bfloat16, "rmsnorm_bwd_up.dt")
+    T, d = x.shape
+    assert AT.shape == (d, 64) and AT.is_contiguous() and dt.shape[0] == T and dt.stride(1) == 1 and dy.shape == (T, d)
+    out = torch.empty((T, d), dtype=torch.bfloat16, device=x.device)
+    kb = keep_bits if p > 0 else None
+    lib().call("mp_rmsnorm_bwd_up_bf16", _p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0, _p(out),
+               out.stride(0), T, d, float(eps), _p(dt), dt.stride(0), _p(AT), int(R), float(p), int(seed), _p(kb), kb.stride(0) if kb is not None else 0,
+               _stream())
+    return out
+
+
 def swiglu_pair_fwd(gu, out=None, counts=None, cap=0):
     """counts / cap: the rows are capacity slabs [E * cap, .]; only the first counts[e] rows of slab e are processed (the rest is left alone)."""
     T, ff2 = gu.shape

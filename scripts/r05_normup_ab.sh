@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_lora_fused.py -x -q -m gpu 2>&1 | tail -5
+timeout 1500 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "lora" 2>&1 | grep -E "passed|failed|Error" | tail -4
+run() { tag=$1; shift
+  env "$@" python bench.py --lora --steps 12 --warmup 3 --no-kernel-timer --no-cpu-baseline --no-secondary --no-live-traffic 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d.get('host_issue_ms_per_step'))"
+}
+run nu_off MP_LORA_FUSE_NORM_UP=0; run nu_on; run nu_off2 MP_LORA_FUSE_NORM_UP=0; run nu_on2

@@ -89,3 +89,33 @@ def test_tn_skinny_down_is_the_two_kernels_in_one_pass(T, N, R):
         old = ops.lora_down(dy, Bt, torch.empty((T, 64), dtype=torch.bfloat16, device=dev), R, alpha=2.0)
         d = (old[:, :R].float() - dt[:, :R].float()).abs().max().item()
         assert d <= 2 ** -7 * want.abs().max().item(), d              # one bf16 ulp of the largest entry: different fp32 summation order only
+
+
+@pytest.mark.parametrize("T,R,p,with_add", [(100, 16, 0.0, True), (1300, 16, 0.05, True), (777, 8, 0.1, False), (5112, 16, 0.05, True), (1, 8, 0.0, False)])
+def test_rmsnorm_bwd_with_the_adapter_term_folded_in_is_bit_identical(T, R, p, with_add):
+    """Round 5: mp_rmsnorm_bwd_up_bf16 = mp_lora_up_add_bf16 followed by mp_rmsnorm_bwd_bf16 (the gate|up adapter's input gradient has one reader),
+    same bits — with the mask regenerated from the seed and with the forward's mask bytes."""
+    dev = torch.device("cuda:0")
+    d = 4096
+    g = torch.Generator(device=dev).manual_seed(T + R)
+    x = torch.randn(T, d, generator=g, device=dev).to(torch.bfloat16)
+    w = 1.0 + 0.1 * torch.randn(d, generator=g, device=dev)
+    dy = torch.randn(T, d, generator=g, device=dev).to(torch.bfloat16)
+    add = torch.randn(T, d, generator=g, device=dev).to(torch.bfloat16) if with_add else None
+    dt = (torch.randn(T, 64, generator=g, device=dev) * 0.3).to(torch.bfloat16)
+    AT = torch.zeros(d, 64, dtype=torch.bfloat16, device=dev)
+    AT[:, :R] = (torch.randn(d, R, generator=g, device=dev) * 0.2).to(torch.bfloat16)
+    seed = 99 + T
+    keep = dy.clone()
+    ref = ops.rmsnorm_bwd(x, w, ops.lora_up_add(dt, AT, dy.clone(), R, p, seed), 1e-5, add=add)
+    got = ops.rmsnorm_bwd_up(x, w, dy, 1e-5, dt, AT, R, p, seed, add=add)
+    torch.cuda.synchronize()
+    assert torch.equal(dy, keep)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), f"{(got != ref).sum().item()} of {got.numel()} values differ"
+    assert not torch.equal(ref, ops.rmsnorm_bwd(x, w, dy, 1e-5, add=add))            # the adapter term is not a no-op in this test
+    if p > 0:
+        kb = ops.keep_bits_for(x)
+        A = AT.t().contiguous()
+        ops.lora_down(x, A, torch.empty((T, 64), dtype=torch.bfloat16, device=dev), R, p, seed, keep_bits=kb)     # the forward leaves the mask bytes
+        got2 = ops.rmsnorm_bwd_up(x, w, dy, 1e-5, dt, AT, R, p, seed, add=add, keep_bits=kb)
+        assert torch.equal(got2.view(torch.int16), ref.view(torch.int16))
