@@ -411,6 +411,15 @@ int mp_tn_skinny_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, flo
 int mp_tn_skinny_down_f32(const void* X, int64_t ldx, const void* G, int64_t ldg, float* out, float* partial, int64_t partial_floats,
                           const void* Bt, int64_t ldb, void* dt, int64_t lddt, float* dt_partial, int64_t dt_partial_floats, int64_t tokens,
                           int N, int R, float scale, float alpha, hipStream_t stream);
+/* The dense LlamaMLP's backward between its two input-gradient GEMMs in ONE kernel, for adapters on gate / up / down_proj (HF modeling_llama.py
+ * LlamaMLP.forward via medplib_moe_llama.py:127-141; peft lora.Linear, call sites train_ds_medplib.py:262-303): mp_lora_up_add_swiglu_bwd_bf16
+ * (dact, gu, dt_down, AT_down, p, seed [, keep_bits] -> dgu [tokens, 2 ff]) and mp_tn_skinny_down_f32 on that dgu (t_gu, Bt_gu -> out / partial = the
+ * gate|up adapter's dB, dt_gu) — dgu is written for the main GEMM but not read back.  Same bits as the two calls. */
+int mp_swiglu_bwd_skinny_f32(const void* dact, int64_t lddact, const void* gu, void* dgu, const void* dt_down, int64_t lddtd, const void* AT_down,
+                             int R_down, float p, uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits, const void* t_gu, int64_t ldg,
+                             float* out, float* partial, int64_t partial_floats, const void* Bt_gu, int64_t ldb, void* dt_gu, int64_t lddt,
+                             float* dt_partial, int64_t dt_partial_floats, int64_t tokens, int ff, int R_gu, float scale, float alpha,
+                             hipStream_t stream);
 /* d_logits = gconst * gscale[0] * (softmax(logits) - onehot(labels)) for the supervised rows (medplib_moe_llama.py:392-408), bf16
  * [rows, ldo] with the columns V..ldo-1 zeroed (ldo = V padded to the GEMM's K granularity). */
 int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits, int64_t ldo,

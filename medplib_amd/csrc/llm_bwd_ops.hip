@@ -919,6 +919,182 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_up_kernel(const bf16_t* __re
   }
 }
 
+// Round 5: the dense MLP's backward between its two input-gradient GEMMs as ONE kernel.  mp_lora_up_add_swiglu_bwd_bf16 writes
+// d gate|up [T, 2 ff] (225 MB at 7B) and mp_tn_skinny_down_f32 reads it straight back for the gate|up adapter's dB = d_gu^T t and dt = d_gu B.
+// Here the workgroup of tn_skinny_down_mfma_kernel (256 columns of d_gu = 128 channels x a chunk of 256 tokens) PRODUCES its tile instead of
+// loading it: a thread owns one 8-channel group (its A^T rank vectors in registers) and four token rows per step, forms
+// d_act' = bf16(d_act + dropout(bf16(dt_down A_down))) and d gate / d up exactly as lora_up_add_kernel<., true> does, stores them to d_gu (the
+// main input-gradient GEMM reads it) AND into the LDS image the two MFMA products read.  Same bits as the two kernels for d_gu, dB and dt.
+template <int RP, int RG>
+__global__ __launch_bounds__(256) void swiglu_bwd_skinny_kernel(const bf16_t* __restrict__ dact, int64_t lddact, const bf16_t* __restrict__ gu, bf16_t* __restrict__ dgu,
+                                                                const bf16_t* __restrict__ dtd, int64_t lddtd, const bf16_t* __restrict__ ATd, float p, uint64_t seed,
+                                                                const uint8_t* __restrict__ keep_bits, int64_t ld_bits,
+                                                                const bf16_t* __restrict__ G, int64_t ldg, float* __restrict__ partial, const bf16_t* __restrict__ Bt,
+                                                                int64_t ldb, float* __restrict__ dt_partial, int64_t T, int ff, int R) {
+  __shared__ __attribute__((aligned(16))) char xt[64 * 512];      // [64 tokens][256 columns of d_gu] bf16, 16-byte chunk c of row r at (c ^ (r & 7))
+  __shared__ __attribute__((aligned(16))) char gt[64 * 128];      // [64 tokens][64 columns] of the forward's t (columns >= 16 * RG never read)
+  __shared__ __attribute__((aligned(16))) char at[16 * RG * 512]; // [16 RG rank rows of B^T][this block's 256 columns]
+  const int N = 2 * ff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n_base = blockIdx.x * 256;                            // d_gu column of the tile = 4 blocks of (32 gate | 32 up) = channels blockIdx.x * 128 ..
+  const int64_t t0 = (int64_t)blockIdx.y * TN_CHUNK;
+  const int rows = (int)max((int64_t)0, min((int64_t)TN_CHUNK, T - t0));
+  const int nsteps = (rows + 63) / 64;
+  // producer role: channel group o (8 channels), token rows pr + 16 i of a step
+  const int po = tid & 15, pr = tid >> 4;
+  const int ch = blockIdx.x * 128 + po * 8;
+  const bool ch_live = ch < ff;
+  const int chc = ch_live ? ch : 0;
+  const int64_t gcol = (int64_t)(chc >> 5) * 64 + (chc & 31);     // gate column of the group in d_gu / gu; its up column is + 32
+  const int cg = (po >> 2) * 8 + (po & 3), cu = cg + 4;           // the two 16-byte chunks of the tile row the group fills
+  bf16x2_t a[8][RP];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < RP / 4; ++q) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(ATd + (int64_t)(chc + j) * 64 + q * 8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[j][q * 4 + r] = bf16x2_t{v[2 * r], v[2 * r + 1]};
+    }
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned th = dropout_thresh(p);
+  f32x4 acc[4][RG];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < (16 * RG * 32 + 255) / 256; ++u) {          // B^T piece of this column block, once per workgroup
+    const int idx = tid + u * 256;
+    if (idx < 16 * RG * 32) {
+      const int r = idx >> 5, c = idx & 31;
+      bf16x8 v = bf16x8{};
+      if (n_base + c * 8 < N) v = *reinterpret_cast<const bf16x8*>(Bt + (int64_t)r * ldb + n_base + c * 8);
+      *reinterpret_cast<bf16x8*>(at + r * 512 + ((c ^ (r & 7)) << 4)) = v;
+    }
+  }
+  bf16x8 dv[4], gv[4], uv[4], dtv[4][RP / 4], tv[(64 * 2 * RG + 255) / 256];
+  unsigned km[4];
+  auto load_step = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = step * 64 + pr + 16 * i;
+      dv[i] = bf16x8{}; gv[i] = bf16x8{}; uv[i] = bf16x8{}; km[i] = 0xffu;
+#pragma unroll
+      for (int q = 0; q < RP / 4; ++q) dtv[i][q] = bf16x8{};
+      if (r < rows && ch_live) {
+        const int64_t tok = t0 + r;
+        dv[i] = *reinterpret_cast<const bf16x8*>(dact + tok * lddact + chc);
+        gv[i] = *reinterpret_cast<const bf16x8*>(gu + tok * N + gcol);
+        uv[i] = *reinterpret_cast<const bf16x8*>(gu + tok * N + gcol + 32);
+#pragma unroll
+        for (int q = 0; q < RP / 4; ++q) dtv[i][q] = *reinterpret_cast<const bf16x8*>(dtd + tok * lddtd + q * 8);
+        if (p > 0.f) km[i] = keep_bits ? keep_bits[tok * ld_bits + (chc >> 3)] : dropout_keep8(seed, ((uint64_t)tok * (uint64_t)ff + (uint64_t)chc) >> 2, th);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = step * 64 + idx / (2 * RG), c = idx % (2 * RG);
+      tv[u] = bf16x8{};
+      if (idx < 64 * 2 * RG && r < rows) tv[u] = *reinterpret_cast<const bf16x8*>(G + (t0 + r) * ldg + c * 8);
+    }
+  };
+  if (nsteps > 0) load_step(0);
+  for (int step = 0; step < nsteps; ++step) {
+    // ---- produce the step's tile rows from the operands requested a step ago (lora_up_add_kernel<RP, true>'s arithmetic), one token row
+    //      at a time straight into LDS and d_gu (all four in registers first cost 256 registers per lane: one wave per SIMD)
+    __syncthreads();                                       // the previous step's fragment reads are done (and, first time, `at` is written)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float ac[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ac[j] = 0.f;
+#pragma unroll
+      for (int q = 0; q < RP / 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16x2_t d2 = bf16x2_t{dtv[i][q][2 * r], dtv[i][q][2 * r + 1]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ac[j] = __builtin_amdgcn_fdot2_f32_bf16(a[j][q * 4 + r], d2, ac[j], false);
+        }
+      bf16x8 dgs, dus;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = (float)(bf16_t)ac[j];
+        if (p > 0.f) v = ((km[i] >> j) & 1u) ? (float)(bf16_t)(v * keep_scale) : 0.f;
+        const float df = (float)(bf16_t)((float)dv[i][j] + v);
+        const float gf = (float)gv[i][j], uf = (float)uv[i][j];
+        const float sg = mp_sigmoid_fast(gf);
+        dus[j] = (bf16_t)(df * gf * sg);
+        dgs[j] = (bf16_t)(df * uf * sg * (1.f + gf * (1.f - sg)));
+      }
+      const int r = pr + 16 * i;
+      const int64_t tok = t0 + step * 64 + r;
+      const bool cell_live = step * 64 + r < rows && ch_live;
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((cg ^ (r & 7)) << 4)) = cell_live ? dgs : bf16x8{};
+      *reinterpret_cast<bf16x8*>(xt + r * 512 + ((cu ^ (r & 7)) << 4)) = cell_live ? dus : bf16x8{};
+      if (cell_live) {
+        *reinterpret_cast<bf16x8*>(dgu + tok * N + gcol) = dgs;
+        *reinterpret_cast<bf16x8*>(dgu + tok * N + gcol + 32) = dus;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < (64 * 2 * RG + 255) / 256; ++u) {
+      const int idx = tid + u * 256;
+      const int r = idx / (2 * RG), c = idx % (2 * RG);
+      if (idx < 64 * 2 * RG) *reinterpret_cast<bf16x8*>(gt + r * 128 + ((c ^ (r & 7)) << 4)) = tv[u];
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) load_step(step + 1);            // in flight under this step's MFMAs and the next step's production
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 gf[RG];
+#pragma unroll
+      for (int jf = 0; jf < RG; ++jf) gf[jf] = tn_tr_frag<128>(gt, kp, jf, fr, fq);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const bf16x8 xf = tn_tr_frag<512>(xt, kp, wave * 4 + nf, fr, fq);
+#pragma unroll
+        for (int jf = 0; jf < RG; ++jf) acc[nf][jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[jf], acc[nf][jf], 0, 0, 0);
+      }
+    }
+    f32x4 dacc[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) dacc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int c = kk * 4 + fq;
+      const int xrow = wave * 16 + fr;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + xrow * 512 + ((c ^ (xrow & 7)) << 4));
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        const int arow = rg * 16 + fr;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(at + arow * 512 + ((c ^ (arow & 7)) << 4));
+        dacc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, dacc[rg], 0, 0, 0);
+      }
+    }
+    const int64_t tok = t0 + step * 64 + wave * 16 + fr;
+    if (tok < T) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        *reinterpret_cast<f32x4*>(dt_partial + ((int64_t)blockIdx.x * T + tok) * (16 * RG) + rg * 16 + fq * 4) = dacc[rg];
+    }
+  }
+  float* pout = partial + ((int64_t)blockIdx.y * N) * R;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int jf = 0; jf < RG; ++jf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_base + (wave * 4 + nf) * 16 + fq * 4 + r, j = jf * 16 + fr;
+        if (n < N && j < R) pout[(int64_t)n * R + j] = acc[nf][jf][r];
+      }
+}
+
 // The inverse of lora_pack for gradients: one adapter's slices of the fused group's padded gradients (dB [W, R] rows rows[o] columns k0..,
 // dA^T [fin, R] columns k0..) ADDED into the parameter-shaped gradient tensors (lora_B.grad [fout, r], lora_A.grad [r, fin]) -- the engine's
 // flat buffer; one launch instead of a gather, a transpose-copy and two adds per adapter (192 adapters' worth of 5-us kernels per step).
@@ -1415,6 +1591,34 @@ extern "C" int mp_tn_skinny_down_f32(const void* X, int64_t ldx, const void* G, 
   if (out)
     hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
   return mp_check_launch("mp_tn_skinny_down_f32");
+}
+
+extern "C" int mp_swiglu_bwd_skinny_f32(const void* dact, int64_t lddact, const void* gu, void* dgu, const void* dt_down, int64_t lddtd, const void* AT_down,
+                                        int R_down, float p, uint64_t seed, const uint8_t* keep_bits, int64_t ld_bits, const void* t_gu, int64_t ldg,
+                                        float* out, float* partial, int64_t partial_floats, const void* Bt_gu, int64_t ldb, void* dt_gu, int64_t lddt,
+                                        float* dt_partial, int64_t dt_partial_floats, int64_t tokens, int ff, int R_gu, float scale, float alpha,
+                                        hipStream_t stream) {
+  MP_REQUIRE(tokens > 0 && tokens < (1ll << 31) && ff > 0 && ff % 32 == 0 && (R_down == 8 || R_down == 16) && (R_gu == 8 || R_gu == 16 || R_gu == 32), MP_ERR_SHAPE,
+             "mp_swiglu_bwd_skinny_f32: ff %% 32 == 0, R_down in {8, 16}, R_gu in {8, 16, 32} (got ff %d, R %d / %d)", ff, R_down, R_gu);
+  MP_REQUIRE(lddact % 8 == 0 && lddtd % 8 == 0 && ldg % 8 == 0 && ldb % 8 == 0 && lddt % 4 == 0 && p >= 0.f && p < 1.f && dact && gu && dgu && dt_down && AT_down
+                 && t_gu && Bt_gu && dt_gu && (!keep_bits || (p > 0.f && ld_bits * 8 >= ff)), MP_ERR_ARG, "mp_swiglu_bwd_skinny_f32: bad strides / p / null operand");
+  const int N = 2 * ff;
+  const int chunks = (int)mp_cdiv(tokens, TN_CHUNK), blocks = (int)mp_cdiv(N, 256), rg = (R_gu + 15) / 16;
+  MP_REQUIRE(partial && partial_floats >= (int64_t)chunks * N * R_gu, MP_ERR_WORKSPACE, "mp_swiglu_bwd_skinny_f32: partial needs %lld floats",
+             (long long)((int64_t)chunks * N * R_gu));
+  MP_REQUIRE(dt_partial && dt_partial_floats >= (int64_t)blocks * tokens * 16 * rg, MP_ERR_WORKSPACE, "mp_swiglu_bwd_skinny_f32: dt_partial needs %lld floats",
+             (long long)((int64_t)blocks * tokens * 16 * rg));
+  const dim3 grid((unsigned)blocks, (unsigned)chunks);
+#define MP_GO(RP, RGG) hipLaunchKernelGGL((swiglu_bwd_skinny_kernel<RP, RGG>), grid, dim3(256), 0, stream, (const bf16_t*)dact, lddact, (const bf16_t*)gu, (bf16_t*)dgu, \
+    (const bf16_t*)dt_down, lddtd, (const bf16_t*)AT_down, p, seed, keep_bits, ld_bits, (const bf16_t*)t_gu, ldg, partial, (const bf16_t*)Bt_gu, ldb, dt_partial, tokens, ff, R_gu)
+  if (R_down == 8) { if (rg == 1) MP_GO(4, 1); else MP_GO(4, 2); }
+  else { if (rg == 1) MP_GO(8, 1); else MP_GO(8, 2); }
+#undef MP_GO
+  hipLaunchKernelGGL(lora_down_finish_kernel, GRID1D(tokens * 16), dt_partial, (bf16_t*)dt_gu, lddt, (int)tokens, 16 * rg, blocks, alpha, (const int*)nullptr);
+  const int64_t NR = (int64_t)N * R_gu;
+  if (out)
+    hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)mp_cdiv(NR, 256)), dim3(256), 0, stream, partial, out, NR, chunks, scale);
+  return mp_check_launch("mp_swiglu_bwd_skinny_f32");
 }
 
 extern "C" int mp_ce_rows_bwd(const float* logits, int64_t ldl, const int64_t* labels, const float* gscale, float gconst, void* dlogits,

@@ -355,6 +355,7 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_FUSE_SWSK = os.environ.get("MP_LORA_FUSE_SWIGLU_SKINNY", "1") != "0"   # A/B: 0 = d gate|up written by one kernel, read back by the gate|up adapter's products
 _FUSE_NORM_UP = os.environ.get("MP_LORA_FUSE_NORM_UP", "1") != "0"      # A/B: 0 = mp_lora_up_add_bf16, then mp_rmsnorm_bwd_bf16
 _FUSE_DY = os.environ.get("MP_LORA_FUSE_DY", "1") != "0"                # A/B: 0 = dy B and dy^T t as two kernels, two reads of dy
 _KEEP_BITS = os.environ.get("MP_LORA_KEEP_BITS", "1") != "0"            # A/B: 0 = every kernel regenerates the lora_dropout mask from the seed
@@ -704,7 +705,7 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False, defer_up=False):
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False, defer_up=False, done=None):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
     adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed.  dx = None: nothing trainable lies in front of
     this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
@@ -712,7 +713,9 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=Fal
     # [T, 64] = scaling * dy B: the down-projection kernel with B^T as its matrix (reads dy once; no dropout on this side)
     # partials: the chunk partials are handed on unsummed (ops.SkinnyPartial) — the gradient unpack into the flat buffer adds them up itself
     partials = partials and R <= 32
-    if _FUSE_DY and R <= 32 and dy.stride(0) % 8 == 0 and dy.shape[1] % 8 == 0:
+    if done is not None:
+        dB, dt = done                                          # the kernel that produced dy took both products of it on the way (ops.swiglu_bwd_skinny)
+    elif _FUSE_DY and R <= 32 and dy.stride(0) % 8 == 0 and dy.shape[1] % 8 == 0:
         dB, dt = ops.tn_skinny_down(dy, t, BT, R, lora.scaling, lora.scaling, reduce=not partials)       # both products of dy in one pass over it
     else:
         dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
@@ -802,7 +805,22 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             dy_mlp = dx if rows_last is None else ops.gather_rows_bf16(dx, rows_last)      # the pruned last layer: its MLP saw these rows only
             d_act = ops.gemm(dy_mlp, lw["down_T"])
             d_gu = None
-            if "down" in pad:
+            gu_done = None                                      # (dB, dt) of the gate|up adapter when the one-kernel form below produced them
+            if ("down" in pad and "gu" in pad and _FUSE_SWSK and _FUSE_UP_SWIGLU and _FUSE_DY and pad["down"][4] <= 16 and pad["gu"][4] <= 32
+                    and d_act.stride(0) % 8 == 0 and dy_mlp.stride(0) % 8 == 0 and s["gu"].is_contiguous()):
+                # both adapters: the down adapter's two products of dy, its weight gradient over act, then ONE kernel from d_act to d gate|up
+                # that also takes the gate|up adapter's two products of it (the 225 MB tensor is written once and not read back)
+                _, ATd, _, BTd, Rd, _ = pad["down"]
+                _, _, _, BTg, Rg, _ = pad["gu"]
+                sd = s["seed"] + 1
+                dBd, dtd = ops.tn_skinny_down(dy_mlp, s["t_d"], BTd, Rd, lora.scaling, lora.scaling, reduce=not part_ok)
+                kbd = getattr(lora, "keep_bits", {}).get(sd)
+                dATd = ops.tn_skinny(s["actd"], dtd, Rd, 1.0, lora.p_active, sd, reduce=not part_ok, keep_bits=kbd)
+                take(i, pad["down"], dBd, dATd)
+                d_gu, dBg, dtg = ops.swiglu_bwd_skinny(dtd, ATd, d_act, s["gu"], Rd, lora.p_active, sd, s["t_gu"], BTg, Rg, lora.scaling, lora.scaling,
+                                                       reduce=not part_ok, keep_bits=kbd)
+                gu_done, d_act = (dBg, dtg), None
+            elif "down" in pad:
                 fused = _FUSE_UP_SWIGLU and pad["down"][4] <= 32 and d_act.stride(0) % 8 == 0
                 d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dy_mlp, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok)
                 take(i, pad["down"], dB, dAT)
@@ -820,7 +838,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                 # the adapter's input gradient has one reader, the post-attention norm's backward below: that kernel adds it on its way in
                 defer = (_FUSE_NORM_UP and not stop_here and rows_last is None and d == 4096 and (i, "ln2") not in lora.norm_names
                          and pad["gu"][4] <= 16 and d_h2.stride(0) % 8 == 0)
-                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok, defer_up=defer)
+                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok, defer_up=defer, done=gu_done)
                 if defer:
                     d_h2, up_late = d_h2
                 take(i, pad["gu"], dB, dAT)

@@ -520,6 +520,27 @@ def tn_skinny_down(x, g, Bt, R, scale=1.0, alpha=1.0, reduce=True):
     return (out if reduce else SkinnyPartial(partial, chunks, float(scale), N, int(R))), dt
 
 
+def swiglu_bwd_skinny(dt_down, AT_down, dact, gu, R_down, p, seed, t_gu, Bt_gu, R_gu, scale=1.0, alpha=1.0, reduce=True, keep_bits=None):
+    """lora_up_add_swiglu_bwd(dt_down, AT_down, dact, gu, R_down, p, seed) and tn_skinny_down(that, t_gu, Bt_gu, R_gu, scale, alpha) in one kernel
+    (mp_swiglu_bwd_skinny_f32), the same bits: -> (d gate|up [T, 2 ff] bf16, dB_gu (or its chunk partials), dt_gu [T, 64] bf16)."""
+    _chk(dact, torch.bfloat16, "swiglu_bwd_skinny.dact"); _chk(gu, torch.bfloat16, "swiglu_bwd_skinny.gu"); _chk(t_gu, torch.bfloat16, "swiglu_bwd_skinny.t")
+    T, ff = dact.shape
+    N, rg = 2 * ff, (R_gu + 15) // 16
+    assert AT_down.shape == (ff, 64) and AT_down.is_contiguous() and gu.shape == (T, N) and gu.is_contiguous() and dact.stride(1) == 1
+    assert R_gu <= 32 and t_gu.shape[1] >= 16 * rg and Bt_gu.shape[1] == N and Bt_gu.shape[0] >= 16 * rg and Bt_gu.stride(1) == 1 and t_gu.stride(1) == 1
+    chunks, blocks = (T + 255) // 256, (N + 255) // 256
+    dgu = torch.empty_like(gu)
+    partial = torch.empty(chunks * N * R_gu, dtype=torch.float32, device=dact.device)
+    dtp = torch.empty(blocks * T * 16 * rg, dtype=torch.float32, device=dact.device)
+    dt = torch.empty((T, 64), dtype=torch.bfloat16, device=dact.device)
+    out = torch.empty((N, R_gu), dtype=torch.float32, device=dact.device) if reduce else None
+    kb = keep_bits if p > 0 else None
+    lib().call("mp_swiglu_bwd_skinny_f32", _p(dact), dact.stride(0), _p(gu), _p(dgu), _p(dt_down), dt_down.stride(0), _p(AT_down), int(R_down), float(p),
+               int(seed), _p(kb), kb.stride(0) if kb is not None else 0, _p(t_gu), t_gu.stride(0), _p(out), _p(partial), partial.numel(), _p(Bt_gu),
+               Bt_gu.stride(0), _p(dt), dt.stride(0), _p(dtp), dtp.numel(), T, ff, int(R_gu), float(scale), float(alpha), _stream())
+    return dgu, (out if reduce else SkinnyPartial(partial, chunks, float(scale), N, int(R_gu))), dt
+
+
 def lora_grad_unpack_partials(dB, dAT, rows, k0, gB, gA):
     """lora_grad_unpack from two SkinnyPartial (mp_lora_grad_unpack_partials_f32): the chunk sums happen in the unpack itself."""
     fout, r = gB.shape

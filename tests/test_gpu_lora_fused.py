@@ -119,3 +119,29 @@ def test_rmsnorm_bwd_with_the_adapter_term_folded_in_is_bit_identical(T, R, p, w
         ops.lora_down(x, A, torch.empty((T, 64), dtype=torch.bfloat16, device=dev), R, p, seed, keep_bits=kb)     # the forward leaves the mask bytes
         got2 = ops.rmsnorm_bwd_up(x, w, dy, 1e-5, dt, AT, R, p, seed, add=add, keep_bits=kb)
         assert torch.equal(got2.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("T,ff,Rd,Rg,p", [(300, 512, 8, 16, 0.0), (1000, 11008, 8, 16, 0.05), (65, 544, 16, 32, 0.1), (777, 1024, 8, 8, 0.05)])
+def test_swiglu_bwd_and_both_gate_up_adapter_products_in_one_kernel(T, ff, Rd, Rg, p):
+    """Round 5: mp_swiglu_bwd_skinny_f32 = mp_lora_up_add_swiglu_bwd_bf16 (d gate|up from d_act, the down adapter's term and gate|up) followed
+    by mp_tn_skinny_down_f32 on its result (the gate|up adapter's dB and dt) — d gate|up is produced in the tile the products read: same bits."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T + ff)
+    dact = torch.randn(T, ff, generator=g, device=dev).to(torch.bfloat16)
+    gu = torch.randn(T, 2 * ff, generator=g, device=dev).to(torch.bfloat16)
+    dtd = (torch.randn(T, 64, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    ATd = torch.zeros(ff, 64, dtype=torch.bfloat16, device=dev); ATd[:, :Rd] = (torch.randn(ff, Rd, generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    tg = (torch.randn(T, 64, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    Bt = torch.zeros(64, 2 * ff, dtype=torch.bfloat16, device=dev); Bt[:Rg] = (torch.randn(Rg, 2 * ff, generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    seed = 31337
+    ref_dgu = ops.lora_up_add_swiglu_bwd(dtd, ATd, dact, gu, Rd, p, seed)
+    ref_dB, ref_dt = ops.tn_skinny_down(ref_dgu, tg, Bt, Rg, 2.0, 2.0)
+    dgu, dB, dt = ops.swiglu_bwd_skinny(dtd, ATd, dact, gu, Rd, p, seed, tg, Bt, Rg, 2.0, 2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(dgu.view(torch.int16), ref_dgu.view(torch.int16)), f"{(dgu != ref_dgu).sum().item()} of {dgu.numel()} d gate|up values differ"
+    assert torch.equal(dB, ref_dB) and torch.equal(dt, ref_dt) and dB.abs().max() > 0 and dt.float().abs().max() > 0
+    if p > 0 and ff % 256 == 0:
+        kb = ops.keep_bits_for(dact)
+        ops.lora_down(dact, ATd.t().contiguous(), torch.empty((T, 64), dtype=torch.bfloat16, device=dev), Rd, p, seed, keep_bits=kb)
+        dgu2, dB2, dt2 = ops.swiglu_bwd_skinny(dtd, ATd, dact, gu, Rd, p, seed, tg, Bt, Rg, 2.0, 2.0, keep_bits=kb)
+        assert torch.equal(dgu2.view(torch.int16), ref_dgu.view(torch.int16)) and torch.equal(dB2, ref_dB) and torch.equal(dt2, ref_dt)
