@@ -145,3 +145,30 @@ def test_swiglu_bwd_and_both_gate_up_adapter_products_in_one_kernel(T, ff, Rd, R
         ops.lora_down(dact, ATd.t().contiguous(), torch.empty((T, 64), dtype=torch.bfloat16, device=dev), Rd, p, seed, keep_bits=kb)
         dgu2, dB2, dt2 = ops.swiglu_bwd_skinny(dtd, ATd, dact, gu, Rd, p, seed, tg, Bt, Rg, 2.0, 2.0, keep_bits=kb)
         assert torch.equal(dgu2.view(torch.int16), ref_dgu.view(torch.int16)) and torch.equal(dB2, ref_dB) and torch.equal(dt2, ref_dt)
+
+
+@pytest.mark.parametrize("T,fin,fout,r,k0,R", [(5112, 4096, 11008, 8, 8, 16), (600, 1024, 512, 8, 0, 8), (300, 512, 768, 16, 16, 32), (257, 520, 264, 6, 0, 8)])
+def test_lora_grad_unpack_from_chunk_partials(T, fin, fout, r, k0, R):
+    """mp_lora_grad_unpack_partials_f32: gB += scaleB * sum_c dBp[c][rows[o], k0 + j], gA += scaleA * sum_c dATp[c][col, k0 + i], chunks ascending.
+    (A four-ranks-per-thread form of the kernel — 16-byte loads instead of one float per 64-byte line for gA — was measured in round 5: the
+    LoRA step did not move, 123.9 against 124.0 ms, and it was not kept.)"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T + fin)
+    W = fout + 40                                                    # rows of the fused group's padded B
+    rows = torch.randperm(W, generator=g, device=dev)[:fout].sort().values
+    x = torch.randn(T, W, generator=g, device=dev).to(torch.bfloat16)
+    t = torch.randn(T, 64, generator=g, device=dev).to(torch.bfloat16)
+    xin = torch.randn(T, fin, generator=g, device=dev).to(torch.bfloat16)
+    dB = ops.tn_skinny(x, t, R, 1.5, reduce=False)
+    dAT = ops.tn_skinny(xin, t, R, 1.0, reduce=False)
+    gB = torch.randn(fout, r, generator=g, device=dev); gA = torch.randn(r, fin, generator=g, device=dev)
+    wantB, wantA = gB.clone(), gA.clone()
+    sB = torch.zeros(W * R, device=dev); sA = torch.zeros(fin * R, device=dev)
+    for c in range(dB.chunks):
+        sB = sB + dB.partial.view(dB.chunks, -1)[c]; sA = sA + dAT.partial.view(dAT.chunks, -1)[c]
+    wantB += 1.5 * sB.view(W, R)[rows][:, k0:k0 + r]
+    wantA += sA.view(fin, R)[:, k0:k0 + r].t()
+    ops.lora_grad_unpack_partials(dB, dAT, rows, k0, gB, gA)
+    torch.cuda.synchronize()
+    for got, want in ((gB, wantB), (gA, wantA)):
+        assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-7      # (a fused multiply-add against a multiply and an add)
