@@ -1,4 +1,6 @@
 #!/bin/bash
+# LoRA stage-III step: the adapter-branch switches of round 5 (MP_LORA_FUSE_SWIGLU_SKINNY, MP_LORA_FUSE_NORM_UP, MP_LORA_FUSE_DY, MP_LORA_KEEP_BITS) and the
+# pruned last layer (MP_PRUNE_LAST_MLP): tests, the newest switch off / on twice, then everything of the round off — same box
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 1200 python -m pytest tests/test_gpu_lora_fused.py tests/test_gpu_prune_last_mlp.py -x -q -m gpu 2>&1 | tail -4
 timeout 1500 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "lora" 2>&1 | grep -E "passed|failed|Error" | tail -4

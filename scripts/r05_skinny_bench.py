@@ -71,3 +71,42 @@ for N in (4096, 11008, 22016):
 for k, v in res.items():
     print(f"{k:50s} {v['us']:8.1f} us  {v['GBps']:8.1f} GB/s")
 json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_skinny_bench.json"), "w"), indent=1)
+
+
+# ---- the two fused passes of the backward against the kernels they replace (T = 5112)
+def _timed_fixed(fn, n, reps=5):
+    best = 1e9
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); s.record()
+        for i in range(n):
+            fn(i)
+        e.record(); torch.cuda.synchronize(); best = min(best, s.elapsed_time(e) * 1e3 / n)
+    return best
+
+
+def fused_passes():
+    d, R, n = 4096, 16, 6
+    mk = lambda k, *s: [torch.randn(*s, generator=g, device=dev).to(torch.bfloat16) for _ in range(k)]
+    xs, dys, adds, dts = mk(n, T, d), mk(n, T, d), mk(n, T, d), mk(n, T, 64)
+    w = torch.ones(d, device=dev); AT = mk(1, d, 64)[0]
+    kb = [torch.randint(0, 256, (T, d // 8), dtype=torch.uint8, device=dev) for _ in range(n)]
+    for p in (0.0, 0.05):
+        a_ = _timed_fixed(lambda i: ops.rmsnorm_bwd(xs[i], w, dys[i], 1e-5, add=adds[i]), n)
+        b_ = _timed_fixed(lambda i: ops.lora_up_add(dts[i], AT, dys[i], R, p, 7), n)
+        c_ = _timed_fixed(lambda i: ops.rmsnorm_bwd_up(xs[i], w, dys[i], 1e-5, dts[i], AT, R, p, 7, add=adds[i], keep_bits=kb[i] if p > 0 else None), n)
+        print(f"rmsnorm_bwd + lora_up_add p={p}: {a_:.1f} + {b_:.1f} us; rmsnorm_bwd_up{' (mask bytes)' if p > 0 else ''} {c_:.1f} us")
+    del xs, dys, adds, dts, kb
+    ff, n = 11008, 3
+    dact, gu, dtd, tg = mk(n, T, ff), mk(n, T, 2 * ff), mk(n, T, 64), mk(n, T, 64)
+    ATd = mk(1, ff, 64)[0]; Bt = mk(1, 64, 2 * ff)[0]
+    for p in (0.0, 0.05):
+        def two(i):
+            dg = ops.lora_up_add_swiglu_bwd(dtd[i], ATd, dact[i], gu[i], 8, p, 7)
+            ops.tn_skinny_down(dg, tg[i], Bt, 16, 2.0, 2.0, reduce=False)
+        a_ = _timed_fixed(two, n)
+        b_ = _timed_fixed(lambda i: ops.swiglu_bwd_skinny(dtd[i], ATd, dact[i], gu[i], 8, p, 7, tg[i], Bt, 16, 2.0, 2.0, reduce=False), n)
+        print(f"lora_up_add_swiglu_bwd + tn_skinny_down p={p}: {a_:.1f} us; swiglu_bwd_skinny {b_:.1f} us")
+
+
+fused_passes()
