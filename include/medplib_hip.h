@@ -370,12 +370,13 @@ int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void*
                           int64_t dq_sb, int64_t dq_ss, void* dK, int64_t dk_sb, int64_t dk_ss, void* dV, int64_t dv_sb, int64_t dv_ss,
                           const uint8_t* key_valid, int B, int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream);
 /* The same with delta computed inside the dQ kernel from the forward's output O (no separate pass over O and dO); delta_ws is a
- * [B*H, Sq] fp32 workspace the dQ kernel fills for the dK/dV kernel that follows it on the stream. */
+ * [B*H, Sq] fp32 workspace the dQ kernel fills for the dK/dV kernel that follows it on the stream.  rope_cos / rope_sin (optional, [positions, D / 2] fp32): dQ and dK are stored ROTATED by the given tables at the row's position — with the
+ * forward's cos and the NEGATED sin this is the transpose of RoPE, i.e. mp_rope_qk_bf16 on the result folded into the store (the same bits). */
 int mp_attention_bwd_fused_bf16(const void* Q, int64_t q_sb, int64_t q_ss, const void* K, int64_t k_sb, int64_t k_ss, const void* V,
                                 int64_t v_sb, int64_t v_ss, const void* O, int64_t o_sb, int64_t o_ss, const void* dO, int64_t do_sb,
                                 int64_t do_ss, const float* lse2, float* delta_ws, void* dQ, int64_t dq_sb, int64_t dq_ss, void* dK,
                                 int64_t dk_sb, int64_t dk_ss, void* dV, int64_t dv_sb, int64_t dv_ss, const uint8_t* key_valid, int B,
-                                int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream);
+                                int H, int Sq, int Sk, int D, int causal, float scale, const float* rope_cos, const float* rope_sin, hipStream_t stream);
 
 /* ---- decoder backward pieces (LoRA training; train_ds_medplib.py:262-303, scripts/train_stage3.sh) -------- */
 /* Autograd of LlamaRMSNorm w.r.t. its input: dx = rs * (dy*w - xhat * mean(dy*w*xhat)) [+ add], xhat = x*rs; rs_out (optional, [rows])

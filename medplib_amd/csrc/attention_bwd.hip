@@ -44,6 +44,7 @@ struct AttnBwdArgs {
   float scale;
   const bf16_t* O; int64_t o_sb, o_ss;              // optional forward output: the dQ kernel then computes delta itself and writes it to delta_out
   float* delta_out;
+  const float* rope_cos; const float* rope_sin;      // optional [positions, D / 2] fp32: dQ and dK are stored rotated (see the store)
 };
 
 // XOR key of a tile row's 16-byte chunks.  A tile is read BOTH ways: row-major (ds_read_b128: 16 lanes = 16 consecutive rows, one chunk
@@ -349,12 +350,34 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(AttnBwdArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int ri = rw0 + j * 16 + fr;
     if (ri >= Sres) continue;
+    if (a.rope_cos) {
+      // Round 5: the transpose of RoPE applied to dQ / dK on the way out (the LoRA backward ran mp_rope_qk_bf16 with -sin over the fused
+      // [T, 3 d] gradient right after this kernel: a read-modify-write of 2/3 of it per layer).  Dims d and d + D/2 of a row are fragments
+      // n and n + NF/2 of the same lane and register, the position is the resident row.  Same values as the two kernels: the gradient is
+      // rounded to bf16 first (what this kernel stored), then lo' = lo cos - hi sin, hi' = hi cos + lo sin with every product and sum
+      // rounded to fp32 on its own (what rope_qk_bf16_kernel compiles to: checked on the ties where a fused form differs), rounded to bf16.
+      const float* cs_row = a.rope_cos + (int64_t)ri * (D / 2);
+      const float* sn_row = a.rope_sin + (int64_t)ri * (D / 2);
+#pragma unroll
+      for (int n = 0; n < NF / 2; ++n) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_row + n * 16 + fq * 4), sn = *reinterpret_cast<const f32x4*>(sn_row + n * 16 + fq * 4);
+        bf16x4 vlo, vhi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lo = (float)(bf16_t)(o1[n][j][r] * a.scale), hi = (float)(bf16_t)(o1[n + NF / 2][j][r] * a.scale);
+          vlo[r] = (bf16_t)__fsub_rn(__fmul_rn(lo, cs[r]), __fmul_rn(hi, sn[r]));      // rope_qk_bf16_kernel rounds both products (no fused form)
+          vhi[r] = (bf16_t)__fadd_rn(__fmul_rn(hi, cs[r]), __fmul_rn(lo, sn[r]));
+        }
+        *reinterpret_cast<bf16x4*>(O1 + (int64_t)ri * o1_ss + n * 16 + fq * 4) = vlo;
+        *reinterpret_cast<bf16x4*>(O1 + (int64_t)ri * o1_ss + D / 2 + n * 16 + fq * 4) = vhi;
+      }
+    }
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
       bf16x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o1[n][j][r] * a.scale);
-      *reinterpret_cast<bf16x4*>(O1 + (int64_t)ri * o1_ss + n * 16 + fq * 4) = v;
+      if (!a.rope_cos) *reinterpret_cast<bf16x4*>(O1 + (int64_t)ri * o1_ss + n * 16 + fq * 4) = v;
       if (DKV) {
         bf16x4 w;
 #pragma unroll
@@ -440,7 +463,7 @@ extern "C" int mp_attention_bwd_bf16(const void* Q, int64_t q_sb, int64_t q_ss, 
   MP_REQUIRE(lse2 && delta, MP_ERR_ARG, "mp_attention_bwd_bf16: needs the forward's log-sum-exp and delta");
   AttnBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, lse2, delta,
                 q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, do_sb, do_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, key_valid, B, H, Sq, Sk, causal, scale,
-                nullptr, 0, 0, nullptr};
+                nullptr, 0, 0, nullptr, nullptr, nullptr};
   return D == 64 ? launch_bwd<64>(a, stream) : launch_bwd<128>(a, stream);
 }
 
@@ -448,14 +471,16 @@ extern "C" int mp_attention_bwd_fused_bf16(const void* Q, int64_t q_sb, int64_t 
                                            int64_t v_sb, int64_t v_ss, const void* O, int64_t o_sb, int64_t o_ss, const void* dO, int64_t do_sb,
                                            int64_t do_ss, const float* lse2, float* delta_ws, void* dQ, int64_t dq_sb, int64_t dq_ss, void* dK,
                                            int64_t dk_sb, int64_t dk_ss, void* dV, int64_t dv_sb, int64_t dv_ss, const uint8_t* key_valid, int B,
-                                           int H, int Sq, int Sk, int D, int causal, float scale, hipStream_t stream) {
+                                           int H, int Sq, int Sk, int D, int causal, float scale, const float* rope_cos, const float* rope_sin,
+                                           hipStream_t stream) {
   MP_REQUIRE(D == 64 || D == 128, MP_ERR_SHAPE, "mp_attention_bwd_fused_bf16: head_dim %d unsupported (64/128)", D);
+  MP_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr) && (!rope_cos || Sq == Sk), MP_ERR_ARG, "mp_attention_bwd_fused_bf16: rope_cos / rope_sin come together (self-attention)");
   MP_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, MP_ERR_SHAPE, "mp_attention_bwd_fused_bf16: bad shape");
   MP_REQUIRE(q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && do_ss % 8 == 0 && o_ss % 8 == 0 && dq_ss % 4 == 0 && dk_ss % 4 == 0 && dv_ss % 4 == 0,
              MP_ERR_SHAPE, "mp_attention_bwd_fused_bf16: input sequence strides must be multiples of 8 elements, output ones of 4");
   MP_REQUIRE(lse2 && delta_ws && O, MP_ERR_ARG, "mp_attention_bwd_fused_bf16: needs the forward's output, its log-sum-exp and a [B*H, Sq] fp32 workspace");
   AttnBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, lse2, delta_ws,
                 q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, do_sb, do_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, key_valid, B, H, Sq, Sk, causal, scale,
-                (const bf16_t*)O, o_sb, o_ss, delta_ws};
+                (const bf16_t*)O, o_sb, o_ss, delta_ws, rope_cos, rope_sin};
   return D == 64 ? launch_bwd<64>(a, stream) : launch_bwd<128>(a, stream);
 }

@@ -355,6 +355,7 @@ def _ext_rows(T, K, dev):
     return buf, buf[:, :K], buf[:, K:]
 
 
+_ROPE_IN_ATTN_BWD = os.environ.get("MP_ATTN_BWD_ROPE", "1") != "0"      # A/B: 0 = mp_rope_qk_bf16 over the fused gradient after the attention backward
 _FUSE_SWSK = os.environ.get("MP_LORA_FUSE_SWIGLU_SKINNY", "1") != "0"   # A/B: 0 = d gate|up written by one kernel, read back by the gate|up adapter's products
 _FUSE_NORM_UP = os.environ.get("MP_LORA_FUSE_NORM_UP", "1") != "0"      # A/B: 0 = mp_lora_up_add_bf16, then mp_rmsnorm_bwd_bf16
 _FUSE_DY = os.environ.get("MP_LORA_FUSE_DY", "1") != "0"                # A/B: 0 = dy B and dy^T t as two kernels, two reads of dy
@@ -865,10 +866,13 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3, partials=part_ok)
             take(i, pad["o"], dB, dAT)
         q5 = s["qkv"].unflatten(0, (B, S)).unflatten(2, (3, H, D))
+        # the transpose of a rotation is the rotation by -theta: the attention backward stores dq / dk rotated (same bits as mp_rope_qk_bf16 on its result)
+        rot = _ROPE_IN_ATTN_BWD and D == 128 and s["attn"].stride(-2) % 8 == 0
         _, _, _, dqkv = ops.attention_bwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], s["attn"], d_attn.view(B, S, d), s["lse"], causal=True,
-                                          key_valid=saved["key_valid"])
+                                          key_valid=saved["key_valid"], rope=(llm.cos, llm.sin_neg) if rot else None)
         dqkv = dqkv.flatten(0, 1).flatten(1)                    # [T, 3d] view of the (row-padded) buffer
-        ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)           # the transpose of a rotation is the rotation by -theta
+        if not rot:
+            ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)
         d_h1 = ops.gemm(dqkv, lw["qkv_T"])
         if "qkv" in pad:
             d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2, partials=part_ok)

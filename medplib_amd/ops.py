@@ -391,9 +391,10 @@ def attention_fwd_lse(q, k, v, causal=True, key_valid=None, scale=None, out=None
     return out, lse2
 
 
-def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=None, fused_delta=True):
+def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=None, fused_delta=True, rope=None):
     """Backward of softmax(scale q k^T + mask) v.  q,k,v [B,S,H,D] bf16 views, out / d_out [B,Sq,H*D] bf16, lse2 from attention_fwd_lse.
     fused_delta: delta = rowsum(dO o O) inside the dQ kernel (default) instead of the separate mp_attention_delta_bf16 pass.
+    rope = (cos, sin) fp32 [positions, D / 2]: dq and dk come back rotated by them (pass the negated sin for the transpose of RoPE).
     -> (dq, dk, dv, dqkv): [B,S,H,D] views of one [B,S,3,H,D] buffer (the layout of the fused qkv projection output) and the buffer."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
@@ -408,8 +409,9 @@ def attention_bwd(q, k, v, out, d_out, lse2, causal=True, key_valid=None, scale=
         lib().call("mp_attention_bwd_fused_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0),
                    v.stride(1), _p(out), out.stride(0), out.stride(1), _p(d_out), d_out.stride(0), d_out.stride(1), _p(lse2), _p(delta),
                    _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0), dv.stride(1),
-                   _p(key_valid), B, H, Sq, Sk, D, int(bool(causal)), sc, _stream())
+                   _p(key_valid), B, H, Sq, Sk, D, int(bool(causal)), sc, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None, _stream())
         return dq, dk, dv, dqkv
+    assert rope is None, "attention_bwd: the rotated store needs the fused-delta form"
     lib().call("mp_attention_delta_bf16", _p(out), out.stride(0), out.stride(1), _p(d_out), d_out.stride(0), d_out.stride(1), _p(delta),
                B, H, Sq, D, _stream())
     lib().call("mp_attention_bwd_bf16", _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),

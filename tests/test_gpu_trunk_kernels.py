@@ -546,6 +546,34 @@ def test_attention_backward_vs_autograd(dev, B, H, S, D, ragged):
             assert float(dk[0, S - 17:].abs().max()) == 0.0 and float(dv[0, S - 17:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,S,ragged", [(2, 3, 150, True), (1, 2, 639, False), (3, 2, 64, False)])
+def test_attention_backward_stores_dq_dk_rotated(dev, B, H, S, ragged):
+    """Round 5: mp_attention_bwd_fused_bf16 with rope tables = the same call without them followed by mp_rope_qk_bf16 over the fused gradient
+    (the LoRA backward's transpose of RoPE, folded into the store of dQ / dK): the same bits, dV untouched."""
+    from medplib_amd import ops
+    D = 128
+    g = torch.Generator().manual_seed(900 + S)
+    qkv = (torch.randn(B, S, 3, H, D, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    d_out = torch.randn(B, S, H * D, generator=g).to(torch.bfloat16).to(dev)
+    kvd = None
+    if ragged:
+        kv = torch.ones(B, S, dtype=torch.uint8); kv[0, S - 17:] = 0; kvd = kv.to(dev)
+    ang = torch.rand(S, D // 2, generator=g) * 6.28
+    cos_t, sin_neg = torch.cos(ang).to(dev).contiguous(), (-torch.sin(ang)).to(dev).contiguous()
+    out, lse2 = ops.attention_fwd_lse(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True, key_valid=kvd)
+    _, _, dv0, ref = ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, d_out, lse2, causal=True, key_valid=kvd)
+    ref2 = ref.flatten(0, 1).flatten(1)
+    plain = ref2.clone()
+    ops.rope_qk_(ref2, cos_t, sin_neg, S, H, D)
+    _, _, dv1, got = ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, d_out, lse2, causal=True, key_valid=kvd, rope=(cos_t, sin_neg))
+    got2 = got.flatten(0, 1).flatten(1)
+    torch.cuda.synchronize()
+    n = 3 * H * D
+    assert torch.equal(got2[:, :n].view(torch.int16), ref2[:, :n].view(torch.int16)), f"{(got2[:, :n] != ref2[:, :n]).sum().item()} values differ"
+    assert not torch.equal(ref2[:, :2 * H * D], plain[:, :2 * H * D])              # the rotation is not a no-op here
+    assert torch.equal(dv0, dv1)
+
+
 def test_decoder_backward_row_kernels(dev):
     """rmsnorm_bwd / swiglu_pair fwd+bwd / tn_skinny / ce_rows_bwd / dropout vs torch autograd on the CPU (fp32 math on the same
     bf16-rounded inputs; outputs rounded to bf16 once: 1 bf16 ulp of the output scale + fp32 noise)."""
