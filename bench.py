@@ -36,10 +36,10 @@ def pruned_tflop_per_step(model, cfg, lora):
     """TFLOP per step the last decoder layer's MLP does NOT execute because nothing reads those rows (medplib.model_forward: the MLP of
     the last layer runs on the supervised + <SEG> rows; MP_PRUNE_LAST_MLP=0 turns that off) — taken out of `model_tflops_per_gpu`, which
     therefore counts executed algorithmic work.  -> (TFLOP, "n of T" text or None)."""
-    nr = getattr(model.model.llm, "needed_rows", None)
+    nr = getattr(model, "last_pruned", None)
     if nr is None:
         return 0.0, None
-    n, T = int(nr[0].numel()), int(nr[1].numel())
+    n, T = nr
     per_row = 6.0 * cfg.hidden_size * cfg.intermediate_size            # gate, up, down: 2 flop per multiply-add
     return (T - n) * per_row * (2 if lora else 1) / 1e12, f"{n} of {T}"     # with adapters also the three input-gradient GEMMs
 

@@ -167,6 +167,7 @@ class MedPLIBForCausalLM(nn.Module):
         self._tail_stream_obj = None
         self.active_tail_stream = None
         self.capture_intermediates = False      # tests: keep the trunk outputs that feed the trainable tail
+        self.last_pruned = None                 # (rows, of rows) the last decoder layer's MLP ran on in the latest training forward, or None
         self.captured = {}
 
     # ------------------------------------------------------------------ plumbing
@@ -587,6 +588,10 @@ class MedPLIBForCausalLM(nn.Module):
             with torch.no_grad():
                 last_hidden, aux_sum, _ = LL.forward_train(m.llm, embeds, key_valid)
                 ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, [aux_sum] if m.llm.moe_layers else [])
+        # the row set belonged to THIS pass through the stack: a later direct call of the stack (evaluate(), a test) computes every row
+        nr = m.llm.needed_rows
+        self.last_pruned = (int(nr[0].numel()), int(nr[1].numel())) if nr is not None else None      # (rows the last layer's MLP ran on, rows of the batch): bench.py reports it
+        m.llm.needed_rows = None
         if not seg_flag:
             z = torch.zeros(1, dtype=torch.float32, device=dev)
             ce_w = ce * cfg.ce_loss_weight if ce.requires_grad else ops.mean_plus(ce, cfg.ce_loss_weight)          # ce * ce_loss_weight

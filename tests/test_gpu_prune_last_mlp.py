@@ -32,8 +32,9 @@ def _run(dev, cfg, W, batch, prune, lora_kw=None, adapter_init=None):
         gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
         gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
         out = eng(**gb)
-        active = m.model.llm.needed_rows is not None
-        n_rows = int(m.model.llm.needed_rows[0].numel()) if active else 0
+        active = m.last_pruned is not None
+        n_rows = m.last_pruned[0] if active else 0
+        assert m.model.llm.needed_rows is None                       # the row set does not outlive the pass it was made for
         eng.backward(out["loss"])
         torch.cuda.synchronize()
         losses = {k: out[k].detach().float().cpu().clone() for k in O.LOSS_KEYS}
