@@ -99,6 +99,7 @@ class LoRAState(torch.nn.Module):
         self._bufs = {}
         self.ext = {}                                           # (layer, group) -> extended weight [out, in + 64] (enable_lora)
         self.p_active = self.p                                  # dropout in effect: p while training, 0 in eval (set per forward)
+        self.keep_bits = {}                                     # seed -> lora_dropout mask bytes the forward left for the same step's backward
 
     def _modules_of(self, i, t):
         if i in self.moe_layers and t in MLP_TARGETS:
@@ -721,7 +722,7 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=Fal
     else:
         dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
         dB = ops.tn_skinny(dy, t, R, lora.scaling, reduce=not partials)                 # [out, R] = scaling * dy^T t
-    kb = getattr(lora, "keep_bits", {}).get(seed)              # the forward's mask bytes (None: regenerate from the seed)
+    kb = lora.keep_bits.get(seed)                              # the forward's mask bytes (None: regenerate from the seed)
     dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials, keep_bits=kb)        # [in, R]  = dropout(x)^T (scaling * dy B)
     if dx is None:
         return None, dB, dAT
@@ -815,7 +816,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                 _, _, _, BTg, Rg, _ = pad["gu"]
                 sd = s["seed"] + 1
                 dBd, dtd = ops.tn_skinny_down(dy_mlp, s["t_d"], BTd, Rd, lora.scaling, lora.scaling, reduce=not part_ok)
-                kbd = getattr(lora, "keep_bits", {}).get(sd)
+                kbd = lora.keep_bits.get(sd)
                 dATd = ops.tn_skinny(s["actd"], dtd, Rd, 1.0, lora.p_active, sd, reduce=not part_ok, keep_bits=kbd)
                 take(i, pad["down"], dBd, dATd)
                 d_gu, dBg, dtg = ops.swiglu_bwd_skinny(dtd, ATd, d_act, s["gu"], Rd, lora.p_active, sd, s["t_gu"], BTg, Rg, lora.scaling, lora.scaling,
