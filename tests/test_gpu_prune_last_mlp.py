@@ -47,10 +47,10 @@ def _run(dev, cfg, W, batch, prune, lora_kw=None, adapter_init=None):
         llama_lora._PRUNE_ROWS = True
 
 
-def _long_batch(cfg, B, seed):
+def _long_batch(cfg, B, seed, ragged=False):
     """make_batch with most of the answer tokens unsupervised, so the read rows are a minority of the sequence (as in the real data:
     ~1 % of 5112 rows at the benchmark's shapes)."""
-    batch = OM.make_batch(cfg, B, seed=seed)
+    batch = OM.make_batch(cfg, B, seed=seed, ragged=ragged)
     lab = batch["labels"].clone()
     for b in range(B):
         sup = (lab[b] != -100).nonzero().flatten()
@@ -60,11 +60,11 @@ def _long_batch(cfg, B, seed):
     return batch
 
 
-@pytest.mark.parametrize("moe", [True, False])
-def test_frozen_trunk_last_layer_mlp_on_read_rows_is_bit_identical(dev, moe):
+@pytest.mark.parametrize("moe,ragged", [(True, False), (False, False), (True, True)])
+def test_frozen_trunk_last_layer_mlp_on_read_rows_is_bit_identical(dev, moe, ragged):
     cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2)
     W = OM.init_hf_weights(cfg)
-    batch = _long_batch(cfg, 3, seed=11)
+    batch = _long_batch(cfg, 4 if ragged else 3, seed=11, ragged=ragged)
     l0, g0, a0, _ = _run(dev, cfg, W, batch, prune=False)
     l1, g1, a1, n1 = _run(dev, cfg, W, batch, prune=True)
     assert not a0 and a1 and n1 > 0, "the pruned path did not engage: the test would be vacuous"    # (the dense frozen trunk ignores the row set)
@@ -76,11 +76,12 @@ def test_frozen_trunk_last_layer_mlp_on_read_rows_is_bit_identical(dev, moe):
     print(f"frozen MoE trunk: {n1} read rows; {len(l0)} losses and {len(g0)} gradients bit-identical")
 
 
-@pytest.mark.parametrize("targets,p", [("gate_proj,up_proj,down_proj", 0.0), ("q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj", 0.0)])
-def test_lora_last_layer_mlp_on_read_rows(dev, targets, p):
+@pytest.mark.parametrize("targets,p,ragged", [("gate_proj,up_proj,down_proj", 0.0, False), ("q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj", 0.0, False),
+                                              ("gate_proj,up_proj,down_proj", 0.0, True)])      # ragged: right-padded samples (key padding mask on)
+def test_lora_last_layer_mlp_on_read_rows(dev, targets, p, ragged):
     cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=2)
     W = OM.init_hf_weights(cfg)
-    batch = _long_batch(cfg, 3, seed=12)
+    batch = _long_batch(cfg, 4 if ragged else 3, seed=12, ragged=ragged)
 
     def init(lora):
         g = torch.Generator().manual_seed(31)
