@@ -15,8 +15,11 @@
 // Inter-workgroup visibility follows the microarchitecture guide's XCD-hierarchical barrier: every wave drains its stores, the last
 // workgroup of an XCD issues the agent-scope release (L2 write-back) and meets the other XCDs on a top counter, everyone polls ONE word
 // relaxed with s_sleep, then ONE agent-scope acquire (L1 invalidate) + __syncthreads covers the workgroup.  Data produced inside the launch is never read through const __restrict__
-// pointers (no scalar-cache path).  The spin is bounded: a barrier that cannot complete within tens of seconds sets sync[1] and traps the launch.
+// pointers (no scalar-cache path).  The spin is bounded: a barrier that cannot complete within tens of seconds sets sync[1] and every workgroup leaves
+// the launch (no trap); the host reads sync[1] back and falls back to the op-by-op tail.
 #include "common.h"
+
+int mp_device_cus();            // gemm256_bf16.hip (cached per device)
 
 namespace {
 
@@ -581,52 +584,64 @@ __device__ void copy2d_tile(const TailOp& g, const Slots& S, int tile) {
 // (their own CU's L1).  Eight write-backs and eight pollers of the top word per barrier instead of 256 of each.
 // sync words: [0] top counter, [1] give-up flag, [2] prologue counter, [8..15] per-XCD arrivals, [16..23] per-XCD generation, [24..31] members.
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// Bounded poll.  A barrier that cannot complete (a workgroup of the grid never became resident within tens of seconds) sets the give-up flag
+// and returns false; every other poller sees the flag within 256 polls and returns false too, so the launch ENDS (no trap: the context stays
+// usable) with sync[1] != 0, which the host reads back and treats as "this launch's results are void" (medplib_amd/tail_program.py falls
+// back to the op-by-op tail from then on).
 __device__ __forceinline__ bool spin_until(unsigned* w, unsigned target, unsigned* flag) {
   unsigned spins = 0;
   while (__hip_atomic_load(w, RLX_AGENT) < target) {
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1u << 24)) {          // tens of seconds: a workgroup of this grid never became resident.  Say so and ABORT the launch — results
-      __hip_atomic_store(flag, 1u, RLX_AGENT);   // computed past a barrier that did not hold would be silently wrong; a trapped kernel surfaces as a
-      __builtin_trap();                          // launch failure at the caller's next synchronisation
+    ++spins;
+    if ((spins & 255u) == 0u && __hip_atomic_load(flag, RLX_AGENT) != 0u) return false;
+    if (spins > (1u << 24)) {
+      __hip_atomic_store(flag, 1u, RLX_AGENT);
       return false;
     }
   }
   return true;
 }
-struct BarrierCtx { unsigned xcc, members, nx; };
-__device__ void barrier_prologue(unsigned* sync, BarrierCtx* ctx) {
+struct BarrierCtx { unsigned xcc, members, nx, dead; };
+__device__ bool barrier_prologue(unsigned* sync, BarrierCtx* ctx) {
   if (threadIdx.x == 0) {
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     x &= 7u;
     __hip_atomic_fetch_add(sync + 24 + x, 1u, RLX_AGENT);
-    __hip_atomic_fetch_add(sync + 2, 1u, RLX_AGENT);
-    spin_until(sync + 2, gridDim.x, sync + 1);
+    // the arrival is a RELEASE (the membership increment above has completed before it is visible) and the counts are read behind an
+    // ACQUIRE: whoever sees all gridDim.x arrivals sees every membership increment (two relaxed atomics on different words carry no order)
+    __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = spin_until(sync + 2, gridDim.x, sync + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     unsigned nx = 0;
     for (int i = 0; i < 8; ++i) nx += __hip_atomic_load(sync + 24 + i, RLX_AGENT) != 0u;
-    ctx->xcc = x; ctx->members = __hip_atomic_load(sync + 24 + x, RLX_AGENT); ctx->nx = nx;
+    ctx->xcc = x; ctx->members = __hip_atomic_load(sync + 24 + x, RLX_AGENT); ctx->nx = nx; ctx->dead = ok ? 0u : 1u;
   }
   __syncthreads();
+  return ctx->dead == 0u;
 }
-__device__ void grid_barrier(unsigned* sync, unsigned epoch, const BarrierCtx* ctx) {
+__device__ bool grid_barrier(unsigned* sync, unsigned epoch, BarrierCtx* ctx) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains: its stores are in the XCD's L2
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned x = ctx->xcc;
+    bool ok;
     const unsigned old = __hip_atomic_fetch_add(sync + 8 + x, 1u, RLX_AGENT);
     if (old + 1u == ctx->members * epoch) {                // the last of this XCD
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the post-write-back wait where the compiler cannot drop it (guide, pitfall 12)
       __hip_atomic_fetch_add(sync, 1u, RLX_AGENT);
-      spin_until(sync, ctx->nx * epoch, sync + 1);
+      ok = spin_until(sync, ctx->nx * epoch, sync + 1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(sync + 16 + x, epoch, RLX_AGENT);
     } else {
-      spin_until(sync + 16 + x, epoch, sync + 1);
+      ok = spin_until(sync + 16 + x, epoch, sync + 1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    if (!ok) ctx->dead = 1u;
   }
   __syncthreads();
+  return ctx->dead == 0u;
 }
 
 __global__ __launch_bounds__(256) void tail_program_kernel(const TailOp* ops, const int* phase_ops, const int* phase_tiles, int n_phases,
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256) void tail_program_kernel(const TailOp* ops, co
   __shared__ uint64_t s_slots[8];
   if (threadIdx.x < 8) s_slots[threadIdx.x] = SA.base[threadIdx.x];
   const Slots S{s_slots};
-  barrier_prologue(sync, &bctx);
+  if (!barrier_prologue(sync, &bctx)) return;
   for (int ph = 0; ph < n_phases; ++ph) {
     const int ob = phase_ops[ph], oe = phase_ops[ph + 1], nt = phase_tiles[ph];
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(256) void tail_program_kernel(const TailOp* ops, co
         default: break;
       }
     }
-    if (ph + 1 < n_phases) grid_barrier(sync, (unsigned)(ph + 1), &bctx);
+    if (ph + 1 < n_phases && !grid_barrier(sync, (unsigned)(ph + 1), &bctx)) return;    // gave up: sync[1] is set, the results are void
     if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[ph] = wall_clock64();
   }
 }
@@ -670,13 +685,20 @@ extern "C" int mp_tail_program_run(const void* ops, const int* phase_ops, const 
   MP_REQUIRE(ops && phase_ops && phase_tiles && slots && sync, MP_ERR_ARG, "mp_tail_program_run: null argument");
   MP_REQUIRE(n_phases >= 1 && grid >= 1, MP_ERR_ARG, "mp_tail_program_run: n_phases, grid >= 1");
   MP_REQUIRE(slots[0] == 0, MP_ERR_ARG, "mp_tail_program_run: slot 0 is the absolute address space (base 0)");
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  // every workgroup must be resident for the barrier: at most one per compute unit of THIS device (mp_device_cus caches per device), and the
+  // occupancy query must admit at least one (64 KB of LDS per workgroup; the query is cached per device as well)
+  const int cus = mp_device_cus();
+  static int per_cu[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int di = dev >= 0 && dev < 64 ? dev : 0;
+  if (per_cu[di] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tail_program_kernel, 256, 0) != hipSuccess) nb = 0;
+    per_cu[di] = nb > 0 ? nb : -1;
   }
-  if (grid > cus) grid = cus;                              // one resident workgroup per compute unit at most: the barrier needs them all
+  MP_REQUIRE(per_cu[di] >= 1, MP_ERR_LAUNCH, "mp_tail_program_run: the occupancy query admits no resident workgroup of the program kernel");
+  if (grid > cus) grid = cus;
   SlotArgs S;
   for (int i = 0; i < 8; ++i) S.base[i] = slots[i];
   if (hipMemsetAsync(sync, 0, 128, stream) != hipSuccess) { mp_set_error("mp_tail_program_run: memset failed"); return MP_ERR_LAUNCH; }

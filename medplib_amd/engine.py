@@ -99,6 +99,7 @@ class FlatAdamW:
         ops.sumsq_accum(self.flat_grad, self.sumsq)
         ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, self.max_norm, self.sumsq, grad_scale)
+        ops.PARAM_EPOCH += 1                                   # the kernel wrote the parameters through raw pointers: no tensor _version moved
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
@@ -413,6 +414,7 @@ class Engine:
         named = dict(self.module.named_parameters())
         for n, v in ck["module"].items():
             named[n].data.copy_(v)
+        ops.PARAM_EPOCH += 1
         self.optimizer.load_state_dict(ck["optimizer"])
         if self.scheduler and ck.get("lr_scheduler"):
             self.scheduler.load_state_dict(ck["lr_scheduler"])

@@ -203,6 +203,7 @@ class LlamaStack:
                 gates, cap, self._gate_draws(i, T, E, gumbel=False), want_slot_token=True)
             act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
             if needed is not None:
+                self.pruned_rows = int(getattr(self, "needed_rows")[0].numel())      # the pruning HAPPENED (model_forward reports only this)
                 # the last layer: only the rows something reads go through the experts (the routing above saw every token: capacity drops,
                 # l_aux and the counts are those of the whole batch); a row that is not computed keeps the residual stream, which nobody reads
                 slot_token, kept = ops.moe_filter_slots(slot_token, kept, needed)

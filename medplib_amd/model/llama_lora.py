@@ -257,7 +257,9 @@ class LoRAState(torch.nn.Module):
                     self._bufs[i][grp] = (torch.zeros(lead + (64, fin), dtype=bf, device=dev), torch.zeros(lead + (fin, 64), dtype=bf, device=dev),
                                           torch.zeros(lead + (W, 64), dtype=bf, device=dev), torch.zeros(lead + (64, W), dtype=bf, device=dev), tg)
         out = {}
-        fresh = getattr(self, "_packed_at", None) == self.step and self.step > 0       # pack_all() already rewrote every slice this step
+        # pack_all() already rewrote every slice this step AND nothing has written the parameters since (the optimizer step bumps ops.PARAM_EPOCH;
+        # a caller between optimizer.step() and the next forward — a merge, an eval helper — must not get the previous values' images)
+        fresh = getattr(self, "_packed_at", None) == self.step and self.step > 0 and getattr(self, "_packed_epoch", None) == ops.PARAM_EPOCH
         for grp, (A, AT, B, BT, tg) in self._bufs[i].items():
             batched = A.dim() == 3
             for k, t in enumerate(tg):
@@ -311,7 +313,7 @@ def pack_all(lora, n_layers):
         lora._pack_tab = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(lora.rows["q_proj"].device)
         lora._pack_key, lora._pack_max = key, max(int(x[9]) * int(x[10]) + int(x[11]) * int(x[9]) for x in recs)
     ops.lib().call("mp_lora_pack_batched", lora._pack_tab.data_ptr(), len(recs), int(lora._pack_max), ops._stream())
-    lora._packed_at = lora.step
+    lora._packed_at, lora._packed_epoch = lora.step, ops.PARAM_EPOCH
 
 
 def _transposed(w):
@@ -658,6 +660,7 @@ def forward_train(llm, embeds, key_valid):
             # have drawn; forward and backward use the same one).  x_mid's read rows are replaced in place: it becomes this layer's output.
             rows = needed[0]
             n_r = rows.numel()
+            llm.pruned_rows = int(n_r)                              # the pruning HAPPENED (model_forward reports only this)
             if "gu_x" in lw:
                 h2x_c, h2_c, t3_c = _ext_rows(n_r, d, x.device)
                 ops.gather_rows_bf16(h2, rows, out=h2_c)
@@ -886,6 +889,7 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             pre = f"model.layers.{i}."
             lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
     grads["__d_embeds__"] = dx                                     # gradient of the decoder's input rows (for embed_tokens)
+    lora.keep_bits = {}                                            # the step's mask bytes (T K / 8 per adapter and layer) die with its backward, not at the next forward
     return grads
 
 

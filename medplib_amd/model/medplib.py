@@ -561,6 +561,7 @@ class MedPLIBForCausalLM(nn.Module):
             # MLP is row-wise, so it runs on those rows only (unread rows are not computed; every read row has the bits it
             # would have had).  Off while a test captures the whole hidden state, at inference, or by MP_PRUNE_LAST_MLP=0.
             m.llm.needed_rows = None
+            m.llm.pruned_rows = None
             if (_PRUNE_LAST_MLP and self.training and not inference and not self.capture_intermediates
                     and kwargs.get("icl_image_counts") is None):
                 need = np.union1d(np.asarray(sup_rows, dtype=np.int64), np.asarray(seg_rows if seg_flag else [], dtype=np.int64))
@@ -589,8 +590,10 @@ class MedPLIBForCausalLM(nn.Module):
                 last_hidden, aux_sum, _ = LL.forward_train(m.llm, embeds, key_valid)
                 ce = m.llm.cross_entropy(last_hidden, sup_rows_d, sup_labels_d, [aux_sum] if m.llm.moe_layers else [])
         # the row set belonged to THIS pass through the stack: a later direct call of the stack (evaluate(), a test) computes every row
-        nr = m.llm.needed_rows
-        self.last_pruned = (int(nr[0].numel()), int(nr[1].numel())) if nr is not None else None      # (rows the last layer's MLP ran on, rows of the batch): bench.py reports it
+        nr, done = m.llm.needed_rows, getattr(m.llm, "pruned_rows", None)
+        # (rows the last layer's MLP ran on, rows of the batch) when the stack really pruned (top-1 fused-gate MoE branch / dense last layer with
+        # frozen ln2 under adapters: it records llm.pruned_rows), else None — bench.py reports and subtracts FLOPs only from this
+        self.last_pruned = (int(done), int(nr[1].numel())) if (nr is not None and done is not None) else None
         m.llm.needed_rows = None
         if not seg_flag:
             z = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -109,6 +109,8 @@ class KernelTimer:
 
 
 GEMM_TIMER = None     # set to a KernelTimer by bench.py
+PARAM_EPOCH = 0       # bumped by whatever rewrites parameter VALUES through raw pointers (the fused AdamW step, checkpoint loads): caches of
+                      # derived operand images (llama_lora.LoraState.padded) are fresh only within one epoch
 
 
 # ------------------------------------------------------------------ bf16 trunk ------------------------------------------------

@@ -382,9 +382,11 @@ class TailProgram:
         d hyper0 and the bias / LayerNorm2d gradients from its per-task rows, and the two ConvTranspose2d weight gradients (dW1 = dy1^T src,
         dW2 = dy2^T a1) written straight into the [Cin, Cout, 2, 2] gradient tensors (mask_decoder.py:53-59)."""
         self.n, self.C, self.Tk = n, dec.dim, dec.grid * dec.grid
+        self.dec = dec
         self.device = dec.iou_token.weight.device
         n, C, Tk = self.n, self.C, self.Tk
         grad_offsets = grad_offsets or {}
+        self.grad_offsets = dict(grad_offsets)
 
         def grad_of(t):
             off = grad_offsets.get(id(t))
@@ -538,7 +540,7 @@ class TailProgram:
         for tag, (arr, po, pt, _) in (("f", self.fwd_packed), ("b", self.bwd_packed)):
             d[tag] = (torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(dev), torch.from_numpy(po.copy()).to(dev),
                       torch.from_numpy(pt.copy()).to(dev), len(pt))
-        d["sync"] = torch.zeros(32, dtype=torch.int32, device=dev)
+        d["sync"] = None                                            # the LAST launch's barrier words (every launch takes its own 128 bytes)
         d["wb"] = torch.empty(max(self.bwd_bytes, 256) // 4, dtype=torch.float32, device=dev)
         self._dev = d
         return d
@@ -548,8 +550,37 @@ class TailProgram:
         d = self._upload()
         o, po, pt, nph = d[tag]
         arr = (ctypes.c_uint64 * 8)(*slots)
-        ops.lib().call("mp_tail_program_run", o.data_ptr(), po.data_ptr(), pt.data_ptr(), nph, ctypes.addressof(arr), d["sync"].data_ptr(),
+        self.check_previous()
+        # the barrier words belong to the LAUNCH, not to the program: the forward of an eval pass on one stream and the backward of a training step on
+        # another may walk the same cached program at once (the caching allocator hands out per-stream blocks; mp_tail_program_run zeroes them)
+        sync = torch.empty(32, dtype=torch.int32, device=self.device)
+        ops.lib().call("mp_tail_program_run", o.data_ptr(), po.data_ptr(), pt.data_ptr(), nph, ctypes.addressof(arr), sync.data_ptr(),
                        stamps.data_ptr() if stamps is not None else None, int(grid), ops._stream())
+        d["sync"] = sync
+        # the give-up word comes back without a host wait: one 4-byte copy into pinned memory behind the launch, read at a LATER launch
+        # (at most one read-back in flight: the pinned word is shared)
+        if self._pending is None:
+            if self._flag_host is None:
+                self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_host.copy_(sync[1:2], non_blocking=True)
+            self._pending = torch.cuda.Event()
+            self._pending.record()
+
+    _pending = None
+    _flag_host = None
+
+    def check_previous(self):
+        """A barrier of an EARLIER launch of this program gave up (a workgroup of its grid never became resident): its results were void.  Raises —
+        after switching the owning decoder to the op-by-op tail, so a caller that catches and repeats the step gets a working path."""
+        ev = self._pending
+        if ev is None or not ev.query():
+            return
+        self._pending = None
+        if int(self._flag_host[0]) != 0:
+            self._flag_host.zero_()
+            self.dec.use_program = False
+            raise RuntimeError("the mask tail's program launch gave up at a grid barrier (sync[1] != 0): the results of that step are void; "
+                               "the decoder now runs the op-by-op tail (MP_TAIL_PROGRAM=0 selects it from the start)")
 
     def run_forward(self, x_in, image_tokens, grid=256, stamps=None):
         """x_in: hidden rows [n, Dh] (with fcs) or text embeddings [n, C]; image_tokens [n, Tk, C] fp32 -> (workspace, src [n, Tk, C],
@@ -568,7 +599,7 @@ class TailProgram:
     def run_backward(self, ws, d_src2, d_hyper0, d_iou, grad_base, grid=256, stamps=None):
         """d_src2 [2, n, Tk, C] (the fused upsampler's two dx halves; pass a zero second half for a single gradient), d_hyper0 [n, 32],
         d_iou [n]; grad_base: address of the gradient buffer the program's offsets refer to (accumulated into).  -> gradient of the input
-        rows [n, in_dim] (a view of the program's scratch: consume it before the next backward) or None."""
+        rows [n, in_dim] (a copy: the program's scratch is rewritten by the next backward) or None."""
         for t in (d_src2, d_hyper0, d_iou):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert d_src2.numel() == 2 * self.n * self.Tk * self.C and d_hyper0.numel() == self.n * self.out["hyper0"].cols and d_iou.numel() == self.n
@@ -579,7 +610,7 @@ class TailProgram:
             return None
         r = self.d_in
         flat = d["wb"][r.off // 4: r.off // 4 + (r.rows - 1) * r.ld + r.cols]
-        return flat.as_strided((r.rows, r.cols), (r.ld, 1))
+        return flat.as_strided((r.rows, r.cols), (r.ld, 1)).clone()        # autograd may keep it: never a view of the program's scratch
 
     def run_backward_fused(self, ws, ups_buf, src_bf16, d_iou, grad_base, grid=256, stamps=None):
         """The fused-upsampler form: ups_buf = mask_upsample_fused_bwd's one-buffer outputs, src_bf16 = the bf16 tokens its forward read."""
@@ -591,14 +622,37 @@ class TailProgram:
             return None
         r = self.d_in
         flat = d["wb"][r.off // 4: r.off // 4 + (r.rows - 1) * r.ld + r.cols]
-        return flat.as_strided((r.rows, r.cols), (r.ld, 1))
+        return flat.as_strided((r.rows, r.cols), (r.ld, 1)).clone()
 
     def check_sync(self):
         """True when no barrier of the last launches gave up (reads the device: tests only)."""
-        return int(self._upload()["sync"][1].item()) == 0
+        sync = self._upload()["sync"]
+        return sync is None or int(sync[1].item()) == 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------- autograd face
+def _direct_still_valid(base, params, offs):
+    """The 'direct' form writes through addresses taken at FORWARD time (base + the program's offsets = each trainable parameter's .grad).  Between
+    forward and backward a caller may have dropped or re-homed the gradients (zero_grad(set_to_none=True), a re-flattening engine): then those
+    addresses are not the parameters' gradients any more — possibly freed memory."""
+    for p_ in params:
+        if p_.requires_grad:
+            g = p_.grad
+            if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + offs[id(p_)]:
+                return False
+    return True
+
+
+def _detached_grads(prog_backward, params, offs, dev):
+    """Fallback of the direct form when the .grad tensors moved: the same program (its offsets are relative to a base) run on a fresh zero buffer
+    spanning the old layout; the parameter gradients go back to autograd as views of it."""
+    span = max((offs[id(p_)] // 4 + p_.numel() for p_ in params if p_.requires_grad), default=0)
+    gflat = torch.zeros(max(span, 64), dtype=torch.float32, device=dev)
+    d_in = prog_backward(gflat.data_ptr())
+    grads = [gflat[offs[id(p_)] // 4: offs[id(p_)] // 4 + p_.numel()].view(p_.shape) if p_.requires_grad else None for p_ in params]
+    return d_in, grads
+
+
 class TailProgramFn(torch.autograd.Function):
     """(x_in, image_tokens) -> (src [n, Tk, C], hyper0 [n, 32], iou [n]) through the forward program; the backward program writes every
     parameter gradient itself: straight into the parameters' `.grad` (the engine's flat buffer) when they all live in one buffer — autograd
@@ -610,6 +664,7 @@ class TailProgramFn(torch.autograd.Function):
         prog, base, layout = runner.program(x_in.shape[0], params, x_in.requires_grad)
         ws, src, hyper0, iou4 = prog.run_forward(x_in.detach().contiguous(), image_tokens.detach().contiguous(), grid=runner.grid)
         ctx.prog, ctx.ws, ctx.runner, ctx.base, ctx.layout, ctx.n_params = prog, ws, runner, base, layout, len(params)
+        ctx.params = params
         return src, hyper0, iou4[:, 0]
 
     @staticmethod
@@ -626,7 +681,9 @@ class TailProgramFn(torch.autograd.Function):
             d_src2[0].copy_(d_src.reshape(d_src2[0].shape))
         d_hy = zeros["hy"] if d_hyper0 is None else d_hyper0.contiguous()
         d_io = zeros["iou"] if d_iou is None else d_iou.contiguous()
-        if ctx.base is not None:                                # direct: accumulate into the flat gradient buffer
+        if ctx.base is not None and not _direct_still_valid(ctx.base, ctx.params, runner.direct_offsets(ctx.params, ctx.base, prog)):
+            d_in, grads = _detached_grads(lambda b: prog.run_backward(ctx.ws, d_src2, d_hy, d_io, b, grid=runner.grid), ctx.params, prog.grad_offsets, dev)
+        elif ctx.base is not None:                              # direct: accumulate into the flat gradient buffer
             d_in = prog.run_backward(ctx.ws, d_src2, d_hy, d_io, ctx.base, grid=runner.grid)
             grads = [None] * ctx.n_params
         else:
@@ -658,6 +715,7 @@ class TailFusedFn(torch.autograd.Function):
                                            hyper=hyper0, want_up=False, eps=eps)
         ctx.prog, ctx.ws, ctx.runner, ctx.base, ctx.layout, ctx.n_params = prog, ws, runner, base, layout, len(params)
         ctx.ups = (src_bf, w1p, w2p, w1t, w2t, hyper0, eps)
+        ctx.params = params
         return masks, iou4[:, 0]
 
     @staticmethod
@@ -673,7 +731,9 @@ class TailFusedFn(torch.autograd.Function):
         *_, ubuf = ops.mask_upsample_fused_bwd(src_bf, w1p, up[0].bias.detach(), up[1].weight.detach(), up[1].bias.detach(), w2p, up[3].bias.detach(),
                                                hyper0, dm, g, g, eps=eps, w1t=w1t, w2t=w2t, one_buffer=True)
         d_io = zeros["iou"] if d_iou is None else d_iou.contiguous()
-        if ctx.base is not None:
+        if ctx.base is not None and not _direct_still_valid(ctx.base, ctx.params, runner.direct_offsets(ctx.params, ctx.base, prog)):
+            d_in, grads = _detached_grads(lambda b: prog.run_backward_fused(ctx.ws, ubuf, src_bf, d_io, b, grid=runner.grid), ctx.params, prog.grad_offsets, dev)
+        elif ctx.base is not None:
             d_in = prog.run_backward_fused(ctx.ws, ubuf, src_bf, d_io, ctx.base, grid=runner.grid)
             grads = [None] * ctx.n_params
         else:
@@ -706,6 +766,10 @@ class TailRunner:
             up = d.output_upscaling
             ps += [up[0].weight, up[0].bias, up[1].weight, up[1].bias, up[3].weight, up[3].bias]
         return ps
+
+    @staticmethod
+    def direct_offsets(params, base, prog):
+        return prog.grad_offsets
 
     def zeros(self, n, dev):
         z = self._zeros.get(n)

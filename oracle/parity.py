@@ -56,6 +56,14 @@ def check_full_size(r, layers, moe):
     need(r["hidden_p999_rel_err_agreeing_rows"] <= HIDDEN_P999_ALL_ROWS,
          f"hidden (agreeing rows, 99.9th percentile element): {r['hidden_p999_rel_err_agreeing_rows']:.4g} > {HIDDEN_P999_ALL_ROWS}")
     few_flips = r["rows_agreeing_in_every_layer"] >= 0.95
+    # an ABSOLUTE floor, so that a regression which flips many tokens cannot loosen its own acceptance (the all-rows bounds below switch off and
+    # the bad-row allowance grows with the flips): every standing (aliased-weights) configuration keeps >= 95 % of the rows in agreement in every
+    # layer (measured 95.5-99.4 %), and the distinct-weights run, where independent random gates flip a sixth of the rows over 32 layers, >= 75 %
+    floor = 0.75 if r.get("distinct_weights") else 0.93               # 0.93: two points under the measured worst (0.955 at 32 layers, B = 8)
+    need(r["rows_agreeing_in_every_layer"] >= floor,
+         f"only {r['rows_agreeing_in_every_layer']:.4f} of the rows agree with the oracle's routing in every layer (floor {floor})")
+    need(r["hidden_bad_rows"] <= (0.25 if r.get("distinct_weights") else 0.05) * r.get("rows_total", float("inf")),
+         f"hidden: {r['hidden_bad_rows']} bad rows of {r.get('rows_total')}: above the absolute cap")
     need(not few_flips or r["hidden_p999_rel_err"] <= HIDDEN_P999_ALL_ROWS,
          f"hidden (all rows, 99.9th percentile element): {r['hidden_p999_rel_err']:.4g} > {HIDDEN_P999_ALL_ROWS}")
     need(r["hidden_bad_rows"] <= 2 * r["flipped_tokens_total"],
@@ -312,6 +320,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            # a token that picked the other expert somewhere is a different computation from there on: bound the rest
            "hidden_rel_err_agreeing_rows": float((hid.view(-1, d)[same] - href.view(-1, d)[same]).abs().max() / href.abs().max()),
            "rows_agreeing_in_every_layer": float(same.float().mean()),
+           "rows_total": int(same.numel()),
            "mask": mask_summary,
            # kept for continuity with earlier rounds' lines (Dice of mask 0 at the reference cut; see `mask` for what bites)
            "dice_gpu": reports[0]["cut_ref"]["dice_pred"], "dice_cpu": reports[0]["cut_ref"]["dice_ref"],
@@ -322,6 +331,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "routing_agreement_per_layer": [round(a, 4) for a in agree],
            "routing_layer_local": local,
            "oracle_forward_seconds": round(t_oracle, 2),
+           "distinct_weights": bool(distinct_weights),
            "weights": ("DISTINCT seeded weights in every decoder layer, both sides" if distinct_weights
                        else "one decoder layer's seeded weights aliased over all layers, both sides")}
     if per_layer and "first_choice_agreement" in per_layer[0]:        # top-2 layers
