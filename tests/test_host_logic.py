@@ -733,8 +733,13 @@ def test_check_full_size_names_every_violated_bound():
     bad(["hidden_bad_rows"], 11)                       # more damaged rows than 2 x the flipped tokens can explain
     bad(["hidden_p999_rel_err_agreeing_rows"], 0.06)
     bad(["hidden_mean_rel_err_agreeing_rows"], 0.02)
-    r16 = dict(good, rows_agreeing_in_every_layer=0.84, hidden_p999_rel_err=0.081, hidden_mean_rel_err=0.033)    # a sixth of the rows flipped: the all-rows figures are not held
+    r16 = dict(good, rows_agreeing_in_every_layer=0.84, hidden_p999_rel_err=0.081, hidden_mean_rel_err=0.033, distinct_weights=True)    # a sixth of the rows flipped (32 independent gates): the all-rows figures are not held
     assert check_full_size(r16, 4, True) == []
+    # ... but ONLY the distinct-weights run may flip that much: on the standing (aliased) configurations heavy flipping fails on the absolute floor
+    # instead of loosening its own acceptance (round-5 advisor)
+    assert any("floor" in m for m in check_full_size(dict(r16, distinct_weights=False), 4, True))
+    assert any("floor" in m for m in check_full_size(dict(r16, rows_agreeing_in_every_layer=0.7), 4, True))
+    assert any("absolute cap" in m for m in check_full_size(dict(good, rows_total=100, hidden_bad_rows=6, flipped_tokens_total=6), 4, True))
     bad(["hidden_mean_rel_err"], 0.02)
     bad(["mask", "max_abs_dlogit"], MASK_LOGIT_TOL + 1e-3)
     bad(["mask", "cut_zero", "flipped_le_near_cut_every_mask"], False)
