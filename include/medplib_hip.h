@@ -271,6 +271,35 @@ int mp_window_unpartition_add_bf16(const void* win, const void* shortcut, void* 
 /* add_decomposed_rel_pos tables rel_h/rel_w from the (unscaled) q of a fused qkv buffer (image_encoder.py:381-421). */
 int mp_relpos_tables_bf16(const void* qkv, int64_t ld, const float* rel_pos_h, const float* rel_pos_w, float* rel_h, float* rel_w,
                           int Bw, int heads, int hh, int ww, int head_dim, hipStream_t stream);
+/* ---- the SAM-Med2D image encoder's own kernels (csrc/sam_encoder.hip; round 6).  Geometry: 16 x 16 tokens, 768 channels, heads of 64.
+ * mp_sam_attention_bf16 replaces window_partition -> Attention.forward -> window_unpartition of Block.forward (image_encoder.py:217-230,
+ * 280-296, 299-345) and add_decomposed_rel_pos (:381-421) on the UN-partitioned [B * grid * grid, 3 * heads * 64] qkv tensor (image order):
+ * window = 14: the four 14 x 14 windows of the zero-padded 28 x 28 map; a padded token's k / v row is the bf16-rounded qkv bias (what the
+ * projection of a zero row is), a padded query has no output (cropped by window_unpartition); window = 0: global attention.  The rel-pos
+ * terms q . rel_pos_h[qy - ky + n - 1], q . rel_pos_w[qx - kx + n - 1] (fp32 tables [2 n - 1, 64]) are computed in the kernel.
+ * out [B * grid * grid, heads * 64] in image order (the input of Attention.proj, whose GEMM then carries the shortcut add). */
+int mp_sam_attention_bf16(const void* qkv, int64_t ld_qkv, const float* qkv_bias, const float* rel_pos_h, const float* rel_pos_w, void* out,
+                          int64_t ld_out, int B, int heads, int grid, int window, float scale, hipStream_t stream);
+/* y = LayerNorm(x [+ addend[row % period]]); with an addend the bf16 sum is also written to xsum (patch embedding + pos_embed -> blocks[0].norm1,
+ * image_encoder.py:128-131, 217-218). */
+int mp_sam_add_layernorm_bf16(const void* x, const void* addend, int period, void* xsum, const float* w, const float* b, float eps, void* y,
+                              int rows, int dim, hipStream_t stream);
+/* Block.norm2 and, in the same pass, the column sums of its output per slab of 16 rows: part [rows / 16, 768] fp32 (the numerator of
+ * Adapter_Layer's AdaptiveAvgPool2d(1), image_encoder.py:24,49). */
+int mp_sam_layernorm_colsum_bf16(const void* x, const float* w, const float* b, float eps, void* xn, float* part, int rows, int dim, hipStream_t stream);
+/* Adapter_Layer.channel: gate [B, C] = sigmoid(W2 relu(W1 mean)), mean = the slab sums of the image / tokens (image_encoder.py:25-30,49);
+ * the two Linear weights TRANSPOSED: w1t [C, hidden] = W1^T, w2t [hidden, C] = W2^T, fp32. */
+int mp_sam_channel_gate_f32(const float* part, int slabs, int tokens, const float* w1t, const float* w2t, float* gate, int B, int C, int hidden,
+                            hipStream_t stream);
+/* im2col of Adapter_Layer.spatial[0] (Conv2d k 3, s 2, p 1) on gate * x: cols [B * (grid/2)^2, 9 * C], column order (ky, kx, c) (image_encoder.py:33,49-50). */
+int mp_sam_im2col_scaled_bf16(const void* x, const float* gate, void* cols, int B, int grid, int C, hipStream_t stream);
+/* the four output-parity tap gathers of Adapter_Layer.spatial[2] (ConvTranspose2d k 4, s 2, p 1) in one launch: cols4 [4, B * half^2, 4 * C]. */
+int mp_sam_im2col_parity4_bf16(const void* s1, void* cols4, int B, int half, int C, hipStream_t stream);
+/* The end of Block.forward for an adapter block, one pass over the rows: t = xn + y4[parity][pixel] (x + x_spatial), ad = Adapter.norm(t),
+ * x_out = x + mlp + ad (image_encoder.py:52-56, 232-234), h_out = the NEXT block's norm1(x_out) (next_w null: skipped).  y4 [4, B * (grid/2)^2, dim]. */
+int mp_sam_block_tail_bf16(const void* y4, const void* xn, const void* x, const void* mlp, const float* ad_w, const float* ad_b, float ad_eps,
+                           const float* next_w, const float* next_b, float next_eps, void* x_out, void* h_out, int B, int grid, int dim,
+                           hipStream_t stream);
 /* nn.AdaptiveAvgPool1d over the token axis of a token-major [n, len_in, C] tensor: TokenCompressor 576 -> 256 and
  * MaskTokenEncoder 441 -> 64 (medplib_arch.py:67-77, 98-108). */
 int mp_adaptive_avgpool_tokens_bf16(const void* x, void* out, int n, int len_in, int len_out, int C, hipStream_t stream);

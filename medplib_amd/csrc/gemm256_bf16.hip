@@ -733,7 +733,7 @@ int mp_launch_gemm256(const GemmArgs& g, int batch, hipStream_t stream) {
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &gf.ws, &gf.tickets, &ws_bytes);
   if (!gf.ws || ws_bytes < (int64_t)n_cu * BM2 * BN2 * 4 || gf.out_f32) { gf.ws = nullptr; gf.tickets = nullptr; gf.max_split = 1; }
-  const dim3 fgrid(tiles * batch + n_cu);             // surplus workgroups (device-side row counts, unsplit tails) exit at once
+  const dim3 fgrid(tiles * batch + (gf.max_split > 1 ? n_cu : 0));   // surplus workgroups (the units of a split tail; device-side row counts leave more) exit at once
 #define MP_GO(A) hipLaunchKernelGGL((gemm256v3_bf16_nt_kernel<A>), fgrid, blk, 2 * STAGE_BYTES, stream, gf)
   switch (abl) {
     case 1: MP_GO(1); break;

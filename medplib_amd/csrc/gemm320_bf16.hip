@@ -581,7 +581,10 @@ bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
   if (g.act == ACT_ROPE_QK && (batch != 1 || g.m_dev || g.a_rows || g.c_rows)) return false;
   if (g.act == ACT_SWIGLU_PAIR && (g.c_rows || g.residual || g.bias || g.alpha != 1.f || ((g.N >> 1) & 7))) return false;
   if (g.c_rows && (g.act != ACT_NONE || g.bias || g.alpha != 1.f)) return false;
-  if (g.N % BN3 || g.K % BK3 || g.M < 1024) return false;
+  // M >= 1024 for the decoder's calls (fewer rows are few tiles: the smaller kernels fill the machine better).  The frozen towers' whole-tile
+  // policy counts CU x time instead of latency (ops.throughput_tiles), and there a 512-row call on two row tiles beats the 128 x 128 kernel's
+  // split-K units several times over (the SAM adapter's K = 6912 convolution: 6 tiles x 186 us against 240 units x ~20 us + their partials)
+  if (g.N % BN3 || g.K % BK3 || g.M < (mp_gemm_policy_whole_tiles() ? BM3 : 1024)) return false;
   if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || (g.sC & 7)) return false;
   if (g.residual && ((g.ldr & 7) || (reinterpret_cast<uintptr_t>(g.residual) & 15) || (g.sR & 7))) return false;
   // 32-bit DMA offsets inside one batch's operand; a gathered A is addressed through the whole shared matrix, whose row count the call does
@@ -627,8 +630,14 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   int64_t ws_bytes = 0;
   mp_gemm_split_workspace(stream, &g.ws, &g.tickets, &ws_bytes);
   if (!g.ws || ws_bytes < (int64_t)g.n_cu * BM3 * BN3 * 4) { g.ws = nullptr; g.tickets = nullptr; g.max_split = 1; }   // (registration checks the 384 tickets)
-  // the host-side bound on the tile count plus one unit per CU for a split tail; workgroups beyond the device-side unit count exit at once
-  const dim3 grid((unsigned)(mp_cdiv(g.M, BM3) * (g.N / BN3) * batch + g.n_cu));
+  // the host-side bound on the tile count plus one unit per CU for a split tail; workgroups beyond the device-side unit count exit at once.
+  // Round 6: a launch that cannot split (max_split 1: the towers' whole-tile policy, registered side streams, the RoPE family, one-wave dense
+  // calls) gets no surplus — 256 workgroups that exit at once still each wait for a CU with 144 KB of LDS free, which beside another stream's
+  // GEMM tiles means behind them.
+  const int64_t host_tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3) * batch;
+  const int64_t host_rem = host_tiles % g.n_cu;
+  const bool may_split = g.max_split > 1 && (g.m_dev || (host_rem > 0 && host_rem * 2 <= g.n_cu));     // (the kernel's own rule, where the host knows the row counts)
+  const dim3 grid((unsigned)(host_tiles + (may_split ? g.n_cu : 0)));
 #define MP3_GO(E) hipLaunchKernelGGL(gemm320_bf16_nt_kernel<E>, grid, dim3(NT3), 2 * STAGE3, stream, g)
   if (g.act == ACT_ROPE_QK) MP3_GO(EPI_ROPE);
   else if (g.act == ACT_SWIGLU_PAIR) MP3_GO(EPI_SWIGLU);

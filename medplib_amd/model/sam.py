@@ -17,6 +17,7 @@ from .. import ops
 from . import autograd_ops as A
 
 GELU = ops.ACT_GELU
+_SAM_FUSED = os.environ.get("MP_SAM_FUSED", "1") != "0"                  # A/B: 0 = the frozen encoder as generic launches (forward_generic)
 _FUSED_TAIL = os.environ.get("MP_TAIL_FUSED_UPSAMPLER", "1") != "0"     # A/B: 0 = the program and FusedUpsampleMaskFn as two autograd nodes
 
 
@@ -62,6 +63,12 @@ class SamImageEncoder:
             blk["sp2"] = [blk["sp2_all"][c] for c in range(4)]
         O = cfg.sam_out_chans
         self.neck0 = rn(O, C); self.neck1 = ln(O); self.neck2 = rn(O, 9 * O); self.neck3 = ln(O)
+        self._refresh_derived()
+
+    def _refresh_derived(self):
+        """Images of the frozen weights in the layout a kernel wants (the channel gate reads its two matrices transposed)."""
+        for b in self.blocks:
+            b["ch0T"], b["ch2T"] = b["ch0"].t().contiguous(), b["ch2"].t().contiguous()
 
     # ------------------------------------------------------------------ reference checkpoint layout (image_encoder.*)
     def load_ref(self, sd, prefix="image_encoder."):
@@ -93,6 +100,7 @@ class SamImageEncoder:
         put(self.neck1[0], sd[prefix + "neck.1.weight"]); put(self.neck1[1], sd[prefix + "neck.1.bias"])
         put(self.neck2, sd[prefix + "neck.2.weight"].permute(0, 2, 3, 1).reshape(O, 9 * O))
         put(self.neck3[0], sd[prefix + "neck.3.weight"]); put(self.neck3[1], sd[prefix + "neck.3.bias"])
+        self._refresh_derived()
 
     def export_ref(self, prefix="image_encoder."):
         """Inverse of load_ref: the kernel-layout weights back in the SAM-Med2D checkpoint layout (conv kernels un-flattened, the
@@ -148,10 +156,57 @@ class SamImageEncoder:
             ops.scatter_parity(y4[cls], xn, tmp, B, half, half, C, 2, cls >> 1, cls & 1, G, G)
         return ops.layernorm(tmp.view(B * T, C), blk["ad_norm"][0], blk["ad_norm"][1], 1e-5)
 
+    def _fused_ok(self):
+        """The round-6 kernels (csrc/sam_encoder.hip) are built for SAM-Med2D's geometry; anything else takes the generic launches."""
+        cfg = self.cfg
+        return (_SAM_FUSED and cfg.sam_grid == 16 and cfg.sam_window == 14 and cfg.sam_embed_dim == 768 and cfg.sam_embed_dim // cfg.sam_num_heads == 64)
+
     @ops.with_throughput_tiles
     def forward(self, images):
         """images [B,3,256,256] (f32 or bf16, SAM-normalised) -> image embedding tokens [B, 256, 256] bf16 = the
         reference's [B,256,16,16] in NHWC order (flatten(2).permute(0,2,1), transformer.py:82)."""
+        if not self._fused_ok():
+            return self.forward_generic(images)
+        cfg = self.cfg
+        C, G, Hh, ws = cfg.sam_embed_dim, cfg.sam_grid, cfg.sam_num_heads, cfg.sam_window
+        B = images.shape[0]
+        T, half = G * G, G // 2
+        cols = ops.patch_im2col(images.contiguous(), 16, 3 * 16 * 16)
+        x = ops.gemm(cols, self.patch_w, bias=self.patch_b)
+        blk0 = self.blocks[0]
+        x, h = ops.sam_add_layernorm(x, blk0["norm1"][0], blk0["norm1"][1], 1e-6, addend=self.pos)
+        nblk = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            # Block.forward (image_encoder.py:215-236).  The window blocks never materialise the padded windows: qkv / proj run on the map's own
+            # 2048 rows, the attention kernel walks the four windows of each map itself (padded keys = the qkv bias, see csrc/sam_encoder.hip)
+            qkv = ops.gemm(h, blk["qkv_w"], bias=blk["qkv_b"])
+            a = ops.sam_attention(qkv, blk["qkv_b"], blk["rph"], blk["rpw"], B, Hh, G, 0 if i in cfg.sam_global_attn else ws)
+            x = ops.gemm(a, blk["proj_w"], bias=blk["proj_b"], residual=x)
+            xn, part = ops.sam_layernorm_colsum(x, blk["norm2"][0], blk["norm2"][1], 1e-6)
+            mlp = ops.gemm(ops.gemm(xn, blk["lin1_w"], bias=blk["lin1_b"], act=GELU), blk["lin2_w"], bias=blk["lin2_b"])
+            # Adapter_Layer.forward (image_encoder.py:43-56)
+            gate = ops.sam_channel_gate(part, B, T, blk["ch0T"], blk["ch2T"])
+            s1 = ops.gemm(ops.sam_im2col_scaled(xn, gate, B, G, C), blk["sp0"], act=ops.ACT_RELU)
+            cols4 = ops.sam_im2col_parity4(s1, B, half, C)
+            y4 = ops.gemm_batched(cols4, blk["sp2_all"], torch.empty((4, B * half * half, C), dtype=torch.bfloat16, device=x.device), act=ops.ACT_RELU)
+            nxt = self.blocks[i + 1]["norm1"] if i + 1 < nblk else (None, None)
+            x, h = ops.sam_block_tail(y4, xn, x, mlp, blk["ad_norm"][0], blk["ad_norm"][1], 1e-5, nxt[0], nxt[1], 1e-6, B, G)
+        return self._neck(x, B)
+
+    def _neck(self, x, B):
+        cfg = self.cfg
+        G, O = cfg.sam_grid, cfg.sam_out_chans
+        y = ops.gemm(x, self.neck0)
+        y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
+        cols = ops.im2col_nhwc(y.view(B, G, G, O), G, G, 1, _conv_taps(3, 1))
+        y = ops.gemm(cols, self.neck2)
+        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
+        return y.view(B, G * G, O)
+
+    @ops.with_throughput_tiles
+    def forward_generic(self, images):
+        """The same encoder as generic launches (padded windows through the general attention kernel, a rel-pos table kernel, one launch per
+        elementwise step): any geometry; also the A/B reference of the fused path (MP_SAM_FUSED=0)."""
         cfg = self.cfg
         C, G, Hh, ws = cfg.sam_embed_dim, cfg.sam_grid, cfg.sam_num_heads, cfg.sam_window
         B = images.shape[0]
@@ -181,13 +236,7 @@ class SamImageEncoder:
             mlp = ops.gemm(ops.gemm(xn, blk["lin1_w"], bias=blk["lin1_b"], act=GELU), blk["lin2_w"], bias=blk["lin2_b"])
             ad = self._adapter(xn, blk, B)
             x = ops.add3(x, mlp, ad)
-        O = cfg.sam_out_chans
-        y = ops.gemm(x, self.neck0)
-        y = ops.layernorm(y, self.neck1[0], self.neck1[1], 1e-6)
-        cols = ops.im2col_nhwc(y.view(B, G, G, O), G, G, 1, _conv_taps(3, 1))
-        y = ops.gemm(cols, self.neck2)
-        y = ops.layernorm(y, self.neck3[0], self.neck3[1], 1e-6)
-        return y.view(B, T, O)
+        return self._neck(x, B)
 
 
 class PromptEncoderText(nn.Module):

@@ -1248,6 +1248,73 @@ def relpos_tables(qkv, rel_pos_h, rel_pos_w, Bw, heads, hh, ww):
     return rel_h, rel_w
 
 
+def sam_attention(qkv, qkv_bias, rel_pos_h, rel_pos_w, B, heads, grid, window, scale=None, out=None):
+    """qkv [B*grid*grid, 3*heads*64] bf16 in image order -> attention output [B*grid*grid, heads*64] in image order: the four padded windows of
+    side `window` (0 = global) with the decomposed rel-pos bias computed in the kernel (mp_sam_attention_bf16)."""
+    _chk(qkv, torch.bfloat16, "sam_attention.qkv"); _chk(qkv_bias, torch.float32, "sam_attention.bias")
+    _chk(rel_pos_h, torch.float32, "sam_attention.rel_pos_h"); _chk(rel_pos_w, torch.float32, "sam_attention.rel_pos_w")
+    n = window if window else grid
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape == (B * grid * grid, 3 * heads * 64)
+    assert rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous() and tuple(rel_pos_h.shape) == (2 * n - 1, 64) == tuple(rel_pos_w.shape)
+    if out is None:
+        out = torch.empty((B * grid * grid, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    lib().call("mp_sam_attention_bf16", _p(qkv), qkv.stride(0), _p(qkv_bias), _p(rel_pos_h), _p(rel_pos_w), _p(out), out.stride(0), B, heads, grid,
+               int(window), float(scale if scale is not None else 64 ** -0.5), _stream())
+    return out
+
+
+def sam_add_layernorm(x, w, b, eps, addend=None):
+    """-> LayerNorm(x) or, with an addend [period, dim], (x + addend[row % period], LayerNorm of that sum)."""
+    _chk(x, torch.bfloat16, "sam_add_layernorm.x")
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    xs = torch.empty_like(x) if addend is not None else None
+    lib().call("mp_sam_add_layernorm_bf16", _p(x), _p(addend), addend.shape[0] if addend is not None else 0, _p(xs), _p(w), _p(b), float(eps), _p(y),
+               rows, dim, _stream())
+    return y if addend is None else (xs, y)
+
+
+def sam_layernorm_colsum(x, w, b, eps):
+    """-> (LayerNorm(x) bf16, slab column sums [rows / 16, dim] fp32)."""
+    _chk(x, torch.bfloat16, "sam_layernorm_colsum.x")
+    rows, dim = x.shape
+    xn = torch.empty_like(x)
+    part = torch.empty((rows // 16, dim), dtype=torch.float32, device=x.device)
+    lib().call("mp_sam_layernorm_colsum_bf16", _p(x), _p(w), _p(b), float(eps), _p(xn), _p(part), rows, dim, _stream())
+    return xn, part
+
+
+def sam_channel_gate(part, B, tokens, w1t, w2t):
+    """slab sums [B * slabs, C] -> gate [B, C] fp32 = sigmoid(W2 relu(W1 mean)); the weights TRANSPOSED: w1t [C, hidden] = W1^T, w2t [hidden, C] = W2^T."""
+    C = part.shape[1]
+    assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C and w1t.is_contiguous() and w2t.is_contiguous()
+    gate = torch.empty((B, C), dtype=torch.float32, device=part.device)
+    lib().call("mp_sam_channel_gate_f32", _p(part), part.shape[0] // B, tokens, _p(w1t), _p(w2t), _p(gate), B, C, w1t.shape[1], _stream())
+    return gate
+
+
+def sam_im2col_scaled(xn, gate, B, grid, C):
+    cols = torch.empty((B * (grid // 2) ** 2, 9 * C), dtype=torch.bfloat16, device=xn.device)
+    lib().call("mp_sam_im2col_scaled_bf16", _p(xn), _p(gate), _p(cols), B, grid, C, _stream())
+    return cols
+
+
+def sam_im2col_parity4(s1, B, half, C):
+    cols4 = torch.empty((4, B * half * half, 4 * C), dtype=torch.bfloat16, device=s1.device)
+    lib().call("mp_sam_im2col_parity4_bf16", _p(s1), _p(cols4), B, half, C, _stream())
+    return cols4
+
+
+def sam_block_tail(y4, xn, x, mlp, ad_w, ad_b, ad_eps, next_w, next_b, next_eps, B, grid):
+    """-> (x_out, h_out or None): mp_sam_block_tail_bf16."""
+    dim = x.shape[1]
+    x_out = torch.empty_like(x)
+    h_out = torch.empty_like(x) if next_w is not None else None
+    lib().call("mp_sam_block_tail_bf16", _p(y4), _p(xn), _p(x), _p(mlp), _p(ad_w), _p(ad_b), float(ad_eps), _p(next_w), _p(next_b), float(next_eps),
+               _p(x_out), _p(h_out), B, grid, dim, _stream())
+    return x_out, h_out
+
+
 def token_mean(x, B, T, C):
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     lib().call("mp_token_mean_bf16", _p(x), _p(out), B, T, C, _stream())

@@ -28,6 +28,10 @@ MASK_LOGIT_TOL = 0.066         # stated tolerance on the mask logits of the bf16
                                # Round 5, more samples of the same quantity (the advisor's point: one seed is thin): 0.0534 (driver run r04), 0.0534
                                # (r05c, another box), 0.0489 (32 layers of DISTINCT weights, B = 1, profiles/r05_distinct_parity.json): the bound holds
                                # 19-26 % above every one of them
+MASK_LOGIT_TOL_FP32_TAIL = 0.045   # the same quantity with the strict fp32 tail (config.fused_bf16_upsampler=False): everything it holds is the bf16
+                               # TRUNK's error carried through an fp32 decoder (measured 0.038 at 32 layers, B = 8).  Asserted beside the fused bound
+                               # (tests/test_gpu_model.py::test_full_depth_parity_fp32_tail_binds_the_trunk) so that a trunk regression cannot hide in
+                               # the fused kernel's larger allowance (round-5 review, weak 1b)
 HIDDEN_P999_ALL_ROWS = 0.05    # the 99.9th-percentile element error of the last hidden state over ALL rows, relative to the largest reference entry.
 HIDDEN_BAD_ROW = 0.1           # a row is "bad" when its worst element is off by more than this (same scale).  A token that picked the other
                                # expert in some layer is a different computation from there on: its row differs by O(its own magnitude) and
@@ -76,7 +80,8 @@ def check_full_size(r, layers, moe):
          f"hidden mean error over the agreeing rows {r['hidden_mean_rel_err_agreeing_rows']:.4g} >= {mean_bound:.4g}")
     need(r["rows_agreeing_in_every_layer"] < 0.95 or r["hidden_mean_rel_err"] < mean_bound, f"hidden mean error {r['hidden_mean_rel_err']:.4g} >= {mean_bound:.4g}")
     mk = r["mask"]
-    need(mk["max_abs_dlogit"] <= MASK_LOGIT_TOL, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {MASK_LOGIT_TOL}")
+    tol = MASK_LOGIT_TOL if r.get("fused_bf16_upsampler", True) else MASK_LOGIT_TOL_FP32_TAIL
+    need(mk["max_abs_dlogit"] <= tol, f"mask logits: max |d| {mk['max_abs_dlogit']:.4g} > {tol}")
     for c in ("cut_ref", "cut_zero"):
         need(mk[c]["flipped_le_near_cut_every_mask"], f"{c}: a mask has more flipped pixels than pixels inside the error band")
         need(mk[c]["max_abs_ddice"] <= 1e-3, f"{c}: |dDice| {mk[c]['max_abs_ddice']:.4g} > 1e-3")
@@ -332,6 +337,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "routing_layer_local": local,
            "oracle_forward_seconds": round(t_oracle, 2),
            "distinct_weights": bool(distinct_weights),
+           "fused_bf16_upsampler": bool(getattr(cfg, "fused_bf16_upsampler", False)),
            "weights": ("DISTINCT seeded weights in every decoder layer, both sides" if distinct_weights
                        else "one decoder layer's seeded weights aliased over all layers, both sides")}
     if per_layer and "first_choice_agreement" in per_layer[0]:        # top-2 layers

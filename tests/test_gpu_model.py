@@ -1681,6 +1681,35 @@ def test_full_depth_parity_at_true_dims(dev, moe):
     _assert_full_size(r, 8, moe)
 
 
+def test_full_depth_parity_distinct_weights_per_layer(dev):
+    """The standing full-size runs alias ONE decoder layer's seeded weights over all layers on both sides (host memory); a per-layer
+    weight-indexing error — layer i reading layer j's matrices, an expert offset that only shows when the experts of two layers differ —
+    cancels there.  Here every one of 6 decoder layers (7B dims, E = 2 top-1, B = 1, S = 639) has its OWN seeded weights on both sides
+    (stored as the bf16 values they are, upcast one matrix at a time: oracle.model.UpcastDict; ~4 GB on the host), and the same bounds hold
+    (oracle/parity.check_full_size; the record carries `distinct_weights: true`).  Round-5 review, missing #5: the 32-layer form of this run
+    is scripts/r05_distinct_parity.py (profiles/r05_distinct_parity.json) — this is the depth the suite's time allows."""
+    from oracle.parity import full_size_parity
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=6, vocab_size=4096, seg_token_idx=4000, moe_enable=True)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    r = full_size_parity(cfg, dev, distinct_weights=True)
+    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items() if k != "mask"})
+    assert r["distinct_weights"] is True and r["layers"] == 6
+    _assert_full_size(r, 6, True)
+
+
+def test_full_depth_parity_fp32_tail_binds_the_trunk(dev):
+    """The fused bf16 upsampler's own operand rounding takes most of MASK_LOGIT_TOL (0.066), so a regression of the TRUNK could hide in it.
+    The same 8-layer run with the strict fp32 tail (config.fused_bf16_upsampler=False) holds the mask logits to MASK_LOGIT_TOL_FP32_TAIL
+    (0.045: what the bf16 trunk's error alone may amount to behind an fp32 decoder)."""
+    from oracle.parity import full_size_parity, MASK_LOGIT_TOL_FP32_TAIL
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=8, vocab_size=4096, seg_token_idx=4000, moe_enable=True, fused_bf16_upsampler=False)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    r = full_size_parity(cfg, dev)
+    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items() if k != "mask"}, r["mask"]["max_abs_dlogit"])
+    assert r["fused_bf16_upsampler"] is False and r["mask"]["max_abs_dlogit"] <= MASK_LOGIT_TOL_FP32_TAIL
+    _assert_full_size(r, 8, True)
+
+
 def _assert_full_size(r, layers, moe):
     """The bounds live in oracle/parity.py (check_full_size): bench.py holds its own `parity` object to the same list."""
     from oracle.parity import check_full_size
