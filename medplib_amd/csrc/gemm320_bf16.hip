@@ -64,7 +64,9 @@ __device__ __forceinline__ int lds_off3(int r, int c) { return r * 128 + ((c ^ (
 // RoPE path and spilled 362 VGPRs; the PLAIN path then wrote and re-read its accumulators through scratch (K sweep at 256 tiles: 35 us of
 // fixed cost per launch, 28 of them the epilogue).
 // EPI: 0 = alpha / bias / QuickGELU / residual, 1 = RoPE pairing (fused qkv), 2 = SwiGLU pairing (gate|up), 3 = MoE combine (row scatter)
-constexpr int EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_COMBINE = 3;
+constexpr int EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_COMBINE = 3, EPI_RELU = 4, EPI_GELU = 5;
+// EPI_RELU / EPI_GELU (round 6): the PLAIN family with ONE other activation sweep each — what the SAM-Med2D encoder's GEMMs need (Adapter.spatial:
+// ReLU, mlp.lin1: erf-GELU).  One sweep per instantiation: with two or three in one function the allocator spills ~300 VGPRs, each alone none.
 // `items`: which of the wave tile's 20 (fragment row i, fragment pair) items this call finishes — bit i * 4 + pair, pair = 2 consecutive
 // fragments = 32 columns; all twenty for an unsplit tile, a unit's share of them in the cooperative fix-up of a split tail tile (every
 // unit reduces and stores a share).  The SwiGLU family pairs fragments j and j + 2, so its items come as the two pairs of a column half.
@@ -227,7 +229,9 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = (EXPR); }         \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-  if (g.act == ACT_QUICK_GELU) { MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) }
+  if constexpr (EPI == EPI_RELU) { MP3_ACT_SWEEP(fmaxf(v, 0.f)) }
+  else if constexpr (EPI == EPI_GELU) { MP3_ACT_SWEEP(gelu_erf_fast(v)) }
+  else if (g.act == ACT_QUICK_GELU) { MP3_ACT_SWEEP(v * mp_sigmoid_fast(v, 1.702f)) }
 #undef MP3_ACT_SWEEP
   // ---- stores, in two column halves of the wave tile (the residual pieces of a half are all requested before the first is used)
   const bf16_t* R = g.residual ? g.residual + batch * g.sR : nullptr;
@@ -577,7 +581,8 @@ bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
   if (batch < 1 || batch > MAX_FLAT_BATCH3 || g.out_f32) return false;
   if (g.keep_gu && (batch != 1 || (g.ld_gu & 7) || (reinterpret_cast<uintptr_t>(g.keep_gu) & 15))) return false;
   // (the other activations' sweeps over 40 fragments do not fit beside 160 accumulators: the allocator then spills accumulators inside the K loop)
-  if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK || g.act == ACT_SWIGLU_PAIR)) return false;
+  if (!(g.act == ACT_NONE || g.act == ACT_QUICK_GELU || g.act == ACT_ROPE_QK || g.act == ACT_SWIGLU_PAIR || g.act == ACT_RELU || g.act == ACT_GELU)) return false;
+  if ((g.act == ACT_RELU || g.act == ACT_GELU) && (g.c_rows || g.a_rows)) return false;      // the EPI_RELU / EPI_GELU families: dense / plain batched calls
   if (g.act == ACT_ROPE_QK && (batch != 1 || g.m_dev || g.a_rows || g.c_rows)) return false;
   if (g.act == ACT_SWIGLU_PAIR && (g.c_rows || g.residual || g.bias || g.alpha != 1.f || ((g.N >> 1) & 7))) return false;
   if (g.c_rows && (g.act != ACT_NONE || g.bias || g.alpha != 1.f)) return false;
@@ -601,6 +606,8 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
     (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
     (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_COMBINE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
+    (void)hipFuncSetAttribute((const void*)gemm320_bf16_nt_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3);
     attr = true;
   }
   GemmArgs g = g0;
@@ -642,6 +649,8 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   if (g.act == ACT_ROPE_QK) MP3_GO(EPI_ROPE);
   else if (g.act == ACT_SWIGLU_PAIR) MP3_GO(EPI_SWIGLU);
   else if (g.c_rows) MP3_GO(EPI_COMBINE);
+  else if (g.act == ACT_RELU) MP3_GO(EPI_RELU);
+  else if (g.act == ACT_GELU) MP3_GO(EPI_GELU);
   else MP3_GO(EPI_PLAIN);
 #undef MP3_GO
   return mp_check_launch("mp_gemm_bf16_nt(320)");

@@ -175,3 +175,31 @@ def test_encoder_fused_and_generic_against_reference_golden(dev, golden_dir):
     for name, out in (("fused", enc.forward(img)), ("generic", enc.forward_generic(img))):
         _stat(f"sam image embedding ({name}) vs REFERENCE golden", out[0], ref, atol=0.08)
         assert (out[0].float().cpu() - ref).abs().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("M,N,K,act", [(2048, 3072, 768, "gelu"), (512, 768, 6912, "relu"), (2048, 768, 768, "relu")])
+def test_tower_policy_gemms_on_320_row_tiles_with_relu_and_gelu(dev, M, N, K, act):
+    """Round 6: under the frozen towers' whole-tile policy the SAM encoder's mlp.lin1 (erf-GELU) and Adapter.spatial (ReLU, M = 512) GEMMs take
+    the 320-row kernel's EPI_GELU / EPI_RELU families instead of the 128 x 128 kernel.  Against an fp32 product of the same bf16 operands
+    (bf16 output: 2^-8 relative) and against the 128 x 128 kernel's result for the same call (same activation expression on a differently
+    ordered fp32 sum: a bf16 ulp)."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g) * 0.2
+    code = ops.ACT_GELU if act == "gelu" else ops.ACT_RELU
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    with ops.throughput_tiles():
+        y = ops.gemm(ad, wd, bias=bd, act=code)
+        assert ops.gemm_last_kernel() == 320
+    ops.gemm_tile_policy(0)
+    try:
+        y0 = ops.gemm(ad, wd, bias=bd, act=code)
+        assert ops.gemm_last_kernel() != 320
+    finally:
+        ops.gemm_tile_policy(-1)
+    pre = a.float() @ w.float().t() + bias
+    ref = F.gelu(pre) if act == "gelu" else torch.relu(pre)
+    _stat(f"320-row {act} M={M} N={N} K={K} vs fp32", y, ref, atol=2e-2, rtol=1e-2)
+    _stat(f"320-row {act} vs the other kernel", y, y0, atol=1.6e-2, rtol=8e-3)
