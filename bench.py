@@ -206,9 +206,13 @@ def live_traffic(pass_timeout=170):
     t0 = time.perf_counter()
     avg = {}
     try:
+        clk = []                                         # (shader clocks, ns) of every decoder launch of the WRITE_SIZE pass
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="mp_pmc_", dir="/tmp")
-            cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
+            # GRBM_GUI_ACTIVE rides the WRITE_SIZE pass (the GRBM block's slots are independent of the TCC's, MI355X_MICROARCH.md "rocprofv3 PMC slots"):
+            # the launch's duration in shader clocks, summed over the 8 XCDs -> the clock the chip held under the kernel (round-5 review, item 4)
+            pmc = [c] + (["GRBM_GUI_ACTIVE"] if c == "WRITE_SIZE" else [])
+            cmd = [exe, "--kernel-trace", "--pmc", *pmc, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
                    "--warmup", "1", "--no-cpu-baseline", "--no-lora-line", "--no-secondary", "--no-kernel-timer", "--no-live-traffic"]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             env["TMPDIR"] = "/tmp"
@@ -217,16 +221,26 @@ def live_traffic(pass_timeout=170):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     n = row["Kernel_Name"]
-                    if row["Counter_Name"] == c and "gemm320" in n and "kernel<0>" not in n:      # epilogue families 1-3: the decoder's launches
+                    if row["Counter_Name"] == c and "gemm320" in n and any(f"kernel<{e}>" in n for e in (1, 2, 3)):      # epilogue families 1-3: the decoder's launches
                         vals.append(float(row["Counter_Value"]))
+                    if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and "gemm320" in n and any(f"kernel<{e}>" in n for e in (1, 2, 3)):
+                        try:
+                            clk.append((float(row["Counter_Value"]) / 8.0, float(row["End_Timestamp"]) - float(row["Start_Timestamp"])))
+                        except (KeyError, ValueError):
+                            pass
             shutil.rmtree(d, ignore_errors=True)
             if r.returncode != 0 or not vals:
                 return {"error": f"{c} pass: rc {r.returncode}, {len(vals)} launches; {r.stderr[-300:]}"}
             avg[c] = (sum(vals) / len(vals), len(vals))
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
-    return {"read_bytes_per_launch": round(2 * 1024 * avg["FETCH_SIZE"][0]), "write_bytes_per_launch": round(1024 * avg["WRITE_SIZE"][0]),
-            "launches": avg["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
+    out = {"read_bytes_per_launch": round(2 * 1024 * avg["FETCH_SIZE"][0]), "write_bytes_per_launch": round(1024 * avg["WRITE_SIZE"][0]),
+           "launches": avg["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
+    clk = [(cy, ns) for cy, ns in clk if cy > 0 and ns > 0]
+    if clk:
+        out["shader_clocks_per_launch"] = round(sum(cy for cy, _ in clk) / len(clk))
+        out["effective_clock_ghz"] = round(sum(cy for cy, _ in clk) / sum(ns for _, ns in clk), 3)
+    return out
 
 
 def cpu_baseline(cfg, device, warmup=3, timed=5):
@@ -553,6 +567,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 child passes that measure `roofline.traffic` in this run "
                     "(the committed profile's figure is reported instead, marked as such)")
+    ap.add_argument("--fold-input-norm", action="store_true",
+                    help="config.fold_input_norm: both RMSNorms of every frozen MoE decoder layer folded into their consumer GEMMs (A/B; moves a rounding point)")
     ap.add_argument("--towers-in-order", action="store_true",
                     help="debug / A-B: the frozen CLIP tower of a step queues behind the previous step's decoder instead of starting on its own "
                          "stream when the step is issued (model.towers_run_ahead, the default since round 3: +2.6 %% samples/s)")
@@ -671,7 +687,7 @@ def gpu_main(args, emit):
         args.no_cpu_baseline = True                          # the host leg and the parity object belong to the default configuration
     else:
         cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=args.layers, num_experts=args.experts, top_k_experts=args.top_k,
-                                       use_residual=args.use_residual)
+                                       use_residual=args.use_residual, fold_input_norm=bool(args.fold_input_norm))
         if (args.experts, args.top_k, args.use_residual) != (2, 1, False):
             args.no_cpu_baseline = True                      # the host leg and the parity object belong to the reported configuration
         model = MedPLIBForCausalLM(cfg, device=device).train()
@@ -875,9 +891,17 @@ def gpu_main(args, emit):
                     roof["traffic"] = live["read_bytes_per_launch"] + live["write_bytes_per_launch"]
                     roof["traffic_detail"] = {"kernel": fams[dom], "read_bytes_per_launch": live["read_bytes_per_launch"],
                                               "write_bytes_per_launch": live["write_bytes_per_launch"], "launches": live["launches"],
+                                              # GRBM_GUI_ACTIVE / 8 XCDs / the launch's wall time in the same child pass: the shader clock the chip held
+                                              # under the dominant kernel (the MFMA peak is quoted at 2.4 GHz)
+                                              "shader_clocks_per_launch": live.get("shader_clocks_per_launch"), "effective_clock_ghz": live.get("effective_clock_ghz"),
                                               "source": "measured in THIS run: two child passes of this command (2 steps after 1) under rocprofv3 --kernel-trace --pmc "
                                                         "FETCH_SIZE | WRITE_SIZE, the decoder's 320-row launches (epilogue families 1-3), read = 2 x FETCH_SIZE per the "
                                                         f"gfx950 correction; {live['seconds']} s", "stale": False, "kernel_source_sha": kernel_source_sha()}
+                    if live.get("effective_clock_ghz"):
+                        # beside `frac` (against the peak quoted at the 2.4 GHz maximum clock): the same achieved rate against the MFMA peak AT THE
+                        # CLOCK THE CHIP HELD under this kernel — what the schedule leaves on the table once the power-limited clock is taken out
+                        roof["effective_clock_ghz"] = live["effective_clock_ghz"]
+                        roof["frac_at_effective_clock"] = round(roof["achieved"] / (MFMA_BF16_PEAK_TFLOPS * live["effective_clock_ghz"] / 2.4), 4)
                 elif tj and not args.lora and not args.ep:
                     now, then = kernel_source_sha(), tjs.get("kernel_source_sha")
                     roof["traffic"] = tj["read_bytes_per_launch"] + tj["write_bytes_per_launch"]
@@ -928,6 +952,8 @@ def gpu_main(args, emit):
                        "global_batch": world * args.batch, "seq_len": seq_len,
                        "parallelism": (f"ep{epx.ep} x dp{max(world // epx.ep, 1)}" if args.ep else f"dp{world}"),
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel,
+                       # decoder layers whose two RMSNorms ran folded into their consumer GEMMs in the timed steps (config.fold_input_norm; 0 = HF's rounding points)
+                       "folded_norm_layers": int(getattr(model.model.llm, "folded_layers", 0)),
                        # the last decoder layer's MLP runs on the rows the filtered CE and the <SEG> gather read (bit-identical losses and
                        # gradients: tests/test_gpu_prune_last_mlp.py); "all" under MP_PRUNE_LAST_MLP=0
                        "last_layer_mlp_rows": pruned_tflop_per_step(model, cfg, args.lora)[1] or "all",

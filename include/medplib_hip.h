@@ -378,6 +378,23 @@ int mp_gate_noise_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, int
  * bf16 h.  Bit-identical with mp_rmsnorm_bf16 followed by mp_moe_gate_bf16.  n_experts = 0: the norm alone.  dim 2048 / 4096 / 8192. */
 int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg, float* logits,
                          float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream);
+/* The folded-norm form of the above (config.fold_input_norm): rstd [tokens] fp32 = 1 / sqrt(mean(x^2) + eps) instead of the normalised rows — the
+ * consumer GEMM reads x itself with ln_w folded into its weight's columns and multiplies by rstd in its epilogue (mp_gemm_qkv_rope_scaled_bf16,
+ * mp_gemm_bf16_nt_batched_rows_scaled).  logits / gates exactly as mp_rmsnorm_gate_bf16 computes them (from the HF-rounded bf16 h, which never
+ * leaves the registers): the routing does not move.  n_experts = 0: rstd alone. */
+int mp_rmsnorm_gate_rstd_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, const float* wg, float* logits, float* gates,
+                              float* rstd, int64_t tokens, int dim, int n_experts, hipStream_t stream);
+/* The two consumer GEMMs of the folded input norms: the fused qkv projection + RoPE and the experts' gate|up projection + SwiGLU on the RAW residual
+ * stream, the norm weight multiplied into the weight's columns on the host (once, at load), rstd applied to the fp32 accumulators in the epilogue
+ * before the projection's own bf16 rounding (LlamaRMSNorm -> q/k/v_proj, -> gate/up_proj; medplib_moe_llama.py:121-148).  320-row kernel shapes only
+ * (mp_gemm_fold_ok: M >= 1024, N % 256 == 0, K % 64 == 0) — anything else is an error, the caller keeps the unfolded kernels for it. */
+int mp_gemm_qkv_rope_scaled_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
+                                 const float* sin_t, const float* row_scale, int M, int N, int K, int seq, int pos_offset, int head_dim,
+                                 hipStream_t stream);
+int mp_gemm_bf16_nt_batched_rows_scaled(const void* A, int64_t lda, const int* a_rows, const float* a_row_scale, const void* W, int64_t ldw,
+                                        int64_t strideW, void* C, int64_t ldc, int64_t strideC, int rows_stride, int batch, int M, int N,
+                                        int K, const int* m_dev, hipStream_t stream);
+int mp_gemm_fold_ok(int M, int N, int K);
 int mp_moe_dispatch_bf16(const void* x, int64_t ldx, const int* expert, const int* slot, void* buf, int64_t ldbuf, int64_t tokens, int dim,
                          int capacity, int top_k, hipStream_t stream);   /* buf: [E, capacity, ldbuf >= dim] slabs (ldbuf > dim: row-padded, e.g. a K-extension) */
 int mp_moe_combine_bf16(const void* y, const int* expert, const int* slot, const float* weight, const void* residual, void* out,

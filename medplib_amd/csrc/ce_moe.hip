@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
 template <int NCH, bool LDSW>      // 16-byte chunks per lane: dim = NCH * 512
 __global__ __launch_bounds__(512) void rmsnorm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, float eps,
                                                            bf16_t* __restrict__ h, int64_t ldh, const float* __restrict__ wg, int E,
-                                                           float* __restrict__ logits, float* __restrict__ gates, int64_t T) {
+                                                           float* __restrict__ logits, float* __restrict__ gates, int64_t T, float* __restrict__ rstd = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];
   constexpr int dim = NCH * 512;
   const int lane = threadIdx.x & 63;
@@ -133,6 +133,10 @@ __global__ __launch_bounds__(512) void rmsnorm_gate_kernel(const bf16_t* __restr
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) ss += wave_sum(part[wv]);
     const float rs = rsqrtf(ss / (float)dim + eps);
+    // the folded-norm form (mp_rmsnorm_gate_rstd_bf16): the consumer GEMM takes the raw rows and applies rs in its epilogue, so the normalised
+    // row is never written — only its scale; the gate is still computed from the HF-rounded h values, so the routing does not move
+    if (rstd && lane == 0) rstd[tok] = rs;
+    if (!h && E == 0) continue;
     float acc[MAXE];
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(512) void rmsnorm_gate_kernel(const bf16_t* __restr
         const bf16_t t = (bf16_t)((float)v[k][j] * rs);          // HF: the normalised value is cast to the input dtype first
         o[j] = (bf16_t)((j < 4 ? w0[j & 3] : w1[j & 3]) * (float)t);
       }
-      *reinterpret_cast<bf16x8*>(hr + i) = o;
+      if (h) *reinterpret_cast<bf16x8*>(hr + i) = o;
 #pragma unroll
       for (int e = 0; e < MAXE; ++e) {
         if (e < E) {
@@ -856,8 +860,8 @@ extern "C" int mp_moe_gate_bf16(const void* x, int64_t ldx, const float* wg, flo
   return mp_check_launch("mp_moe_gate_bf16");
 }
 
-extern "C" int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg,
-                                    float* logits, float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream) {
+static int rmsnorm_gate_launch(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg,
+                                    float* logits, float* gates, int64_t tokens, int dim, int n_experts, float* rstd, hipStream_t stream) {
   MP_REQUIRE(n_experts >= 0 && n_experts <= MAXE && ldx % 8 == 0 && ldh % 8 == 0, MP_ERR_SHAPE, "mp_rmsnorm_gate_bf16: bad shape (E <= %d)", MAXE);
   MP_REQUIRE(dim == 2048 || dim == 4096 || dim == 8192, MP_ERR_SHAPE, "mp_rmsnorm_gate_bf16: dim %d (2048, 4096 or 8192)", dim);
   MP_REQUIRE(n_experts == 0 || (wg != nullptr && gates != nullptr), MP_ERR_ARG, "mp_rmsnorm_gate_bf16: gate outputs missing");
@@ -871,13 +875,28 @@ extern "C" int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_
 #define MP_RG(N)                                                                                                                                   \
   do {                                                                                                                                             \
     if (stage) hipLaunchKernelGGL((rmsnorm_gate_kernel<N, true>), grid, blk, lds, stream, (const bf16_t*)x, ldx, ln_w, eps, (bf16_t*)h, ldh, wg,   \
-                                  n_experts, logits, gates, tokens);                                                                               \
+                                  n_experts, logits, gates, tokens, rstd);                                                                               \
     else hipLaunchKernelGGL((rmsnorm_gate_kernel<N, false>), grid, blk, 0, stream, (const bf16_t*)x, ldx, ln_w, eps, (bf16_t*)h, ldh, wg,          \
-                            n_experts, logits, gates, tokens);                                                                                     \
+                            n_experts, logits, gates, tokens, rstd);                                                                                     \
   } while (0)
   if (dim == 2048) MP_RG(4); else if (dim == 4096) MP_RG(8); else MP_RG(16);
 #undef MP_RG
   return mp_check_launch("mp_rmsnorm_gate_bf16");
+}
+
+extern "C" int mp_rmsnorm_gate_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, void* h, int64_t ldh, const float* wg, float* logits,
+                                    float* gates, int64_t tokens, int dim, int n_experts, hipStream_t stream) {
+  MP_REQUIRE(h != nullptr, MP_ERR_ARG, "mp_rmsnorm_gate_bf16: h is null (mp_rmsnorm_gate_rstd_bf16 is the form without the normalised rows)");
+  return rmsnorm_gate_launch(x, ldx, ln_w, eps, h, ldh, wg, logits, gates, tokens, dim, n_experts, nullptr, stream);
+}
+
+// The folded-norm form: rstd [tokens] fp32 = 1 / sqrt(mean(x^2) + eps) instead of the normalised rows (the consumer GEMM reads x itself, its
+// weights carry ln_w, its epilogue multiplies by rstd); logits / gates exactly as mp_rmsnorm_gate_bf16 computes them (from the bf16 h values,
+// which stay in registers).  n_experts = 0: rstd alone (wg unused).
+extern "C" int mp_rmsnorm_gate_rstd_bf16(const void* x, int64_t ldx, const float* ln_w, float eps, const float* wg, float* logits, float* gates,
+                                         float* rstd, int64_t tokens, int dim, int n_experts, hipStream_t stream) {
+  MP_REQUIRE(rstd != nullptr && ln_w != nullptr, MP_ERR_ARG, "mp_rmsnorm_gate_rstd_bf16: rstd and ln_w required");
+  return rmsnorm_gate_launch(x, ldx, ln_w, eps, nullptr, 8, wg, logits, gates, tokens, dim, n_experts, rstd, stream);
 }
 
 extern "C" int mp_moe_route_top1(const float* gates, const float* rts_uniform, int tokens, int n_experts, int capacity, int* expert,

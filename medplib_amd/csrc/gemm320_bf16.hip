@@ -79,6 +79,15 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
   if constexpr (EPI == EPI_SWIGLU) {
     // W rows are [gate 0..31 | up 0..31 | gate 32..63 | up 32..63 | ...]: of the wave's 8 fragments 0,1 / 4,5 are gate columns and 2,3 / 6,7
     // the matching up columns; gate and up are rounded to bf16 first, like the unfused GEMM + SwiGLU kernel pair (and gemm256_epilogue_t)
+    // folded post-attention norm: rstd of the token behind A row `row` (null: 1.f) multiplies the fp32 accumulators before their bf16 rounding
+    float rsc[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
+    if (g.a_scale) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int row = m0 + wr * 80 + i * 16 + fr;
+        if (row < M) rsc[i] = g.a_scale[g.a_rows ? g.a_rows[batch * g.rows_stride + row] : row];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int row = m0 + wr * 80 + i * 16 + fr;
@@ -90,6 +99,8 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            acc[i][jb * 4 + jj][r] *= rsc[i];
+            acc[i][jb * 4 + jj + 2][r] *= rsc[i];
             const float gf = (float)(bf16_t)acc[i][jb * 4 + jj][r];
             const float uf = (float)(bf16_t)acc[i][jb * 4 + jj + 2][r];
             o[jj][r] = (bf16_t)(gf * mp_sigmoid_fast(gf) * uf);
@@ -164,9 +175,11 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
     const bool is_v = n0 >= (N / 3) * 2;                  // wave-uniform
     const int head0 = (cw >> 7) << 7;
     f32x4 cs[2][2][2], sn[2][2][2];                       // [buffer][jb][j]
+    float rsc[2] = {1.f, 1.f};                            // folded input norm: rstd of the fragment row's token (null: 1.f)
     auto fetch = [&](int i, int buf) {
       const int row = m0 + wr * 80 + i * 16 + fr;
       const int pos = (row < M ? row : 0) % g.rope_seq + g.rope_pos0;
+      if (g.a_scale) rsc[buf] = g.a_scale[row < M ? row : 0];
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -187,7 +200,7 @@ __device__ __forceinline__ void gemm320_epilogue(const GemmArgs& g, f32x4 (&acc)
         bf16x4 olo[2], ohi[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          const bf16x4 qa = round4(acc[i][jb * 4 + jj]), qb = round4(acc[i][jb * 4 + jj + 2]);   // the projection output's own rounding point
+          const bf16x4 qa = round4(acc[i][jb * 4 + jj] * rsc[i & 1]), qb = round4(acc[i][jb * 4 + jj + 2] * rsc[i & 1]);   // the projection output's own rounding point
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float a = (float)qa[r], b = (float)qb[r];
@@ -589,6 +602,7 @@ bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
   // M >= 1024 for the decoder's calls (fewer rows are few tiles: the smaller kernels fill the machine better).  The frozen towers' whole-tile
   // policy counts CU x time instead of latency (ops.throughput_tiles), and there a 512-row call on two row tiles beats the 128 x 128 kernel's
   // split-K units several times over (the SAM adapter's K = 6912 convolution: 6 tiles x 186 us against 240 units x ~20 us + their partials)
+  if (g.a_scale && !(g.act == ACT_ROPE_QK || g.act == ACT_SWIGLU_PAIR)) return false;
   if (g.N % BN3 || g.K % BK3 || g.M < (mp_gemm_policy_whole_tiles() ? BM3 : 1024)) return false;
   if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || (g.sC & 7)) return false;
   if (g.residual && ((g.ldr & 7) || (reinterpret_cast<uintptr_t>(g.residual) & 15) || (g.sR & 7))) return false;

@@ -505,6 +505,28 @@ extern "C" int mp_gemm_qkv_rope_bf16(const void* A, int64_t lda, const void* Wi,
   return mp_launch_gemm256(g, 1, stream);
 }
 
+// The same with the input RMSNorm folded in (config.fold_input_norm): A = the RAW residual stream, Wi = the interleaved qkv weight with the norm
+// weight multiplied into its columns, row_scale [M] = rstd of every row (mp_rmsnorm_gate_rstd_bf16 with n_experts = 0): the epilogue multiplies
+// the fp32 accumulators by rstd before the projection's bf16 rounding and the rotation.  320-row kernel only: a shape it does not take is an error
+// (the caller keeps the unfolded path for those).
+extern "C" int mp_gemm_qkv_rope_scaled_bf16(const void* A, int64_t lda, const void* Wi, int64_t ldw, void* C, int64_t ldc, const float* cos_t,
+                                            const float* sin_t, const float* row_scale, int M, int N, int K, int seq, int pos_offset, int head_dim,
+                                            hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0, MP_ERR_SHAPE, "mp_gemm_qkv_rope_scaled_bf16: K must be a multiple of %d", BK);
+  MP_REQUIRE(head_dim == 128 && N % 3 == 0 && (N / 3) % 256 == 0, MP_ERR_SHAPE, "mp_gemm_qkv_rope_scaled_bf16: head_dim 128 and hidden %% 256 == 0");
+  MP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && cos_t && sin_t && row_scale && seq > 0, MP_ERR_ARG, "mp_gemm_qkv_rope_scaled_bf16: bad arguments");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wi; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.act = ACT_ROPE_QK; g.out_f32 = 0; g.alpha = 1.f;
+  g.group_m = gemm_group_m();
+  g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_seq = seq; g.rope_pos0 = pos_offset;
+  g.a_scale = row_scale;
+  MP_REQUIRE(gemm_variant() == 2 && mp_gemm320_eligible(g, 1), MP_ERR_SHAPE, "mp_gemm_qkv_rope_scaled_bf16: M=%d N=%d K=%d is not a 320-row-kernel shape (M >= 1024, N %% 256 == 0)", M, N, K);
+  g_last_gemm_kernel = 320;
+  return mp_launch_gemm320(g, 1, stream);
+}
+
 // gate|up projection of a TRAINING forward: act = silu(gate) * up from the fused epilogue AND the bf16 gate|up values themselves (the
 // backward's operands), one launch instead of GEMM + mp_swiglu_pair_fwd_bf16 (which re-read the [tokens, 2 ff] tensor).
 extern "C" int mp_gemm_swiglu_keep_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* act_out, int64_t ld_act, void* gu_out,
@@ -599,3 +621,26 @@ extern "C" int mp_gemm_bf16_nt_batched_rows(const void* A, int64_t lda, int64_t 
   launch_gemm(g, dim3(tiles, batch), stream);
   return mp_check_launch("mp_gemm_bf16_nt_batched_rows");
 }
+
+// The expert gate|up projection with the post-attention RMSNorm folded in: A = the RAW residual stream [tokens, K] gathered through a_rows, W = the
+// interleaved gate|up weights with the norm weight multiplied into their columns, a_row_scale [tokens] = rstd (mp_rmsnorm_gate_rstd_bf16).  The
+// SwiGLU epilogue multiplies the fp32 accumulators by rstd[token of the row] before their bf16 rounding.  SWIGLU_PAIR, 320-row kernel only.
+extern "C" int mp_gemm_bf16_nt_batched_rows_scaled(const void* A, int64_t lda, const int* a_rows, const float* a_row_scale, const void* W, int64_t ldw,
+                                                   int64_t strideW, void* C, int64_t ldc, int64_t strideC, int rows_stride, int batch, int M, int N,
+                                                   int K, const int* m_dev, hipStream_t stream) {
+  MP_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0 && a_rows && a_row_scale, MP_ERR_ARG, "mp_gemm_bf16_nt_batched_rows_scaled: a_rows and a_row_scale required");
+  MP_REQUIRE(K % BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && strideW % 8 == 0 && N % 64 == 0 && ldc % 8 == 0, MP_ERR_SHAPE, "mp_gemm_bf16_nt_batched_rows_scaled: bad strides");
+  if (M == 0) return MP_OK;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+  g.m_dev = m_dev; g.M = M; g.N = N; g.K = K; g.act = ACT_SWIGLU_PAIR; g.out_f32 = 0; g.alpha = 1.f;
+  g.sA = 0; g.sW = strideW; g.sC = strideC; g.m_dev_stride = 1; g.group_m = gemm_group_m();
+  g.a_rows = a_rows; g.rows_stride = rows_stride; g.a_scale = a_row_scale;
+  MP_REQUIRE(gemm_variant() == 2 && mp_gemm320_eligible(g, batch), MP_ERR_SHAPE,
+             "mp_gemm_bf16_nt_batched_rows_scaled: M=%d N=%d K=%d batch=%d is not a 320-row-kernel shape (M >= 1024, N %% 256 == 0)", M, N, K, batch);
+  g_last_gemm_kernel = 320;
+  return mp_launch_gemm320(g, batch, stream);
+}
+
+// Whether the two folded-norm GEMM entry points take a call of this size (the host keeps the unfolded path otherwise)
+extern "C" int mp_gemm_fold_ok(int M, int N, int K) { return (gemm_variant() == 2 && M >= 1024 && N % 256 == 0 && K % 64 == 0) ? 1 : 0; }

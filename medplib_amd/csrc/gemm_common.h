@@ -47,6 +47,10 @@ struct GemmArgs {
   // ACT_SWIGLU_PAIR with keep_gu: the rounded gate|up values are ALSO stored (interleaved [M, N] layout, ld_gu) -- training keeps them for
   // the backward, and the stand-alone SwiGLU pass over the [tokens, 2 ff] tensor disappears (mp_gemm_swiglu_keep_bf16)
   bf16_t* keep_gu; int64_t ld_gu;
+  // folded input norms (320-row kernel, RoPE and SwiGLU families only): the accumulator of output row r is multiplied by a_scale[source row of
+  // A row r] before the family's first rounding — rstd of an RMSNorm whose weight is folded into W's columns (mp_gemm_qkv_rope_scaled_bf16,
+  // mp_gemm_bf16_nt_batched_rows_scaled).  null = 1.
+  const float* a_scale;
 };
 
 // GELU(erf) without erff: gelu(x) = relu(x) - a Phi(-a), a = |x|, log2 Phi(-a) fitted by a degree-5 polynomial (minimax on the absolute

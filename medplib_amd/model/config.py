@@ -67,6 +67,11 @@ class MedPLIBConfig:
     # (autograd_ops.FusedUpsampleMaskFn).  False = six fp32 launches forward, fourteen backward (the strict-parity tail: 2e-4 / 2e-3
     # against the oracle on the same trunk outputs, where the fused form holds 2e-3 / 3e-2).  Needs a 16-multiple token grid.
     fused_bf16_upsampler: bool = True
+    # Both RMSNorms of a frozen top-1 MoE decoder layer folded into their consumer GEMMs (round 6): the qkv and the experts'
+    # gate|up projections read the raw residual stream, the norm weights are multiplied into the frozen weights' columns once, rstd is applied in the
+    # GEMM epilogue.  Moves HF's rounding point (the normalised row is never a bf16 tensor; the folded weight is rounded instead), the MoE gate still
+    # sees HF's bf16 h.  Multi-row frozen forwards of 320-row-kernel shapes only; everything else keeps the two norm kernels.
+    fold_input_norm: bool = False
 
     @property
     def head_dim(self):

@@ -70,6 +70,18 @@ class LlamaStack:
                 lw["qkv_rope"] = ops.rope_interleave_qkv(lw["qkv"], self.cfg.num_attention_heads, self.cfg.head_dim)
             else:
                 lw.pop("qkv_rope", None)
+        self.refresh_folded_norms()
+
+    def refresh_folded_norms(self):
+        """config.fold_input_norm: the frozen weights with the norm weights multiplied into their columns — W' = bf16(W * ln_w[None, :]) — for the two
+        consumer GEMMs of a top-1 MoE layer's RMSNorms (qkv + RoPE, experts' gate|up).  Call after anything that writes ln1 / ln2 / qkv / gu.
+        (+ 0.46 GB per layer at 7B, E = 2: the unfolded weights stay for decode, export and the adapter path.)"""
+        on = bool(getattr(self.cfg, "fold_input_norm", False)) and self.fuse_rope and self.cfg.top_k_experts == 1 and not self.cfg.use_residual
+        for i, lw in enumerate(self.layers):
+            lw.pop("qkv_rope_f", None); lw.pop("gu_f", None)
+            if on and i in self.moe_layers:
+                lw["qkv_rope_f"] = (lw["qkv_rope"].float() * lw["ln1"][None, :]).to(torch.bfloat16)
+                lw["gu_f"] = (lw["gu"].float() * lw["ln2"][None, None, :]).to(torch.bfloat16)
 
     def enable_expert_parallel(self, ep):
         """Shard the experts over an expert-parallel group (DeepSpeed `ep_size`, medplib_moe_llama.py:604-614): every rank keeps the
@@ -171,11 +183,11 @@ class LlamaStack:
             self._draws_key = key
         return self._draws_all[i * T * E:(i + 1) * T * E]
 
-    def _mlp(self, i, lw, h, x, gate=None, needed=None):
+    def _mlp(self, i, lw, h, x, gate=None, needed=None, rstd=None):
         """x + MLP(h): h = post-attention RMSNorm output [T,d], x = residual stream [T,d]; gate = (logits, gates) when the caller's fused
         norm kernel already produced them (ops.rmsnorm_gate)."""
         cfg = self.cfg
-        T = h.shape[0]
+        T = x.shape[0]
         if i not in self.moe_layers:
             if T <= 8:
                 return ops.gemv(ops.gemv(h, lw["gu"], act=ops.ACT_SWIGLU_PAIR), lw["down"], residual=x), None, None
@@ -201,7 +213,7 @@ class LlamaStack:
             # the capacity-dropped ones get the residual stream from a fill kernel
             expert, slot, weight, kept, counts, l_aux, slot_token = ops.moe_route_top1(
                 gates, cap, self._gate_draws(i, T, E, gumbel=False), want_slot_token=True)
-            act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=h.device)
+            act = torch.empty((E, cap, ff), dtype=torch.bfloat16, device=x.device)
             if needed is not None:
                 self.pruned_rows = int(getattr(self, "needed_rows")[0].numel())      # the pruning HAPPENED (model_forward reports only this)
                 # the last layer: only the rows something reads go through the experts (the routing above saw every token: capacity drops,
@@ -209,7 +221,10 @@ class LlamaStack:
                 slot_token, kept = ops.moe_filter_slots(slot_token, kept, needed)
             if ops.GEMM_TIMER is not None:
                 ops.GEMM_TIMER.batched_tag = i          # the expert GEMMs are credited with the rows `kept` holds after the region
-            ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
+            if rstd is not None:        # folded post-attention norm: the experts read the raw stream, W carries ln2, the epilogue applies rstd
+                ops.gemm_batched_rows(x, lw["gu_f"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap, a_row_scale=rstd)
+            else:
+                ops.gemm_batched_rows(h, lw["gu"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap)
             # Round 4: the combine writes INTO the residual stream (out = residual = x).  Every (routed row, 16-byte column piece) has
             # exactly one owner in the down projection's epilogue — a tile, or one unit's share of a split tail tile — which reads the
             # residual piece and stores the sum at the same address; a capacity-dropped token's row is simply left as it is, which is
@@ -285,7 +300,29 @@ class LlamaStack:
         pos0 = kv_cache["len"] if kv_cache is not None else 0
         # a handful of rows (the single-token decode steps): the projections are weight streams -> GEMV kernel (HBM-bound)
         lin = (lambda a, w, **kw: ops.gemv(a, w, **kw)) if B * S <= 8 else (lambda a, w, **kw: ops.gemm(a, w, **kw))
+        ff = cfg.intermediate_size
+        # folded norms (config.fold_input_norm): frozen top-1 MoE layers of 320-row-kernel shapes, one rank, no intermediate capture
+        fold = ("qkv_rope_f" in self.layers[0] if self.layers else False) and kv_cache is None and self.ep is None and self.fuse_moe_gather_scatter \
+            and d in ops.RMSNORM_GATE_DIMS and ops.gemm_fold_ok(B * S, 3 * d, d) and ops.gemm_fold_ok(self.capacity(B * S), 2 * ff, d)
+        self.folded_layers = 0
         for i, lw in enumerate(self.layers):
+            if fold and "qkv_rope_f" in lw:
+                # x -> rstd1; qkv = (x W'^T) * rstd1 -> RoPE; attention; o_proj + residual; x -> rstd2 + gate (from HF's bf16 h); experts on x with W''
+                rstd1, _, _ = ops.rmsnorm_gate_rstd(x, lw["ln1"], cfg.rms_norm_eps)
+                qkv = ops.gemm_qkv_rope(x, lw["qkv_rope_f"], self.cos, self.sin, S, H, D, pos_offset=pos0, out=ops.padded_rows(B * S, 3 * d, x.device),
+                                        row_scale=rstd1)
+                q5 = qkv.unflatten(0, (B, S)).unflatten(2, (3, H, D))
+                attn = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=True, key_valid=key_valid)
+                x = lin(attn.view(B * S, d), lw["o"], residual=x)
+                x_gate_in = x.clone() if collect_routing else None          # (tests / parity only, as below)
+                rstd2, lg, gt = ops.rmsnorm_gate_rstd(x, lw["ln2"], cfg.rms_norm_eps, lw["wg"])
+                x, l_aux, r = self._mlp(i, lw, None, x, gate=(lg, gt), needed=needed_mask if i == len(self.layers) - 1 else None, rstd=rstd2)
+                aux.append(l_aux)
+                if collect_routing:
+                    routing.append(r)
+                    gate_inputs.append(x_gate_in)
+                self.folded_layers += 1
+                continue
             h = ops.rmsnorm(x, lw["ln1"], cfg.rms_norm_eps)
             if self.fuse_rope and B * S > 8:
                 # (row stride of the qkv buffer kept off multiples of 8 KiB: ops.padded_rows)
@@ -313,7 +350,9 @@ class LlamaStack:
                 x, l_aux, r = self._mlp(i, lw, h, x, gate=(lg, gt), needed=needed_mask if i == len(self.layers) - 1 else None)
             else:
                 h = ops.rmsnorm(x, lw["ln2"], cfg.rms_norm_eps)
-                x, l_aux, r = self._mlp(i, lw, h, x)
+                # (the row set also reaches the MoE branch behind the unfused norm — hidden sizes without an rmsnorm_gate instantiation, the tiny
+                #  test dims: _mlp prunes in its top-1 gather / scatter branch whichever kernel produced the gate)
+                x, l_aux, r = self._mlp(i, lw, h, x, needed=needed_mask if (i in self.moe_layers and i == len(self.layers) - 1) else None)
             if l_aux is not None:
                 aux.append(l_aux)
                 if collect_routing:

@@ -798,7 +798,12 @@ def padded_rows(rows, cols, device, dtype=torch.bfloat16):
     return torch.empty((rows, cols + pad), dtype=dtype, device=device)[:, :cols]
 
 
-def gemm_qkv_rope(a, w_interleaved, cos_t, sin_t, seq, heads, head_dim, pos_offset=0, out=None):
+def gemm_fold_ok(M, N, K):
+    """Whether the folded-norm GEMM entry points (row_scale= / a_row_scale=) take a call of this size (mp_gemm_fold_ok)."""
+    return bool(lib().raw("mp_gemm_fold_ok")(int(M), int(N), int(K)))
+
+
+def gemm_qkv_rope(a, w_interleaved, cos_t, sin_t, seq, heads, head_dim, pos_offset=0, out=None, row_scale=None):
     """qkv = a @ W^T with RoPE applied to the q and k thirds in the GEMM epilogue; `w_interleaved` = rope_interleave_qkv(W).  The result
     (standard [tokens, 3*H*D] layout) is bit-identical with gemm(a, W) followed by rope_qk_."""
     _chk(a, torch.bfloat16, "gemm_qkv_rope.a"); _chk(w_interleaved, torch.bfloat16, "gemm_qkv_rope.w"); _chk(cos_t, torch.float32, "gemm_qkv_rope.cos")
@@ -810,8 +815,13 @@ def gemm_qkv_rope(a, w_interleaved, cos_t, sin_t, seq, heads, head_dim, pos_offs
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
-    lib().call("mp_gemm_qkv_rope_bf16", _p(a), a.stride(0), _p(w_interleaved), w_interleaved.stride(0), _p(out), out.stride(0), _p(cos_t),
-               _p(sin_t), M, N, K, int(seq), int(pos_offset), int(head_dim), _stream())
+    if row_scale is not None:       # folded input norm: a = the raw residual stream, w carries the norm weight, row_scale = rstd [M] fp32
+        _chk(row_scale, torch.float32, "gemm_qkv_rope.row_scale"); assert row_scale.is_contiguous() and row_scale.numel() == M
+        lib().call("mp_gemm_qkv_rope_scaled_bf16", _p(a), a.stride(0), _p(w_interleaved), w_interleaved.stride(0), _p(out), out.stride(0), _p(cos_t),
+                   _p(sin_t), _p(row_scale), M, N, K, int(seq), int(pos_offset), int(head_dim), _stream())
+    else:
+        lib().call("mp_gemm_qkv_rope_bf16", _p(a), a.stride(0), _p(w_interleaved), w_interleaved.stride(0), _p(out), out.stride(0), _p(cos_t),
+                   _p(sin_t), M, N, K, int(seq), int(pos_offset), int(head_dim), _stream())
     if GEMM_TIMER is not None:
         GEMM_TIMER.end(2.0 * M * N * K, t0)
     return out
@@ -1420,6 +1430,18 @@ def rmsnorm_gate(x, ln_w, eps, wg=None):
 RMSNORM_GATE_DIMS = (2048, 4096, 8192)
 
 
+def rmsnorm_gate_rstd(x, ln_w, eps, wg=None):
+    """The folded-norm form of rmsnorm_gate: -> (rstd [T] fp32, logits, gates) (logits / gates None without wg); the normalised rows are not written."""
+    _chk(x, torch.bfloat16, "rmsnorm_gate_rstd.x")
+    T, d = x.shape
+    E = 0 if wg is None else wg.shape[0]
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+    logits = torch.empty((T, E), dtype=torch.float32, device=x.device) if E else None
+    gates = torch.empty((T, E), dtype=torch.float32, device=x.device) if E else None
+    lib().call("mp_rmsnorm_gate_rstd_bf16", _p(x), x.stride(0), _p(ln_w), float(eps), _p(wg), _p(logits), _p(gates), _p(rstd), T, d, E, _stream())
+    return rstd, logits, gates
+
+
 def moe_route_top1(gates, capacity, rts_uniform=None, want_slot_token=False):
     """-> (expert, slot, weight, kept, counts, l_aux[, slot_token [E, capacity] int32: token held by each slot])."""
     T, E = gates.shape
@@ -1480,7 +1502,7 @@ def moe_filter_slots(slot_token, kept, needed):
     return st, kp
 
 
-def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, residual=None, act=ACT_NONE, rows_stride=0):
+def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, residual=None, act=ACT_NONE, rows_stride=0, a_row_scale=None):
     """Expert GEMMs with dispatch / combine folded in.  With a_rows: a is the shared [tokens, K] matrix and expert b reads rows
     a_rows[b*rows_stride + r]; else a is [E, M, K].  With c_rows: out is the shared [tokens, N] matrix, row c_rows[...] receives
     residual[row] + c_scale[row] * bf16(acc); else out is [E, M, N(/2 for SWIGLU_PAIR)].  w [E, N, K]; m_dev int32 [E]."""
@@ -1491,9 +1513,15 @@ def gemm_batched_rows(a, w, out, m_dev, a_rows=None, c_rows=None, c_scale=None, 
     ldc, sc = (out.stride(0), 0) if c_rows is not None else (out.stride(1), out.stride(0))
     _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.begin() if GEMM_TIMER is not None else None
-    lib().call("mp_gemm_bf16_nt_batched_rows", _p(a), lda, sa, _p(a_rows), _p(w), w.stride(1), w.stride(0), _p(out), ldc, sc, _p(c_rows),
-               _p(c_scale), _p(residual), residual.stride(0) if residual is not None else 0, int(rows_stride), E, int(M), N, K, act,
-               _p(m_dev), _stream())
+    if a_row_scale is not None:     # folded post-attention norm: a = the raw residual stream, w carries the norm weight, a_row_scale = rstd [tokens]
+        assert a_rows is not None and c_rows is None and residual is None and act == ACT_SWIGLU_PAIR
+        _chk(a_row_scale, torch.float32, "gemm_batched_rows.a_row_scale"); assert a_row_scale.numel() == a.shape[0]
+        lib().call("mp_gemm_bf16_nt_batched_rows_scaled", _p(a), lda, _p(a_rows), _p(a_row_scale), _p(w), w.stride(1), w.stride(0), _p(out), ldc, sc,
+                   int(rows_stride), E, int(M), N, K, _p(m_dev), _stream())
+    else:
+        lib().call("mp_gemm_bf16_nt_batched_rows", _p(a), lda, sa, _p(a_rows), _p(w), w.stride(1), w.stride(0), _p(out), ldc, sc, _p(c_rows),
+                   _p(c_scale), _p(residual), residual.stride(0) if residual is not None else 0, int(rows_stride), E, int(M), N, K, act,
+                   _p(m_dev), _stream())
     if GEMM_TIMER is not None:
         GEMM_TIMER.end(2.0 * E * M * N * K, t0, rows_dev=m_dev, slab_rows=M, flop_per_row=2.0 * N * K)
     return out

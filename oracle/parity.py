@@ -279,6 +279,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
     gb = _to_dev(batch, device)
     with torch.no_grad():
         out = m(**gb)
+        folded_layers = int(getattr(m.model.llm, "folded_layers", 0))       # decoder layers that ran config.fold_input_norm's kernels in THIS pass
         losses_gpu = {k: float(out[k]) for k in O.LOSS_KEYS}
         cap = m.captured
         hid = cap["last_hidden"].float().cpu()
@@ -337,6 +338,7 @@ def full_size_parity(cfg, device, seed=0, batch_seed=42, H=336, Wd=336, cpu_thre
            "routing_layer_local": local,
            "oracle_forward_seconds": round(t_oracle, 2),
            "distinct_weights": bool(distinct_weights),
+           "folded_layers": folded_layers,
            "fused_bf16_upsampler": bool(getattr(cfg, "fused_bf16_upsampler", False)),
            "weights": ("DISTINCT seeded weights in every decoder layer, both sides" if distinct_weights
                        else "one decoder layer's seeded weights aliased over all layers, both sides")}

@@ -15,7 +15,7 @@ for f in glob.glob("gpurun_out/mfma_pmc/p1/**/*counter_collection.csv", recursiv
         fam = ("gemm256v3" if "gemm256v3" in n else "gemm320" if "gemm320" in n else "gemm128" if "gemm_bf16_nt_kernel" in n else "attn_fwd2" if "attn_fwd2" in n else None)
         if fam:
             res[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if "gemm320" in n and "kernel<0>" not in n:      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
+        if "gemm320" in n and any("kernel<%d>" % e in n for e in (1, 2, 3)):      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
             res["gemm320_decoder"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 over bench.py (3 steps, kernels "
                "serialised by the counter collection); per-launch averages; mfma_pipe_util = MFMA_BUSY / (GUI_ACTIVE / 8 XCDs x 1024 SIMDs); "

@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                    "rmsnorm" if "rmsnorm" in n else "moe_combine" if "moe_combine" in n else "rope" if "rope_qk" in n else None)
             if fam:
                 res[fam][c].append(float(r["Counter_Value"]))
-            if "gemm320" in n and "kernel<0>" not in n:      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
+            if "gemm320" in n and any("kernel<%d>" % e in n for e in (1, 2, 3)):      # epilogue families 1-3 (qkv + RoPE, gate|up, down): decoder launches only
                 res["gemm320_decoder"][c].append(float(r["Counter_Value"]))
 import sys; sys.path.insert(0, ".")
 from bench import kernel_source_sha

@@ -1771,6 +1771,19 @@ def test_full_depth_parity_batch8_rts_overflow(dev):
     _assert_full_size(r, 8, True)
 
 
+def test_full_depth_parity_batch8_folded_norms(dev):
+    """config.fold_input_norm against the oracle: the B = 8 configuration of the test above (T = 5112: the shapes the fold is built for), 8 MoE
+    layers, both RMSNorms of every layer folded into their consumer GEMMs.  The SAME bounds (oracle/parity.check_full_size): the fold moves a
+    rounding point, it must not move the result."""
+    from oracle.parity import full_size_parity
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=8, vocab_size=4096, seg_token_idx=4000, moe_enable=True, fold_input_norm=True)
+    torch.set_num_threads(min(64, os.cpu_count()))
+    r = full_size_parity(cfg, dev, B=8, rts_seed=77)
+    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items() if k not in ("mask", "routing")})
+    assert r["tokens"] == 8 * 639 and r.get("folded_layers") == 8, r.get("folded_layers")
+    _assert_full_size(r, 8, True)
+
+
 @pytest.mark.parametrize("layers,r_,targets", [(2, 8, "gate_proj,up_proj,down_proj"), (3, 16, "q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj")])
 def test_lora_gradients_at_true_dims(dev, layers, r_, targets):
     """LoRA training at the 7B layer dimensions (dense decoder layers, B = 1, S = 639; scripts/train_stage3.sh's adapters -- r = 8 on

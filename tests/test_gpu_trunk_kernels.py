@@ -1008,9 +1008,15 @@ def test_gemm_320_row_tile_kernel(dev):
                     assert torch.equal(out, out256), (out.float() - out256.float()).abs().max()
                 else:
                     assert (out.float() - out256.float()).abs().max() <= 4 * BF16_EPS * ref.abs().max()
-        # gelu is not among the 320 kernel's epilogues: the call must fall back, not fail
+        # erf-GELU and ReLU have their own epilogue families since round 6 (EPI_GELU / EPI_RELU: the SAM encoder's GEMMs); SiLU has none: the call
+        # must fall back, not fail
         ops.gemm_tile_policy(2)
-        ops.gemm(ad, wd, act=ops.ACT_GELU)
+        y320 = ops.gemm(ad, wd, act=ops.ACT_GELU)
+        assert ops.gemm_last_kernel() == 320
+        ops.gemm_tile_policy(0)
+        assert (ops.gemm(ad, wd, act=ops.ACT_GELU).float() - y320.float()).abs().max() <= 4 * BF16_EPS * y320.float().abs().max()
+        ops.gemm_tile_policy(2)
+        ops.gemm(ad, wd, act=ops.ACT_SILU)
         assert ops.gemm_last_kernel() != 320
         # RoPE epilogue: equal to the 256x256 kernel's (M = 4096, N = 3 * 1024: 192 tiles of 256 = one unsplit wave)
         M, S, heads, K, D = 4096, 512, 8, 512, 128
