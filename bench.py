@@ -550,8 +550,8 @@ def dry_main(args, emit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU micro-batch (BASELINE config: 8)")
     ap.add_argument("--layers", type=int, default=32, help="debug only; the reported config is 32")
     ap.add_argument("--experts", type=int, default=2, help="debug only: experts per MoE layer (the reported config: 2)")
