@@ -112,7 +112,10 @@ class ClipTower:
         patches = ops.gemm(cols, self.patch_w)
         x = ops.clip_embed(patches, self.cls, self.pos, n, NP, C).view(n * S, C)
         x = ops.layernorm(x, self.pre_ln[0], self.pre_ln[1], cfg.clip_ln_eps)
-        for lw in self.layers[: self.n_run_layers()]:
+        gate = getattr(self, "gate_events", None)           # set by model_forward for a tower that runs ahead (see there): layer j waits for events[j]
+        for j, lw in enumerate(self.layers[: self.n_run_layers()]):
+            if gate is not None and j < len(gate):
+                torch.cuda.current_stream().wait_event(gate[j])
             h = ops.layernorm(x, lw["ln1"][0], lw["ln1"][1], cfg.clip_ln_eps)
             qkv = ops.gemm(h, lw["qkv_w"], bias=lw["qkv_b"])
             q5 = qkv.view(n, S, 3, H, C // H)

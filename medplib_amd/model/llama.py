@@ -221,6 +221,9 @@ class LlamaStack:
                 slot_token, kept = ops.moe_filter_slots(slot_token, kept, needed)
             if ops.GEMM_TIMER is not None:
                 ops.GEMM_TIMER.batched_tag = i          # the expert GEMMs are credited with the rows `kept` holds after the region
+            ev = getattr(self, "layer_events", None)
+            if ev is not None and i < len(ev):
+                ev[i].record()          # "layer i's expert GEMMs start here": what the frozen towers of the NEXT step gate their layers on (medplib.model_forward)
             if rstd is not None:        # folded post-attention norm: the experts read the raw stream, W carries ln2, the epilogue applies rstd
                 ops.gemm_batched_rows(x, lw["gu_f"], act, kept, a_rows=slot_token, act=ops.ACT_SWIGLU_PAIR, rows_stride=cap, a_row_scale=rstd)
             else:

@@ -33,6 +33,8 @@ LOSS_KEYS = ["loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss", 
 
 
 _PRUNE_LAST_MLP = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"
+_GATE_MODE = int(os.environ.get("MP_GATE_TOWERS", "0"))                  # 0 off, 1 gate, 2 = record the events only (A/B of the records' own cost)
+_GATE_TOWERS = _GATE_MODE >= 1              # A/B: towers that run ahead gate their layers on the previous step's decoder layers (model_forward)
 
 
 def _h2d(arr, device):
@@ -523,6 +525,18 @@ class MedPLIBForCausalLM(nn.Module):
                                                              "model.mask_encoder.")) for n in lo_.names)
         ahead = (self.towers_run_ahead and front_frozen and not getattr(self, "_want_raw_feats", False)
                  and not (region_masks is not None and len(region_masks) > 0) and kwargs.get("mask_images") is None and torch.is_tensor(images_clip))
+        # Towers that run ahead are issued BEFORE this step's decoder, i.e. while the device is still inside the PREVIOUS step's decoder: with
+        # gate_towers on, layer j of the CLIP tower / block k of the SAM encoder waits for the event the previous step's decoder recorded where
+        # its layer j / 32 - 12 + k started its expert GEMMs (llama._mlp) — the gate|up launch (5.71 waves of tiles: dynamic, with slack in its last
+        # wave) absorbs side workgroups, the exact-wave qkv / o_proj launches (768 / 256 tiles on 256 CUs) end late by whatever a side workgroup
+        # still holds a CU for at their start.  Events already complete (first step, a host that is not ahead) gate nothing.
+        n_l = len(m.llm.layers)
+        gate_on = bool(ahead and getattr(self, "gate_towers", _GATE_TOWERS) and cfg.moe_enable and n_l >= 24 and self.training and not inference)
+        if gate_on and getattr(m.llm, "layer_events", None) is None:
+            m.llm.layer_events = [torch.cuda.Event() for _ in range(n_l)]
+            for e_ in m.llm.layer_events:
+                e_.record()                                  # so that the first step's waits see a completed record
+        enc = m.visual_model.image_encoder if seg_flag else None
         if seg_flag and self.sam_side_stream:
             main = torch.cuda.current_stream()
             side = self._side_stream()
@@ -530,14 +544,18 @@ class MedPLIBForCausalLM(nn.Module):
                 side.wait_stream(main)
             else:
                 images.record_stream(side)
+            enc.gate_events = m.llm.layer_events[n_l - len(enc.blocks):] if (gate_on and _GATE_MODE != 2) else None
             with torch.cuda.stream(side), torch.no_grad():
                 image_tokens = ops.cast_to_f32(self.get_visual_embs(images))
+            enc.gate_events = None
         if ahead:
             main, vis = torch.cuda.current_stream(), self._vision_stream()
             images_clip.record_stream(vis)
+            m.vision_tower.gate_events = m.llm.layer_events if (gate_on and _GATE_MODE != 2) else None
             with torch.cuda.stream(vis), torch.no_grad():
                 plan, feats = self._encode_and_plan(ids_np, lab_np, att_np, images_clip, None, kwargs.get("image_token_types"),
                                                     kwargs.get("image_token_lengths"))
+            m.vision_tower.gate_events = None
             main.wait_stream(vis)
             feats.record_stream(main)
         with torch.no_grad():

@@ -176,7 +176,10 @@ class SamImageEncoder:
         blk0 = self.blocks[0]
         x, h = ops.sam_add_layernorm(x, blk0["norm1"][0], blk0["norm1"][1], 1e-6, addend=self.pos)
         nblk = len(self.blocks)
+        gate_ev = getattr(self, "gate_events", None)        # set by model_forward for an encoder that runs ahead: block i waits for events[i]
         for i, blk in enumerate(self.blocks):
+            if gate_ev is not None and i < len(gate_ev):
+                torch.cuda.current_stream().wait_event(gate_ev[i])
             # Block.forward (image_encoder.py:215-236).  The window blocks never materialise the padded windows: qkv / proj run on the map's own
             # 2048 rows, the attention kernel walks the four windows of each map itself (padded keys = the qkv bias, see csrc/sam_encoder.hip)
             qkv = ops.gemm(h, blk["qkv_w"], bias=blk["qkv_b"])
