@@ -954,8 +954,10 @@ def gpu_main(args, emit):
                        "llm_layers": cfg.num_hidden_layers, "trainable_params": eng.optimizer.numel,
                        # decoder layers whose two RMSNorms ran folded into their consumer GEMMs in the timed steps (config.fold_input_norm; 0 = HF's rounding points)
                        "folded_norm_layers": int(getattr(model.model.llm, "folded_layers", 0)),
-                       # the last decoder layer's MLP runs on the rows the filtered CE and the <SEG> gather read (bit-identical losses and
-                       # gradients: tests/test_gpu_prune_last_mlp.py); "all" under MP_PRUNE_LAST_MLP=0
+                       # the last decoder layer's MLP runs on the rows the filtered CE and the <SEG> gather read — reported only when the stack really
+                       # pruned (llm.pruned_rows).  Bit-identical losses and gradients on the frozen MoE trunk; with adapters, identical up to fp32 summation
+                       # order at lora_dropout 0 and another sample of the same dropout distribution at p > 0 (tests/test_gpu_prune_last_mlp.py); "all"
+                       # under MP_PRUNE_LAST_MLP=0
                        "last_layer_mlp_rows": pruned_tflop_per_step(model, cfg, args.lora)[1] or "all",
                        "mask_upsampler": ("fused bf16 kernel, forward + recomputing backward (in the step)" if cfg.fused_bf16_upsampler
                                           else "fp32 tail (6 launches forward, 14 backward)")},
