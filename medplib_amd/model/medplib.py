@@ -175,7 +175,9 @@ class MedPLIBForCausalLM(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _side_stream(self):
         if self._sam_stream is None:
-            self._sam_stream = ops.side_stream(self.device_, "sam_encoder", with_gemm_workspace=True)   # own split-K scratch
+            # (A/B, MP_TOWERS_ONE_STREAM=1: the SAM encoder behind the CLIP tower on ONE side stream — one tower kernel in flight at a time)
+            name = "clip_tower" if os.environ.get("MP_TOWERS_ONE_STREAM") == "1" else "sam_encoder"
+            self._sam_stream = ops.side_stream(self.device_, name, with_gemm_workspace=True)   # own split-K scratch
         return self._sam_stream
 
     def _vision_stream(self):

@@ -138,7 +138,11 @@ def side_stream(device, name, with_gemm_workspace=False):
     is not exhausted by short-lived model instances."""
     key = (torch.device(device).index or 0, name)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        import os
+        # MP_SIDE_PRIO (A/B): queue priority of the side streams (-1 = high: a tower's workgroups take freed CUs before the decoder's next tiles, so the
+        # towers are done sooner and fewer of the decoder's exact-wave launches start with a CU still held; 0 = default)
+        prio = int(os.environ.get("MP_SIDE_PRIO_" + name.upper(), os.environ.get("MP_SIDE_PRIO", "0")))
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
     st = _SIDE_STREAMS[key]
     if with_gemm_workspace:
         register_stream_workspace(st)
