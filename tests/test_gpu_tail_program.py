@@ -205,3 +205,62 @@ def test_fused_upsampler_node_matches_two_node_path(dev):
     # (k_proj biases: their gradient is mathematically zero — softmax is invariant to a per-query shift — so both sides hold rounding noise)
     bad = {k: v for k, v in worst.items() if v > 2e-5 and (g0[k] - g1[k]).abs().max() > 2e-6 and not k.endswith("k_proj.bias")}
     assert not bad, bad
+
+
+def test_give_up_is_reported_at_the_next_launch_and_switches_to_the_op_by_op_tail(dev):
+    """Round-5 advisor: a barrier that cannot complete no longer traps the launch (which poisons the context); every workgroup leaves, sync[1] is set, the
+    word comes back through a pinned copy and the NEXT launch of the program raises after switching the decoder to the op-by-op tail.  A barrier that
+    really gives up needs tens of seconds of a non-resident workgroup, so the test plants the flag in the read-back word of a finished launch; it also
+    checks the normal case (flag clear: nothing raised, the per-launch sync words are distinct allocations) and that gradients dropped between forward and
+    backward (zero_grad(set_to_none=True)) do not make the direct form write through stale addresses."""
+    n, Dh = 2, 256
+    dec, pe, fc1, fc2 = _modules(35, Dh, dev)
+    x = torch.randn(n, Dh, device=dev, requires_grad=True)
+    img = torch.randn(n, 256, 256, device=dev) * 0.5
+    low, iou = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=x)
+    (low.sum() + iou.sum()).backward()
+    torch.cuda.synchronize()
+    runner = dec._runner
+    prog = next(iter(runner._cache.values()))
+    assert prog.check_sync()                                   # the launches so far completed their barriers
+    low2, _ = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=x)     # flag clear: nothing raised
+    torch.cuda.synchronize()
+    assert torch.equal(low2, low)
+    # plant a give-up in the word the last launch's read-back filled
+    assert prog._flag_host is not None
+    prog._flag_host[0] = 1
+    ev = torch.cuda.Event(); ev.record(); torch.cuda.synchronize()
+    prog._pending = ev
+    with pytest.raises(RuntimeError, match="gave up at a grid barrier"):
+        dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=x)
+    assert dec.use_program is False
+    low3, _ = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=x)     # the op-by-op tail takes over
+    assert (low3 - low).abs().max() <= 2e-5 * low.abs().max()
+    # direct accumulation with the gradients dropped between forward and backward
+    dec.use_program = True
+    params = [p for p in list(dec.parameters()) + list(fc1.parameters()) + list(fc2.parameters()) if p.requires_grad]
+    flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in params), device=dev)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        off += -(-p.numel() // 64) * 64
+    xa = x.detach().clone().requires_grad_()
+    low4, iou4 = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=xa)
+    for p in params:
+        p.grad = None                                          # zero_grad(set_to_none=True) between forward and backward
+    (low4.sum() + iou4.sum()).backward()
+    torch.cuda.synchronize()
+    assert float(flat.abs().max()) == 0.0                       # nothing was written through the addresses taken at forward time
+    got = [p.grad for p in params]
+    assert all(g is not None for g in got if g is not None) and sum(g is not None for g in got) > 10
+    # ... and the gradients equal the ones of the first (gflat) backward of the same inputs
+    xb = x.detach().clone().requires_grad_()
+    ref_params = {id(p): p.grad.clone() for p in params if p.grad is not None}
+    for p in params:
+        p.grad = None
+    low5, iou5 = dec(img, pe.dense_pe_tokens(), pe.no_mask_embed.weight, None, fcs=(fc1, fc2), hidden_rows=xb)
+    (low5.sum() + iou5.sum()).backward()
+    for p in params:
+        if p.grad is not None:
+            assert (p.grad - ref_params[id(p)]).abs().max() <= 1e-5 * ref_params[id(p)].abs().max() + 1e-7
+    assert (xa.grad - xb.grad).abs().max() <= 1e-5 * xb.grad.abs().max() + 1e-7
