@@ -281,6 +281,9 @@ class Engine:
             self._layer_ranges[i] = [tuple(m) for m in merged]
         self._lora = lora
         lora.grad_sink = self._sink
+        # whether a layer's sink starts a collective on the layer's gradients (the decoder backward's weight-gradient side stream, when on, is
+        # waited for first); on one rank without the debug reduce nothing reads them before the end of backward
+        lora.sink_reduces = self.world > 1 or self.reduce_single_rank
 
     def _sink(self, layer, named_grads):
         """LoRAState.grad_sink: accumulate layer `layer`'s gradients into the flat buffer (they add up over the micro-steps of a

@@ -100,6 +100,7 @@ class LoRAState(torch.nn.Module):
         self.ext = {}                                           # (layer, group) -> extended weight [out, in + 64] (enable_lora)
         self.p_active = self.p                                  # dropout in effect: p while training, 0 in eval (set per forward)
         self.keep_bits = {}                                     # seed -> lora_dropout mask bytes the forward left for the same step's backward
+        self.wgrad_stream = None                                # MP_LORA_WGRAD_STREAM=1: where dA^T = drop(x)^T dt and the gradient unpack run (off the dgrad chain)
 
     def _modules_of(self, i, t):
         if i in self.moe_layers and t in MLP_TARGETS:
@@ -366,6 +367,7 @@ _KEEP_BITS = os.environ.get("MP_LORA_KEEP_BITS", "1") != "0"            # A/B: 0
 _PRUNE_ROWS = os.environ.get("MP_PRUNE_LAST_MLP", "1") != "0"            # A/B: 0 = the last layer's MLP on every row
 _UNPACK_PARTIALS = os.environ.get("MP_LORA_UNPACK_PARTIALS", "1") != "0"  # A/B: 0 = a reduce launch per weight-gradient product, then the unpack
 _PACK_BATCHED = os.environ.get("MP_LORA_PACK_BATCHED", "1") != "0"       # A/B: 0 = one mp_lora_pack launch per adapter and layer
+_WGRAD_STREAM = os.environ.get("MP_LORA_WGRAD_STREAM", "0") == "1"      # A/B: 1 = the adapters' weight-gradient products and their unpack on a side stream
 _FUSE_UP_SWIGLU = os.environ.get("MP_FUSE_UP_SWIGLU", "1") != "0"      # A/B: 0 = lora_up_add then swiglu_pair_bwd (two passes over d_act)
 
 
@@ -710,7 +712,7 @@ def forward_train(llm, embeds, key_valid):
     return out.view(B, S, d), aux_sum, {"layers": saved, "x_last": x, "B": B, "S": S, "key_valid": key_valid}
 
 
-def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False, defer_up=False, done=None):
+def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=False, defer_up=False, done=None, side_run=None):
     """Gradients of one (fused) adapter: dB_pad [out, R], dA^T [in, R] (fp32) and dx += scaling * ((dy B) A) (through the dropout).  x = the
     adapter's UNdropped input; the mask is regenerated from the seed wherever it is needed.  dx = None: nothing trainable lies in front of
     this adapter's input (the lowest layer of a decoder whose input rows are frozen) — only the two weight gradients are produced."""
@@ -726,7 +728,11 @@ def _adapter_bwd(lora, ops_pad, dy, x, t, dx, seed, swiglu_gu=None, partials=Fal
         dt = ops.lora_down(dy, BT, torch.empty((dy.shape[0], 64), dtype=torch.bfloat16, device=dy.device), R, alpha=lora.scaling)
         dB = ops.tn_skinny(dy, t, R, lora.scaling, reduce=not partials)                 # [out, R] = scaling * dy^T t
     kb = lora.keep_bits.get(seed)                              # the forward's mask bytes (None: regenerate from the seed)
-    dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials, keep_bits=kb)        # [in, R]  = dropout(x)^T (scaling * dy B)
+    # [in, R] = dropout(x)^T (scaling * dy B): nothing on the dgrad chain reads it (side_run: backward()'s weight-gradient stream, or None)
+    if side_run is not None:
+        dAT = side_run(lambda: ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials, keep_bits=kb), dt)
+    else:
+        dAT = ops.tn_skinny(x, dt, R, 1.0, lora.p_active, seed, reduce=not partials, keep_bits=kb)
     if dx is None:
         return None, dB, dAT
     if swiglu_gu is not None and R <= 32 and dx.stride(0) % 8 == 0 and _FUSE_UP_SWIGLU:
@@ -798,6 +804,37 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                     grads[na] = dAT[e][:, k * r:(k + 1) * r].t()
 
     part_ok = lora.grad_sink is not None and _UNPACK_PARTIALS and lora.r <= 32      # the unpack into the flat gradient buffer sums the chunk partials itself
+    # MP_LORA_WGRAD_STREAM=1: the dense layers' pure weight-gradient work (dA^T = drop(x)^T dt and the unpack into the flat gradient buffer: two
+    # skinny products and two or three unpack launches per layer, ~2.8 ms of a 120 ms step that nothing on the dgrad chain waits for) goes to a
+    # side stream; same kernels, same operands, same sums — only the queue differs.  The stream waits for the producing stream at every hand-over
+    # and the producing stream waits for it before anything reads the gradients (a layer's sink, the end of backward).
+    side = None
+    if _WGRAD_STREAM and d_hidden.is_cuda and lora.grad_sink is not None:
+        if lora.wgrad_stream is None:
+            lora.wgrad_stream = torch.cuda.Stream(device=d_hidden.device)
+        side = lora.wgrad_stream
+
+    def wg(fn, *used):
+        if side is None:
+            return fn()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            r = fn()
+        for t in used:                                             # allocated on the producing stream, read on this one
+            t = t.partial if isinstance(t, ops.SkinnyPartial) else t
+            if torch.is_tensor(t):
+                t.record_stream(side)
+        return r
+
+    def sink(i):
+        pre = f"model.layers.{i}."
+        ng = {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]}
+        if side is not None and (ng or getattr(lora, "sink_reduces", True)):
+            torch.cuda.current_stream().wait_stream(side)          # the layer's gradients are complete before anything adds to or reduces them
+            for g in ng.values():                                  # (side-stream allocations read on this stream from here on)
+                g.record_stream(torch.cuda.current_stream())
+        lora.grad_sink(i, ng)
+
     dx = ops.rmsnorm_bwd(saved["x_last"], llm.norm_w, d_hidden.reshape(T, d).contiguous(), cfg.rms_norm_eps)
     for i in range(len(llm.layers) - 1, -1, -1):
         lw, s = llm.layers[i], saved["layers"][i]
@@ -820,15 +857,15 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                 sd = s["seed"] + 1
                 dBd, dtd = ops.tn_skinny_down(dy_mlp, s["t_d"], BTd, Rd, lora.scaling, lora.scaling, reduce=not part_ok)
                 kbd = lora.keep_bits.get(sd)
-                dATd = ops.tn_skinny(s["actd"], dtd, Rd, 1.0, lora.p_active, sd, reduce=not part_ok, keep_bits=kbd)
-                take(i, pad["down"], dBd, dATd)
+                wg(lambda: take(i, pad["down"], dBd, ops.tn_skinny(s["actd"], dtd, Rd, 1.0, lora.p_active, sd, reduce=not part_ok, keep_bits=kbd)), dBd, dtd)
                 d_gu, dBg, dtg = ops.swiglu_bwd_skinny(dtd, ATd, d_act, s["gu"], Rd, lora.p_active, sd, s["t_gu"], BTg, Rg, lora.scaling, lora.scaling,
                                                        reduce=not part_ok, keep_bits=kbd)
                 gu_done, d_act = (dBg, dtg), None
             elif "down" in pad:
                 fused = _FUSE_UP_SWIGLU and pad["down"][4] <= 32 and d_act.stride(0) % 8 == 0
-                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dy_mlp, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok)
-                take(i, pad["down"], dB, dAT)
+                d_act, dB, dAT = _adapter_bwd(lora, pad["down"], dy_mlp, s["actd"], s["t_d"], d_act, s["seed"] + 1, swiglu_gu=s["gu"] if fused else None, partials=part_ok,
+                                              side_run=wg if side is not None else None)
+                wg(lambda: take(i, pad["down"], dB, dAT), dB)
                 if fused:
                     d_gu, d_act = d_act, None
             if d_gu is None:
@@ -843,15 +880,15 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
                 # the adapter's input gradient has one reader, the post-attention norm's backward below: that kernel adds it on its way in
                 defer = (_FUSE_NORM_UP and not stop_here and rows_last is None and d == 4096 and (i, "ln2") not in lora.norm_names
                          and pad["gu"][4] <= 16 and d_h2.stride(0) % 8 == 0)
-                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok, defer_up=defer, done=gu_done)
+                d_h2, dB, dAT = _adapter_bwd(lora, pad["gu"], d_gu, s["h2d"], s["t_gu"], d_h2, s["seed"], partials=part_ok, defer_up=defer, done=gu_done,
+                                             side_run=wg if side is not None else None)
                 if defer:
                     d_h2, up_late = d_h2
-                take(i, pad["gu"], dB, dAT)
+                wg(lambda: take(i, pad["gu"], dB, dAT), dB)
             if stop_here:
                 dx = None
                 if lora.grad_sink is not None:
-                    pre = f"model.layers.{i}."
-                    lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
+                    sink(i)
                 break
         if s.get("rows_last") is not None:
             # compact rows back into the layer's full gradient: every other row of dx is zero and stays zero (no MLP branch, no residual)
@@ -867,8 +904,8 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
         # ---- attention: x_mid = x + o(attn(rope(qkv(rmsnorm(x))))) [+ adapters on o and on q / k / v]
         d_attn = ops.gemm(d_mid, lw["o_T"])
         if "o" in pad:
-            d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3, partials=part_ok)
-            take(i, pad["o"], dB, dAT)
+            d_attn, dB, dAT = _adapter_bwd(lora, pad["o"], d_mid, s["attnd"], s["t_o"], d_attn, s["seed"] + 3, partials=part_ok, side_run=wg if side is not None else None)
+            wg(lambda: take(i, pad["o"], dB, dAT), dB)
         q5 = s["qkv"].unflatten(0, (B, S)).unflatten(2, (3, H, D))
         # the transpose of a rotation is the rotation by -theta: the attention backward stores dq / dk rotated (same bits as mp_rope_qk_bf16 on its result)
         rot = _ROPE_IN_ATTN_BWD and D == 128 and s["attn"].stride(-2) % 8 == 0
@@ -879,15 +916,16 @@ def backward(llm, saved, d_hidden, d_aux=None, need_d_embeds=True):
             ops.rope_qk_(dqkv, llm.cos, llm.sin_neg, S, H, D)
         d_h1 = ops.gemm(dqkv, lw["qkv_T"])
         if "qkv" in pad:
-            d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2, partials=part_ok)
-            take(i, pad["qkv"], dB, dAT)
+            d_h1, dB, dAT = _adapter_bwd(lora, pad["qkv"], dqkv, s["h1d"], s["t_qkv"], d_h1, s["seed"] + 2, partials=part_ok, side_run=wg if side is not None else None)
+            wg(lambda: take(i, pad["qkv"], dB, dAT), dB)
         if (i, "ln1") in lora.norm_names:
             dx, grads[lora.norm_names[(i, "ln1")]] = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid, want_wgrad=True)
         else:
             dx = ops.rmsnorm_bwd(s["x"], lw["ln1"], d_h1, cfg.rms_norm_eps, add=d_mid)
         if lora.grad_sink is not None:                              # hand layer i's finished gradients over (bucketed all-reduce)
-            pre = f"model.layers.{i}."
-            lora.grad_sink(i, {n: grads.pop(n) for n in [k for k in grads if k.startswith(pre)]})
+            sink(i)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)              # before the optimizer (and the mask bytes' release below) — one wait per step
     grads["__d_embeds__"] = dx                                     # gradient of the decoder's input rows (for embed_tokens)
     lora.keep_bits = {}                                            # the step's mask bytes (T K / 8 per adapter and layer) die with its backward, not at the next forward
     return grads

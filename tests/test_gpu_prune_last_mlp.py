@@ -103,3 +103,32 @@ def test_lora_last_layer_mlp_on_read_rows(dev, targets, p, ragged):
         # the same products summed in fp32 over fewer rows (the dropped rows contributed exact zeros): fp32 summation order only
         assert err <= 1e-5 * scale + 1e-12, (n, err, scale)
     print(f"LoRA {targets}: {n1} read rows; worst gradient difference {worst:.2e} of the gradient's largest entry")
+
+
+@pytest.mark.parametrize("targets,p", [("gate_proj,up_proj,down_proj", 0.05), ("q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj", 0.0)])
+def test_lora_weight_gradients_on_a_side_stream_are_bit_identical(dev, targets, p):
+    """MP_LORA_WGRAD_STREAM=1 (llama_lora.backward): the adapters' dA^T products and the unpack into the flat gradient buffer run on their own
+    stream — the same kernels on the same operands in the same order per gradient, so every loss and every gradient is the same bit for bit (two
+    independent runs per setting: the comparison also holds run against run)."""
+    from medplib_amd.model import llama_lora
+    cfg = MedPLIBConfig.tiny(moe_enable=False, sam_depth=2, num_hidden_layers=3)
+    W = OM.init_hf_weights(cfg)
+    batch = _long_batch(cfg, 3, seed=13)
+
+    def init(lora):
+        g = torch.Generator().manual_seed(32)
+        return [(torch.randn(p_.shape, generator=g) * (0.05 if "lora_A" in n else 0.03)).to(torch.bfloat16).float() for n, p_ in zip(lora.names, lora.params)]
+    kw = dict(lora_r=8, lora_alpha=16, lora_dropout=p, lora_target_modules=targets)
+    res = {}
+    for side in (False, True):
+        llama_lora._WGRAD_STREAM = side
+        try:
+            res[side] = [_run(dev, cfg, W, batch, True, kw, init) for _ in range(2)]
+        finally:
+            llama_lora._WGRAD_STREAM = False
+    for (l0, g0, _, _), (l1, g1, _, _) in zip(res[False], res[True]):
+        for k in l0:
+            assert torch.equal(l0[k], l1[k]), k
+        assert g0.keys() == g1.keys() and len(g0) > 0
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
