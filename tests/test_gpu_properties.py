@@ -1,0 +1,116 @@
+"""Size-independent properties of the decoder stack AT THE BENCHMARK'S DIMENSIONS (d = 4096, ff = 11008, 32 heads x 128, B = 8, S = 639: the
+5112-row launches bench.py times), where the CPU oracle needs minutes per layer: what the reference's decoder guarantees by construction
+(HF LlamaModel + DeepSpeed MoE, model/medplib/model/language_model/medplib_moe_llama.py:104-148) and every tiling / fusion decision of the HIP path
+has to preserve —
+  * a sample's hidden states do not depend on its position in the batch: bit for bit as long as its rows stay on the same side of a launch's
+    K-split tail region (the one schedule fact a row's rounding depends on), to fp32 summation order across it,
+  * causality: the hidden states of positions < t do not depend on the tokens at positions >= t,
+  * right-padding (attention_mask 0 on a suffix) leaves the valid positions' hidden states untouched,
+  * the top-1 gate is a per-token function: a token's expert does not depend on where the token sits.
+The full-size comparisons against the oracle itself are tests/test_gpu_model.py (8 layers) and bench.py's parity leg (32 layers)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from medplib_amd.model.config import MedPLIBConfig        # noqa: E402
+from oracle import model as OM                      # noqa: E402
+
+
+def _two_layer_weights(cfg):
+    """Two DISTINCT seeded layers at cfg's dims in the HF key layout (oracle.model.init_decoder_layer_weights builds one)."""
+    W, g = OM.init_decoder_layer_weights(cfg, seed=5)
+    W1, _ = OM.init_decoder_layer_weights(cfg, seed=6)
+    for k, v in W1.items():
+        if k.startswith("model.layers.0."):
+            W["model.layers.1." + k[len("model.layers.0."):]] = v
+    return W, g
+
+
+def _stack(cfg, dev, W):
+    from medplib_amd.model.llama import LlamaStack
+    llm = LlamaStack(cfg, dev)
+    llm.load_hf(W)
+    return llm
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_decoder_properties_at_the_benchmark_dims(dev, moe):
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=2, vocab_size=1024, moe_enable=moe, moe_gate_sampling=False)
+    W, g = _two_layer_weights(cfg)
+    llm = _stack(cfg, dev, W)
+    B, S = 8, 639
+    emb = (torch.randn(B, S, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    kv = torch.ones(B, S, dtype=torch.uint8, device=dev)
+    base, _, rt0 = llm.forward(emb, kv, collect_routing=True)
+    again, _, _ = llm.forward(emb, kv, collect_routing=True)
+    assert torch.equal(base, again), "the same launch twice: the stack is run-to-run deterministic"
+
+    # ---- batch permutation.  A row's bits depend on its operands and on ONE schedule fact: whether its output tile is a whole-K tile or one of
+    # the K-split tiles of a launch's last partial wave (csrc/gemm320_bf16.hip: the dense gate|up GEMM at 5112 rows is 1376 tiles = 5 waves + 96
+    # tail tiles cut in two along K: rows >= 3840 x the last 24 column tiles) — the two K halves are added in a fixed order, so the result is
+    # reproducible, but it is another association of the same sum.  Hence: samples that stay inside (or outside) that region keep their bits
+    # wherever they move; samples that cross it agree to fp32 summation order.
+    inner = torch.tensor([3, 0, 4, 1, 2, 5, 6, 7], device=dev)        # shuffles positions 0-4 (rows < 3195), the last three stay put
+    outi, _, rti = llm.forward(emb[inner].contiguous(), kv[inner].contiguous(), collect_routing=True)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)         # moves samples across the region's edge
+    outp, _, rtp = llm.forward(emb[perm].contiguous(), kv[perm].contiguous(), collect_routing=True)
+    if not moe:
+        assert torch.equal(outi, base[inner]), "dense stack: a sample's hidden states moved with its batch position"
+        lower = (perm < 4).nonzero().flatten()                       # old positions 0-3 land on new positions 0, 1, 3, 5: outside the region both times
+        assert torch.equal(outp[lower], base[perm][lower])
+        a, b = outp.float(), base[perm].float()
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        rows = ((a - b).abs() > 0).any(-1)
+        print(f"dense permutation across the K-split region: {int(rows.sum())} of {B * S} rows differ, worst {err:.3e} of {scale:.3f}")
+        assert err <= 2 ** -6 * scale, (err, scale)
+    else:
+        # the gate is row-wise: every token keeps its expert in the first MoE layer (the second layer's input is only equal up to the summation
+        # order below).  The expert GEMMs run on routed slabs: a token's slab row — and with it whether its tile is a whole-K tile or a K-split
+        # tail tile — follows the token order, so the hidden states agree to fp32 summation order, not bit for bit.
+        e0 = rt0[0][0].view(B, S)
+        for pm, rt in ((inner, rti), (perm, rtp)):
+            assert torch.equal(rt[0][0].view(B, S), e0[pm]), "a token's expert changed with its batch position"
+        kept0, keptp = (rt0[0][1].view(B, S) >= 0), (rtp[0][1].view(B, S) >= 0)
+        both = (keptp & kept0[perm]) & ((rtp[1][1].view(B, S) >= 0) & (rt0[1][1].view(B, S) >= 0)[perm]) & (rtp[1][0].view(B, S) == rt0[1][0].view(B, S)[perm])
+        a, b = outp.float()[both], base[perm].float()[both]
+        err = (a - b).abs().max().item()
+        scale = b.abs().max().item()
+        print(f"MoE permutation: {int(both.sum())} of {B * S} rows comparable, worst difference {err:.3e} of {scale:.3f}")
+        assert both.float().mean().item() > 0.95
+        assert err <= 2 ** -6 * scale, (err, scale)                 # a few bf16 roundings of O(1) values that saw another summation order
+
+    # ---- causality: new tokens at positions >= t leave positions < t alone
+    t = 400
+    emb2 = emb.clone()
+    emb2[:, t:] = (torch.randn(B, S - t, cfg.hidden_size, generator=torch.Generator().manual_seed(9)) * 0.5).to(torch.bfloat16).to(dev)
+    out2, _, rt2 = llm.forward(emb2, kv, collect_routing=True)
+    if not moe:
+        assert torch.equal(out2[:, :t], base[:, :t]), "dense stack: positions < t changed with the tokens at >= t"
+    else:
+        same = torch.ones(B, S, dtype=torch.bool, device=dev)
+        for l in range(2):
+            same &= (rt2[l][0].view(B, S) == rt0[l][0].view(B, S)) & (rt2[l][1].view(B, S) >= 0) & (rt0[l][1].view(B, S) >= 0)
+        same = same[:, :t]
+        a, b = out2[:, :t].float()[same], base[:, :t].float()[same]
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        print(f"MoE causality: {int(same.sum())} of {B * t} prefix rows comparable, worst difference {err:.3e} of {scale:.3f}")
+        assert torch.equal(rt2[0][0].view(B, S)[:, :t], rt0[0][0].view(B, S)[:, :t]), "a prefix token's first-layer expert changed with the suffix"
+        assert same.float().mean().item() > 0.95 and err <= 2 ** -6 * scale, (err, scale)
+
+    # ---- right padding: attention_mask 0 on a suffix of some samples leaves their valid positions alone (dense: bit for bit)
+    kv3 = kv.clone()
+    kv3[1, 500:] = 0; kv3[4, 17:] = 0; kv3[6, 638:] = 0
+    out3, _, rt3 = llm.forward(emb, kv3, collect_routing=True)
+    valid = kv3.bool()
+    if not moe:
+        assert torch.equal(out3[valid], base[valid]), "dense stack: valid positions changed under right padding"
+    else:
+        assert torch.equal(rt3[0][0].view(B, S)[valid], rt0[0][0].view(B, S)[valid])
+        same = valid.clone()
+        for l in range(2):
+            same &= (rt3[l][0].view(B, S) == rt0[l][0].view(B, S)) & (rt3[l][1].view(B, S) >= 0) & (rt0[l][1].view(B, S) >= 0)
+        a, b = out3.float()[same], base.float()[same]
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        print(f"MoE padding: {int(same.sum())} of {int(valid.sum())} valid rows comparable, worst difference {err:.3e} of {scale:.3f}")
+        assert err <= 2 ** -6 * scale, (err, scale)
