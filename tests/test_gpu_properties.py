@@ -114,3 +114,69 @@ def test_decoder_properties_at_the_benchmark_dims(dev, moe):
         err, scale = (a - b).abs().max().item(), b.abs().max().item()
         print(f"MoE padding: {int(same.sum())} of {int(valid.sum())} valid rows comparable, worst difference {err:.3e} of {scale:.3f}")
         assert err <= 2 ** -6 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("moe,targets", [(False, "gate_proj,up_proj,down_proj"), (False, "q_proj,k_proj,v_proj,o_proj,gate_proj,up_proj,down_proj"),
+                                         (True, "gate_proj,up_proj,down_proj")])
+def test_fresh_adapters_leave_the_forward_unchanged(dev, moe, targets):
+    """peft's initialisation (lora_B = 0, peft.tuners.lora.LoraLayer.reset_lora_parameters; the reference attaches its adapters this way,
+    train_ds_medplib.py:262-303) makes a freshly wrapped model compute the base model: y = W x + (alpha / r) B A dropout(x) = W x.  Here the adapter
+    product rides as 64 extension columns of the frozen projection's K dimension through the training-mode kernels (unfused
+    gate|up + SwiGLU pair, kept activations), so the property also says those kernels round where the frozen path's fused ones do: every loss of
+    the wrapped model equals the frozen model's bit for bit, with lora_dropout active."""
+    from medplib_amd import engine
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
+    from oracle import ops as O
+    cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2, num_hidden_layers=3)
+    W = OM.init_hf_weights(cfg)
+    batch = OM.make_batch(cfg, 3, seed=17, ragged=True)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+    losses = []
+    for wrap in (False, True):
+        torch.manual_seed(1234)
+        m = (MedPLIBForCausalLM if moe else LISAForCausalLM)(cfg, device=dev)
+        m.load_hf_state_dict(W)
+        m.train()
+        if wrap:
+            m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.05, lora_target_modules=targets)
+        eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                         config={"optimizer": {"params": {"lr": 1e-4, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0})
+        out = eng(**gb)
+        torch.cuda.synchronize()
+        losses.append({k: out[k].detach().float().cpu().clone() for k in O.LOSS_KEYS})
+    for k in losses[0]:
+        assert torch.equal(losses[0][k], losses[1][k]), (k, losses[0][k].item(), losses[1][k].item())
+
+
+@pytest.mark.parametrize("h,w,B", [(64, 64, 8), (16, 16, 8), (24, 48, 3)])
+def test_fused_upsampler_is_token_local(dev, h, w, B):
+    """Both transposed convolutions have kernel = stride = 2 and LayerNorm2d normalises over channels at ONE pixel
+    (model/segment_anything_med2d/modeling/mask_decoder.py:53-59, common.py LayerNorm2d): the 4 x 4 output patch of a token is a function of that
+    token alone (and of its image's hypernetwork row for the mask).  So for ANY shuffle of the tokens over the grid positions and the images of the
+    batch, the fused kernel's output patches must be the same patches, shuffled — bit for bit (whichever wave, workgroup or XCD a token lands on) —
+    at the roofline benchmark's own size (64 x 64 tokens, batch 8: the 50.5 MB launch) and at the model's geometry."""
+    from medplib_amd import ops
+    from oracle import sam as OS
+    W = OS.init_weights(seed=7)
+    g = torch.Generator().manual_seed(h * 131 + w)
+    tok = (torch.randn(B, h * w, 256, generator=g)).to(torch.bfloat16).to(dev)
+    hyper = torch.randn(1, 32, generator=g).expand(B, 32).contiguous().to(dev)       # one hypernetwork row for all images: patches may cross images
+    w1p, w2p = ops.pack_upsampler_weights(W["mask_decoder.output_upscaling.0.weight"].to(dev), W["mask_decoder.output_upscaling.3.weight"].to(dev))
+    d = lambda k: W[k].to(dev)
+    tail = (w1p, d("mask_decoder.output_upscaling.0.bias"), d("mask_decoder.output_upscaling.1.weight"), d("mask_decoder.output_upscaling.1.bias"),
+            w2p, d("mask_decoder.output_upscaling.3.bias"), h, w)
+    up0, mask0 = ops.mask_upsample_fused(tok, *tail, hyper=hyper)
+    perm = torch.randperm(B * h * w, generator=g).to(dev)
+    tok1 = tok.reshape(B * h * w, 256)[perm].reshape(B, h * w, 256).contiguous()
+    up1, mask1 = ops.mask_upsample_fused(tok1, *tail, hyper=hyper)
+    torch.cuda.synchronize()
+
+    def patches(up, mask):                       # [B, 32, 4h, 4w], [B, 4h, 4w] -> per token [B h w, 32, 4, 4], [B h w, 4, 4]
+        u = up.view(B, 32, h, 4, w, 4).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, 32, 4, 4)
+        m = mask.view(B, h, 4, w, 4).permute(0, 1, 3, 2, 4).reshape(B * h * w, 4, 4)
+        return u, m
+    u0, m0 = patches(up0, mask0)
+    u1, m1 = patches(up1, mask1)
+    assert torch.equal(u1, u0[perm]), "an upscaled patch changed with its token's position"
+    assert torch.equal(m1, m0[perm]), "a mask patch changed with its token's position"
