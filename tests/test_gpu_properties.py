@@ -180,3 +180,32 @@ def test_fused_upsampler_is_token_local(dev, h, w, B):
     u1, m1 = patches(up1, mask1)
     assert torch.equal(u1, u0[perm]), "an upscaled patch changed with its token's position"
     assert torch.equal(m1, m0[perm]), "a mask patch changed with its token's position"
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_greedy_decode_is_prefix_consistent_at_true_dims(dev, moe):
+    """Greedy decoding is a deterministic function of the prefix (HF generate with a KV cache, model/MedPLIB.py:574-680): the first n tokens of a
+    40-token generation are the n-token generation, and two calls return the same ids.  At the 7B layer dims (2 layers, S = 639 after the splice)
+    this walks what the 5-token oracle comparison (tests/test_gpu_model.py: test_evaluate_at_true_dims) cannot afford: cache lengths that cross a
+    64-key tile edge of the flash-decoding kernel (640 -> 679), the graph replay across two of its every-16-token EOS checks, and the device-side
+    cache length.  eos_token_id = -1: random weights must not end the generation early."""
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=2, vocab_size=4096, seg_token_idx=4000, moe_enable=moe, moe_gate_sampling=False)
+    W = OM.init_hf_weights_aliased(cfg, seed=5)
+    m = (MedPLIBForCausalLM if moe else LISAForCausalLM)(cfg, device=dev)
+    m.load_hf_state_dict(W)
+    m.eval()
+    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=11)
+    ic, im = batch["images_clip"].to(torch.bfloat16).float().to(dev), batch["images"].to(torch.bfloat16).float().to(dev)
+    n_in = batch["input_ids"].shape[1]
+
+    def gen(n):
+        ids, _ = m.evaluate(ic, im, batch["input_ids"], batch["resize_list"], batch["label_list"], max_new_tokens=n, eos_token_id=-1)
+        return ids[0].tolist()
+    long = gen(40)
+    assert len(long) == n_in + 40 and long[:n_in] == batch["input_ids"][0].tolist()
+    for n in (1, 12, 17, 33):
+        short = gen(n)
+        assert short == long[:n_in + n], (n, short[n_in:], long[n_in:n_in + n])
+    assert gen(40) == long
+    assert len(set(long[n_in:])) > 1, "a constant generation would make the prefix check vacuous"
