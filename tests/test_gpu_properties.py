@@ -209,3 +209,39 @@ def test_greedy_decode_is_prefix_consistent_at_true_dims(dev, moe):
         assert short == long[:n_in + n], (n, short[n_in:], long[n_in:n_in + n])
     assert gen(40) == long
     assert len(set(long[n_in:])) > 1, "a constant generation would make the prefix check vacuous"
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_decode_steps_equal_the_prefill_of_the_same_tokens(dev, moe):
+    """A KV cache is an optimisation, not a model change (HF generate: prepare_inputs_for_generation, medplib_moe_llama.py:451-485): the hidden
+    state the decode step computes for generated token t must be the hidden state a PREFILL over prompt + generated tokens computes at that
+    position.  Two disjoint kernel sets meet here at the 7B layer dims — M = 1 GEMVs (shared / expert-indexed, norm-folded, K-split), RoPE at the
+    device-side position + cache append, flash-decoding attention with its split merge, the fused norm + gate + routing launch, HIP-graph replay
+    — against the 320-row GEMMs, the RoPE epilogue, the tiled causal attention and the batched expert GEMMs.  Equal to bf16 rounding of O(1)
+    values under another summation order (bound: 2^-5 of the largest entry = 4 bf16 ulps there; measured 2 ulps worst, 1 median); a MoE token whose two gate probabilities are within that
+    noise may take the other expert in one of the two paths, so there the bound must hold on all but at most two of the rows."""
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
+    cfg = MedPLIBConfig.medplib_7b(num_hidden_layers=2, vocab_size=4096, seg_token_idx=4000, moe_enable=moe, moe_gate_sampling=False)
+    W = OM.init_hf_weights_aliased(cfg, seed=5)
+    m = (MedPLIBForCausalLM if moe else LISAForCausalLM)(cfg, device=dev)
+    m.load_hf_state_dict(W)
+    m.eval()
+    batch = OM.make_batch(cfg, 1, L=64, H=336, Wd=336, seed=11)
+    ic = batch["images_clip"].to(torch.bfloat16).float().to(dev)
+    ids = batch["input_ids"][:1].numpy()
+    n_new = 20
+    out_ids, hid = m._greedy(ids, ic, n_new, -1)
+    assert out_ids.shape[1] == ids.shape[1] + n_new and len(hid) == n_new            # the prompt's states + one state per FED token (the last is not fed)
+    S = hid[0].shape[1]
+    steps = torch.cat([h.reshape(1, -1) for h in hid[1:]], 0).float()                # [n_new - 1, d]: decode path
+    _, hid2 = m._greedy(out_ids[:, :ids.shape[1] + n_new - 1], ic, 1, -1)            # prefill over prompt + the 19 fed tokens
+    full = hid2[0][0].float()
+    assert full.shape[0] == S + n_new - 1
+    assert torch.equal(full[:S].to(torch.bfloat16), hid[0][0]) or (full[:S] - hid[0][0].float()).abs().max().item() <= 2 ** -6 * full.abs().max().item(), \
+        "the prompt's own states moved with the longer prefill"
+    pre = full[S:]
+    scale = pre.abs().max().item()
+    err = (steps - pre).abs().amax(1)
+    print(f"moe={moe}: decode vs prefill over {n_new - 1} tokens: worst row error {err.max().item():.3e}, median {err.median().item():.3e}, scale {scale:.3f}")
+    bad = int((err > 2 ** -5 * scale).sum())
+    assert bad <= (2 if moe else 0), (bad, err.tolist())
