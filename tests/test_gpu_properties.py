@@ -245,3 +245,51 @@ def test_decode_steps_equal_the_prefill_of_the_same_tokens(dev, moe):
     print(f"moe={moe}: decode vs prefill over {n_new - 1} tokens: worst row error {err.max().item():.3e}, median {err.median().item():.3e}, scale {scale:.3f}")
     bad = int((err > 2 ** -5 * scale).sum())
     assert bad <= (2 if moe else 0), (bad, err.tolist())
+
+
+@pytest.mark.parametrize("moe,lora", [(True, False), (False, True), (True, True)])
+def test_two_equal_micro_steps_are_one_step(dev, moe, lora):
+    """DeepSpeed's accumulation window (engine.backward scales the loss by 1 / gradient_accumulation_steps and sums gradients until the
+    boundary; the reference trains with --grad_accumulation_steps, train_ds_medplib.py:96,412-419): feeding the SAME micro-batch twice under
+    gradient_accumulation_steps = 2 accumulates g / 2 + g / 2 = g exactly (halving and the sum of two equal halves are exact in binary floating
+    point), so the optimizer step must leave the parameters of a one-step run bit for bit — which holds only if every gradient producer ADDS into
+    the flat buffer in the second micro-step (the tail program's direct gradient stores, the adapters' unpack launches, the fused upsampler's
+    backward) and nothing steps, zeroes or re-packs in between."""
+    from medplib_amd import engine
+    from medplib_amd.model.medplib import LISAForCausalLM, MedPLIBForCausalLM
+    cfg = MedPLIBConfig.tiny(moe_enable=moe, sam_depth=2, num_hidden_layers=2)
+    W = OM.init_hf_weights(cfg)
+    batch = OM.make_batch(cfg, 3, seed=19)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gb["masks_list"] = [x.to(dev) for x in batch["masks_list"]]
+
+    def run(gas, micro):
+        torch.manual_seed(1234)
+        m = (MedPLIBForCausalLM if moe else LISAForCausalLM)(cfg, device=dev)
+        m.load_hf_state_dict(W)
+        m.train()
+        if lora:
+            lo = m.enable_lora(lora_r=8, lora_alpha=16, lora_dropout=0.0, lora_target_modules="gate_proj,up_proj,down_proj",
+                               sft_modules="mask_decoder,text_hidden_fcs")
+            g = torch.Generator().manual_seed(33)
+            for n, p_ in zip(lo.names, lo.params):
+                if "lora_" in n:
+                    p_.data.copy_((torch.randn(p_.shape, generator=g) * 0.04).to(torch.bfloat16).float().to(dev))
+        eng, _, _, _ = engine.initialize(model=m, model_parameters=m.trainable_parameters(),
+                                         config={"optimizer": {"params": {"lr": 1e-3, "betas": (0.9, 0.95)}}, "gradient_clipping": 1.0,
+                                                 "gradient_accumulation_steps": gas})
+        snaps = [[p_.detach().float().cpu().clone() for p_ in eng.optimizer.params]]          # [0]: as initialised
+        for _ in range(micro):
+            out = eng(**gb)
+            eng.backward(out["loss"])
+            eng.step()
+            torch.cuda.synchronize()
+            snaps.append([p_.detach().float().cpu().clone() for p_ in eng.optimizer.params])
+        return snaps
+    init, one = run(1, 1)
+    two = run(2, 2)
+    assert all(torch.equal(a, b) for a, b in zip(init, two[0])), "the two runs start from different parameters"
+    assert any(not torch.equal(a, b) for a, b in zip(init, one)), "the single step changed nothing: the comparison would be vacuous"
+    assert all(torch.equal(a, b) for a, b in zip(init, two[1])), "a parameter moved before the accumulation boundary"
+    bad = [i for i, (a, b) in enumerate(zip(one, two[2])) if not torch.equal(a, b)]
+    assert not bad, f"{len(bad)} of {len(one)} parameters differ between one step and two equal half-steps (first: {bad[:5]})"
