@@ -613,6 +613,27 @@ bool mp_gemm320_eligible(const GemmArgs& g, int batch) {
   return true;
 }
 
+// Round 6, late: a DENSE call of at most half a wave of tiles (116 <= tiles <= 128 at 256 CUs: the N = 4096 projections at 2556 rows = BASELINE configs[1],
+// the dense VQA forward at batch 4: o_proj and down_proj are 8 x 16 = 128 tiles) may cut every tile in two or three along K with the cooperative
+// fix-up, instead of holding half the CUs for a whole tile-time (or 160 of them on 256-row tiles).  One rule for the selection model
+// (use_320, gemm_bf16.hip) and the launcher.  K >= 8192 only (the fix-up's 2 x 84 MB of partials cost ~25 us whatever K is), M >= 1024 (a tile row
+// mostly valid), never for the families that cannot split.  MP_GEMM320_SUBWAVE=0: off (A/B).  Returns the split factor (1: no split).
+int mp_gemm320_subwave_split(const GemmArgs& g, int batch) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MP_GEMM320_SUBWAVE"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  if (!on || batch != 1 || g.m_dev || g.act == ACT_ROPE_QK || g.M < 1024 || g.K < 8192) return 1;      // K = 4096 (o_proj) measured neutral: 96.3 against 97.9 us
+  if (mp_gemm_policy_whole_tiles()) return 1;
+  const int C = std::min(mp_device_cus(), 256);
+  const int64_t tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3);
+  if (tiles * 2 > C || tiles * 4 <= C) return 1;
+  // ... and only when the units then fill the chip (>= 90 % of the CUs): 96 tiles cut in two are 192 units, and measured SLOWER than 120 whole
+  // 256-row tiles (down_proj at 1917 rows: 164.6-167.3 against 160.8-161.5 us) — a launch on fewer CUs runs at a higher clock, which the
+  // wave model does not know; 128 tiles cut in two measured 223 -> 195 us (down_proj) and 97.9 -> 96.3 (o_proj), profiles/r06_subwave_bench.txt
+  const int64_t S = std::min<int64_t>(C / tiles, g.K / BK3 / 4);
+  if (S < 2 || S * tiles * 10 < (int64_t)C * 9) return 1;
+  return (int)S;
+}
+
 int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
@@ -637,7 +658,7 @@ int mp_launch_gemm320(const GemmArgs& g0, int batch, hipStream_t stream) {
   static int dense_split = -1;
   if (dense_split < 0) { const char* e = getenv("MP_GEMM320_DENSE_SPLIT"); dense_split = (e && atoi(e) == 0) ? 0 : 1; }
   const int64_t dense_tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3);
-  g.max_split = (batch > 1 || g.m_dev) ? max_split : ((dense_split && dense_tiles > g.n_cu) ? max_split : 1);
+  g.max_split = (batch > 1 || g.m_dev) ? max_split : ((dense_split && (dense_tiles > g.n_cu || mp_gemm320_subwave_split(g, batch) > 1)) ? max_split : 1);
   if (g.act == ACT_ROPE_QK) g.max_split = 1;            // the RoPE family's epilogue has no item mask (its calls are dense qkv projections)
   // Units of a split tail WAIT for their siblings, so only one such kernel may be in flight on the device: a second one on a concurrent
   // stream can hold the CUs the first one's unscheduled units need while waiting for CUs the first one holds (B = 16 with the towers

@@ -336,6 +336,8 @@ static bool use_256_rule(const GemmArgs& g, int batch) {
 int mp_device_cus();
 bool mp_gemm320_eligible(const GemmArgs& g, int batch);
 int mp_launch_gemm320(const GemmArgs& g, int batch, hipStream_t stream);
+int mp_gemm320_subwave_split(const GemmArgs& g, int batch);
+bool mp_gemm_stream_registered(hipStream_t stream);
 
 // 320-row tiles, or the kernel the call would otherwise get?  Modelled time in microseconds, from K sweeps at one full wave of tiles
 // (scripts/gemm_ksweep.py, same box): a wave of 256x256 tiles costs 8.5 + 1.45 per 64-deep K step (prologue + epilogue, then 1480-1530
@@ -346,7 +348,7 @@ int mp_launch_gemm320(const GemmArgs& g, int batch, hipStream_t stream);
 // rule does not apply (short K with a small second wave, narrow N) the alternative is the 128x128 kernel at the ~560 TFLOP/s it reaches
 // on such shapes (CLIP fc1: 72 us against 43.5 on 320-row tiles).  MP_GEMM320 = 0 never, 2 whenever eligible, default 1 = by this model.
 static thread_local int g_tile_policy = -1;          // mp_gemm_tile_policy(): -1 = the process default (MP_GEMM320, else 1)
-static bool use_320(const GemmArgs& g, int batch) {
+static bool use_320(const GemmArgs& g, int batch, hipStream_t stream = nullptr) {
   static int env_mode = -1;
   if (env_mode < 0) { const char* e = getenv("MP_GEMM320"); env_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
   const int mode = g_tile_policy >= 0 ? g_tile_policy : env_mode;
@@ -354,12 +356,22 @@ static bool use_320(const GemmArgs& g, int batch) {
   if (mode >= 2) return true;
   const int C = std::min(mp_device_cus(), 256);
   const int64_t t256 = mp_cdiv(g.M, 256) * mp_cdiv(g.N, 256), t320 = mp_cdiv(g.M, 320) * (g.N / 256);
-  if (t320 * 2 < C) return false;                     // fewer workgroups than half the CUs: the smaller tiles (or a K split) fill the machine better
+  if (t320 * 2 < C && (mp_gemm_stream_registered(stream) || mp_gemm320_subwave_split(g, batch) <= 1)) return false;   // fewer workgroups than half the CUs: the smaller tiles (or a K split) fill the machine better
   const double k = g.K / 64.0;
   const double epi = (g.residual ? 8.0 : 0.0) + (g.act == ACT_QUICK_GELU ? 6.0 : 0.0);
   const double rope320 = g.act == ACT_ROPE_QK ? MP_GEMM320_ROPE_EXTRA_US : 0.0;
   const double w320 = (double)mp_cdiv(t320, C);          // dense calls run whole waves (the kernel's tail split is for the batched expert calls)
-  const double c320 = w320 * (4.5 + epi + rope320 + 1.685 * k);
+  double c320 = w320 * (4.5 + epi + rope320 + 1.685 * k);
+  // at most half a wave of tiles and a long K: every tile cut S ways with the cooperative fix-up (mp_gemm320_subwave_split; the primary stream only,
+  // like every split).  MP_GEMM320_SUBWAVE_FIX_US: the fix-up's price in the model (partials written and read back: ~2 x 84 MB at S = 2)
+  if (!mp_gemm_stream_registered(stream)) {
+    const int S = mp_gemm320_subwave_split(g, batch);
+    if (S > 1) {
+      static double fix_us = -1.0;
+      if (fix_us < 0) { const char* e = getenv("MP_GEMM320_SUBWAVE_FIX_US"); fix_us = (e && atof(e) > 0) ? atof(e) : 28.0; }
+      c320 = std::min(c320, 4.5 + epi + 1.685 * k / S + fix_us);
+    }
+  }
   double other;
   if (use_256_rule(g, batch)) {
     const int64_t rem = t256 % C;
@@ -477,7 +489,7 @@ extern "C" int mp_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
   g.bias = bias; g.residual = (const bf16_t*)residual; g.ldr = ldr; g.m_dev = m_dev; g.M = M; g.N = N; g.K = K;
   g.act = act; g.out_f32 = (out_dtype == MP_F32); g.alpha = alpha;
   g.sA = g.sW = g.sC = g.sR = g.sBias = 0; g.m_dev_stride = 0; g.group_m = gemm_group_m();
-  if (use_320(g, 1)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, 1, stream); }
+  if (use_320(g, 1, stream)) { g_last_gemm_kernel = 320; return mp_launch_gemm320(g, 1, stream); }
   if (use_256(g, 1)) return mp_launch_gemm256(g, 1, stream);
   const int tiles = (int)(mp_cdiv(M, BM) * mp_cdiv(N, BN));
   g.max_split = split128(g, 1, stream, &g.ws, &g.tickets);

@@ -1065,3 +1065,35 @@ def test_rmsnorm_gate_fusion_is_bit_identical(dev, d, E, T):
         assert torch.equal(lg, lg_ref) and torch.equal(gt, gt_ref)
     else:
         assert lg is None and gt is None
+
+
+def test_gemm320_dense_half_wave_splits_in_two(dev):
+    """A dense call of exactly half a wave of 320 x 256 tiles with a long K (the N = 4096 projections at 2556 rows: BASELINE configs[1], the dense
+    VQA forward at batch 4) is cut in two along K with the cooperative fix-up (gemm320_bf16.hip: mp_gemm320_subwave_split; 223 -> 191 us for the
+    down projection).  The selection picks the 320-row kernel there and only there (1917 rows = 96 tiles would leave a quarter of the CUs idle
+    and stays on 256-row tiles); five launches back to back are bit-identical (the two K halves are added in split order); the result agrees with
+    the 256-row tiling to two bf16 ulps and with the fp32 product to bf16 rounding; residual and bias epilogues included."""
+    from medplib_amd import ops
+    g = torch.Generator().manual_seed(78)
+    N, K = 4096, 11008
+    for M, want in ((2556, 320), (2241, 320), (1917, 256)):
+        a = _bf(torch.randn(M, K, generator=g) * 0.5).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) * 0.02).to(dev)
+        res = _bf(torch.randn(M, N, generator=g)).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        runs = []
+        for _ in range(5):
+            runs.append(ops.gemm(a, w, bias=bias, residual=res))
+            assert ops.gemm_last_kernel() == want, (M, ops.gemm_last_kernel())
+        torch.cuda.synchronize()
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0]), "a split tile's result depends on the arrival order (or a counter did not re-arm)"
+        try:
+            ops.gemm_tile_policy(0)
+            other = ops.gemm(a, w, bias=bias, residual=res)
+            assert ops.gemm_last_kernel() == 256
+        finally:
+            ops.gemm_tile_policy(-1)
+        _report(f"dense half-wave GEMM at {M} rows vs 256-row tiling", runs[0], other.float(), rtol=2 * BF16_EPS, atol=2e-2)
+        ref = ((a.float() @ w.float().T) + bias).to(torch.bfloat16).float() + res.float()
+        _report(f"dense half-wave GEMM at {M} rows vs fp32", runs[0], ref, rtol=2 * BF16_EPS, atol=2e-2)
