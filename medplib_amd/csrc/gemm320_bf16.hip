@@ -626,9 +626,11 @@ int mp_gemm320_subwave_split(const GemmArgs& g, int batch) {
   const int C = std::min(mp_device_cus(), 256);
   const int64_t tiles = (int64_t)mp_cdiv(g.M, BM3) * (g.N / BN3);
   if (tiles * 2 > C || tiles * 4 <= C) return 1;
-  // ... and only when the units then fill the chip (>= 90 % of the CUs): 96 tiles cut in two are 192 units, and measured SLOWER than 120 whole
-  // 256-row tiles (down_proj at 1917 rows: 164.6-167.3 against 160.8-161.5 us) — a launch on fewer CUs runs at a higher clock, which the
-  // wave model does not know; 128 tiles cut in two measured 223 -> 195 us (down_proj) and 97.9 -> 96.3 (o_proj), profiles/r06_subwave_bench.txt
+  // ... and only when the units then fill the chip (>= 90 % of the CUs): 96 tiles cut in two are 192 units, and measured SLOWER (down_proj at 1917
+  // rows: 164.6-167.3 us) than what the 256-row kernel already does there with ITS tail rule — 8 x 16 = 128 tiles of 256 rows cut in two = 256
+  // units, 158-161 us.  The 256-row kernel's rule (rem * 2 <= CUs) stops at 128 tiles; at 2556 rows it has 160 whole tiles on 160 CUs (218-223 us)
+  // and this rule takes over: 128 tiles of 320 rows cut in two, 184-195 us (down_proj); 97.9 -> 96.3 for o_proj (K = 4096: neutral, not taken).
+  // profiles/r06_subwave_bench.txt, profiles/r06_subwave_grid.txt
   const int64_t S = std::min<int64_t>(C / tiles, g.K / BK3 / 4);
   if (S < 2 || S * tiles * 10 < (int64_t)C * 9) return 1;
   return (int)S;
