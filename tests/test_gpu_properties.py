@@ -277,3 +277,33 @@ def test_two_equal_micro_steps_are_one_step(dev, moe, lora):
     assert all(torch.equal(a, b) for a, b in zip(init, two[1])), "a parameter moved before the accumulation boundary"
     bad = [i for i, (a, b) in enumerate(zip(one, two[2])) if not torch.equal(a, b)]
     assert not bad, f"{len(bad)} of {len(one)} parameters differ between one step and two equal half-steps (first: {bad[:5]})"
+
+
+@pytest.mark.parametrize("mode", ["moe", "dense_lora"])
+def test_identical_ranks_are_one_rank(dev, mode, tmp_path):
+    """Data parallelism averages the ranks' gradients (DeepSpeed engine allreduce, train_ds_medplib.py:412-419): two ranks that hold the SAME
+    micro-batch reduce g + g and scale by 1 / 2 — both exact — so two optimizer steps must leave the parameters of a one-rank run bit for bit:
+    the bucketed SUM all-reduce (one bucket for the frozen trunk, per-layer buckets from inside the decoder backward with adapters), grad_scale
+    = 1 / world inside the AdamW kernel and the clipping norm all sit on that path.  Two real processes on cuda:0 over gloo (RCCL refuses two
+    ranks on one device; tests/_dp_equiv_worker.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for n in (1, 2):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update({"OMP_NUM_THREADS": "4", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = str(tmp_path / f"params_{n}.pt")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "tests", "_dp_equiv_worker.py"), out, mode]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        outs[n] = torch.load(out)
+    assert len(outs[1]) == len(outs[2]) and len(outs[1]) > 0
+    bad = [i for i, (a, b) in enumerate(zip(outs[1], outs[2])) if not torch.equal(a, b)]
+    assert not bad, f"{len(bad)} of {len(outs[1])} parameters differ between one rank and two identical ranks (first: {bad[:5]})"
